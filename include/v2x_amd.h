@@ -1,0 +1,159 @@
+/* v2x_amd.h -- C ABI of libv2x_amd.so: the MI355X (gfx950) hot path of the V2X-Sim
+ * collaborative-perception baselines.
+ *
+ * What each entry point replaces.  The reference checkout holds no code: the
+ * whole path lives in the un-vendored submodule `coperception`
+ * (/root/reference/.gitmodules:1-3; /root/reference/README.md:101 names the
+ * det/seg benchmarks, README.md:45 the create_data.py voxelisation).  The
+ * reference has no FFI/plugin interface of its own -- its "operator API" is
+ * torch.nn.Module.forward -- so every entry below cites the upstream python
+ * function (path only; no line numbers exist in the tree) whose arithmetic it
+ * takes over.  INTEGRATION.md shows the ctypes stub a maintainer would add.
+ *
+ * Conventions: plain pointers and sizes only (no torch types); all pointers are
+ * DEVICE pointers unless marked host; the caller owns every buffer (no internal
+ * allocation, no global mutable state); `stream` is a hipStream_t passed as
+ * void*; calls are asynchronous on that stream and re-entrant; the return value
+ * is 0 or a negative errno-style code, and v2x_last_error() gives the text for
+ * the calling thread.  bf16 tensors are passed as uint16_t*.
+ *
+ * Tensor layouts: activations are NHWC ("BEV pixel major, channels fastest"),
+ * which is the reference's own (X, Y, Z) voxel-grid layout with Z as channels.
+ */
+#ifndef V2X_AMD_H
+#define V2X_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2X_AMD_ABI_VERSION 1
+
+#define V2X_OK 0
+#define V2X_EINVAL (-22) /* bad argument / unsupported shape */
+#define V2X_EIO (-5)     /* HIP launch failure */
+
+typedef void *v2x_stream_t; /* hipStream_t */
+
+int v2x_abi_version(void);
+const char *v2x_last_error(void);
+
+/* ---------------------------------------------------------------- a1: voxel scatter
+ * Replaces coperception/utils/data_util.py::voxelize_occupy (range filter,
+ * floor(p / voxel) in fp64, dedupe, dense occupancy) and the densify scatter of
+ * coperception/datasets/V2XSimDet.py::__getitem__.
+ *
+ * pts:   [n_clouds][max_pts][pt_stride] fp32, x,y,z first; cloud i holds n_pts[i] points.
+ * extents {xlo,xhi,ylo,yhi,zlo,zhi}, voxel {vx,vy,vz}: HOST fp64 arrays.
+ * bits:  [n_clouds][X][Y] uint32, bit z set iff voxel (x,y,z) is occupied (Z <= 32).
+ *        The call clears `bits` itself (memset node on `stream`) before scattering. */
+int v2x_voxelize_bits(const float *pts, const int32_t *n_pts, int n_clouds, int max_pts, int pt_stride,
+                      const double *extents, const double *voxel, const int32_t *dims_xyz,
+                      uint32_t *bits, v2x_stream_t stream);
+
+/* bits -> the reference's dense padded_voxel_points layout [n][X][Y][Z] fp32 {0,1}. */
+int v2x_bits_to_dense_f32(const uint32_t *bits, int n, int X, int Y, int Z, float *out, v2x_stream_t stream);
+
+/* bits -> network input: NHWC bf16 [n][X][Y][c_pad], channels >= Z are zero. c_pad % 8 == 0. */
+int v2x_bits_to_nhwc_bf16(const uint32_t *bits, int n, int X, int Y, int Z, int c_pad, uint16_t *out,
+                          v2x_stream_t stream);
+
+/* dense fp32 bevs [n][X][Y][Z] (what the reference Dataset hands the model) -> NHWC bf16 [n][X][Y][c_pad]. */
+int v2x_dense_f32_to_nhwc_bf16(const float *bev, int n, int X, int Y, int Z, int c_pad, uint16_t *out,
+                               v2x_stream_t stream);
+
+/* bits -> sorted (x,y,z)-lexicographic voxel indices, as voxelize_occupy(return_indices=True).
+ * idx: [n][cap][3] int32; counts: [n] int32 (true count even if > cap; only `cap` are written).
+ * scratch: [n][X] int32 device workspace. */
+int v2x_bits_to_indices(const uint32_t *bits, int n, int X, int Y, int Z, int32_t *idx, int cap, int32_t *counts,
+                        int32_t *scratch, v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- a2/a4/a6/a7/a8: convolutions
+ * One implicit-GEMM MFMA kernel family covers
+ *   - coperception/models/det/backbone/Backbone.py::LidarEncoder / LidarDecoder
+ *     (3x3 stride 1/2 conv + BN + ReLU; the 1x1x1 "Conv3D"; F.interpolate(x2) +
+ *      torch.cat + conv fused through the two-source loader),
+ *   - convolutional_rnn.Conv2dGRU one cell step with h0 = 0 (V2VNet.py), gates
+ *     fused in the epilogue,
+ *   - DetModelBase.py::ClassificationHead / SingleRegressionHead and the seg head,
+ *   - When2com.py::PolicyNet4 convs and KmGenerator linears (as 1x1 convs on 1x1 maps).
+ */
+enum {
+    V2X_EPI_BF16 = 0, /* y = acc*scale[c] + shift[c], optional ReLU, bf16 NHWC out          */
+    V2X_EPI_F32 = 1,  /* same, fp32 NHWC out (logits)                                        */
+    V2X_EPI_GRU = 2   /* rows are (r,z,n) gate triples; out = (1-z)*n, bf16; see DESIGN.md   */
+};
+
+typedef struct v2x_conv_desc {
+    const uint16_t *in0; /* bf16 NHWC [N][H>>up0][W>>up0][C0]                                     */
+    const uint16_t *in1; /* bf16 NHWC [N][H][W][C1] or NULL; logical input = cat(up(in0), in1)   */
+    int32_t C0, C1;      /* C0 % 8 == 0, C1 % 8 == 0                                              */
+    int32_t up0;         /* log2 nearest-neighbour upsample applied to in0 (0 or 1)              */
+    int32_t N, H, W;     /* logical input extent                                                 */
+    int32_t ksize;       /* 1 or 3                                                               */
+    int32_t stride;      /* 1 or 2                                                               */
+    int32_t pad;         /* 0 or 1                                                               */
+    int32_t Cout;        /* logical output channels (GRU: hidden channels)                       */
+    int32_t w_rows;      /* packed weight rows (multiple of v2x_conv_tile_rows)                  */
+    int32_t w_kpad;      /* packed K extent, multiple of 64, >= ksize*ksize*(C0+C1)              */
+    const uint16_t *weight; /* bf16 [w_rows][w_kpad], k = (ky*ksize+kx)*(C0+C1) + c              */
+    const float *scale;  /* fp32 [w_rows]   (GRU: float4 [Cout] = b_ir+b_hr, b_iz+b_hz, b_in, b_hn) */
+    const float *shift;  /* fp32 [w_rows]   (GRU: unused)                                        */
+    int32_t epilogue;    /* V2X_EPI_*                                                            */
+    int32_t relu;
+    void *out;           /* NHWC [N][Ho][Wo][out_cstride], written at channel offset out_coff    */
+    int32_t out_cstride, out_coff;
+    void *out2;          /* optional second NHWC output: channels >= split go to out2[..][c-split] */
+    int32_t split;       /* multiple of 4; 0 = no split (out2 ignored)                           */
+    int32_t out2_cstride;
+} v2x_conv_desc;
+
+/* Rows-per-tile the kernel will use for (Cout, epilogue); the weight packer pads w_rows to a multiple. */
+int v2x_conv_tile_rows(int Cout, int epilogue);
+int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- a3 (+ the sum of a4/a5): warp + fuse
+ * Replaces DetModelBase.py::feature_transformation (affine_grid + grid_sample twice,
+ * bilinear, zeros, align_corners=False) together with the reduction that consumes
+ * it: torch.mean(torch.stack(neighbours)) in V2VNet.py and the attention-weighted
+ * sum of MIMOGeneralDotProductAttention in When2com.py.
+ *
+ * feat:  bf16 NHWC [A*Bt][H][W][C], item index = agent*Bt + frame (agent-major, as the
+ *        reference batches agents).
+ * trans: fp32 [Bt][A][A][4][4]; trans[f][ego][nb] is the pose used to bring nb into ego.
+ * items: int32 [n_out][2] = (ego agent, frame) of every output map (lets a rank fuse only
+ *        the items it owns after the all-gather).
+ * coef:  fp32 [n_out][A] weight of source agent j for output m (0 = skip). j == ego is
+ *        taken unwarped.
+ * mode:  V2X_FUSE_WSUM  out = sum_j coef*warp_j ;  V2X_FUSE_MEAN  out = (sum_{coef!=0} warp_j) / count
+ * out:   bf16 NHWC [n_out][H][W][C].   C % 8 == 0. */
+enum { V2X_FUSE_WSUM = 0, V2X_FUSE_MEAN = 1 };
+int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
+                  const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
+                  v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- a5: attention handshake
+ * Replaces When2com.py::MIMOGeneralDotProductAttention (query projection, key.query
+ * scores, softmax over the keys) and the inference-time selection
+ * (activated_select: threshold 0.2 / argmax_select: top-1).
+ *
+ * keys:  fp32 [A*Bt][key_size], querys: fp32 [A*Bt][query_size] (agent-major items)
+ * w_lin: fp32 [key_size][query_size], b_lin: fp32 [key_size]   (attention_net.linear)
+ * prob:  fp32 [Bt][A(k)][A(q)] softmax scores;  coef: same shape after selection
+ * mode:  0 softmax (training / 'softmax'), 1 'activated' (coef = p * (p > thres)), 2 'argmax_test' */
+int v2x_attn_handshake(const float *keys, const float *querys, const float *w_lin, const float *b_lin, int A,
+                       int Bt, int key_size, int query_size, int mode, float thres, float *prob, float *coef,
+                       v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- a8: seg argmax + confusion matrix
+ * logits fp32 NHWC [n][H][W][n_cls]; label uint8 [n][H][W]; pred uint8 [n][H][W] (may be NULL);
+ * conf int64 [n_cls][n_cls] (rows = label, cols = prediction), accumulated (caller zeroes). */
+int v2x_seg_argmax_confusion(const float *logits, const uint8_t *label, int n, int H, int W, int n_cls,
+                             uint8_t *pred, long long *conf, v2x_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* V2X_AMD_H */

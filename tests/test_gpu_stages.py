@@ -1,0 +1,329 @@
+"""GPU parity tests, one block per SURVEY.md section 8 row, calling the HIP kernels through the
+C ABI (v2x_sim_amd.ops -> libv2x_amd.so) and checking against the build-owned CPU oracle and
+the committed golden vectors.  PARITY UNPINNED w.r.t. the reference (no code in /root/reference).
+
+Bars: bit-exact for voxel indices / occupancy / confusion matrices; for floating point the
+tolerance is written next to each assert (bf16 storage, fp32 accumulation)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import coperception_ref as R
+from oracle import voxelize_ref as VR
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def to_nhwc_bf16(x_nchw, dev):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(dev)
+
+
+def from_nhwc(y):
+    return y.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------------------------- a1
+def _voxel_gpu(pts_list, dev, grid=None):
+    from v2x_sim_amd import ops
+    grid = grid or ops.VoxelGrid()
+    n = len(pts_list)
+    mp = max(1, max(p.shape[0] for p in pts_list))
+    buf = np.zeros((n, mp, 4), np.float32)
+    cnt = np.zeros((n,), np.int32)
+    for i, p in enumerate(pts_list):
+        buf[i, :p.shape[0]] = p
+        cnt[i] = p.shape[0]
+    bits = ops.voxelize_bits(torch.from_numpy(buf).to(dev), torch.from_numpy(cnt).to(dev), grid)
+    return bits, grid
+
+
+@pytest.mark.parametrize("sizes", [(65536, 65536, 65536, 65536, 65536), (4096, 0, 17, 300), (2048,)])
+def test_voxelize_bit_exact(device, sizes):
+    from v2x_sim_amd import ops
+    clouds = [VR.synthetic_points(n, seed=100 + i, n_edge=min(64, n // 4)) if n else np.zeros((0, 4), np.float32)
+              for i, n in enumerate(sizes)]
+    bits, grid = _voxel_gpu(clouds, device)
+    X, Y, Z = grid.dims
+    assert (X, Y, Z) == (256, 256, 13)
+    dense = ops.bits_to_dense(bits, Z).cpu().numpy()
+    cap = 65536
+    idx, counts = ops.bits_to_indices(bits, Z, cap)
+    idx, counts = idx.cpu().numpy(), counts.cpu().numpy()
+    nhwc = ops.bits_to_nhwc(bits, Z, 16).float().cpu().numpy()
+    for i, pts in enumerate(clouds):
+        ref_grid, ref_idx = VR.voxelize_occupy(pts, return_indices=True)
+        assert np.array_equal(dense[i], ref_grid)                      # bit-exact occupancy
+        assert counts[i] == ref_idx.shape[0]
+        assert np.array_equal(idx[i, :counts[i]], ref_idx.astype(np.int32))  # bit-exact, same order
+        assert np.array_equal(nhwc[i, :, :, :13], ref_grid) and nhwc[i, :, :, 13:].sum() == 0
+
+
+def test_voxelize_golden_and_idempotent(device):
+    from v2x_sim_amd import ops
+    g = np.load(os.path.join(GOLD, "voxel_2048.npz"))
+    bits, grid = _voxel_gpu([g["points"]], device)
+    idx, counts = ops.bits_to_indices(bits, 13, 4096)
+    assert np.array_equal(idx[0, :int(counts[0])].cpu().numpy(), g["indices"])
+    # scattering the same cloud twice (duplicates of every point) changes nothing
+    twice = np.concatenate([g["points"], g["points"]])
+    bits2, _ = _voxel_gpu([twice], device)
+    assert torch.equal(bits, bits2)
+
+
+def test_voxelize_edges_and_cross_road_extents(device):
+    from v2x_sim_amd import ops
+    on = np.array([[-32, 0, 0, 0], [32, 0, 0, 0], [0, -32, 0, 0], [0, 32, 0, 0], [0, 0, -3, 0], [0, 0, 2, 0],
+                   [0.25, -0.25, np.float32(0.4), 0], [0, 0, np.float32(1.2), 0]], np.float32)
+    bits, _ = _voxel_gpu([on], device)
+    idx, counts = ops.bits_to_indices(bits, 13, 16)
+    assert int(counts[0]) == 2
+    assert idx[0, :2].cpu().tolist() == [[128, 128, 11], [129, 127, 9]]
+    grid = ops.VoxelGrid(area_extents=((-32, 32), (-32, 32), (-8, -3)))
+    pts = VR.synthetic_points(8192, seed=3)
+    pts[:, 2] -= 5.0
+    bits, _ = _voxel_gpu([pts], device, grid)
+    ext = np.array([[-32.0, 32.0], [-32.0, 32.0], [-8.0, -3.0]])
+    ref = VR.voxelize_occupy(pts, VR.VOXEL_SIZE, ext)
+    assert np.array_equal(ops.bits_to_dense(bits, 13)[0].cpu().numpy(), ref)
+
+
+def test_dense_to_nhwc(device):
+    from v2x_sim_amd import ops
+    bev = (torch.rand(3, 32, 48, 13) < 0.1).float()
+    out = ops.dense_to_nhwc(bev.to(device), 16).float().cpu()
+    assert torch.equal(out[..., :13], bev) and out[..., 13:].abs().sum() == 0
+
+
+# ------------------------------------------------------------------------------------- a2/a6/a7
+def _run_conv(dev, x, w, scale, shift, *, stride=1, relu=True, x_skip=None, up0=0, f32=False, cin_pad=None):
+    """x (N,C0,h,w) [+ x_skip (N,C1,H,W)] NCHW fp32 (bf16-representable) -> NCHW fp32 result."""
+    from v2x_sim_amd import ops, packing
+    C0 = x.shape[1] if cin_pad is None else cin_pad
+    C1 = 0 if x_skip is None else x_skip.shape[1]
+    pc = packing.pack_conv("t", w, scale, shift, stride=stride, C0=C0, C1=C1, up0=up0, relu=relu,
+                           epilogue=ops.V2X_EPI_F32 if f32 else ops.V2X_EPI_BF16, cin_pad=cin_pad, device=dev)
+    xin = x if cin_pad is None else F.pad(x, (0, 0, 0, 0, 0, cin_pad - x.shape[1]))
+    y = ops.conv2d(pc, to_nhwc_bf16(xin, dev), None if x_skip is None else to_nhwc_bf16(x_skip, dev))
+    return from_nhwc(y)
+
+
+def _ref_conv(x, w, scale, shift, stride, relu, x_skip=None, up0=0):
+    if x_skip is not None:
+        up = F.interpolate(x, scale_factor=(2, 2)) if up0 else x
+        x = torch.cat((up, x_skip), 1)
+    y = F.conv2d(x, bf16r(w), None, stride, (w.shape[-1] - 1) // 2)
+    y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    return F.relu(y) if relu else y
+
+
+CONV_CASES = [
+    # (N, Cin, Cout, H, W, k, stride)  -- covers every tile config (32/48/64/128 rows) and K tails
+    (2, 16, 32, 24, 40, 3, 1),    # first-layer shape class (Cin=16 -> 4 taps per K chunk)
+    (1, 32, 32, 33, 19, 3, 1),    # odd extents, M tail
+    (2, 32, 64, 32, 32, 3, 2),    # stride 2
+    (1, 64, 64, 20, 20, 1, 1),    # 1x1 ("Conv3D")
+    (1, 64, 128, 16, 16, 3, 2),
+    (3, 128, 256, 8, 8, 3, 1),    # 128-row tiles, 2 channel tiles
+    (1, 256, 48, 8, 12, 1, 1),    # 48-row tile
+    (1, 512, 512, 4, 4, 3, 1),    # deep K (72 chunks), tiny M
+    (5, 32, 12, 16, 16, 1, 1),    # Cout not a multiple of 16
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_vs_torch(device, case):
+    N, Cin, Cout, H, W, k, stride = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bf16r(torch.randn(N, Cin, H, W, generator=g))
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (Cin * k * k)) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.2
+    ref = _ref_conv(x, w, scale, shift, stride, True)
+    got32 = _run_conv(device, x, w, scale, shift, stride=stride, relu=True, f32=True)
+    # fp32 epilogue: only the accumulation order differs -> 1e-4 abs on O(1) values
+    assert got32.shape == ref.shape
+    assert torch.allclose(got32, ref, atol=2e-4, rtol=1e-4), float((got32 - ref).abs().max())
+    got = _run_conv(device, x, w, scale, shift, stride=stride, relu=True)
+    # bf16 epilogue: one bf16 rounding of the same value (rel 2^-8) on top
+    assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
+
+
+def test_conv_transpose_detecting(device):
+    """Asymmetric check (guide rule 16): single hot input pixel/channel -> the weight slice appears,
+    spatially flipped, at the right place and channel order."""
+    N, Cin, Cout, H, W = 1, 32, 64, 16, 16
+    x = torch.zeros(N, Cin, H, W)
+    x[0, 5, 7, 3] = 1.0
+    w = torch.arange(Cout * Cin * 9, dtype=torch.float32).view(Cout, Cin, 3, 3) % 251 / 64.0
+    ref = _ref_conv(x, w, torch.ones(Cout), torch.zeros(Cout), 1, False)
+    got = _run_conv(device, x, w, torch.ones(Cout), torch.zeros(Cout), relu=False, f32=True)
+    assert torch.equal(got, ref)
+
+
+def test_conv_first_layer_channel_pad(device):
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(2, 13, 32, 32, generator=g) < 0.1).float()
+    w = torch.randn(32, 13, 3, 3, generator=g) * 0.2
+    ref = _ref_conv(x, w, torch.ones(32), torch.zeros(32), 1, True)
+    got = _run_conv(device, x, w, torch.ones(32), torch.zeros(32), cin_pad=16, f32=True)
+    assert torch.allclose(got, ref, atol=1e-4)
+
+
+@pytest.mark.parametrize("cup,cskip,cout", [(64, 32, 32), (128, 64, 64), (512, 256, 256)])
+def test_conv_upsample_concat(device, cup, cskip, cout):
+    g = torch.Generator().manual_seed(cup)
+    H, W = (8, 8) if cup == 512 else (16, 24)
+    x_up = bf16r(torch.randn(2, cup, H // 2, W // 2, generator=g))
+    x_sk = bf16r(torch.randn(2, cskip, H, W, generator=g))
+    w = torch.randn(cout, cup + cskip, 3, 3, generator=g) * (2.0 / ((cup + cskip) * 9)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
+    ref = _ref_conv(x_up, w, scale, shift, 1, True, x_skip=x_sk, up0=1)
+    got = _run_conv(device, x_up, w, scale, shift, x_skip=x_sk, up0=1, f32=True)
+    assert torch.allclose(got, ref, atol=3e-4, rtol=1e-4), float((got - ref).abs().max())
+
+
+def test_conv_golden(device):
+    g = np.load(os.path.join(GOLD, "conv_small.npz"))
+    x, w = torch.from_numpy(g["x"]), torch.from_numpy(g["w"])
+    scale, shift = torch.from_numpy(g["scale"]), torch.from_numpy(g["shift"])
+    for s in (1, 2):
+        got = _run_conv(device, x, w, scale, shift, stride=s, f32=True)
+        assert torch.allclose(got, torch.from_numpy(g["y_s%d" % s]), atol=2e-4)
+    got = _run_conv(device, torch.from_numpy(g["x_up"]), torch.from_numpy(g["w2"]), scale, shift,
+                    x_skip=x, up0=1, f32=True)
+    assert torch.allclose(got, torch.from_numpy(g["y_upcat"]), atol=2e-4)
+
+
+def test_conv_split_outputs(device):
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(9)
+    x = bf16r(torch.randn(2, 64, 16, 16, generator=g))
+    w = torch.randn(48, 64, 1, 1, generator=g) * 0.2
+    b = torch.randn(48, generator=g)
+    pc = packing.pack_conv("t", w, torch.ones(48), b, relu=False, epilogue=ops.V2X_EPI_F32, device=device)
+    a, c = ops.conv2d(pc, to_nhwc_bf16(x, device), split=12)
+    ref = _ref_conv(x, w, torch.ones(48), b, 1, False)
+    assert a.shape == (2, 16, 16, 12) and c.shape == (2, 16, 16, 36) and a.is_contiguous() and c.is_contiguous()
+    assert torch.allclose(from_nhwc(a), ref[:, :12], atol=2e-4) and torch.allclose(from_nhwc(c), ref[:, 12:], atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------- a4
+def test_gru_golden_and_random(device):
+    from v2x_sim_amd import ops, packing
+    g = np.load(os.path.join(GOLD, "gru_32.npz"))
+    x = torch.from_numpy(g["x"])  # (1, 64, 8, 8): first 32 = ego, last 32 = neighbour mean
+    pc = packing.pack_gru("gru", torch.from_numpy(g["w_ih"]), torch.from_numpy(g["b_ih"]),
+                          torch.from_numpy(g["b_hh"]), C0=32, C1=32, device=device)
+    h = ops.conv2d(pc, to_nhwc_bf16(x[:, :32], device), to_nhwc_bf16(x[:, 32:], device))
+    got = from_nhwc(h)
+    # same bf16-rounded operands, fp32 accumulate, bf16 output: <= 1 bf16 ulp of an O(1) value
+    assert torch.allclose(got, torch.from_numpy(g["h"]), atol=2 ** -8, rtol=2 ** -7)
+    # fp32 spec (un-rounded weights): bf16 weight rounding adds ~1e-2 on |h| <= 1
+    assert torch.allclose(got, torch.from_numpy(g["h_fp32"]), atol=3e-2)
+    # full-size cell, 256 hidden, several maps
+    torch.manual_seed(5)
+    cell = R.Conv2dGRUCell(512, 256, 3)
+    gen = torch.Generator().manual_seed(6)
+    with torch.no_grad():
+        for p in cell.parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.02)
+        xx = bf16r(torch.randn(3, 512, 32, 32, generator=gen))
+        ref = cell(xx, None, emulate=True)
+    pc = packing.pack_gru("gru", cell.weight_ih_l0, cell.bias_ih_l0, cell.bias_hh_l0, C0=256, C1=256, device=device)
+    h = ops.conv2d(pc, to_nhwc_bf16(xx[:, :256], device), to_nhwc_bf16(xx[:, 256:], device))
+    assert torch.allclose(from_nhwc(h), ref, atol=2 ** -7, rtol=2 ** -7), float((from_nhwc(h) - ref).abs().max())
+
+
+# ------------------------------------------------------------------------------------- a3
+def _warp_ref(feat, T, items, coef, A, Bt, mode):
+    n_out = len(items)
+    C, H, W = feat.shape[1:]
+    out = torch.zeros(n_out, C, H, W)
+    for m, (ego, f) in enumerate(items):
+        acc = torch.zeros(C, H, W)
+        cnt = 0
+        for j in range(A):
+            c = float(coef[m, j])
+            if c == 0:
+                continue
+            cnt += 1
+            v = feat[j * Bt + f] if j == ego else R.feature_transformation(feat[j * Bt + f], T[f, ego, j], (1, C, H, W))
+            acc = acc + (v if mode == 1 else c * v)
+        out[m] = acc / cnt if (mode == 1 and cnt) else acc
+    return out
+
+
+def test_warp_golden_and_identity(device):
+    from v2x_sim_amd import ops
+    g = np.load(os.path.join(GOLD, "warp_2agent.npz"))
+    feat = torch.from_numpy(g["feat"])
+    T = torch.zeros(1, 2, 2, 4, 4)
+    T[0, 0, 1] = torch.from_numpy(g["T"])
+    T[0, 1, 0] = torch.eye(4)
+    items = torch.tensor([[0, 0], [1, 0]], dtype=torch.int32, device=device)
+    coef = torch.tensor([[0.0, 1.0], [1.0, 0.0]], device=device)
+    out = ops.warp_fuse(to_nhwc_bf16(feat, device), 2, 1, T.to(device), items, coef, ops.V2X_FUSE_MEAN)
+    got = from_nhwc(out)
+    # fp32 interpolation of bf16 maps, output rounded to bf16: 1 ulp (2^-8 rel) + 1e-3 abs
+    assert torch.allclose(got[0], bf16r(torch.from_numpy(g["warped"])), atol=2e-3, rtol=2 ** -7)
+    # identity pose reproduces the neighbour map exactly (bilinear weights are exactly 1/0)
+    assert torch.allclose(got[1], feat[0], atol=1e-6)
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_warp_fuse_vs_oracle(device, mode):
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.utils.synthetic import synthetic_poses
+    A, Bt, C, H, W = 5, 2, 64, 32, 32
+    g = torch.Generator().manual_seed(21 + mode)
+    feat = bf16r(torch.randn(A * Bt, C, H, W, generator=g))
+    T = torch.from_numpy(synthetic_poses(Bt, A, seed=4))
+    items = [(a, f) for a in range(A) for f in range(Bt)]
+    if mode == 1:
+        coef = torch.ones(len(items), A)
+        for m, (a, f) in enumerate(items):
+            coef[m, a] = 0
+        coef[3, 4] = 0  # a frame with fewer neighbours
+    else:
+        coef = torch.rand(len(items), A, generator=g)
+        coef[coef < 0.3] = 0
+    ref = _warp_ref(feat, T, items, coef, A, Bt, mode)
+    out = ops.warp_fuse(to_nhwc_bf16(feat, device), A, Bt, T.to(device),
+                        torch.tensor(items, dtype=torch.int32, device=device), coef.to(device), mode)
+    got = from_nhwc(out)
+    assert torch.allclose(got, bf16r(ref), atol=4e-3, rtol=2 ** -7), float((got - ref).abs().max())
+
+
+# ------------------------------------------------------------------------------------- a5
+def test_attention_golden(device):
+    from v2x_sim_amd import ops
+    g = np.load(os.path.join(GOLD, "attn_5x5.npz"))
+    d = lambda k: torch.from_numpy(g[k]).to(device)
+    prob, coef = ops.attn_handshake(d("keys"), d("querys"), d("w"), d("b"), 5, 2, "activated")
+    assert torch.allclose(prob.cpu(), torch.from_numpy(g["prob"]), atol=1e-5)   # fp32, order of summation only
+    assert torch.allclose(coef.cpu(), torch.from_numpy(g["coef_activated"]), atol=1e-5)
+    _, coef = ops.attn_handshake(d("keys"), d("querys"), d("w"), d("b"), 5, 2, "argmax_test")
+    assert torch.equal(coef.cpu(), torch.from_numpy(g["coef_argmax"]))
+    p2, c2 = ops.attn_handshake(d("keys"), d("querys"), d("w"), d("b"), 5, 2, "softmax")
+    assert torch.equal(p2, c2)
+
+
+# ------------------------------------------------------------------------------------- a8
+def test_seg_argmax_confusion_exact(device):
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(3, 64, 64, 8, generator=g)
+    label = torch.randint(0, 8, (3, 64, 64), generator=g).to(torch.uint8)
+    pred, conf = ops.seg_argmax_confusion(logits.to(device), label.to(device))
+    ref_pred = logits.argmax(-1)
+    assert torch.equal(pred.cpu().long(), ref_pred)
+    assert torch.equal(conf.cpu(), R.confusion_matrix(ref_pred, label))   # integer-exact
+    assert int(conf.sum()) == 3 * 64 * 64

@@ -1,0 +1,138 @@
+// a5 -- when2com / who2com attention handshake, and a8 -- seg argmax + confusion matrix.
+//
+// Replaces upstream coperception/models/det/When2com.py::MIMOGeneralDotProductAttention
+// (query projection nn.Linear(query_size, key_size), bmm(key, query^T), softmax over the
+// keys) and the inference-time selections activated_select (p * (p > 0.2)) and
+// argmax_select (one-hot of the arg-max key) -- code absent from /root/reference, see
+// include/v2x_amd.h.  The whole handshake of a frame is a 5x5 problem with 1024-long dot
+// products: one workgroup per frame, projected queries kept in LDS, one wave per
+// (key, query) pair with a 64-lane shuffle reduction, softmax over <= 32 keys by a single
+// thread per query.  fp32 throughout.
+#include "common.h"
+
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attn_handshake_kernel(const float *__restrict__ keys,
+                                                             const float *__restrict__ querys,
+                                                             const float *__restrict__ w_lin,
+                                                             const float *__restrict__ b_lin, int A, int Bt,
+                                                             int key_size, int query_size, int mode, float thres,
+                                                             float *__restrict__ prob, float *__restrict__ coef) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float *qp = reinterpret_cast<float *>(smem_raw);  // [A][key_size] projected queries
+    float *sc = qp + (size_t)A * key_size;             // [A(k)][A(q)] scores
+    const int f = blockIdx.x;
+    // 1. query projection: qp[q][d] = b[d] + sum_s w[d][s] * query[q][s]
+    for (int i = threadIdx.x; i < A * key_size; i += blockDim.x) {
+        const int q = i / key_size, d = i - q * key_size;
+        const float *qv = querys + ((size_t)q * Bt + f) * query_size;
+        const float *wr = w_lin + (size_t)d * query_size;
+        float s = 0.f;
+        for (int t = 0; t < query_size; ++t) s += wr[t] * qv[t];
+        qp[i] = s + b_lin[d];
+    }
+    __syncthreads();
+    // 2. scores[k][q] = key_k . qp_q   (one wave per pair)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int pair = wave; pair < A * A; pair += nw) {
+        const int k = pair / A, q = pair - k * A;
+        const float *kv = keys + ((size_t)k * Bt + f) * key_size;
+        const float *qv = qp + (size_t)q * key_size;
+        float s = 0.f;
+        for (int d = lane; d < key_size; d += 64) s += kv[d] * qv[d];
+        s = wave_sum(s);
+        if (lane == 0) sc[k * A + q] = s;
+    }
+    __syncthreads();
+    // 3. softmax over keys k for every query q, then the selection
+    if (threadIdx.x < A) {
+        const int q = threadIdx.x;
+        float mx = -INFINITY;
+        for (int k = 0; k < A; ++k) mx = fmaxf(mx, sc[k * A + q]);
+        float den = 0.f;
+        for (int k = 0; k < A; ++k) den += expf(sc[k * A + q] - mx);
+        int arg = 0;
+        float best = -INFINITY;
+        for (int k = 0; k < A; ++k) {
+            const float p = expf(sc[k * A + q] - mx) / den;
+            prob[((size_t)f * A + k) * A + q] = p;
+            if (p > best) {  // first maximum wins, as torch.max
+                best = p;
+                arg = k;
+            }
+        }
+        for (int k = 0; k < A; ++k) {
+            const float p = prob[((size_t)f * A + k) * A + q];
+            float c;
+            if (mode == 0) c = p;
+            else if (mode == 1) c = (p > thres) ? p : 0.f;
+            else c = (k == arg) ? 1.f : 0.f;
+            coef[((size_t)f * A + k) * A + q] = c;
+        }
+    }
+}
+
+extern "C" int v2x_attn_handshake(const float *keys, const float *querys, const float *w_lin, const float *b_lin,
+                                  int A, int Bt, int key_size, int query_size, int mode, float thres, float *prob,
+                                  float *coef, v2x_stream_t stream) {
+    V2X_REQUIRE(keys && querys && w_lin && b_lin && prob && coef, "v2x_attn_handshake: null pointer");
+    V2X_REQUIRE(A > 0 && A <= 32 && Bt > 0 && key_size > 0 && query_size > 0, "v2x_attn_handshake: bad dims");
+    V2X_REQUIRE(mode >= 0 && mode <= 2, "v2x_attn_handshake: mode must be 0 (softmax), 1 (activated) or 2 (argmax_test)");
+    const size_t smem = ((size_t)A * key_size + (size_t)A * A) * sizeof(float);
+    V2X_REQUIRE(smem <= 64 * 1024, "v2x_attn_handshake: A*key_size too large for LDS staging");
+    hipLaunchKernelGGL(attn_handshake_kernel, dim3(Bt), dim3(256), smem, (hipStream_t)stream, keys, querys, w_lin,
+                       b_lin, A, Bt, key_size, query_size, mode, thres, prob, coef);
+    V2X_CHECK_LAUNCH("attn_handshake_kernel");
+    return V2X_OK;
+}
+
+// ---- a8: per-pixel argmax over class logits + LDS-binned integer confusion matrix ----------
+__global__ __launch_bounds__(256) void seg_argmax_confusion_kernel(const float *__restrict__ logits,
+                                                                   const uint8_t *__restrict__ label, size_t n_pix,
+                                                                   int n_cls, uint8_t *__restrict__ pred,
+                                                                   unsigned long long *__restrict__ conf) {
+    extern __shared__ unsigned int bins[];  // [n_cls*n_cls]
+    for (int i = threadIdx.x; i < n_cls * n_cls; i += blockDim.x) bins[i] = 0u;
+    __syncthreads();
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < n_pix; p += (size_t)gridDim.x * blockDim.x) {
+        const float *l = logits + p * n_cls;
+        int arg = 0;
+        float best = l[0];
+        for (int c = 1; c < n_cls; ++c) {
+            const float v = l[c];
+            if (v > best) {  // first maximum wins, as torch.argmax
+                best = v;
+                arg = c;
+            }
+        }
+        if (pred) pred[p] = (uint8_t)arg;
+        if (label) {
+            const int lb = label[p];
+            if (lb < n_cls) atomicAdd(&bins[lb * n_cls + arg], 1u);
+        }
+    }
+    __syncthreads();
+    if (label)
+        for (int i = threadIdx.x; i < n_cls * n_cls; i += blockDim.x)
+            if (bins[i]) atomicAdd(&conf[i], (unsigned long long)bins[i]);
+}
+
+extern "C" int v2x_seg_argmax_confusion(const float *logits, const uint8_t *label, int n, int H, int W, int n_cls,
+                                        uint8_t *pred, long long *conf, v2x_stream_t stream) {
+    V2X_REQUIRE(logits, "v2x_seg_argmax_confusion: null logits");
+    V2X_REQUIRE(n >= 0 && H > 0 && W > 0 && n_cls > 0 && n_cls <= 64, "v2x_seg_argmax_confusion: bad dims (n_cls <= 64)");
+    V2X_REQUIRE((label == nullptr) == (conf == nullptr), "v2x_seg_argmax_confusion: label and conf go together");
+    V2X_REQUIRE(pred || label, "v2x_seg_argmax_confusion: nothing to compute");
+    if (n == 0) return V2X_OK;
+    const size_t n_pix = (size_t)n * H * W;
+    size_t g = (n_pix + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(seg_argmax_confusion_kernel, dim3((unsigned)g), dim3(256), n_cls * n_cls * sizeof(unsigned int),
+                       (hipStream_t)stream, logits, label, n_pix, n_cls, pred,
+                       reinterpret_cast<unsigned long long *>(conf));
+    V2X_CHECK_LAUNCH("seg_argmax_confusion_kernel");
+    return V2X_OK;
+}

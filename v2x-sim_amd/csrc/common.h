@@ -1,0 +1,44 @@
+// Shared helpers for the gfx950 kernels of libv2x_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/v2x_amd.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// thread-local error text behind v2x_last_error()
+void v2x_set_error(const char *fmt, ...);
+
+#define V2X_REQUIRE(cond, ...)            \
+    do {                                  \
+        if (!(cond)) {                    \
+            v2x_set_error(__VA_ARGS__);   \
+            return V2X_EINVAL;            \
+        }                                 \
+    } while (0)
+
+#define V2X_CHECK_LAUNCH(name)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            v2x_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return V2X_EIO;                                                      \
+        }                                                                        \
+    } while (0)
+
+// fp32 -> bf16, round-to-nearest-even (matches torch .to(torch.bfloat16) for finite values)
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16_rne(lo) | ((uint32_t)f32_to_bf16_rne(hi) << 16);
+}

@@ -1,0 +1,90 @@
+"""ctypes binding of libv2x_amd.so (the C ABI declared in include/v2x_amd.h).
+
+There is NO fallback: if the HIP library is missing or a call fails the product
+path raises.  (The CPU oracle under /oracle is test infrastructure and is never
+imported from this package.)
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
+
+V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU = 0, 1, 2
+V2X_FUSE_WSUM, V2X_FUSE_MEAN = 0, 1
+ABI_VERSION = 1
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `struct v2x_conv_desc` (include/v2x_amd.h)."""
+    _fields_ = [
+        ("in0", C.c_void_p), ("in1", C.c_void_p),
+        ("C0", C.c_int32), ("C1", C.c_int32), ("up0", C.c_int32),
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("Cout", C.c_int32), ("w_rows", C.c_int32), ("w_kpad", C.c_int32),
+        ("weight", C.c_void_p), ("scale", C.c_void_p), ("shift", C.c_void_p),
+        ("epilogue", C.c_int32), ("relu", C.c_int32),
+        ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
+        ("out2", C.c_void_p), ("split", C.c_int32), ("out2_cstride", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/v2x_amd.h declares
+SIGNATURES = {
+    "v2x_abi_version": (C.c_int, []),
+    "v2x_last_error": (C.c_char_p, []),
+    "v2x_voxelize_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                     C.c_void_p, C.c_void_p]),
+    "v2x_bits_to_dense_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_bits_to_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_void_p]),
+    "v2x_dense_f32_to_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                              C.c_void_p]),
+    "v2x_bits_to_indices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_conv_tile_rows": (C.c_int, [C.c_int, C.c_int]),
+    "v2x_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "v2x_warp_fuse": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_attn_handshake": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_seg_argmax_confusion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+class V2XLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libv2x_amd.so, bind every declared symbol and check the ABI version."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise V2XLibraryError(
+            "libv2x_amd.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C v2x-sim_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise V2XLibraryError("libv2x_amd.so does not export %s" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.v2x_abi_version() != ABI_VERSION:
+        raise V2XLibraryError("ABI mismatch: library %d, binding %d" % (lib.v2x_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().v2x_last_error()
+        raise V2XLibraryError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,252 @@
+"""Host-side mirror of upstream coperception/models/det/backbone/Backbone.py and
+coperception/models/det/base/{DetModelBase,IntermediateModelBase,NonIntermediateModelBase}.py
+(not present in /root/reference; README.md:101 names the benchmarks they implement).
+
+The nn.Module tree below exists to hold parameters under the upstream attribute names
+(`u_encoder.conv1_1.weight`, `decoder.bn5_1.running_var`, `classification.conv1.weight`,
+`regression.box_prediction.0.weight`, ...) so upstream-style checkpoints / optimizers see the
+same state_dict.  None of these torch modules is ever *called*: forward() packs the
+parameters once (packing.py) and runs the hand-written HIP kernels through ops.py.  On a
+machine without the MI355X library the forward raises -- there is no eager fallback.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops, packing
+from ...ops import V2X_EPI_BF16, V2X_EPI_F32  # noqa: F401
+
+LAYER_SHAPES = {0: (32, 256, 256), 1: (64, 128, 128), 2: (128, 64, 64), 3: (256, 32, 32), 4: (512, 16, 16)}
+
+
+class _ParamsOnly(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard
+        raise RuntimeError("%s is a parameter container; the compute path is the HIP engine of the owning model"
+                           % type(self).__name__)
+
+
+class Conv3D(_ParamsOnly):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv3d = nn.Conv3d(cin, cout, kernel_size=(1, 1, 1), stride=1, padding=(0, 0, 0))
+        self.bn3d = nn.BatchNorm3d(cout)
+
+
+class LidarEncoder(_ParamsOnly):
+    """13 -> 32,32 @256^2 -> 64,64 (+1x1) @128^2 -> 128,128 (+1x1) @64^2 -> 256,256 @32^2 -> 512,512 @16^2."""
+
+    def __init__(self, height_feat_size=13):
+        super().__init__()
+        self.height_feat_size = height_feat_size
+        self.conv_pre_1 = nn.Conv2d(height_feat_size, 32, 3, 1, 1)
+        self.conv_pre_2 = nn.Conv2d(32, 32, 3, 1, 1)
+        self.bn_pre_1 = nn.BatchNorm2d(32)
+        self.bn_pre_2 = nn.BatchNorm2d(32)
+        self.conv3d_1 = Conv3D(64, 64)
+        self.conv3d_2 = Conv3D(128, 128)
+        self.conv1_1 = nn.Conv2d(32, 64, 3, 2, 1)
+        self.conv1_2 = nn.Conv2d(64, 64, 3, 1, 1)
+        self.conv2_1 = nn.Conv2d(64, 128, 3, 2, 1)
+        self.conv2_2 = nn.Conv2d(128, 128, 3, 1, 1)
+        self.conv3_1 = nn.Conv2d(128, 256, 3, 2, 1)
+        self.conv3_2 = nn.Conv2d(256, 256, 3, 1, 1)
+        self.conv4_1 = nn.Conv2d(256, 512, 3, 2, 1)
+        self.conv4_2 = nn.Conv2d(512, 512, 3, 1, 1)
+        for n, c in (("1_1", 64), ("1_2", 64), ("2_1", 128), ("2_2", 128),
+                     ("3_1", 256), ("3_2", 256), ("4_1", 512), ("4_2", 512)):
+            setattr(self, "bn" + n, nn.BatchNorm2d(c))
+
+    def pack(self, prefix, device):
+        cin_pad = (self.height_feat_size + 7) // 8 * 8
+        P = packing.pack_conv_bn
+        plan = [P(prefix + "conv_pre_1", self.conv_pre_1, self.bn_pre_1, cin_pad=cin_pad, device=device),
+                P(prefix + "conv_pre_2", self.conv_pre_2, self.bn_pre_2, device=device)]
+        for lvl in ("1", "2", "3", "4"):
+            plan.append(P(prefix + "conv%s_1" % lvl, getattr(self, "conv%s_1" % lvl), getattr(self, "bn%s_1" % lvl),
+                          device=device))
+            plan.append(P(prefix + "conv%s_2" % lvl, getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl),
+                          device=device))
+            if lvl in ("1", "2"):
+                c3 = getattr(self, "conv3d_" + lvl)
+                plan.append(P(prefix + "conv3d_" + lvl, c3.conv3d, c3.bn3d, device=device))
+        return plan
+
+    @staticmethod
+    def run(plan, x):
+        """x: (N, 256, 256, c_pad) bf16 NHWC -> [x, x_1, x_2, x_3, x_4]."""
+        it = iter(plan)
+        x = ops.conv2d(next(it), x)
+        x = ops.conv2d(next(it), x)
+        feats = [x]
+        for lvl in range(1, 5):
+            x = ops.conv2d(next(it), x)
+            x = ops.conv2d(next(it), x)
+            if lvl <= 2:
+                x = ops.conv2d(next(it), x)
+            feats.append(x)
+        return feats
+
+
+class LidarDecoder(_ParamsOnly):
+    """4 x [nearest x2 upsample, concat skip, conv+BN+ReLU x2]; the upsample+concat never exists
+    in memory -- the first conv of each level reads both sources directly."""
+
+    def __init__(self, height_feat_size=13):
+        super().__init__()
+        self.conv5_1 = nn.Conv2d(512 + 256, 256, 3, 1, 1)
+        self.conv5_2 = nn.Conv2d(256, 256, 3, 1, 1)
+        self.conv6_1 = nn.Conv2d(256 + 128, 128, 3, 1, 1)
+        self.conv6_2 = nn.Conv2d(128, 128, 3, 1, 1)
+        self.conv7_1 = nn.Conv2d(128 + 64, 64, 3, 1, 1)
+        self.conv7_2 = nn.Conv2d(64, 64, 3, 1, 1)
+        self.conv8_1 = nn.Conv2d(64 + 32, 32, 3, 1, 1)
+        self.conv8_2 = nn.Conv2d(32, 32, 3, 1, 1)
+        for n, c in (("5_1", 256), ("5_2", 256), ("6_1", 128), ("6_2", 128),
+                     ("7_1", 64), ("7_2", 64), ("8_1", 32), ("8_2", 32)):
+            setattr(self, "bn" + n, nn.BatchNorm2d(c))
+
+    def pack(self, prefix, device):
+        P = packing.pack_conv_bn
+        plan = []
+        for lvl, (cup, cskip) in (("5", (512, 256)), ("6", (256, 128)), ("7", (128, 64)), ("8", (64, 32))):
+            plan.append(P(prefix + "conv%s_1" % lvl, getattr(self, "conv%s_1" % lvl), getattr(self, "bn%s_1" % lvl),
+                          C0=cup, C1=cskip, up0=1, device=device))
+            plan.append(P(prefix + "conv%s_2" % lvl, getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl),
+                          device=device))
+        return plan
+
+    @staticmethod
+    def run(plan, x, x_1, x_2, x_3, x_4):
+        it = iter(plan)
+        y = x_4
+        for skip in (x_3, x_2, x_1, x):
+            y = ops.conv2d(next(it), y, skip)
+            y = ops.conv2d(next(it), y)
+        return y
+
+
+class ClassificationHead(_ParamsOnly):
+    def __init__(self, config):
+        super().__init__()
+        channel = 32
+        self.conv1 = nn.Conv2d(channel, channel, kernel_size=3, stride=1, padding=1)
+        self.conv2 = nn.Conv2d(channel, config.category_num * len(config.anchor_size), kernel_size=1, stride=1,
+                               padding=0)
+        self.bn1 = nn.BatchNorm2d(channel)
+
+
+class SingleRegressionHead(_ParamsOnly):
+    def __init__(self, config):
+        super().__init__()
+        channel = 32
+        out_seq_len = 1 if config.only_det else config.pred_len
+        self.box_prediction = nn.Sequential(
+            nn.Conv2d(channel, channel, kernel_size=3, stride=1, padding=1), nn.BatchNorm2d(channel), nn.ReLU(),
+            nn.Conv2d(channel, len(config.anchor_size) * config.box_code_size * out_seq_len, kernel_size=1,
+                      stride=1, padding=0))
+
+
+class DetModelBase(nn.Module):
+    """Abstract detection model (upstream DetModelBase): heads + agent<->batch helpers + the
+    packed-parameter cache shared by every concrete model."""
+
+    def __init__(self, config, layer=3, in_channels=13, kd_flag=True, p_com_outage=0.0, num_agent=5,
+                 only_v2i=False):
+        super().__init__()
+        if kd_flag not in (0, False):
+            raise NotImplementedError("knowledge distillation (DiscoNet teacher) is out of scope (DESIGN.md s8)")
+        self.motion_state = config.motion_state
+        self.out_seq_len = 1 if config.only_det else config.pred_len
+        self.box_code_size = config.box_code_size
+        self.category_num = config.category_num
+        self.use_map = config.use_map
+        self.anchor_num_per_loc = len(config.anchor_size)
+        self.classification = ClassificationHead(config)
+        self.regression = SingleRegressionHead(config)
+        self.agent_num = num_agent
+        self.kd_flag = kd_flag
+        self.layer = layer
+        self.in_channels = in_channels
+        self._packed = None
+        self._packed_key = None
+
+    # ---- packed-parameter cache -----------------------------------------------------------
+    def _pack(self, device):  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def packed(self, device=None):
+        if device is None:
+            device = next(self.parameters()).device
+        if torch.device(device).type != "cuda":
+            raise RuntimeError("v2x_sim_amd models run on the MI355X only: move the model to 'cuda' "
+                               "(no CPU fallback exists in the product path)")
+        key = (str(device), sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers()))
+        if self._packed is None or self._packed_key != key:
+            with torch.no_grad():
+                self._packed = self._pack(device)
+            self._packed_key = key
+        return self._packed
+
+    def repack(self):
+        self._packed = None
+
+    # ---- shared pieces --------------------------------------------------------------------
+    def _pack_heads(self, device):
+        bp = self.regression.box_prediction
+        return packing.pack_heads("heads", self.classification.conv1, self.classification.bn1,
+                                  self.classification.conv2, bp[0], bp[1], bp[3], device=device)
+
+    def _input_nhwc(self, bevs):
+        """(N, 1, X, Y, Z) fp32 dense BEV (the reference Dataset format) -> (N, X, Y, c_pad) bf16."""
+        if bevs.dim() != 5 or bevs.shape[1] != 1:
+            raise ValueError("bevs must be (batch*agents, 1, X, Y, Z); got %s" % (tuple(bevs.shape),))
+        c_pad = (bevs.shape[-1] + 7) // 8 * 8
+        return ops.dense_to_nhwc(bevs[:, 0].to(torch.float32).contiguous(), c_pad)
+
+    def get_cls_loc_result(self, x, heads):
+        hidden, final, ncls = heads
+        h = ops.conv2d(hidden, x)
+        cls, loc = ops.conv2d(final, h, split=ncls)  # fp32 NHWC == upstream's permute(0, 2, 3, 1)
+        n = cls.shape[0]
+        cls_preds = cls.view(n, -1, self.category_num)
+        loc_preds = loc.view(-1, loc.size(1), loc.size(2), self.anchor_num_per_loc, self.out_seq_len,
+                             self.box_code_size)
+        return {"loc": loc_preds, "cls": cls_preds}
+
+    @staticmethod
+    def agents_to_batch(feats):
+        return torch.cat([feats[:, i] for i in range(feats.shape[1])], 0)
+
+
+class NonIntermediateModelBase(DetModelBase):
+    pass
+
+
+class IntermediateModelBase(DetModelBase):
+    """Models that exchange an intermediate feature map (upstream IntermediateModelBase/FusionBase)."""
+
+    def __init__(self, config, layer=3, in_channels=13, kd_flag=True, p_com_outage=0.0, num_agent=5,
+                 compress_level=0, only_v2i=False):
+        super().__init__(config, layer, in_channels, kd_flag, p_com_outage, num_agent, only_v2i)
+        if compress_level != 0 or only_v2i or p_com_outage != 0.0:
+            raise NotImplementedError("compress_level / only_v2i / p_com_outage are out of scope (DESIGN.md s8)")
+        self.u_encoder = LidarEncoder(in_channels)
+        self.decoder = LidarDecoder(in_channels)
+
+    def fusion_shape(self):
+        return LAYER_SHAPES[self.layer]
+
+    @staticmethod
+    def frame_plan(num_agent_tensor, batch_size, agent_num):
+        """Host-side bookkeeping shared by the fusion models.
+
+        num_agent_tensor (B, A) -- [b, 0] is the number of real agents of frame b (upstream
+        convention).  Returns python lists: items [(agent, frame)] in agent-major order for every
+        real agent, and the flat row of each item in the (A*B) agent-major batch."""
+        nat = num_agent_tensor.detach().to("cpu") if isinstance(num_agent_tensor, torch.Tensor) else num_agent_tensor
+        counts = [int(nat[b][0]) for b in range(batch_size)]
+        for c in counts:
+            if c < 1 or c > agent_num:
+                raise ValueError("num_agent_tensor[b, 0]=%d outside [1, %d]" % (c, agent_num))
+        items = [(a, f) for a in range(agent_num) for f in range(batch_size) if a < counts[f]]
+        rows = [a * batch_size + f for a, f in items]
+        return counts, items, rows

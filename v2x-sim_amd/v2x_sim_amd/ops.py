@@ -1,0 +1,268 @@
+"""Stage-level python wrappers over the C ABI (one per SURVEY.md section 8 row).
+
+PyTorch is plumbing here: it owns device memory and the stream; all arithmetic
+happens inside libv2x_amd.so.  Every wrapper refuses non-device tensors -- there
+is deliberately no eager/CPU fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_FUSE_MEAN, V2X_FUSE_WSUM  # noqa: F401
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# Optional per-launch instrumentation used by bench.py's roofline pass: when PROFILE is a list,
+# every wrapper appends (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event)
+# with HIP events recorded on the stream the kernel is launched on.
+PROFILE = None
+
+
+class _Prof:
+    __slots__ = ("rec",)
+
+    def __init__(self, name, flops, nbytes):
+        self.rec = None
+        if PROFILE is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.rec = (name, float(flops), float(nbytes), e0, e1)
+            e0.record(torch.cuda.current_stream())
+
+    def done(self):
+        if self.rec is not None:
+            self.rec[4].record(torch.cuda.current_stream())
+            PROFILE.append(self.rec)
+
+
+_CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 128: (128, 128, 2, 2), 96: (96, 128, 2, 2)}
+
+
+def conv_kernel_name(pc):
+    """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
+    rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
+    return "conv_igemm_kernel<%d, %d, %d, %d, %d>" % (_CONV_TILES[rows] + (pc.epilogue,))
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError("%s must be a tensor on the MI355X (cuda) device; the v2x_sim_amd hot path has no CPU "
+                           "fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------ a1
+class VoxelGrid:
+    """Geometry of the BEV grid (upstream Config.voxel_size / area_extents)."""
+
+    def __init__(self, voxel_size=(0.25, 0.25, 0.4), area_extents=((-32.0, 32.0), (-32.0, 32.0), (-3.0, 2.0))):
+        import math
+        self.voxel = tuple(float(v) for v in voxel_size)
+        self.extents = tuple((float(lo), float(hi)) for lo, hi in area_extents)
+        self.dims = tuple(int(math.ceil(hi / v) - 1 - math.floor(lo / v) + 1)
+                          for (lo, hi), v in zip(self.extents, self.voxel))
+        self._ext = (C.c_double * 6)(*[x for lohi in self.extents for x in lohi])
+        self._vox = (C.c_double * 3)(*self.voxel)
+        self._dims = (C.c_int32 * 3)(*self.dims)
+
+
+def voxelize_bits(points, n_pts, grid, out=None):
+    """points (n_clouds, max_pts, stride>=3) fp32, n_pts (n_clouds,) int32 -> bits (n_clouds, X, Y) int32."""
+    lib = _lib.load()
+    if points.dim() != 3:
+        raise ValueError("points must be (n_clouds, max_pts, stride)")
+    n, mp, st = points.shape
+    X, Y, Z = grid.dims
+    if out is None:
+        out = torch.empty((n, X, Y), dtype=torch.int32, device=points.device)
+    prof = _Prof("voxelize_scatter_kernel", 0, points.numel() * 4 + 2 * out.numel() * 4)
+    rc = lib.v2x_voxelize_bits(_dev(points, torch.float32, "points"), _dev(n_pts, torch.int32, "n_pts"), n, mp, st,
+                               grid._ext, grid._vox, grid._dims, _dev(out, torch.int32, "bits"), _stream())
+    prof.done()
+    _lib.check(rc, "v2x_voxelize_bits")
+    return out
+
+
+def bits_to_dense(bits, Z):
+    lib = _lib.load()
+    n, X, Y = bits.shape
+    out = torch.empty((n, X, Y, Z), dtype=torch.float32, device=bits.device)
+    _lib.check(lib.v2x_bits_to_dense_f32(_dev(bits, torch.int32, "bits"), n, X, Y, Z, _dev(out, torch.float32, "out"),
+                                         _stream()), "v2x_bits_to_dense_f32")
+    return out
+
+
+def bits_to_nhwc(bits, Z, c_pad=16, out=None):
+    lib = _lib.load()
+    n, X, Y = bits.shape
+    if out is None:
+        out = torch.empty((n, X, Y, c_pad), dtype=torch.bfloat16, device=bits.device)
+    prof = _Prof("bits_to_nhwc_bf16_kernel", 0, bits.numel() * 4 + out.numel() * 2)
+    rc = lib.v2x_bits_to_nhwc_bf16(_dev(bits, torch.int32, "bits"), n, X, Y, Z, c_pad,
+                                   _dev(out, torch.bfloat16, "out"), _stream())
+    prof.done()
+    _lib.check(rc, "v2x_bits_to_nhwc_bf16")
+    return out
+
+
+def dense_to_nhwc(bev, c_pad=16, out=None):
+    """bev (n, X, Y, Z) fp32 -> (n, X, Y, c_pad) bf16."""
+    lib = _lib.load()
+    n, X, Y, Z = bev.shape
+    if out is None:
+        out = torch.empty((n, X, Y, c_pad), dtype=torch.bfloat16, device=bev.device)
+    _lib.check(lib.v2x_dense_f32_to_nhwc_bf16(_dev(bev, torch.float32, "bev"), n, X, Y, Z, c_pad,
+                                              _dev(out, torch.bfloat16, "out"), _stream()),
+               "v2x_dense_f32_to_nhwc_bf16")
+    return out
+
+
+def bits_to_indices(bits, Z, cap):
+    """-> (idx (n, cap, 3) int32 sorted lexicographically, counts (n,) int32)."""
+    lib = _lib.load()
+    n, X, Y = bits.shape
+    idx = torch.zeros((n, cap, 3), dtype=torch.int32, device=bits.device)
+    counts = torch.zeros((n,), dtype=torch.int32, device=bits.device)
+    scratch = torch.empty((n, X), dtype=torch.int32, device=bits.device)
+    _lib.check(lib.v2x_bits_to_indices(_dev(bits, torch.int32, "bits"), n, X, Y, Z, _dev(idx, torch.int32, "idx"), cap,
+                                       _dev(counts, torch.int32, "counts"), _dev(scratch, torch.int32, "scratch"),
+                                       _stream()), "v2x_bits_to_indices")
+    return idx, counts
+
+
+# ------------------------------------------------------------------ a2/a4/a6/a7/a8
+class PackedConv:
+    """Device-resident packed parameters of one conv layer (see packing.py)."""
+
+    __slots__ = ("weight", "scale", "shift", "C0", "C1", "Cout", "ksize", "stride", "pad", "up0", "epilogue", "relu",
+                 "w_rows", "w_kpad", "name")
+
+    def __init__(self, **kw):
+        for k in self.__slots__:
+            setattr(self, k, kw.get(k))
+
+
+def conv_out_hw(pc, H, W):
+    Ho = (H + 2 * pc.pad - pc.ksize) // pc.stride + 1
+    Wo = (W + 2 * pc.pad - pc.ksize) // pc.stride + 1
+    return Ho, Wo
+
+
+def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0):
+    """in0 (N, H>>up0, W>>up0, C0) bf16 NHWC [, in1 (N, H, W, C1)] -> out (N, Ho, Wo, Cout) NHWC.
+
+    split > 0: returns (out[..., :split], out2[..., Cout-split]) as two contiguous tensors."""
+    lib = _lib.load()
+    d = ConvDesc()
+    d.in0 = _dev(in0, torch.bfloat16, "in0").value
+    N = in0.shape[0]
+    if in1 is not None:
+        d.in1 = _dev(in1, torch.bfloat16, "in1").value
+        H, W = in1.shape[1], in1.shape[2]
+        if in1.shape[3] != pc.C1 or in1.shape[0] != N:
+            raise ValueError("in1 shape %s does not match C1=%d" % (tuple(in1.shape), pc.C1))
+        if (in0.shape[1] << pc.up0, in0.shape[2] << pc.up0) != (H, W):
+            raise ValueError("in0 %s (up0=%d) does not match in1 %s" % (tuple(in0.shape), pc.up0, tuple(in1.shape)))
+    else:
+        if pc.C1:
+            raise ValueError("layer %s expects a second source" % pc.name)
+        d.in1 = None
+        H, W = in0.shape[1] << pc.up0, in0.shape[2] << pc.up0
+    if in0.shape[3] != pc.C0:
+        raise ValueError("in0 has %d channels, layer %s expects %d" % (in0.shape[3], pc.name, pc.C0))
+    Ho, Wo = conv_out_hw(pc, H, W)
+    odt = torch.float32 if pc.epilogue == V2X_EPI_F32 else torch.bfloat16
+    out2 = None
+    if split:
+        out = torch.empty((N, Ho, Wo, split), dtype=odt, device=in0.device)
+        out2 = torch.empty((N, Ho, Wo, pc.Cout - split), dtype=odt, device=in0.device)
+    elif out is None:
+        out = torch.empty((N, Ho, Wo, pc.Cout), dtype=odt, device=in0.device)
+    elif tuple(out.shape[:3]) != (N, Ho, Wo):
+        raise ValueError("out shape %s != %s" % (tuple(out.shape), (N, Ho, Wo, "*")))
+    d.C0, d.C1, d.up0 = pc.C0, pc.C1, pc.up0
+    d.N, d.H, d.W = N, H, W
+    d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
+    d.Cout, d.w_rows, d.w_kpad = pc.Cout, pc.w_rows, pc.w_kpad
+    d.weight = pc.weight.data_ptr()
+    d.scale = pc.scale.data_ptr()
+    d.shift = pc.shift.data_ptr() if pc.shift is not None else None
+    d.epilogue, d.relu = pc.epilogue, int(bool(pc.relu))
+    d.out = _dev(out, odt, "out").value
+    d.out_cstride, d.out_coff = out.shape[3], out_coff
+    if split:
+        d.out2, d.split, d.out2_cstride = out2.data_ptr(), split, out2.shape[3]
+    prof = None
+    if PROFILE is not None:
+        rows_logical = 3 * pc.Cout if pc.epilogue == V2X_EPI_GRU else pc.Cout
+        k_logical = pc.ksize * pc.ksize * (pc.C0 + pc.C1)
+        M = N * Ho * Wo
+        nbytes = in0.numel() * 2 + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
+            + M * pc.Cout * (4 if pc.epilogue == V2X_EPI_F32 else 2)
+        prof = _Prof(conv_kernel_name(pc), 2.0 * M * rows_logical * k_logical, nbytes)
+    rc = lib.v2x_conv2d(C.byref(d), _stream())
+    if prof is not None:
+        prof.done()
+    _lib.check(rc, "v2x_conv2d(%s)" % pc.name)
+    return (out, out2) if split else out
+
+
+# ------------------------------------------------------------------ a3
+def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
+    """feat (A*Bt, H, W, C) bf16; trans (Bt, A, A, 4, 4) fp32; items (n_out, 2) int32; coef (n_out, A) fp32."""
+    lib = _lib.load()
+    n_items, H, W, Cc = feat.shape
+    if n_items != A * Bt:
+        raise ValueError("feat holds %d maps, expected A*Bt=%d" % (n_items, A * Bt))
+    if tuple(trans.shape) != (Bt, A, A, 4, 4):
+        raise ValueError("trans must be (Bt, A, A, 4, 4), got %s" % (tuple(trans.shape),))
+    n_out = items.shape[0]
+    if tuple(coef.shape) != (n_out, A):
+        raise ValueError("coef must be (n_out, A)")
+    if out is None:
+        out = torch.empty((n_out, H, W, Cc), dtype=torch.bfloat16, device=feat.device)
+    prof = _Prof("warp_fuse_kernel", 0, (n_out * (A - 1) + n_out) * H * W * Cc * 2)
+    rc = lib.v2x_warp_fuse(_dev(feat, torch.bfloat16, "feat"), A, Bt, H, W, Cc, _dev(trans, torch.float32, "trans"),
+                           _dev(items, torch.int32, "items"), n_out, _dev(coef, torch.float32, "coef"), mode,
+                           _dev(out, torch.bfloat16, "out"), _stream())
+    prof.done()
+    _lib.check(rc, "v2x_warp_fuse")
+    return out
+
+
+# ------------------------------------------------------------------ a5
+ATTN_MODES = {"softmax": 0, "activated": 1, "argmax_test": 2}
+
+
+def attn_handshake(keys, querys, w_lin, b_lin, A, Bt, mode, thres=0.2):
+    """keys (A*Bt, K) fp32, querys (A*Bt, Q) fp32 -> prob, coef (Bt, A_key, A_query) fp32."""
+    lib = _lib.load()
+    K, Q = keys.shape[1], querys.shape[1]
+    prob = torch.empty((Bt, A, A), dtype=torch.float32, device=keys.device)
+    coef = torch.empty_like(prob)
+    _lib.check(lib.v2x_attn_handshake(_dev(keys, torch.float32, "keys"), _dev(querys, torch.float32, "querys"),
+                                      _dev(w_lin, torch.float32, "w_lin"), _dev(b_lin, torch.float32, "b_lin"), A, Bt,
+                                      K, Q, ATTN_MODES[mode], C.c_float(thres), _dev(prob, torch.float32, "prob"),
+                                      _dev(coef, torch.float32, "coef"), _stream()), "v2x_attn_handshake")
+    return prob, coef
+
+
+# ------------------------------------------------------------------ a8
+def seg_argmax_confusion(logits, label=None, want_pred=True):
+    """logits (n, H, W, n_cls) fp32 NHWC; label (n, H, W) uint8 -> (pred uint8, conf int64 [n_cls, n_cls])."""
+    lib = _lib.load()
+    n, H, W, ncls = logits.shape
+    pred = torch.empty((n, H, W), dtype=torch.uint8, device=logits.device) if want_pred else None
+    conf = torch.zeros((ncls, ncls), dtype=torch.int64, device=logits.device) if label is not None else None
+    _lib.check(lib.v2x_seg_argmax_confusion(
+        _dev(logits, torch.float32, "logits"), _dev(label, torch.uint8, "label") if label is not None else None,
+        n, H, W, ncls, _dev(pred, torch.uint8, "pred") if pred is not None else None,
+        _dev(conf, torch.int64, "conf") if conf is not None else None, _stream()), "v2x_seg_argmax_confusion")
+    return pred, conf

@@ -1,0 +1,124 @@
+"""Host-side weight packing: torch parameters -> the device layouts libv2x_amd.so consumes.
+
+  * conv weight [Cout, Cin, k, k] fp32  ->  bf16 [w_rows][w_kpad], k = (ky*k + kx)*Cin + c
+    (K-contiguous rows = MFMA "A" operand), rows padded to the kernel's channel tile,
+    K padded to a multiple of 64 (zero weights, so the padded taps contribute nothing);
+  * eval-mode BatchNorm folded to an fp32 (scale, shift) pair applied AFTER the fp32
+    accumulation:  y = acc*scale + shift,  scale = gamma/sqrt(var+eps),
+    shift = beta + scale*(conv_bias - mean)   (DESIGN.md section 3.2);
+  * ConvGRU (h0 = 0): W_ih rows regrouped as (r,z,n) triples of 16 hidden channels so one
+    wave owns all three gates of its channels; biases packed float4 per hidden channel.
+"""
+import torch
+
+from . import _lib
+from .ops import PackedConv, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU
+
+
+def _ceil_to(x, m):
+    return (x + m - 1) // m * m
+
+
+def fold_bn(conv_bias, bn, cout):
+    """-> (scale, shift) fp32 on CPU for y = acc*scale + shift."""
+    if bn is None:
+        scale = torch.ones(cout, dtype=torch.float32)
+        shift = conv_bias.detach().float().cpu() if conv_bias is not None else torch.zeros(cout)
+        return scale, shift
+    g, b = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
+    mu, var = bn.running_mean.detach().float().cpu(), bn.running_var.detach().float().cpu()
+    scale = g / torch.sqrt(var + bn.eps)
+    cb = conv_bias.detach().float().cpu() if conv_bias is not None else torch.zeros(cout)
+    shift = b + scale * (cb - mu)
+    return scale, shift
+
+
+def pack_conv(name, weight, scale, shift, *, stride=1, pad=None, C0=None, C1=0, up0=0, relu=True,
+              epilogue=V2X_EPI_BF16, cin_pad=None, device="cuda"):
+    """weight [Cout, Cin, k, k] (any float dtype, CPU or device) -> PackedConv on `device`."""
+    lib = _lib.load()
+    w = weight.detach().float().cpu()
+    cout, cin, k, _ = w.shape
+    if pad is None:
+        pad = (k - 1) // 2
+    cin_p = cin if cin_pad is None else cin_pad
+    if C0 is None:
+        C0 = cin_p
+    if C0 + C1 != cin_p:
+        raise ValueError("%s: C0+C1=%d != Cin=%d" % (name, C0 + C1, cin_p))
+    w = w.permute(0, 2, 3, 1)  # [Cout, ky, kx, Cin]
+    if cin_p != cin:
+        w = torch.nn.functional.pad(w, (0, cin_p - cin))
+    K = k * k * cin_p
+    tile = lib.v2x_conv_tile_rows(cout, epilogue)
+    rows, kpad = _ceil_to(cout, tile), _ceil_to(K, 64)
+    wp = torch.zeros((rows, kpad), dtype=torch.float32)
+    wp[:cout, :K] = w.reshape(cout, K)
+    sc = torch.zeros(rows, dtype=torch.float32)
+    sf = torch.zeros(rows, dtype=torch.float32)
+    sc[:cout] = scale
+    sf[:cout] = shift
+    return PackedConv(name=name, weight=wp.to(torch.bfloat16).to(device).contiguous(), scale=sc.to(device),
+                      shift=sf.to(device), C0=C0, C1=C1, Cout=cout, ksize=k, stride=stride, pad=pad, up0=up0,
+                      epilogue=epilogue, relu=relu, w_rows=rows, w_kpad=kpad)
+
+
+def pack_conv_bn(name, conv, bn, *, relu=True, epilogue=V2X_EPI_BF16, device="cuda", **kw):
+    scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
+    w = conv.weight
+    if w.dim() == 5:  # Conv3d 1x1x1 over a length-1 sequence
+        w = w[:, :, 0]
+    return pack_conv(name, w, scale, shift, stride=conv.stride[-1], pad=conv.padding[-1], relu=relu,
+                     epilogue=epilogue, device=device, **kw)
+
+
+def pack_linear(name, lin, *, relu, epilogue=V2X_EPI_BF16, col_perm=None, device="cuda"):
+    """nn.Linear as a 1x1 conv on a 1x1 map.  col_perm re-orders input features (NCHW -> NHWC flatten)."""
+    w = lin.weight.detach().float().cpu()
+    if col_perm is not None:
+        w = w[:, col_perm]
+    scale, shift = fold_bn(lin.bias, None, w.shape[0])
+    return pack_conv(name, w[:, :, None, None], scale, shift, stride=1, pad=0, relu=relu, epilogue=epilogue,
+                     device=device)
+
+
+def pack_heads(name, cls_conv1, cls_bn1, cls_conv2, reg_conv1, reg_bn1, reg_conv2, device="cuda"):
+    """Fuse the two det heads: one 3x3 conv 32 -> 64 (cls | reg hidden), one block-diagonal 1x1
+    conv 64 -> (n_cls + n_reg) writing cls and loc to two contiguous fp32 NHWC tensors."""
+    s1, t1 = fold_bn(cls_conv1.bias, cls_bn1, cls_conv1.out_channels)
+    s2, t2 = fold_bn(reg_conv1.bias, reg_bn1, reg_conv1.out_channels)
+    w1 = torch.cat([cls_conv1.weight.detach().float().cpu(), reg_conv1.weight.detach().float().cpu()], 0)
+    hidden = pack_conv(name + ".hidden", w1, torch.cat([s1, s2]), torch.cat([t1, t2]), stride=1, pad=1, relu=True,
+                       device=device)
+    hc, hr = cls_conv1.out_channels, reg_conv1.out_channels
+    ncls, nreg = cls_conv2.out_channels, reg_conv2.out_channels
+    w2 = torch.zeros((ncls + nreg, hc + hr, 1, 1), dtype=torch.float32)
+    w2[:ncls, :hc] = cls_conv2.weight.detach().float().cpu()
+    w2[ncls:, hc:] = reg_conv2.weight.detach().float().cpu()
+    b2 = torch.cat([cls_conv2.bias.detach().float().cpu(), reg_conv2.bias.detach().float().cpu()])
+    final = pack_conv(name + ".final", w2, torch.ones(ncls + nreg), b2, stride=1, pad=0, relu=False,
+                      epilogue=V2X_EPI_F32, device=device)
+    return hidden, final, ncls
+
+
+def pack_gru(name, weight_ih, bias_ih, bias_hh, *, C0, C1, device="cuda"):
+    """ConvGRU cell step with h0 = 0 (the only way upstream V2VNet calls it: convgru(x, None)).
+    W_hh * 0 contributes exactly b_hh, so only W_ih is packed."""
+    w = weight_ih.detach().float().cpu()
+    three_h, cin, k, _ = w.shape
+    hid = three_h // 3
+    if hid % 32 != 0 or cin != C0 + C1:
+        raise ValueError("%s: hidden %d must be a multiple of 32 and Cin %d == C0+C1" % (name, hid, cin))
+    K = k * k * cin
+    kpad = _ceil_to(K, 64)
+    wk = w.permute(0, 2, 3, 1).reshape(three_h, K)
+    groups = hid // 16
+    wp = torch.zeros((groups * 48, kpad), dtype=torch.float32)
+    # packed row g*48 + gate*16 + e  <-  gate row gate*hid + g*16 + e
+    src = wk.view(3, groups, 16, K).permute(1, 0, 2, 3).reshape(groups * 48, K)
+    wp[:, :K] = src
+    bi, bh = bias_ih.detach().float().cpu().view(3, hid), bias_hh.detach().float().cpu().view(3, hid)
+    bias4 = torch.stack([bi[0] + bh[0], bi[1] + bh[1], bi[2], bh[2]], dim=1).contiguous()  # [hid][4]
+    return PackedConv(name=name, weight=wp.to(torch.bfloat16).to(device).contiguous(), scale=bias4.to(device),
+                      shift=None, C0=C0, C1=C1, Cout=hid, ksize=k, stride=1, pad=(k - 1) // 2, up0=0,
+                      epilogue=V2X_EPI_GRU, relu=False, w_rows=groups * 48, w_kpad=kpad)

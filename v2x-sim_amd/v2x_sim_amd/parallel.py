@@ -1,0 +1,109 @@
+"""Agent-sharded multi-GPU execution (new functionality -- the reference
+is single-process, so the correctness oracle is "R-rank result == 1-rank result").
+
+Work items are the (agent, frame) maps of the agent-major batch (row = agent*Bt + frame, the
+reference's own batching of agents).  Rank r of R owns the contiguous slice
+[r*L, (r+1)*L), L = A*Bt/R.  Encoder, decoder and heads are independent per item; the ONLY
+exchange is the fusion-layer feature map (256x32x32 bf16 = 512 KiB per item): one RCCL
+all-gather over xGMI per GNN round puts every item's map on every rank, after which each rank
+warps/fuses only the (ego, frame) pairs it owns.  Poses and agent counts are replicated (tiny).
+With R = 1 there is no collective at all.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._lib import V2X_FUSE_MEAN
+from .models.det.base import LidarDecoder, LidarEncoder
+
+
+class AgentShard:
+    """Partition of the A*Bt agent-major work items over `world` ranks."""
+
+    def __init__(self, agent_num, total_frames, rank=0, world=1):
+        total = agent_num * total_frames
+        if total % world != 0:
+            raise ValueError("A*Bt=%d items do not divide over %d ranks: choose the frame count as a multiple of "
+                             "the rank count" % (total, world))
+        self.A, self.Bt, self.rank, self.world = agent_num, total_frames, rank, world
+        self.per_rank = total // world
+        self.lo, self.hi = rank * self.per_rank, (rank + 1) * self.per_rank
+        self.rows = list(range(self.lo, self.hi))
+        self.items = [(r // total_frames, r % total_frames) for r in self.rows]  # (agent, frame)
+
+    def fusion_plan(self, num_agent_tensor, device):
+        """items / coef of the maps this rank fuses (real agents only) + their local row index."""
+        nat = num_agent_tensor.detach().to("cpu") if isinstance(num_agent_tensor, torch.Tensor) else num_agent_tensor
+        counts = [int(nat[f][0]) for f in range(self.Bt)]
+        if min(counts) < 2:
+            raise RuntimeError("V2VNet needs >= 2 agents in every frame (stack expects a non-empty TensorList)")
+        sel, coef = [], []
+        for local, (a, f) in enumerate(self.items):
+            if a < counts[f]:
+                sel.append(local)
+                coef.append([1.0 if (j != a and j < counts[f]) else 0.0 for j in range(self.A)])
+        items = [self.items[i] for i in sel]
+        full = len(sel) == self.per_rank
+        return {"items": torch.tensor(items, dtype=torch.int32, device=device).view(-1, 2),
+                "coef": torch.tensor(coef, dtype=torch.float32, device=device).view(-1, self.A),
+                "local_rows": None if full else torch.tensor(sel, device=device), "n": len(sel)}
+
+
+def exchange_features(local_feat, world, group=None, out=None):
+    """All-gather of the per-rank fusion-layer maps: (L, H, W, C) -> (world*L, H, W, C), rank-major
+    (= agent-major row order, because shards are contiguous).  RCCL on GPUs, gloo in the CPU tests."""
+    if world == 1:
+        return local_feat
+    shape = (world * local_feat.shape[0],) + tuple(local_feat.shape[1:])
+    if out is None:
+        out = torch.empty(shape, dtype=local_feat.dtype, device=local_feat.device)
+    src = local_feat.contiguous()
+    if src.dtype == torch.bfloat16 and not src.is_cuda:
+        # gloo has no bf16: move the bits (tests only; RCCL handles bf16 natively)
+        dist.all_gather_into_tensor(out.view(torch.int16), src.view(torch.int16), group=group)
+    else:
+        dist.all_gather_into_tensor(out, src, group=group)
+    return out
+
+
+class ShardedV2VNet:
+    """Runs a v2x_sim_amd V2VNet over this rank's shard.  `exchange` is injectable so that a
+    single GPU can emulate R ranks in the equivalence test."""
+
+    def __init__(self, model, shard, exchange=None, group=None):
+        self.model, self.shard, self.group = model, shard, group
+        self.exchange = exchange or (lambda t: exchange_features(t, shard.world, group))
+        self.grid = ops.VoxelGrid()
+
+    def encode_points(self, points, n_pts, pk):
+        """points (L, max_pts, stride) fp32 of this rank's items -> encoder pyramid."""
+        X, Y, Z = self.grid.dims
+        bits = ops.voxelize_bits(points, n_pts, self.grid)
+        x0 = ops.bits_to_nhwc(bits, Z, (Z + 7) // 8 * 8)
+        return LidarEncoder.run(pk["enc"], x0)
+
+    def fuse_local(self, feats, trans, plan, pk):
+        m, sh = self.model, self.shard
+        local = feats[m.layer]
+        cur = local
+        gathered0 = self.exchange(local)
+        for it in range(m.gnn_iter_num):
+            src = gathered0 if (m.neighbor_source == "initial" or it == 0) else self.exchange(cur)
+            mean = ops.warp_fuse(src, sh.A, sh.Bt, trans, plan["items"], plan["coef"], V2X_FUSE_MEAN)
+            rows = plan["local_rows"]
+            ego = cur if rows is None else cur.index_select(0, rows)
+            h = ops.conv2d(pk["gru"], ego, mean)
+            if rows is None:
+                cur = h
+            else:
+                cur = cur.clone()
+                cur.index_copy_(0, rows, h)
+        return cur
+
+    def forward_points(self, points, n_pts, trans, plan):
+        m = self.model
+        pk = m.packed(points.device)
+        feats = self.encode_points(points, n_pts, pk)
+        feats[m.layer] = self.fuse_local(feats, trans, plan, pk)
+        x = LidarDecoder.run(pk["dec"], *feats)
+        return m.get_cls_loc_result(x, pk["heads"])
