@@ -60,7 +60,7 @@ def exchange_features(local_feat, world, group=None, out=None):
     src = local_feat.contiguous()
     if src.dtype == torch.bfloat16 and not src.is_cuda:
         # gloo has no bf16: move the bits (tests only; RCCL handles bf16 natively)
-        dist.all_gather_into_tensor(out.view(torch.int16), src.view(torch.int16), group=group)
+        dist.all_gather_into_tensor(out.view(torch.uint8), src.view(torch.uint8), group=group)
     else:
         dist.all_gather_into_tensor(out, src, group=group)
     return out
