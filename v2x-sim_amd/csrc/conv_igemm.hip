@@ -18,8 +18,10 @@
 //     so Cin only has to be a multiple of 8 (first layer: 13 -> 16 channels).
 //   * LDS tiles are [row][64 bf16] = 128-B rows with the 16-B slot index XOR (row&7):
 //     conflict-free for both the ds_write_b128 fill and the ds_read_b128 fragment reads
-//     (MI355X_MICROARCH.md LDS lane groups).  Two stages, one barrier per chunk; global
-//     loads for chunk t+1 are issued before the MFMAs of chunk t (register staging).
+//     (MI355X_MICROARCH.md LDS lane groups).  Tiles arrive by LDS-DMA (global_load_lds_dwordx4):
+//     no staging VGPRs, no ds_write pass; the swizzle is applied to the per-lane SOURCE address
+//     and padding taps read a zero page.  Two stages, one barrier per chunk; the DMA of chunk
+//     t+1 is issued before the MFMAs of chunk t.
 #include "common.h"
 
 struct ConvArgs {
@@ -42,15 +44,28 @@ enum { EPI_BF16 = V2X_EPI_BF16, EPI_F32 = V2X_EPI_F32, EPI_GRU = V2X_EPI_GRU };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// 64 B of zeros: padding taps / K-tail slots / out-of-range pixels point their LDS-DMA source here.
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+// 16 B per lane, global -> LDS without a VGPR round trip (global_load_lds_dwordx4).  The LDS
+// destination is wave-uniform base + lane*16, so the XOR swizzle lives in the per-lane SOURCE
+// address (guide rule 21): lane l fills physical slot (l&7) of row (l>>3) with logical slot
+// (l&7)^((l>>3)&7).
+__device__ __forceinline__ void glds16(const void *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
 template <int BCO, int BPX, int WCO, int WPX, int EPI>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int TCO = BCO / WCO / 16;  // MFMA tiles per wave along output channels
     constexpr int TPX = BPX / WPX / 16;  // ... along pixels
     static_assert(WCO * WPX == 4, "4 waves per workgroup");
     static_assert(BCO % (WCO * 16) == 0 && BPX % (WPX * 16) == 0, "tile shape");
-    static_assert(BPX % 32 == 0, "pixel tile must be a multiple of 32 rows");
-    constexpr int A_VEC = BCO * 8;                // 16-B vectors per weight stage
-    constexpr int A_IT = (A_VEC + 255) / 256;
+    static_assert(BPX % 32 == 0 && BCO % 8 == 0, "tile rows are moved 8 per wave instruction");
+    constexpr int A_IT = (BCO + 31) / 32;  // wave instructions (8 rows each) per wave for the weight tile
     constexpr int B_IT = BPX / 32;
     constexpr int STAGE_BYTES = (BCO + BPX) * 128;
 
@@ -58,59 +73,74 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wco = wave / WPX;
     const int wpx = wave % WPX;
 
+    // XCD-aware tile order (guide T1): workgroup b runs on XCD b%8; give every XCD a contiguous run
+    // of tiles so the channel tiles of one pixel tile (same activations) and neighbouring pixel
+    // tiles (shared halos) hit the same L2.  Bijective for any grid size.
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
     const int n_co_tiles = a.w_rows / BCO;
-    const int co_tile = blockIdx.x % n_co_tiles;
-    const int px_tile = blockIdx.x / n_co_tiles;
+    const int co_tile = bid % n_co_tiles;
+    const int px_tile = bid / n_co_tiles;
     const int co0 = co_tile * BCO;
     const int px0 = px_tile * BPX;
 
     // ---- per-thread gather bookkeeping (fixed for the whole K loop) -------------------
-    const int slot = tid & 7;  // 16-B slot (8 channels) this thread moves in every row it owns
-    int iy0[B_IT], ix0[B_IT], nimg[B_IT];
+    const int lrow = lane >> 3;                 // row inside the 8-row group one wave instruction moves
+    const int lslot = (lane & 7) ^ (lrow & 7);  // logical 16-B slot (8 channels) this lane fetches
+    int iy0[B_IT], ix0[B_IT], nbase[B_IT];      // nbase = image index (or -1 for rows past M)
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-        const int p = px0 + (tid >> 3) + it * 32;
+        const int p = px0 + (wave + 4 * it) * 8 + lrow;
         if (p < a.M) {
             const int hw = a.Ho * a.Wo;
             const int n = p / hw;
             const int rem = p - n * hw;
             const int oy = rem / a.Wo;
             const int ox = rem - oy * a.Wo;
-            nimg[it] = n;
+            nbase[it] = n;
             iy0[it] = oy * a.stride - a.pad;
             ix0[it] = ox * a.stride - a.pad;
         } else {
-            nimg[it] = -1;
+            nbase[it] = -1;
             iy0[it] = 0;
             ix0[it] = 0;
         }
     }
+    // weight rows: this lane's element offset inside the packed matrix for chunk 0
+    unsigned woff[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+        const int row = (wave + 4 * it) * 8 + lrow;
+        woff[it] = (unsigned)(co0 + row) * (unsigned)a.w_kpad + lslot * 8;
+    }
+    // (tap, c) of this lane's slot, advanced by 64 channels per chunk
+    int k_tap = (lslot * 8) / a.Cin;
+    int k_c = lslot * 8 - k_tap * a.Cin;
 
-    uint4 ra[A_IT], rb[B_IT];
-
-    auto load_global = [&](int t) {
-        // weights: row-major [w_rows][w_kpad]
+    auto stage_chunk = [&](int t, int stage) {
+        char *sa = smem + stage * STAGE_BYTES;
+        char *sb = sa + BCO * 128;
+        // weights
 #pragma unroll
         for (int it = 0; it < A_IT; ++it) {
-            const int v = tid + it * 256;
-            if (A_VEC % 256 == 0 || v < A_VEC) {
-                const int row = v >> 3;
-                ra[it] = *reinterpret_cast<const uint4 *>(a.w + (size_t)(co0 + row) * a.w_kpad + t * 64 + (v & 7) * 8);
-            }
+            if ((wave + 4 * it) * 8 < BCO)  // wave-uniform (only BCO=48 skips)
+                glds16(a.w + woff[it] + (unsigned)t * 64u, sa + (wave + 4 * it) * 1024);
         }
-        // activations: implicit im2col gather
-        const int k = t * 64 + slot * 8;
-        const int tap = k / a.Cin;
-        int c = k - tap * a.Cin;
+        // activations: implicit im2col
+        const int tap = k_tap;
         const bool tap_ok = tap < a.ntaps;
-        const int ky = tap / a.ks;
+        const int ky = (a.ks == 1) ? 0 : ((tap * 11) >> 5);
         const int kx = tap - ky * a.ks;
         const uint16_t *src = a.in0;
-        int cs = a.C0, sh = a.up0;
+        int c = k_c, cs = a.C0, sh = a.up0;
         if (c >= a.C0) {
             src = a.in1;
             c -= a.C0;
@@ -122,31 +152,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         for (int it = 0; it < B_IT; ++it) {
             const int iy = iy0[it] + ky;
             const int ix = ix0[it] + kx;
-            const bool ok = tap_ok && nimg[it] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            uint4 v = make_uint4(0u, 0u, 0u, 0u);
-            if (ok) {
-                const size_t off = (((size_t)nimg[it] * Hs + (iy >> sh)) * Ws + (ix >> sh)) * cs + c;
-                v = *reinterpret_cast<const uint4 *>(src + off);
-            }
-            rb[it] = v;
+            const bool ok = tap_ok && nbase[it] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            // 24-bit multiplies: every factor is < 2^24 (host checks N*H*W < 2^24 rows), product < 2^32
+            const unsigned pix = __umul24(__umul24((unsigned)nbase[it], (unsigned)Hs) + (unsigned)(iy >> sh), (unsigned)Ws) +
+                                 (unsigned)(ix >> sh);
+            const unsigned off = pix * (unsigned)cs + (unsigned)c;
+            const void *g = ok ? (const void *)(src + off) : (const void *)g_zero_page;
+            glds16(g, sb + (wave + 4 * it) * 1024);
         }
-    };
-
-    auto store_lds = [&](int stage) {
-        char *sa = smem + stage * STAGE_BYTES;
-        char *sb = sa + BCO * 128;
-#pragma unroll
-        for (int it = 0; it < A_IT; ++it) {
-            const int v = tid + it * 256;
-            if (A_VEC % 256 == 0 || v < A_VEC) {
-                const int row = v >> 3;
-                *reinterpret_cast<uint4 *>(sa + row * 128 + (((v & 7) ^ (row & 7)) << 4)) = ra[it];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < B_IT; ++it) {
-            const int row = (tid >> 3) + it * 32;
-            *reinterpret_cast<uint4 *>(sb + row * 128 + ((slot ^ (row & 7)) << 4)) = rb[it];
+        // advance this lane's (tap, c) to the next chunk
+        k_c += 64;
+        while (k_c >= a.Cin) {
+            k_c -= a.Cin;
+            ++k_tap;
         }
     };
 
@@ -160,13 +178,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     const int frow = lane & 15;  // row inside a 16-row fragment
     const int fk = lane >> 4;    // 8-element k group inside a 32-deep MFMA step
 
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
+    stage_chunk(0, 0);
+    __syncthreads();  // (the compiler drains vmcnt before the barrier while LDS-DMA is in flight)
 
     for (int t = 0; t < nchunks; ++t) {
-        const bool more = (t + 1) < nchunks;
-        if (more) load_global(t + 1);
+        if (t + 1 < nchunks) stage_chunk(t + 1, (t + 1) & 1);  // next tile's DMA overlaps this tile's MFMAs
 
         const char *sa = smem + (t & 1) * STAGE_BYTES;
         const char *sb = sa + BCO * 128;
@@ -190,8 +206,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 for (int j = 0; j < TPX; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-
-        if (more) store_lds((t + 1) & 1);
         __syncthreads();
     }
 
@@ -359,6 +373,9 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
     a.Wo = (d->W + 2 * d->pad - d->ksize) / d->stride + 1;
     const long long M = (long long)d->N * a.Ho * a.Wo;
     V2X_REQUIRE(M > 0 && M < (1ll << 31) - 512, "v2x_conv2d: too many output pixels");
+    V2X_REQUIRE((long long)d->N * d->H * d->W < (1ll << 24), "v2x_conv2d: N*H*W must be < 2^24 (24-bit row arithmetic)");
+    V2X_REQUIRE((long long)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 32) &&
+                (long long)d->w_rows * d->w_kpad < (1ll << 32), "v2x_conv2d: tensor exceeds 32-bit element offsets");
     a.M = (int)M;
     a.Cout = d->Cout;
     a.w_rows = d->w_rows;
