@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 1
+#define V2X_AMD_ABI_VERSION 2
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -108,6 +108,14 @@ typedef struct v2x_conv_desc {
     void *out2;          /* optional second NHWC output: channels >= split go to out2[..][c-split] */
     int32_t split;       /* multiple of 4; 0 = no split (out2 ignored)                           */
     int32_t out2_cstride;
+    /* --- halo-tile kernel (conv_halo.hip): 3x3 stride-1 layers with <= 96 input channels ------ */
+    int32_t w_layout;    /* 0: row-major [w_rows][w_kpad] (gather kernel)                          */
+                         /* 1: k-slot-major [9*Cin/8][Cout][8] (halo kernel; H%8==0, W%32==0)      */
+    int32_t Cout2;       /* > 0: chain a 1x1 conv on the (never stored) Cout-channel result:       */
+    const uint16_t *weight2; /* bf16 [ceil16(Cout2)][Cout] row-major; `epilogue`/`split`/out* then  */
+    const float *scale2; /*   describe the FINAL output, scale/shift/relu the hidden layer and     */
+    const float *shift2; /*   scale2/shift2/relu2 (fp32 [ceil16(Cout2)]) the chained one.          */
+    int32_t relu2;       /*   weight rows must be in the chain order documented in conv_halo.hip.  */
 } v2x_conv_desc;
 
 /* Rows-per-tile the kernel will use for (Cout, epilogue); the weight packer pads w_rows to a multiple. */

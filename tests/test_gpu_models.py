@@ -182,7 +182,7 @@ def test_points_to_logits_path(device):
     grid = ops.VoxelGrid()
     cnt = torch.full((2,), pts.shape[1], dtype=torch.int32, device=device)
     bits = ops.voxelize_bits(torch.from_numpy(pts).to(device), cnt, grid)
-    x0 = ops.bits_to_nhwc(bits, 13, 16)
+    x0 = ops.bits_to_nhwc(bits, 13, 32)
     with torch.no_grad():
         a = pm.forward_nhwc(x0)
         b = pm(bev.to(device))

@@ -327,3 +327,92 @@ def test_seg_argmax_confusion_exact(device):
     assert torch.equal(pred.cpu().long(), ref_pred)
     assert torch.equal(conf.cpu(), R.confusion_matrix(ref_pred, label))   # integer-exact
     assert int(conf.sum()) == 3 * 64 * 64
+
+
+# ------------------------------------------------------------------------------------- halo-tile kernel
+def _halo_ref(x, w, scale, shift, relu, x_up=None):
+    if x_up is not None:
+        x = torch.cat((F.interpolate(x_up, scale_factor=(2, 2)), x), 1)
+    y = F.conv2d(x, bf16r(w), None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    return F.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("cfg", [
+    # (C_up, C, Cout, N, H, W)
+    (0, 32, 32, 2, 16, 64),     # conv_pre_2 / conv8_2 class; several tiles in x, image borders
+    (0, 32, 32, 1, 8, 32),      # a single tile: every border is zero padding
+    (64, 32, 32, 2, 16, 32),    # conv8_1: nearest-x2 upsampled source + skip
+    (0, 64, 64, 3, 24, 32),     # conv7_2 class
+])
+def test_halo_conv_vs_torch(device, cfg):
+    from v2x_sim_amd import ops, packing
+    cup, c, cout, N, H, W = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = bf16r(torch.randn(N, c, H, W, generator=g))
+    x_up = bf16r(torch.randn(N, cup, H // 2, W // 2, generator=g)) if cup else None
+    w = torch.randn(cout, cup + c, 3, 3, generator=g) * (2.0 / ((cup + c) * 9)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    ref = _halo_ref(x, w, scale, shift, True, x_up)
+    pc = packing.pack_conv_halo("t", w, scale, shift, C0=cup if cup else c, C1=c if cup else 0, relu=True, device=device)
+    if cup:
+        y = ops.conv2d(pc, to_nhwc_bf16(x_up, device), to_nhwc_bf16(x, device))
+    else:
+        y = ops.conv2d(pc, to_nhwc_bf16(x, device))
+    got = from_nhwc(y)
+    assert got.shape == ref.shape
+    # bf16 output: one rounding of the fp32 result
+    assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
+
+
+def test_halo_equals_gather_kernel_bitwise(device):
+    """Same operands, same fp32 accumulation order per output?  Not guaranteed (different K walk), so the
+    two kernels are compared at 1 bf16 ulp; both against the same torch reference elsewhere."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(77)
+    x = bf16r(torch.randn(2, 32, 32, 64, generator=g))
+    w = torch.randn(32, 32, 3, 3, generator=g) * 0.08
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    a = ops.conv2d(packing.pack_conv_halo("h", w, scale, shift, device=device), to_nhwc_bf16(x, device)).float()
+    b = ops.conv2d(packing.pack_conv("g", w, scale, shift, device=device), to_nhwc_bf16(x, device)).float()
+    assert torch.allclose(a, b, atol=1e-3, rtol=2 ** -7)
+    assert float((a != b).float().mean()) < 0.01  # only accumulation-order flips of the bf16 rounding
+
+
+def test_halo_chain_conv1x1_bf16(device):
+    """conv1_2 -> conv3d_1 fusion: 3x3 64->64 +BN+ReLU (hidden, bf16-rounded) then 1x1 64->64 +BN+ReLU."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(5)
+    N, H, W = 2, 16, 32
+    x = bf16r(torch.randn(N, 64, H, W, generator=g))
+    w1 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
+    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    w2 = torch.randn(64, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
+    s2, t2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    hid = bf16r(_halo_ref(x, w1, s1, t1, True))
+    ref = F.relu(F.conv2d(hid, bf16r(w2)) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1))
+    pc = packing.pack_conv_halo("c", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
+    got = from_nhwc(ops.conv2d(pc, to_nhwc_bf16(x, device)))
+    # hidden rounding flips (accumulation order) move a few outputs by ~1e-2; typical error 1 ulp
+    assert torch.allclose(got, ref, atol=3e-2, rtol=2 ** -6), float((got - ref).abs().max())
+    assert float((got - ref).abs().mean()) < 2e-3
+
+
+def test_halo_chain_heads_split_f32(device):
+    """det heads: 3x3 32->64 (+BN+ReLU) chained with 1x1 64->48, fp32, split into cls(12) | loc(36)."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(8)
+    N, H, W = 2, 16, 64
+    x = bf16r(torch.randn(N, 32, H, W, generator=g))
+    w1 = torch.randn(64, 32, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
+    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    w2 = torch.randn(48, 64, 1, 1, generator=g) * 0.2
+    b2 = torch.randn(48, generator=g)
+    hid = bf16r(_halo_ref(x, w1, s1, t1, True))
+    ref = F.conv2d(hid, bf16r(w2)) + b2.view(1, -1, 1, 1)
+    pc = packing.pack_conv_halo("h", w1, s1, t1, relu=True, chain=(w2, torch.ones(48), b2, False),
+                                epilogue=ops.V2X_EPI_F32, device=device)
+    cls, loc = ops.conv2d(pc, to_nhwc_bf16(x, device), split=12)
+    assert cls.shape == (N, H, W, 12) and loc.shape == (N, H, W, 36) and cls.dtype == torch.float32
+    got = torch.cat([from_nhwc(cls), from_nhwc(loc)], 1)
+    assert torch.allclose(got, ref, atol=2e-2, rtol=1e-2), float((got - ref).abs().max())
+    assert float((got - ref).abs().mean()) < 1e-3

@@ -1,0 +1,370 @@
+// Halo-tile 3x3 stride-1 convolution for the full-resolution, small-channel layers
+// (conv_pre_1/2, conv8_1/2, conv1_2, conv7_2 and the detection heads of upstream
+// coperception/models/det/backbone/Backbone.py + DetModelBase.py; code absent from
+// /root/reference, see include/v2x_amd.h).
+//
+// Why a second conv kernel: with Cin <= 96 the gather-style implicit GEMM (conv_igemm.hip) re-reads
+// every input pixel 9x through L2 and spends its issue slots on im2col address math; these layers
+// are HBM-bound (AI 100-350 FLOP/B), so the design goal is "each input byte crosses the memory
+// system once":
+//   * a persistent workgroup keeps the WHOLE weight tensor of the layer in LDS (18-55 KiB) and
+//     walks 8x32-pixel output tiles;
+//   * per tile the (8+2)x(32+2) input patch (and for conv8_1 the 6x18 patch of the half-resolution
+//     source: nearest x2 upsample + concat are address math on the patch) is brought in by LDS-DMA
+//     (global_load_lds_dwordx4), double-buffered so the next tile's patch streams in under the MFMAs;
+//     out-of-image pixels read a zero page;
+//   * all 9 taps x Cin/32 k-steps read their MFMA operands from that patch: 16 consecutive pixels
+//     of one patch row are one ds_read_b128 fragment.  LDS layouts found by exhaustive search over
+//     the ds_read_b128 lane groups (MI355X_MICROARCH.md): pixel-major patch with the 16-B slot XOR
+//     ((x>>1)&3) for 4/12 slots per pixel and (x&7) for 8 -> conflict-free at every tap alignment;
+//     weights k-slot-major [kslot][cout][8] -> conflict-free;
+//   * optional chained 1x1 conv in the epilogue (det heads 32->64->48, conv1_2 -> conv3d_1): the rows
+//     of the first GEMM are ordered so that each lane's accumulators ARE its B-operand fragment of
+//     the second MFMA (hidden channel kappa = 32*(i>>1) + 8*q + 4*(i&1) + r for tile i, lane group q,
+//     register r) -- no cross-lane traffic, the hidden map never exists in memory.
+#include "common.h"
+
+// 64 B of zeros for out-of-image patch pixels (own copy: no relocatable device code needed)
+static __device__ __attribute__((aligned(64))) unsigned int g_zero_page_h[16];
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void glds16h(const void *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+struct HaloArgs {
+    const uint16_t *in0;  // [N][H/2][W/2][C0] (nearest-x2 upsampled on the fly) or nullptr
+    const uint16_t *in1;  // [N][H][W][C1]
+    int N, H, W;
+    const uint16_t *w;    // k-slot-major [9*(C0+C1)/8][COUT][8] bf16
+    const float *scale, *shift;  // [COUT] (chain: in kappa order)
+    int relu;
+    void *out;            // NHWC [N][H][W][out_cstride] (+out_coff)
+    int out_cstride, out_coff;
+    // chained 1x1 (COUT2 > 0)
+    const uint16_t *w2;   // row-major [COUT2][COUT] bf16, K in kappa order
+    const float *scale2, *shift2;
+    int relu2, cout2_real, split;
+    void *out2;
+    int out2_cstride;
+    int tiles_x, tiles_y, n_tiles;
+};
+
+constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
+constexpr int PH0 = TH / 2 + 2, PW0 = TW / 2 + 2;
+
+template <int SPP>
+__device__ __forceinline__ int swz(int slot, int x) {
+    if constexpr (SPP == 8) return slot ^ (x & 7);
+    else return slot ^ ((x >> 1) & 3);  // SPP 4 or 12: permute inside each aligned group of 4 slots
+}
+
+constexpr int round64(int v) { return (v + 63) / 64 * 64; }
+
+// EPI2: 0 = none (plain epilogue, bf16 out), 1 = chained 1x1 with bf16 out, 2 = chained 1x1 with fp32 split out
+template <int C0, int C1, int COUT, int COUT2, int EPI2>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
+    constexpr int SPP0 = C0 / 8, SPP1 = C1 / 8;
+    constexpr int NS1 = round64(PH * PW * SPP1);            // 16-B slots of the full-res patch (padded to whole waves)
+    constexpr int NS0 = C0 ? round64(PH0 * PW0 * SPP0) : 0; // ... of the half-res patch
+    constexpr int PATCH_BYTES = (NS0 + NS1) * 16;
+    constexpr int KSLOTS = 9 * (SPP0 + SPP1);
+    constexpr int W_BYTES = KSLOTS * COUT * 16;
+    constexpr int TCO = COUT / 16;
+    constexpr int TCO2 = COUT2 / 16;
+    static_assert(C1 % 32 == 0 && C0 % 32 == 0, "channel groups of 32 (one MFMA k-step)");
+    static_assert(COUT % 32 == 0, "output channel tiles come in pairs (chain layout)");
+    static_assert(W_BYTES % 1024 == 0, "weights are moved 1 KiB per wave instruction");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_w = smem;
+    char *s_patch = smem + W_BYTES;  // two buffers of PATCH_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15;  // pixel inside a 16-pixel fragment
+    const int fq = lane >> 4;  // k-group (operands) / channel quad (accumulators)
+
+    // ---- weights: one linear LDS-DMA copy, resident for the whole kernel --------------------------
+    for (int off = wave * 1024; off < W_BYTES; off += 4096)
+        glds16h(reinterpret_cast<const char *>(a.w) + off + lane * 16, s_w + off);
+
+    auto load_patch = [&](int tile, int buf) {
+        const int txy = a.tiles_x * a.tiles_y;
+        const int n = tile / txy;
+        const int r = tile - n * txy;
+        const int ty = r / a.tiles_x;
+        const int tx = r - ty * a.tiles_x;
+        const int y0 = ty * TH, x0 = tx * TW;
+        char *pb = s_patch + buf * PATCH_BYTES;
+        // full-resolution source: patch pixel (pr, pc) <- image pixel (y0-1+pr, x0-1+pc)
+        for (int base = wave * 64; base < NS1; base += 256) {
+            const int L = base + lane;
+            const int pix = L / SPP1;
+            const int phys = L - pix * SPP1;
+            const int pr = pix / PW;
+            const int pc = pix - pr * PW;
+            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+            const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned off = ((unsigned)(n * a.H + y) * (unsigned)a.W + (unsigned)x) * (unsigned)C1 + swz<SPP1>(phys, pc) * 8;
+            glds16h(ok ? (const void *)(a.in1 + off) : (const void *)g_zero_page_h, pb + NS0 * 16 + base * 16);
+        }
+        if constexpr (C0 > 0) {
+            // half-resolution source: patch pixel (pr, pc) <- source pixel (y0/2-1+pr, x0/2-1+pc)
+            const int Hs = a.H >> 1, Ws = a.W >> 1;
+            for (int base = wave * 64; base < NS0; base += 256) {
+                const int L = base + lane;
+                const int pix = L / SPP0;
+                const int phys = L - pix * SPP0;
+                const int pr = pix / PW0;
+                const int pc = pix - pr * PW0;
+                const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+                const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+                const unsigned off = ((unsigned)(n * Hs + y) * (unsigned)Ws + (unsigned)x) * (unsigned)C0 + swz<SPP0>(phys, pc) * 8;
+                glds16h(ok ? (const void *)(a.in0 + off) : (const void *)g_zero_page_h, pb + base * 16);
+            }
+        }
+    };
+
+    // chained 1x1: its weight fragments live in registers for the whole kernel
+    bf16x8_t w2f[TCO2 > 0 ? TCO2 : 1][COUT / 32];
+    if constexpr (COUT2 > 0) {
+#pragma unroll
+        for (int i2 = 0; i2 < TCO2; ++i2)
+#pragma unroll
+            for (int s = 0; s < COUT / 32; ++s)
+                w2f[i2][s] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * COUT + s * 32 + fq * 8);
+    }
+
+    int tile = blockIdx.x;
+    int cur = 0;
+    if (tile < a.n_tiles) load_patch(tile, 0);
+
+    for (; tile < a.n_tiles; tile += gridDim.x) {
+        __syncthreads();  // patch[cur] (and, first time, the weights) have landed; everyone left patch[cur^1]
+        const int next = tile + gridDim.x;
+        if (next < a.n_tiles) load_patch(next, cur ^ 1);
+
+        const char *pb = s_patch + cur * PATCH_BYTES;
+        f32x4_t acc[TCO][4];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        // wave w owns tile rows 2w, 2w+1; fragment f = (row f>>1, columns (f&1)*16 .. +15)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            if constexpr (C0 > 0) {
+#pragma unroll
+                for (int kc = 0; kc < C0 / 32; ++kc) {
+                    bf16x8_t fa[TCO], fb[4];
+                    const int kslot = tap * (SPP0 + SPP1) + kc * 4 + fq;
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+                        fa[i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int ly = 2 * wave + (f >> 1), lx = (f & 1) * 16 + fj;
+                        const int pr = ((ly + ky - 1) >> 1) + 1;  // floor((y0+ly+ky-1)/2) - (y0/2-1), y0 even
+                        const int pc = ((lx + kx - 1) >> 1) + 1;
+                        fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + ((pr * PW0 + pc) * SPP0 + swz<SPP0>(kc * 4 + fq, pc)) * 16);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int kc = 0; kc < C1 / 32; ++kc) {
+                bf16x8_t fa[TCO], fb[4];
+                const int kslot = tap * (SPP0 + SPP1) + SPP0 + kc * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int pr = 2 * wave + (f >> 1) + ky;
+                    const int pc = (f & 1) * 16 + fj + kx;
+                    fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + NS0 * 16 + ((pr * PW + pc) * SPP1 + swz<SPP1>(kc * 4 + fq, pc)) * 16);
+                }
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue -----------------------------------------------------------------------------
+        const int txy = a.tiles_x * a.tiles_y;
+        const int n = tile / txy;
+        const int rr = tile - n * txy;
+        const int ty = rr / a.tiles_x;
+        const int tx = rr - ty * a.tiles_x;
+        if constexpr (COUT2 == 0) {
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) {
+                const int co = i * 16 + fq * 4;
+                const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
+                const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
+                    float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
+                    float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
+                    if (a.relu) {
+                        v0 = fmaxf(v0, 0.f);
+                        v1 = fmaxf(v1, 0.f);
+                        v2 = fmaxf(v2, 0.f);
+                        v3 = fmaxf(v3, 0.f);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
+                    uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) +
+                                    ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co;
+                    *reinterpret_cast<uint2 *>(dst) = o;
+                }
+            }
+        } else {
+            // hidden = relu(acc*scale+shift) -> bf16 -> directly the B fragments of the 1x1 GEMM
+            float4 sc[TCO], sf[TCO];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) {
+                // packed row 16i + 4q + r computes hidden channel kappa = 32*(i>>1) + 8q + 4*(i&1) + r
+                const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
+                sc[i] = *reinterpret_cast<const float4 *>(a.scale + kappa);
+                sf[i] = *reinterpret_cast<const float4 *>(a.shift + kappa);
+            }
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                bf16x8_t hb[COUT / 32];
+#pragma unroll
+                for (int s = 0; s < COUT / 32; ++s) {
+                    float h[8];
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const int i = 2 * s + half;
+                        h[half * 4 + 0] = acc[i][f][0] * sc[i].x + sf[i].x;
+                        h[half * 4 + 1] = acc[i][f][1] * sc[i].y + sf[i].y;
+                        h[half * 4 + 2] = acc[i][f][2] * sc[i].z + sf[i].z;
+                        h[half * 4 + 3] = acc[i][f][3] * sc[i].w + sf[i].w;
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = fmaxf(h[e], 0.f);
+                    }
+                    uint4 p;
+                    p.x = pack_bf16x2(h[0], h[1]);
+                    p.y = pack_bf16x2(h[2], h[3]);
+                    p.z = pack_bf16x2(h[4], h[5]);
+                    p.w = pack_bf16x2(h[6], h[7]);
+                    hb[s] = __builtin_bit_cast(bf16x8_t, p);
+                }
+                const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
+                const size_t pix = (size_t)(n * a.H + y) * a.W + x;
+#pragma unroll
+                for (int i2 = 0; i2 < TCO2; ++i2) {
+                    f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < COUT / 32; ++s)
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][s], hb[s], d, 0, 0, 0);
+                    const int co = i2 * 16 + fq * 4;
+                    if (co >= a.cout2_real) continue;
+                    const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
+                    const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
+                    float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
+                    if (a.relu2) {
+                        v0 = fmaxf(v0, 0.f);
+                        v1 = fmaxf(v1, 0.f);
+                        v2 = fmaxf(v2, 0.f);
+                        v3 = fmaxf(v3, 0.f);
+                    }
+                    if constexpr (EPI2 == 2) {
+                        const bool second = a.split > 0 && co >= a.split;
+                        float *dst = second ? reinterpret_cast<float *>(a.out2) + pix * a.out2_cstride + (co - a.split)
+                                            : reinterpret_cast<float *>(a.out) + pix * a.out_cstride + a.out_coff + co;
+                        *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
+                    } else {
+                        uint2 o;
+                        o.x = pack_bf16x2(v0, v1);
+                        o.y = pack_bf16x2(v2, v3);
+                        uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co;
+                        *reinterpret_cast<uint2 *>(dst) = o;
+                    }
+                }
+            }
+        }
+        cur ^= 1;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+template <int C0, int C1, int COUT, int COUT2, int EPI2>
+static int launch_halo(const HaloArgs &a, hipStream_t s) {
+    constexpr int NS1 = round64(PH * PW * (C1 / 8));
+    constexpr int NS0 = C0 ? round64(PH0 * PW0 * (C0 / 8)) : 0;
+    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static bool attr_done = false;
+    auto kern = &conv3x3_halo_kernel<C0, C1, COUT, COUT2, EPI2>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    const int per_cu = (160 * 1024) / smem >= 2 ? 2 : 1;
+    int grid = 256 * per_cu;
+    if (grid > a.n_tiles) grid = a.n_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_halo_kernel");
+    return V2X_OK;
+}
+
+// Returns V2X_OK if handled, 1 if the shape is not one the halo kernel covers (caller falls back
+// to the gather kernel -- which needs the row-major weight layout, so callers decide at pack time).
+int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
+    HaloArgs a;
+    a.in0 = d->C1 ? d->in0 : nullptr;
+    a.in1 = d->C1 ? d->in1 : d->in0;
+    const int C0 = d->C1 ? d->C0 : 0, C1 = d->C1 ? d->C1 : d->C0;
+    a.N = d->N;
+    a.H = d->H;
+    a.W = d->W;
+    a.w = d->weight;
+    a.scale = d->scale;
+    a.shift = d->shift;
+    a.relu = d->relu;
+    a.out = d->out;
+    a.out_cstride = d->out_cstride;
+    a.out_coff = d->out_coff;
+    a.w2 = d->weight2;
+    a.scale2 = d->scale2;
+    a.shift2 = d->shift2;
+    a.relu2 = d->relu2;
+    a.cout2_real = d->Cout2;
+    a.split = d->split;
+    a.out2 = d->out2;
+    a.out2_cstride = d->out2_cstride;
+    a.tiles_x = d->W / TW;
+    a.tiles_y = d->H / TH;
+    a.n_tiles = d->N * a.tiles_x * a.tiles_y;
+    const int co2 = d->Cout2 > 0 ? (d->Cout2 + 15) / 16 * 16 : 0;
+    const int e2 = d->Cout2 > 0 ? (d->epilogue == V2X_EPI_F32 ? 2 : 1) : 0;
+#define HALO_CASE(c0, c1, co, c2, ep) \
+    if (C0 == c0 && C1 == c1 && d->Cout == co && co2 == c2 && e2 == ep) return launch_halo<c0, c1, co, c2, ep>(a, s);
+    HALO_CASE(0, 32, 32, 0, 0)    // conv_pre_1 (13 -> 32 padded), conv_pre_2, conv8_2
+    HALO_CASE(64, 32, 32, 0, 0)   // conv8_1: cat(up(x_7), x)
+    HALO_CASE(0, 64, 64, 0, 0)    // conv7_2
+    HALO_CASE(0, 64, 64, 64, 1)   // conv1_2 -> conv3d_1
+    HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
+    HALO_CASE(0, 32, 32, 16, 2)   // seg: conv8_2 -> outc (8 classes, fp32)
+#undef HALO_CASE
+    return 1;
+}

@@ -45,7 +45,7 @@ enum { EPI_BF16 = V2X_EPI_BF16, EPI_F32 = V2X_EPI_F32, EPI_GRU = V2X_EPI_GRU };
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
 // 64 B of zeros: padding taps / K-tail slots / out-of-range pixels point their LDS-DMA source here.
-__device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
+static __device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -326,8 +326,39 @@ static int dispatch_rows(const ConvArgs &a, int rows, hipStream_t s) {
     }
 }
 
+int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s);  // conv_halo.hip
+
 extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
     V2X_REQUIRE(d, "v2x_conv2d: null descriptor");
+    if (d->w_layout == 1) {
+        V2X_REQUIRE(d->in0 && d->weight && d->scale && d->shift && d->out, "v2x_conv2d(halo): null tensor pointer");
+        V2X_REQUIRE(d->ksize == 3 && d->stride == 1 && d->pad == 1, "v2x_conv2d(halo): 3x3 stride 1 pad 1 only");
+        V2X_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->H % 8 == 0 && d->W % 32 == 0,
+                    "v2x_conv2d(halo): H=%d must be a multiple of 8 and W=%d of 32", d->H, d->W);
+        V2X_REQUIRE((d->C1 == 0 && d->up0 == 0) || (d->C1 > 0 && d->up0 == 1 && d->in1),
+                    "v2x_conv2d(halo): two sources means in0 is the x2-upsampled one");
+        V2X_REQUIRE((long long)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 32),
+                    "v2x_conv2d(halo): tensor exceeds 32-bit element offsets");
+        V2X_REQUIRE(d->epilogue == V2X_EPI_BF16 || d->epilogue == V2X_EPI_F32, "v2x_conv2d(halo): bad epilogue");
+        if (d->Cout2 > 0) {
+            V2X_REQUIRE(d->weight2 && d->scale2 && d->shift2, "v2x_conv2d(halo): chained 1x1 needs weight2/scale2/shift2");
+            const int cfin = d->Cout2;
+            if (d->split > 0)
+                V2X_REQUIRE(d->out2 && d->split % 4 == 0 && d->split < cfin && d->out_cstride >= d->out_coff + d->split &&
+                            d->out2_cstride >= cfin - d->split, "v2x_conv2d(halo): bad split windows");
+            else
+                V2X_REQUIRE(d->out_cstride >= d->out_coff + cfin, "v2x_conv2d(halo): bad output channel window");
+            V2X_REQUIRE(cfin % 4 == 0, "v2x_conv2d(halo): chained Cout2 must be a multiple of 4");
+        } else {
+            V2X_REQUIRE(d->epilogue == V2X_EPI_BF16 && d->split == 0 && d->out_cstride >= d->out_coff + d->Cout,
+                        "v2x_conv2d(halo): plain epilogue is bf16, unsplit");
+        }
+        const int rc = v2x_conv_halo_dispatch(d, (hipStream_t)stream);
+        V2X_REQUIRE(rc != 1, "v2x_conv2d(halo): no halo kernel for C0=%d C1=%d Cout=%d Cout2=%d epilogue=%d", d->C0, d->C1,
+                    d->Cout, d->Cout2, d->epilogue);
+        return rc;
+    }
+    V2X_REQUIRE(d->Cout2 == 0, "v2x_conv2d: chained 1x1 needs the halo layout (w_layout=1)");
     V2X_REQUIRE(d->in0 && d->weight && d->scale && d->out, "v2x_conv2d: null tensor pointer");
     V2X_REQUIRE(d->C0 > 0 && d->C0 % 8 == 0 && d->C1 >= 0 && d->C1 % 8 == 0, "v2x_conv2d: C0=%d C1=%d must be multiples of 8", d->C0, d->C1);
     V2X_REQUIRE(d->C1 == 0 || d->in1, "v2x_conv2d: C1 > 0 needs in1");

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU = 0, 1, 2
 V2X_FUSE_WSUM, V2X_FUSE_MEAN = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(C.Structure):
@@ -27,6 +27,8 @@ class ConvDesc(C.Structure):
         ("epilogue", C.c_int32), ("relu", C.c_int32),
         ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
         ("out2", C.c_void_p), ("split", C.c_int32), ("out2_cstride", C.c_int32),
+        ("w_layout", C.c_int32), ("Cout2", C.c_int32),
+        ("weight2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("relu2", C.c_int32),
     ]
 
 

@@ -97,7 +97,7 @@ class When2com(IntermediateModelBase):
         tower = qk.lidar_encoder.pack("query_key_net.lidar_encoder.", device)
         for i in range(1, 6):
             u = getattr(qk, "conv%d" % i).cbr_unit
-            tower.append(packing.pack_conv_bn("query_key_net.conv%d" % i, u[0], u[1], device=device))
+            tower.append(packing.layer_conv_bn("query_key_net.conv%d" % i, u[0], u[1], device=device))
         lin = self.attention_net.linear
         return {"enc": self.u_encoder.pack("u_encoder.", device),
                 "dec": self.decoder.pack("decoder.", device),
@@ -124,8 +124,8 @@ class When2com(IntermediateModelBase):
         """Policy tower + key/query MLPs + attention scores.  -> prob, coef (B, A_key, A_query)."""
         n_enc = len(pk["tower"]) - 5
         y = LidarEncoder.run(pk["tower"][:n_enc], x0)[4]
-        for pc in pk["tower"][n_enc:]:
-            y = ops.conv2d(pc, y)
+        for layer in pk["tower"][n_enc:]:
+            y = ops.run_layer(layer, y)
         keys = KmGenerator.run(pk["key"], y)
         querys = KmGenerator.run(pk["query"], y)
         return ops.attn_handshake(keys, querys, pk["w_lin"], pk["b_lin"], self.agent_num, batch_size, mode)

@@ -15,6 +15,7 @@ import torch.nn as nn
 from ... import ops, packing
 from ...ops import V2X_EPI_BF16, V2X_EPI_F32  # noqa: F401
 
+INPUT_C_PAD = 32  # BEV height bins (13) zero-padded to one MFMA k-step of channels
 LAYER_SHAPES = {0: (32, 256, 256), 1: (64, 128, 128), 2: (128, 64, 64), 3: (256, 32, 32), 4: (512, 16, 16)}
 
 
@@ -56,32 +57,41 @@ class LidarEncoder(_ParamsOnly):
             setattr(self, "bn" + n, nn.BatchNorm2d(c))
 
     def pack(self, prefix, device):
-        cin_pad = (self.height_feat_size + 7) // 8 * 8
-        P = packing.pack_conv_bn
-        plan = [P(prefix + "conv_pre_1", self.conv_pre_1, self.bn_pre_1, cin_pad=cin_pad, device=device),
-                P(prefix + "conv_pre_2", self.conv_pre_2, self.bn_pre_2, device=device)]
+        """-> list of ops.Layer.  Full-resolution layers carry a halo-kernel packing next to the
+        gather-kernel one; conv1_2 + the 1x1x1 conv3d_1 are one fused layer when the halo kernel runs."""
+        L = packing.layer_conv_bn
+        cin_pad = INPUT_C_PAD
+        plan = [L(prefix + "conv_pre_1", self.conv_pre_1, self.bn_pre_1, cin_pad=cin_pad, device=device),
+                L(prefix + "conv_pre_2", self.conv_pre_2, self.bn_pre_2, device=device)]
         for lvl in ("1", "2", "3", "4"):
-            plan.append(P(prefix + "conv%s_1" % lvl, getattr(self, "conv%s_1" % lvl), getattr(self, "bn%s_1" % lvl),
-                          device=device))
-            plan.append(P(prefix + "conv%s_2" % lvl, getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl),
-                          device=device))
+            c1, b1 = getattr(self, "conv%s_1" % lvl), getattr(self, "bn%s_1" % lvl)
+            c2, b2 = getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl)
+            plan.append(L(prefix + "conv%s_1" % lvl, c1, b1, device=device))
             if lvl in ("1", "2"):
                 c3 = getattr(self, "conv3d_" + lvl)
-                plan.append(P(prefix + "conv3d_" + lvl, c3.conv3d, c3.bn3d, device=device))
+                fb = [packing.pack_conv_bn(prefix + "conv%s_2" % lvl, c2, b2, device=device),
+                      packing.pack_conv_bn(prefix + "conv3d_" + lvl, c3.conv3d, c3.bn3d, device=device)]
+                halo = None
+                if lvl == "1":  # 64 -> 64 3x3, then 64 -> 64 1x1: chained in the halo kernel's epilogue
+                    s1, t1 = packing.fold_bn(c2.bias, b2, c2.out_channels)
+                    s2, t2 = packing.fold_bn(c3.conv3d.bias, c3.bn3d, c3.conv3d.out_channels)
+                    halo = packing.pack_conv_halo(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
+                                                  chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
+                plan.append(ops.Layer(fb, halo, name=prefix + "conv%s_2+conv3d_%s" % (lvl, lvl)))
+            else:
+                plan.append(L(prefix + "conv%s_2" % lvl, c2, b2, device=device))
         return plan
 
     @staticmethod
     def run(plan, x):
-        """x: (N, 256, 256, c_pad) bf16 NHWC -> [x, x_1, x_2, x_3, x_4]."""
+        """x: (N, 256, 256, INPUT_C_PAD) bf16 NHWC -> [x, x_1, x_2, x_3, x_4]."""
         it = iter(plan)
-        x = ops.conv2d(next(it), x)
-        x = ops.conv2d(next(it), x)
+        x = ops.run_layer(next(it), x)
+        x = ops.run_layer(next(it), x)
         feats = [x]
         for lvl in range(1, 5):
-            x = ops.conv2d(next(it), x)
-            x = ops.conv2d(next(it), x)
-            if lvl <= 2:
-                x = ops.conv2d(next(it), x)
+            x = ops.run_layer(next(it), x)
+            x = ops.run_layer(next(it), x)
             feats.append(x)
         return feats
 
@@ -105,12 +115,12 @@ class LidarDecoder(_ParamsOnly):
             setattr(self, "bn" + n, nn.BatchNorm2d(c))
 
     def pack(self, prefix, device):
-        P = packing.pack_conv_bn
+        L = packing.layer_conv_bn
         plan = []
         for lvl, (cup, cskip) in (("5", (512, 256)), ("6", (256, 128)), ("7", (128, 64)), ("8", (64, 32))):
-            plan.append(P(prefix + "conv%s_1" % lvl, getattr(self, "conv%s_1" % lvl), getattr(self, "bn%s_1" % lvl),
+            plan.append(L(prefix + "conv%s_1" % lvl, getattr(self, "conv%s_1" % lvl), getattr(self, "bn%s_1" % lvl),
                           C0=cup, C1=cskip, up0=1, device=device))
-            plan.append(P(prefix + "conv%s_2" % lvl, getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl),
+            plan.append(L(prefix + "conv%s_2" % lvl, getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl),
                           device=device))
         return plan
 
@@ -119,8 +129,8 @@ class LidarDecoder(_ParamsOnly):
         it = iter(plan)
         y = x_4
         for skip in (x_3, x_2, x_1, x):
-            y = ops.conv2d(next(it), y, skip)
-            y = ops.conv2d(next(it), y)
+            y = ops.run_layer(next(it), y, skip)
+            y = ops.run_layer(next(it), y)
         return y
 
 
@@ -191,21 +201,35 @@ class DetModelBase(nn.Module):
 
     # ---- shared pieces --------------------------------------------------------------------
     def _pack_heads(self, device):
+        """cls | reg hidden 3x3 (32 -> 64) chained with the block-diagonal 1x1 (64 -> 12 + 36): one halo
+        launch writes both fp32 logit tensors; the gather-kernel pair is the fallback for odd extents."""
         bp = self.regression.box_prediction
-        return packing.pack_heads("heads", self.classification.conv1, self.classification.bn1,
-                                  self.classification.conv2, bp[0], bp[1], bp[3], device=device)
+        c = self.classification
+        hidden, final, ncls = packing.pack_heads("heads", c.conv1, c.bn1, c.conv2, bp[0], bp[1], bp[3], device=device)
+        s1, t1 = packing.fold_bn(c.conv1.bias, c.bn1, c.conv1.out_channels)
+        s2, t2 = packing.fold_bn(bp[0].bias, bp[1], bp[0].out_channels)
+        w1 = torch.cat([c.conv1.weight.detach().float().cpu(), bp[0].weight.detach().float().cpu()], 0)
+        hc, hr = c.conv1.out_channels, bp[0].out_channels
+        nreg = bp[3].out_channels
+        w2 = torch.zeros((ncls + nreg, hc + hr, 1, 1), dtype=torch.float32)
+        w2[:ncls, :hc] = c.conv2.weight.detach().float().cpu()
+        w2[ncls:, hc:] = bp[3].weight.detach().float().cpu()
+        b2 = torch.cat([c.conv2.bias.detach().float().cpu(), bp[3].bias.detach().float().cpu()])
+        halo = None
+        if (hc + hr, ncls + nreg) == (64, 48):
+            halo = packing.pack_conv_halo("heads.fused", w1, torch.cat([s1, s2]), torch.cat([t1, t2]), relu=True,
+                                          chain=(w2, torch.ones(ncls + nreg), b2, False), epilogue=V2X_EPI_F32,
+                                          device=device)
+        return ops.Layer([hidden, final], halo, split=ncls, name="heads")
 
     def _input_nhwc(self, bevs):
         """(N, 1, X, Y, Z) fp32 dense BEV (the reference Dataset format) -> (N, X, Y, c_pad) bf16."""
         if bevs.dim() != 5 or bevs.shape[1] != 1:
             raise ValueError("bevs must be (batch*agents, 1, X, Y, Z); got %s" % (tuple(bevs.shape),))
-        c_pad = (bevs.shape[-1] + 7) // 8 * 8
-        return ops.dense_to_nhwc(bevs[:, 0].to(torch.float32).contiguous(), c_pad)
+        return ops.dense_to_nhwc(bevs[:, 0].to(torch.float32).contiguous(), INPUT_C_PAD)
 
     def get_cls_loc_result(self, x, heads):
-        hidden, final, ncls = heads
-        h = ops.conv2d(hidden, x)
-        cls, loc = ops.conv2d(final, h, split=ncls)  # fp32 NHWC == upstream's permute(0, 2, 3, 1)
+        cls, loc = ops.run_layer(heads, x)  # fp32 NHWC == upstream's permute(0, 2, 3, 1)
         n = cls.shape[0]
         cls_preds = cls.view(n, -1, self.category_num)
         loc_preds = loc.view(-1, loc.size(1), loc.size(2), self.anchor_num_per_loc, self.out_seq_len,

@@ -43,6 +43,11 @@ _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 12
 
 def conv_kernel_name(pc):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
+    if pc.w_layout == 1:
+        c0, c1 = (pc.C0, pc.C1) if pc.C1 else (0, pc.C0)
+        co2 = (pc.Cout2 + 15) // 16 * 16 if pc.Cout2 else 0
+        e2 = 0 if not pc.Cout2 else (2 if pc.epilogue == V2X_EPI_F32 else 1)
+        return "conv3x3_halo_kernel<%d, %d, %d, %d, %d>" % (c0, c1, pc.Cout, co2, e2)
     rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
     return "conv_igemm_kernel<%d, %d, %d, %d, %d>" % (_CONV_TILES[rows] + (pc.epilogue,))
 
@@ -142,7 +147,7 @@ class PackedConv:
     """Device-resident packed parameters of one conv layer (see packing.py)."""
 
     __slots__ = ("weight", "scale", "shift", "C0", "C1", "Cout", "ksize", "stride", "pad", "up0", "epilogue", "relu",
-                 "w_rows", "w_kpad", "name")
+                 "w_rows", "w_kpad", "name", "w_layout", "Cout2", "weight2", "scale2", "shift2", "relu2")
 
     def __init__(self, **kw):
         for k in self.__slots__:
@@ -179,12 +184,13 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0):
         raise ValueError("in0 has %d channels, layer %s expects %d" % (in0.shape[3], pc.name, pc.C0))
     Ho, Wo = conv_out_hw(pc, H, W)
     odt = torch.float32 if pc.epilogue == V2X_EPI_F32 else torch.bfloat16
+    cfin = pc.Cout2 if pc.Cout2 else pc.Cout  # channels of the tensor that is actually written
     out2 = None
     if split:
         out = torch.empty((N, Ho, Wo, split), dtype=odt, device=in0.device)
-        out2 = torch.empty((N, Ho, Wo, pc.Cout - split), dtype=odt, device=in0.device)
+        out2 = torch.empty((N, Ho, Wo, cfin - split), dtype=odt, device=in0.device)
     elif out is None:
-        out = torch.empty((N, Ho, Wo, pc.Cout), dtype=odt, device=in0.device)
+        out = torch.empty((N, Ho, Wo, cfin), dtype=odt, device=in0.device)
     elif tuple(out.shape[:3]) != (N, Ho, Wo):
         raise ValueError("out shape %s != %s" % (tuple(out.shape), (N, Ho, Wo, "*")))
     d.C0, d.C1, d.up0 = pc.C0, pc.C1, pc.up0
@@ -199,14 +205,19 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0):
     d.out_cstride, d.out_coff = out.shape[3], out_coff
     if split:
         d.out2, d.split, d.out2_cstride = out2.data_ptr(), split, out2.shape[3]
+    d.w_layout = pc.w_layout or 0
+    if pc.Cout2:
+        d.Cout2, d.relu2 = pc.Cout2, int(bool(pc.relu2))
+        d.weight2, d.scale2, d.shift2 = pc.weight2.data_ptr(), pc.scale2.data_ptr(), pc.shift2.data_ptr()
     prof = None
     if PROFILE is not None:
         rows_logical = 3 * pc.Cout if pc.epilogue == V2X_EPI_GRU else pc.Cout
         k_logical = pc.ksize * pc.ksize * (pc.C0 + pc.C1)
         M = N * Ho * Wo
         nbytes = in0.numel() * 2 + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
-            + M * pc.Cout * (4 if pc.epilogue == V2X_EPI_F32 else 2)
-        prof = _Prof(conv_kernel_name(pc), 2.0 * M * rows_logical * k_logical, nbytes)
+            + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
+        flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
+        prof = _Prof(conv_kernel_name(pc), flops, nbytes)
     rc = lib.v2x_conv2d(C.byref(d), _stream())
     if prof is not None:
         prof.done()
@@ -266,3 +277,33 @@ def seg_argmax_confusion(logits, label=None, want_pred=True):
         n, H, W, ncls, _dev(pred, torch.uint8, "pred") if pred is not None else None,
         _dev(conf, torch.int64, "conf") if conf is not None else None, _stream()), "v2x_seg_argmax_confusion")
     return pred, conf
+
+
+# ------------------------------------------------------------------ layer = halo kernel when eligible, else gather kernel(s)
+class Layer:
+    """One logical layer (possibly a fused pair).  `halo` is the k-slot-major packing for
+    conv_halo.hip (3x3 stride 1, H % 8 == 0, W % 32 == 0); `fallback` is the list of gather-kernel
+    convs computing the same thing for any other extent.  `split` > 0: two output tensors."""
+
+    __slots__ = ("halo", "fallback", "split", "name")
+
+    def __init__(self, fallback, halo=None, split=0, name=None):
+        self.fallback, self.halo, self.split = list(fallback), halo, split
+        self.name = name or self.fallback[0].name
+
+
+def halo_eligible(H, W):
+    return H % 8 == 0 and W % 32 == 0
+
+
+def run_layer(layer, in0, in1=None):
+    if in1 is not None:
+        H, W = in1.shape[1], in1.shape[2]
+    else:
+        H, W = in0.shape[1], in0.shape[2]
+    if layer.halo is not None and halo_eligible(H, W):
+        return conv2d(layer.halo, in0, in1, split=layer.split)
+    y = conv2d(layer.fallback[0], in0, in1, split=layer.split if len(layer.fallback) == 1 else 0)
+    for i, pc in enumerate(layer.fallback[1:], 1):
+        y = conv2d(pc, y, split=layer.split if i == len(layer.fallback) - 1 else 0)
+    return y

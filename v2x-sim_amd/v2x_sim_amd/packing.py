@@ -122,3 +122,70 @@ def pack_gru(name, weight_ih, bias_ih, bias_hh, *, C0, C1, device="cuda"):
     return PackedConv(name=name, weight=wp.to(torch.bfloat16).to(device).contiguous(), scale=bias4.to(device),
                       shift=None, C0=C0, C1=C1, Cout=hid, ksize=k, stride=1, pad=(k - 1) // 2, up0=0,
                       epilogue=V2X_EPI_GRU, relu=False, w_rows=groups * 48, w_kpad=kpad)
+
+
+# ------------------------------------------------------------------ halo-tile kernel layouts (conv_halo.hip)
+def _chain_row_order(cout):
+    """packed row rho = 16*i + 4*q + r  computes hidden channel  kappa = 32*(i>>1) + 8*q + 4*(i&1) + r."""
+    rho = torch.arange(cout)
+    i, q, r = rho >> 4, (rho >> 2) & 3, rho & 3
+    return 32 * (i >> 1) + 8 * q + 4 * (i & 1) + r
+
+
+def pack_conv_halo(name, weight, scale, shift, *, C0=None, C1=0, relu=True, cin_pad=None, chain=None,
+                   epilogue=V2X_EPI_BF16, device="cuda"):
+    """3x3 stride-1 conv for the halo kernel: weights k-slot-major [9*Cin/8][Cout][8].
+    chain = (weight2 [Cout2, Cout, 1, 1], scale2, shift2, relu2): 1x1 conv fused in the epilogue; the
+    hidden rows are then stored in the kernel's chain order (scale/shift stay in natural order)."""
+    w = weight.detach().float().cpu()
+    cout, cin, k, _ = w.shape
+    if k != 3:
+        raise ValueError("halo kernel is 3x3 only")
+    cin_p = cin if cin_pad is None else cin_pad
+    if C0 is None:
+        C0 = cin_p
+    if C0 + C1 != cin_p or cin_p % 32 or cout % 32:
+        raise ValueError("%s: halo kernel needs C0+C1 == Cin (multiple of 32) and Cout %% 32 == 0" % name)
+    w = w.permute(0, 2, 3, 1)
+    if cin_p != cin:
+        w = torch.nn.functional.pad(w, (0, cin_p - cin))
+    K = 9 * cin_p
+    wk = w.reshape(cout, K)
+    if chain is not None:
+        wk = wk[_chain_row_order(cout)]
+    wp = wk.view(cout, K // 8, 8).permute(1, 0, 2).contiguous()  # [kslot][cout][8]
+    pc = PackedConv(name=name, weight=wp.to(torch.bfloat16).to(device).contiguous(),
+                    scale=scale.detach().float().to(device).contiguous(),
+                    shift=shift.detach().float().to(device).contiguous(), C0=C0, C1=C1, Cout=cout, ksize=3,
+                    stride=1, pad=1, up0=1 if C1 else 0, epilogue=epilogue, relu=relu, w_rows=cout, w_kpad=K,
+                    w_layout=1, Cout2=0)
+    if chain is not None:
+        w2, s2, t2, relu2 = chain
+        w2 = w2.detach().float().cpu().reshape(w2.shape[0], cout)
+        c2 = w2.shape[0]
+        c2p = _ceil_to(c2, 16)
+        w2p = torch.zeros((c2p, cout), dtype=torch.float32)
+        w2p[:c2] = w2
+        s2p, t2p = torch.zeros(c2p), torch.zeros(c2p)
+        s2p[:c2], t2p[:c2] = s2, t2
+        pc.Cout2, pc.relu2 = c2, relu2
+        pc.weight2 = w2p.to(torch.bfloat16).to(device).contiguous()
+        pc.scale2, pc.shift2 = s2p.to(device), t2p.to(device)
+    return pc
+
+
+def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
+    """conv+BN(+ReLU) as an ops.Layer: gather-kernel packing always, halo packing when the layer is
+    3x3 stride 1 with <= 96 input channels (the kernel instantiations that exist)."""
+    from .ops import Layer
+    fb = pack_conv_bn(name, conv, bn, relu=relu, device=device, **kw)
+    h = None
+    cin_p = fb.C0 + fb.C1
+    if halo and conv.kernel_size[-1] == 3 and conv.stride[-1] == 1 and conv.out_channels % 32 == 0:
+        scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
+        cin_h = _ceil_to(cin_p, 32)
+        key = (fb.C0 if fb.C1 else 0, fb.C1 if fb.C1 else cin_h, conv.out_channels)
+        if key in ((0, 32, 32), (64, 32, 32), (0, 64, 64)):
+            h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
+                               cin_pad=cin_h if not fb.C1 else None, device=device)
+    return Layer([fb], h, name=name)

@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 from . import ops
 from ._lib import V2X_FUSE_MEAN
-from .models.det.base import LidarDecoder, LidarEncoder
+from .models.det.base import INPUT_C_PAD, LidarDecoder, LidarEncoder
 
 
 class AgentShard:
@@ -79,7 +79,7 @@ class ShardedV2VNet:
         """points (L, max_pts, stride) fp32 of this rank's items -> encoder pyramid."""
         X, Y, Z = self.grid.dims
         bits = ops.voxelize_bits(points, n_pts, self.grid)
-        x0 = ops.bits_to_nhwc(bits, Z, (Z + 7) // 8 * 8)
+        x0 = ops.bits_to_nhwc(bits, Z, INPUT_C_PAD)
         return LidarEncoder.run(pk["enc"], x0)
 
     def fuse_local(self, feats, trans, plan, pk):
