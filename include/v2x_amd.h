@@ -111,6 +111,8 @@ typedef struct v2x_conv_desc {
     /* --- halo-tile kernel (conv_halo.hip): 3x3 stride-1 layers with <= 96 input channels ------ */
     int32_t w_layout;    /* 0: row-major [w_rows][w_kpad] (gather kernel)                          */
                          /* 1: k-slot-major [9*Cin/8][Cout][8] (halo kernel; H%8==0, W%32==0)      */
+                         /* 2: streamed slices [co_tile][Cin/32][9][4][rows][8] (conv_stream.hip:    */
+                         /*    3x3 stride 1, C0,C1 % 32 == 0, tiles 8x32 or 16x16)                  */
     int32_t Cout2;       /* > 0: chain a 1x1 conv on the (never stored) Cout-channel result:       */
     const uint16_t *weight2; /* bf16 [ceil16(Cout2)][Cout] row-major; `epilogue`/`split`/out* then  */
     const float *scale2; /*   describe the FINAL output, scale/shift/relu the hidden layer and     */
@@ -120,6 +122,8 @@ typedef struct v2x_conv_desc {
 
 /* Rows-per-tile the kernel will use for (Cout, epilogue); the weight packer pads w_rows to a multiple. */
 int v2x_conv_tile_rows(int Cout, int epilogue);
+/* Same for the streamed-weights kernel (w_layout 2); 0 = that kernel does not cover (Cout, epilogue). */
+int v2x_conv_stream_tile_rows(int Cout, int epilogue);
 int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- a3 (+ the sum of a4/a5): warp + fuse

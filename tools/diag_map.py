@@ -1,0 +1,34 @@
+"""Diagnostic: HIP-vs-oracle mAP gap as a function of score quantile / NMS threshold (random weights)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "v2x-sim_amd"))
+import numpy as np, torch
+from oracle import coperception_ref as R, voxelize_ref as VR
+from v2x_sim_amd.configs import Config
+from v2x_sim_amd.models.det import V2VNet
+from v2x_sim_amd.utils import postprocess as P
+from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
+dev = torch.device("cuda:0"); A, B = 5, 1; cfg = Config("test")
+pm = init_synthetic_weights(V2VNet(cfg), seed=0); om = R.V2VNet().eval(); om.load_state_dict(pm.state_dict()); pm = pm.to(dev)
+pts = synthetic_points(A, 20000, seed=41)
+bev = torch.from_numpy(np.stack([VR.voxelize_occupy(p) for p in pts])[:, None])
+T = torch.from_numpy(synthetic_poses(B, A, seed=42)); nat = torch.full((B, A), A)
+with torch.no_grad():
+    ref = om(bev, T, nat, batch_size=B); got = pm(bev.to(dev), T.to(dev), nat, batch_size=B)
+    om.emulate_bf16 = True; emu = om(bev, T, nat, batch_size=B)
+anchors = P.build_anchor_map(cfg)
+fg_ref = P.softmax_fg(ref["cls"].numpy().reshape(-1, 2)); fg_hip = P.softmax_fg(got["cls"].float().cpu().numpy().reshape(-1, 2))
+print("fg score: mean %.3f std %.3f ; |hip-ref| mean %.4f max %.4f" % (fg_ref.mean(), fg_ref.std(), np.abs(fg_hip - fg_ref).mean(), np.abs(fg_hip - fg_ref).max()))
+for q, nms in ((0.997, 0.01), (0.99, 0.1), (0.98, 0.3), (0.95, 0.5)):
+    thr = float(np.quantile(fg_ref, q))
+    def dets(r):
+        return [P.apply_nms_det(r["loc"][k].float().cpu().numpy(), r["cls"][k].float().cpu().numpy(), anchors, thr, nms) for k in range(A)]
+    d_ref, d_hip, d_emu = dets(ref), dets(got), dets(emu)
+    rng = np.random.default_rng(7); gts = []
+    for d in d_ref:
+        b = d["boxes"][::2].copy(); b[:, :2] += rng.normal(0, 0.15, (b.shape[0], 2)); b[:, 2:4] *= rng.uniform(0.9, 1.1, (b.shape[0], 2)); b[:, 4] += rng.normal(0, 0.05, b.shape[0])
+        gts.append(P.box_corners(b))
+    for iou in (0.5, 0.7):
+        a_ref, info = P.eval_map(d_ref, gts, iou); a_hip, _ = P.eval_map(d_hip, gts, iou); a_emu, _ = P.eval_map(d_emu, gts, iou)
+        print("q=%.3f nms=%.2f thr=%.3f  mAP@%.1f: oracle-fp32 %.2f  oracle-bf16emu %.2f  HIP %.2f  (gt %d, det %d/%d/%d)" % (
+            q, nms, thr, iou, 100 * a_ref, 100 * a_emu, 100 * a_hip, info["num_gt"], sum(len(d["scores"]) for d in d_ref), sum(len(d["scores"]) for d in d_emu), sum(len(d["scores"]) for d in d_hip)))

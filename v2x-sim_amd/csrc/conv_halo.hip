@@ -65,7 +65,7 @@ constexpr int round64(int v) { return (v + 63) / 64 * 64; }
 
 // EPI2: 0 = none (plain epilogue, bf16 out), 1 = chained 1x1 with bf16 out, 2 = chained 1x1 with fp32 split out
 template <int C0, int C1, int COUT, int COUT2, int EPI2>
-__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const HaloArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const HaloArgs a) {
     constexpr int SPP0 = C0 / 8, SPP1 = C1 / 8;
     constexpr int NS1 = round64(PH * PW * SPP1);            // 16-B slots of the full-res patch (padded to whole waves)
     constexpr int NS0 = C0 ? round64(PH0 * PW0 * SPP0) : 0; // ... of the half-res patch
@@ -364,7 +364,6 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     HALO_CASE(0, 64, 64, 0, 0)    // conv7_2
     HALO_CASE(0, 64, 64, 64, 1)   // conv1_2 -> conv3d_1
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
-    HALO_CASE(0, 32, 32, 16, 2)   // seg: conv8_2 -> outc (8 classes, fp32)
 #undef HALO_CASE
     return 1;
 }

@@ -326,7 +326,8 @@ static int dispatch_rows(const ConvArgs &a, int rows, hipStream_t s) {
     }
 }
 
-int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s);  // conv_halo.hip
+int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s);    // conv_halo.hip
+int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s);  // conv_stream.hip
 
 extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
     V2X_REQUIRE(d, "v2x_conv2d: null descriptor");
@@ -359,6 +360,24 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
         return rc;
     }
     V2X_REQUIRE(d->Cout2 == 0, "v2x_conv2d: chained 1x1 needs the halo layout (w_layout=1)");
+    if (d->w_layout == 2) {
+        V2X_REQUIRE(d->in0 && d->weight && d->scale && d->out, "v2x_conv2d(stream): null tensor pointer");
+        V2X_REQUIRE(d->epilogue == V2X_EPI_GRU || d->shift, "v2x_conv2d(stream): null shift");
+        V2X_REQUIRE(d->ksize == 3 && d->stride == 1 && d->pad == 1, "v2x_conv2d(stream): 3x3 stride 1 pad 1 only");
+        V2X_REQUIRE(d->C0 > 0 && d->C0 % 32 == 0 && d->C1 >= 0 && d->C1 % 32 == 0 && (d->C1 == 0 || d->in1),
+                    "v2x_conv2d(stream): C0=%d, C1=%d must be multiples of 32", d->C0, d->C1);
+        V2X_REQUIRE(d->up0 == 0 || (d->up0 == 1 && d->H % 2 == 0 && d->W % 2 == 0), "v2x_conv2d(stream): bad up0");
+        V2X_REQUIRE(d->N > 0 && (long long)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 32),
+                    "v2x_conv2d(stream): tensor exceeds 32-bit element offsets");
+        const int rows = v2x_conv_stream_tile_rows(d->Cout, d->epilogue);
+        const int need = d->epilogue == V2X_EPI_GRU ? 3 * d->Cout : d->Cout;
+        V2X_REQUIRE(rows > 0 && d->w_rows == need && d->w_rows % rows == 0 && d->split == 0 &&
+                    d->out_cstride >= d->out_coff + d->Cout && d->out_coff >= 0,
+                    "v2x_conv2d(stream): unsupported Cout=%d / w_rows=%d / output window", d->Cout, d->w_rows);
+        const int rc = v2x_conv_stream_dispatch(d, (hipStream_t)stream);
+        V2X_REQUIRE(rc != 1, "v2x_conv2d(stream): extent %dx%d not tileable (8x32 or 16x16 tiles)", d->H, d->W);
+        return rc;
+    }
     V2X_REQUIRE(d->in0 && d->weight && d->scale && d->out, "v2x_conv2d: null tensor pointer");
     V2X_REQUIRE(d->C0 > 0 && d->C0 % 8 == 0 && d->C1 >= 0 && d->C1 % 8 == 0, "v2x_conv2d: C0=%d C1=%d must be multiples of 8", d->C0, d->C1);
     V2X_REQUIRE(d->C1 == 0 || d->in1, "v2x_conv2d: C1 > 0 needs in1");

@@ -1,0 +1,304 @@
+// Streamed-weights halo kernel: 3x3 stride-1 convolutions with MANY channels
+// (conv2_2 .. conv7_1 and the ConvGRU of upstream Backbone.py / V2VNet.py; code absent from
+// /root/reference, see include/v2x_amd.h).
+//
+// The gather kernel (conv_igemm.hip) moves 32 KiB through L2->LDS per 2.1 MFLOP (64 FLOP/B) and tops
+// out near 8.7 TB/s of LDS-DMA traffic (~600-800 TFLOP/s).  Here a workgroup owns a 256-pixel spatial
+// tile x BCO output channels and walks K as (32-channel chunk) x (9 taps):
+//   * the (TH+2)x(TW+2) input patch of a channel chunk is DMA'd into LDS ONCE and serves all 9 taps
+//     (for the x2-upsampled decoder source the patch is the half-resolution one: upsample + concat are
+//     address arithmetic on patch coordinates);
+//   * the weights of one (chunk, tap) are an 8 KiB slice [4 k-slots][BCO][8] streamed through a 4-slot
+//     LDS ring, prefetch distance 3, with COUNTED s_waitcnt vmcnt(N) and raw s_barrier (the compiler's
+//     __syncthreads would drain the DMA queue every step -- cdna_hip_programming.md, "Pipelining across
+//     barriers");  every step a wave issues exactly NW weight DMAs + 1 patch DMA, so the counts are static;
+//   * per step a wave does (BCO/16) x 4 MFMAs 16x16x32 from BCO/16 + 4 ds_read_b128 -> ~200 FLOP per
+//     L2 byte, 3x the gather kernel.
+// LDS: 4 x 8 KiB ring + 2 x 24 KiB patch buffers = 80 KiB -> two workgroups per CU (160 KiB).
+// LDS layouts as conv_halo.hip (conflict-free: patch slot ^ ((x>>1)&3), weights k-slot-major).
+#include "common.h"
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void glds16s(const void *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+struct StreamArgs {
+    const uint16_t *in0, *in1;  // in0: first C0 channels (half resolution when up0), in1: next C1 channels
+    int C0, C1, up0;
+    int N, H, W;
+    const uint16_t *w;  // [n_co_tiles][n_chunks][9][4][BCO][8] bf16, followed by 64 B of zeros (the zero page)
+    const float *scale, *shift;
+    int relu;
+    void *out;
+    int out_cstride, out_coff, Cout;
+    int tiles_x, tiles_y, n_px_tiles, n_co_tiles;
+};
+
+constexpr int PATCH_PIECES = 24;             // wave instructions (1 KiB each) per patch buffer
+constexpr int PATCH_BYTES = PATCH_PIECES * 1024;
+constexpr int RING = 4;                      // weight slices in flight + 1 being read
+
+enum { SEPI_BF16 = 0, SEPI_GRU = 2 };
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BCO, int TH, int TW, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream_kernel(const StreamArgs a) {
+    constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
+    constexpr int TCO = BCO / 16;
+    constexpr int W_PIECES = BCO / 16;        // 1 KiB pieces per weight slice (BCO rows x 64 B)
+    constexpr int SLICE_BYTES = BCO * 64;
+    static_assert(PH * PW * 4 <= (PATCH_PIECES - 1) * 64, "patch must fit its buffer and leave the last piece as padding");
+    static_assert(TH * TW == 256 && (TW == 32 || TW == 16), "256-pixel tiles: 8x32 or 16x16");
+    static_assert(W_PIECES >= 4 && W_PIECES <= 8, "1 or 2 weight DMAs per wave per step");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_ring = smem;                              // RING x SLICE_BYTES
+    char *s_patch = smem + RING * SLICE_BYTES;        // 2 x PATCH_BYTES
+    char *s_dummy = s_patch + (PATCH_PIECES - 1) * 1024;  // count-keeping dummy DMAs land in patch padding (never read)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15, fq = lane >> 4;
+    const int NW = (wave + 4 < W_PIECES) ? 2 : 1;     // weight DMAs this wave issues per step (wave-uniform)
+
+    // XCD-aware order (see conv_igemm.hip)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int co_tile = bid % a.n_co_tiles;
+    const int px_tile = bid / a.n_co_tiles;
+    const int txy = a.tiles_x * a.tiles_y;
+    const int n = px_tile / txy;
+    const int trem = px_tile - n * txy;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    const int nc0 = a.C0 >> 5, nchunks = (a.C0 + a.C1) >> 5;
+    const int S = nchunks * 9;
+    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    // zero page for out-of-image patch pixels and count-keeping dummy DMAs: the packer appends 64 B of zeros
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+
+    // ---- DMA issue helpers -------------------------------------------------------------------------
+    auto issue_weights = [&](int s) {  // slice of step s -> ring slot s % RING ; NW instructions
+        char *dst = s_ring + (s & (RING - 1)) * SLICE_BYTES;
+        const uint16_t *src = wbase + (size_t)s * (BCO * 32) + lane * 8;
+        glds16s(src + wave * 512, dst + wave * 1024);
+        if (NW == 2) glds16s(src + (wave + 4) * 512, dst + (wave + 4) * 1024);
+    };
+    auto issue_patch_piece = [&](int kc, int piece, int buf) {  // one 1-KiB piece of chunk kc's patch
+        // branch-free: every source / resolution choice is a wave-uniform select
+        char *dst = s_patch + buf * PATCH_BYTES + piece * 1024;
+        const int L = piece * 64 + lane;
+        const int pix = L >> 2, phys = L & 3;
+        const bool first = kc < nc0;
+        const bool hf = first && a.up0;
+        const int sh = hf ? 1 : 0;
+        const int pw = hf ? PW0 : PW, npix = hf ? PH0 * PW0 : PH * PW;
+        const int pr = hf ? pix / PW0 : pix / PW;
+        const int pc = pix - pr * pw;
+        const int Hs = a.H >> sh, Ws = a.W >> sh;
+        const int y = (y0 >> sh) - 1 + pr, x = (x0 >> sh) - 1 + pc;
+        const bool ok = pix < npix && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        const uint16_t *src = first ? a.in0 : a.in1;
+        const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
+        const unsigned coff = (unsigned)((first ? kc : kc - nc0) * 32 + ((phys ^ ((pc >> 1) & 3)) << 3));
+        const unsigned off = ((unsigned)(n * Hs + y) * (unsigned)Ws + (unsigned)x) * cs + coff;
+        glds16s(ok ? (const void *)(src + off) : zero_page, dst);
+    };
+    auto issue_dummy = [&]() { glds16s(zero_page, s_dummy); };
+
+    // ---- prologue: whole patch of chunk 0 (6 pieces per wave), weight slices of steps 0..2 --------
+#pragma unroll
+    for (int t = 0; t < 6; ++t) issue_patch_piece(0, wave + 4 * t, 0);
+    issue_weights(0);  // S = 9 * chunks >= 9, so steps 1 and 2 always exist
+    issue_weights(1);
+    issue_weights(2);
+
+    f32x4_t acc[TCO][4];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // per-lane pixel coordinates of the 4 fragments
+    int frow[4], fcol[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        if constexpr (TW == 32) {
+            frow[f] = 2 * wave + (f >> 1);
+            fcol[f] = (f & 1) * 16 + fj;
+        } else {
+            frow[f] = 4 * wave + f;
+            fcol[f] = fj;
+        }
+    }
+
+    int s = 0;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const char *pb = s_patch + (kc & 1) * PATCH_BYTES;
+        const bool half = (kc < nc0) && a.up0;
+#pragma unroll 1  // keep the 9 taps rolled: unrolling hoists 72 per-tap LDS offsets and spills (scratch traffic
+                  // would also corrupt the vmcnt bookkeeping below)
+        for (int tap = 0; tap < 9; ++tap, ++s) {
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            // 1. wait for this step's weight slice (and, at tap 0, the chunk's patch): everything older than
+            //    the two most recent groups has landed.  group = NW weight DMAs + 1 patch/dummy DMA.
+            if (s + 3 >= S) wait_vmcnt<0>();                  // tail: nothing (or not everything) is issued below
+            else if (s < 2) { if (NW == 2) wait_vmcnt<4>(); else wait_vmcnt<2>(); }
+            else { if (NW == 2) wait_vmcnt<6>(); else wait_vmcnt<4>(); }
+            // 2. everyone's pieces have landed; everyone is done reading ring slot (s-1) and, at tap 0, the
+            //    other patch buffer
+            __builtin_amdgcn_s_barrier();
+            // 3. keep the pipe full: weight slice of step s+3, one piece of the next chunk's patch
+            if (s + 3 < S) {
+                issue_weights(s + 3);
+                if (tap < 6 && kc + 1 < nchunks) issue_patch_piece(kc + 1, wave + 4 * tap, (kc + 1) & 1);
+                else issue_dummy();
+            }
+            // 4. MFMAs of (chunk kc, tap)
+            const char *ws = s_ring + (s & (RING - 1)) * SLICE_BYTES;
+            bf16x8_t fa[TCO], fb[4];
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+            const int sh = half ? 1 : 0, pw = half ? PW0 : PW;  // wave-uniform: no branches in the step body
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                // full res: (row+ky, col+kx);  half res: floor((row+ky-1)/2)+1, floor((col+kx-1)/2)+1
+                const int pr = ((frow[f] + ky - sh) >> sh) + sh;
+                const int pc = ((fcol[f] + kx - sh) >> sh) + sh;
+                fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + (((pr * pw + pc) << 2) + (fq ^ ((pc >> 1) & 3))) * 16);
+            }
+            // all fragment reads are ISSUED before the first MFMA (hipcc otherwise recycles one A register set
+            // and exposes the LDS latency 8x per step); the MFMAs then wait on counted lgkmcnt as data arrives
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TCO + 4, 0);  // DS reads: all of them first ...
+            __builtin_amdgcn_sched_group_barrier(0x008, TCO * 4, 0);  // ... then the MFMA block
+        }
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------
+    if constexpr (EPI == SEPI_GRU) {
+        // rows are (r,z,n) triples of 16 hidden channels: tiles 3g, 3g+1, 3g+2  (packing.pack_gru_stream)
+#pragma unroll
+        for (int g = 0; g < TCO / 3; ++g) {
+            const int hc = (co_tile * (TCO / 3) + g) * 16 + fq * 4;
+            if (hc >= a.Cout) continue;
+            float4 bias[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[r] = reinterpret_cast<const float4 *>(a.scale)[hc + r];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rg = 1.0f / (1.0f + __expf(-(acc[3 * g][f][r] + bias[r].x)));
+                    const float zg = 1.0f / (1.0f + __expf(-(acc[3 * g + 1][f][r] + bias[r].y)));
+                    const float ng = tanhf(acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w);
+                    h[r] = ng + zg * (0.0f - ng);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(h[0], h[1]);
+                o.y = pack_bf16x2(h[2], h[3]);
+                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + fcol[f];
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + hc) = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int co = co_tile * BCO + i * 16 + fq * 4;
+            if (co >= a.Cout) continue;
+            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
+            const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
+                float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
+                if (a.relu) {
+                    v0 = fmaxf(v0, 0.f);
+                    v1 = fmaxf(v1, 0.f);
+                    v2 = fmaxf(v2, 0.f);
+                    v3 = fmaxf(v3, 0.f);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + fcol[f];
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
+            }
+        }
+    }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+template <int BCO, int TH, int TW, int EPI>
+static int launch_stream(const StreamArgs &a, hipStream_t s) {
+    constexpr int smem = RING * BCO * 64 + 2 * PATCH_BYTES;  // 80 KiB at BCO=128: two workgroups per CU
+    static bool attr_done = false;
+    auto kern = &conv3x3_stream_kernel<BCO, TH, TW, EPI>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_stream_kernel");
+    return V2X_OK;
+}
+
+// rows per channel tile the stream kernel uses for (Cout, epilogue); 0 = unsupported
+extern "C" int v2x_conv_stream_tile_rows(int Cout, int epilogue) {
+    if (epilogue == V2X_EPI_GRU) return (Cout % 32 == 0) ? 96 : 0;
+    if (epilogue != V2X_EPI_BF16) return 0;
+    if (Cout % 128 == 0) return 128;
+    if (Cout % 64 == 0) return 64;
+    return 0;
+}
+
+// Returns V2X_OK if handled, 1 if the shape is not covered.
+int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
+    const int rows = v2x_conv_stream_tile_rows(d->Cout, d->epilogue);
+    if (rows == 0) return 1;
+    const bool t16 = (d->W % 32 != 0);
+    if (t16 ? (d->W % 16 != 0 || d->H % 16 != 0) : (d->H % 8 != 0)) return 1;
+    StreamArgs a;
+    a.in0 = d->in0;
+    a.in1 = d->in1;
+    a.C0 = d->C0;
+    a.C1 = d->C1;
+    a.up0 = d->up0;
+    a.N = d->N;
+    a.H = d->H;
+    a.W = d->W;
+    a.w = d->weight;
+    a.scale = d->scale;
+    a.shift = d->shift;
+    a.relu = d->relu;
+    a.out = d->out;
+    a.out_cstride = d->out_cstride;
+    a.out_coff = d->out_coff;
+    a.Cout = d->Cout;
+    a.tiles_x = d->W / (t16 ? 16 : 32);
+    a.tiles_y = d->H / (t16 ? 16 : 8);
+    a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
+    a.n_co_tiles = d->w_rows / rows;
+    if (d->epilogue == V2X_EPI_GRU) return t16 ? launch_stream<96, 16, 16, SEPI_GRU>(a, s) : launch_stream<96, 8, 32, SEPI_GRU>(a, s);
+    if (rows == 128) return t16 ? launch_stream<128, 16, 16, SEPI_BF16>(a, s) : launch_stream<128, 8, 32, SEPI_BF16>(a, s);
+    return t16 ? launch_stream<64, 16, 16, SEPI_BF16>(a, s) : launch_stream<64, 8, 32, SEPI_BF16>(a, s);
+}

@@ -52,8 +52,12 @@ class V2VNet(IntermediateModelBase):
         return {"enc": self.u_encoder.pack("u_encoder.", device),
                 "dec": self.decoder.pack("decoder.", device),
                 "heads": self._pack_heads(device),
-                "gru": packing.pack_gru("convgru", g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0,
-                                        C0=self.layer_channel, C1=self.layer_channel, device=device)}
+                "gru": ops.Layer(
+                    [packing.pack_gru("convgru", g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0,
+                                      C0=self.layer_channel, C1=self.layer_channel, device=device)],
+                    packing.pack_gru_stream("convgru", g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0,
+                                            C0=self.layer_channel, C1=self.layer_channel, device=device)
+                    if (self.layer_channel % 32 == 0 and packing.STREAM_KERNEL) else None, name="convgru")}
 
     # ---- fusion stage (rows a3 + a4) ------------------------------------------------------
     def make_plan(self, num_agent_tensor, batch_size, device):
@@ -84,7 +88,7 @@ class V2VNet(IntermediateModelBase):
             src = feat if self.neighbor_source == "initial" else cur
             mean = ops.warp_fuse(src, A, batch_size, trans, plan["items"], plan["coef"], V2X_FUSE_MEAN)
             ego = cur if rows is None else cur.index_select(0, rows)
-            h = ops.conv2d(pk["gru"], ego, mean)
+            h = ops.run_layer(pk["gru"], ego, mean)
             if rows is None:
                 cur = h
             else:

@@ -94,10 +94,10 @@ class When2com(IntermediateModelBase):
 
     def _pack(self, device):
         qk = self.query_key_net
-        tower = qk.lidar_encoder.pack("query_key_net.lidar_encoder.", device)
+        tower = {"enc": qk.lidar_encoder.pack("query_key_net.lidar_encoder.", device), "convs": []}
         for i in range(1, 6):
             u = getattr(qk, "conv%d" % i).cbr_unit
-            tower.append(packing.layer_conv_bn("query_key_net.conv%d" % i, u[0], u[1], device=device))
+            tower["convs"].append(packing.layer_conv_bn("query_key_net.conv%d" % i, u[0], u[1], device=device))
         lin = self.attention_net.linear
         return {"enc": self.u_encoder.pack("u_encoder.", device),
                 "dec": self.decoder.pack("decoder.", device),
@@ -122,9 +122,8 @@ class When2com(IntermediateModelBase):
 
     def handshake(self, x0, pk, batch_size, mode):
         """Policy tower + key/query MLPs + attention scores.  -> prob, coef (B, A_key, A_query)."""
-        n_enc = len(pk["tower"]) - 5
-        y = LidarEncoder.run(pk["tower"][:n_enc], x0)[4]
-        for layer in pk["tower"][n_enc:]:
+        y = LidarEncoder.run(pk["tower"]["enc"], x0)[4]
+        for layer in pk["tower"]["convs"]:
             y = ops.run_layer(layer, y)
         keys = KmGenerator.run(pk["key"], y)
         querys = KmGenerator.run(pk["query"], y)

@@ -63,35 +63,36 @@ class LidarEncoder(_ParamsOnly):
         cin_pad = INPUT_C_PAD
         plan = [L(prefix + "conv_pre_1", self.conv_pre_1, self.bn_pre_1, cin_pad=cin_pad, device=device),
                 L(prefix + "conv_pre_2", self.conv_pre_2, self.bn_pre_2, device=device)]
+        levels = [plan]
         for lvl in ("1", "2", "3", "4"):
             c1, b1 = getattr(self, "conv%s_1" % lvl), getattr(self, "bn%s_1" % lvl)
             c2, b2 = getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl)
-            plan.append(L(prefix + "conv%s_1" % lvl, c1, b1, device=device))
-            if lvl in ("1", "2"):
-                c3 = getattr(self, "conv3d_" + lvl)
-                fb = [packing.pack_conv_bn(prefix + "conv%s_2" % lvl, c2, b2, device=device),
-                      packing.pack_conv_bn(prefix + "conv3d_" + lvl, c3.conv3d, c3.bn3d, device=device)]
-                halo = None
-                if lvl == "1":  # 64 -> 64 3x3, then 64 -> 64 1x1: chained in the halo kernel's epilogue
-                    s1, t1 = packing.fold_bn(c2.bias, b2, c2.out_channels)
-                    s2, t2 = packing.fold_bn(c3.conv3d.bias, c3.bn3d, c3.conv3d.out_channels)
-                    halo = packing.pack_conv_halo(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
-                                                  chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
-                plan.append(ops.Layer(fb, halo, name=prefix + "conv%s_2+conv3d_%s" % (lvl, lvl)))
+            stage = [L(prefix + "conv%s_1" % lvl, c1, b1, device=device)]
+            if lvl == "1":
+                # 64 -> 64 3x3, then the 1x1x1 "Conv3D" 64 -> 64: chained in the halo kernel's epilogue
+                c3 = self.conv3d_1
+                fb = [packing.pack_conv_bn(prefix + "conv1_2", c2, b2, device=device),
+                      packing.pack_conv_bn(prefix + "conv3d_1", c3.conv3d, c3.bn3d, device=device)]
+                s1, t1 = packing.fold_bn(c2.bias, b2, c2.out_channels)
+                s2, t2 = packing.fold_bn(c3.conv3d.bias, c3.bn3d, c3.conv3d.out_channels)
+                halo = packing.pack_conv_halo(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
+                                              chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
+                stage.append(ops.Layer(fb, halo, name=prefix + "conv1_2+conv3d_1"))
             else:
-                plan.append(L(prefix + "conv%s_2" % lvl, c2, b2, device=device))
-        return plan
+                stage.append(L(prefix + "conv%s_2" % lvl, c2, b2, device=device))
+                if lvl == "2":
+                    c3 = self.conv3d_2
+                    stage.append(ops.Layer([packing.pack_conv_bn(prefix + "conv3d_2", c3.conv3d, c3.bn3d, device=device)]))
+            levels.append(stage)
+        return levels
 
     @staticmethod
-    def run(plan, x):
+    def run(levels, x):
         """x: (N, 256, 256, INPUT_C_PAD) bf16 NHWC -> [x, x_1, x_2, x_3, x_4]."""
-        it = iter(plan)
-        x = ops.run_layer(next(it), x)
-        x = ops.run_layer(next(it), x)
-        feats = [x]
-        for lvl in range(1, 5):
-            x = ops.run_layer(next(it), x)
-            x = ops.run_layer(next(it), x)
+        feats = []
+        for stage in levels:
+            for layer in stage:
+                x = ops.run_layer(layer, x)
             feats.append(x)
         return feats
 

@@ -41,8 +41,12 @@ class _Prof:
 _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 128: (128, 128, 2, 2), 96: (96, 128, 2, 2)}
 
 
-def conv_kernel_name(pc):
+def conv_kernel_name(pc, H=0, W=0):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
+    if pc.w_layout == 2:
+        rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
+        th, tw = (8, 32) if W % 32 == 0 else (16, 16)
+        return "conv3x3_stream_kernel<%d, %d, %d, %d>" % (rows, th, tw, 2 if pc.epilogue == V2X_EPI_GRU else 0)
     if pc.w_layout == 1:
         c0, c1 = (pc.C0, pc.C1) if pc.C1 else (0, pc.C0)
         co2 = (pc.Cout2 + 15) // 16 * 16 if pc.Cout2 else 0
@@ -217,7 +221,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0):
         nbytes = in0.numel() * 2 + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
-        prof = _Prof(conv_kernel_name(pc), flops, nbytes)
+        prof = _Prof(conv_kernel_name(pc, H, W), flops, nbytes)
     rc = lib.v2x_conv2d(C.byref(d), _stream())
     if prof is not None:
         prof.done()
@@ -292,8 +296,10 @@ class Layer:
         self.name = name or self.fallback[0].name
 
 
-def halo_eligible(H, W):
-    return H % 8 == 0 and W % 32 == 0
+def halo_eligible(H, W, w_layout=1):
+    if H % 8 == 0 and W % 32 == 0:
+        return True
+    return w_layout == 2 and H % 16 == 0 and W % 16 == 0  # the streamed kernel also has 16x16 tiles
 
 
 def run_layer(layer, in0, in1=None):
@@ -301,8 +307,17 @@ def run_layer(layer, in0, in1=None):
         H, W = in1.shape[1], in1.shape[2]
     else:
         H, W = in0.shape[1], in0.shape[2]
-    if layer.halo is not None and halo_eligible(H, W):
-        return conv2d(layer.halo, in0, in1, split=layer.split)
+    h = layer.halo
+    if h is not None and halo_eligible(H, W, h.w_layout):
+        use = True
+        if h.w_layout == 2:
+            # streamed kernel = one 256-pixel x <=128-channel tile per workgroup: with too few workgroups for the
+            # 256 CUs (small maps, small batch) the finer-grained gather kernel fills the chip better
+            # (the rule looks at the map extent only, never at the batch: kernel selection must not change with
+            #  the number of items a rank owns, or R-rank results would stop being bitwise equal to 1-rank results)
+            use = H * W >= 1024
+        if use:
+            return conv2d(h, in0, in1, split=layer.split)
     y = conv2d(layer.fallback[0], in0, in1, split=layer.split if len(layer.fallback) == 1 else 0)
     for i, pc in enumerate(layer.fallback[1:], 1):
         y = conv2d(pc, y, split=layer.split if i == len(layer.fallback) - 1 else 0)

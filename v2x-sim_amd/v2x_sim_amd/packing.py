@@ -188,4 +188,57 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         if key in ((0, 32, 32), (64, 32, 32), (0, 64, 64)):
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
+        elif (cin_p >= 128 and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
+              and STREAM_KERNEL):
+            h = pack_conv_stream(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, up0=fb.up0, relu=relu,
+                                 device=device)
     return Layer([fb], h, name=name)
+
+
+STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
+
+
+# ------------------------------------------------------------------ streamed-weights kernel layout (conv_stream.hip)
+def _stream_layout(wk, rows_tile, cin):
+    """wk [rows][9*cin] with k = tap*cin + c  ->  [co_tile][chunk][tap][slot][row][8] (flattened)."""
+    rows = wk.shape[0]
+    n_tiles, n_chunks = rows // rows_tile, cin // 32
+    w = wk.view(n_tiles, rows_tile, 9, n_chunks, 4, 8)            # [tile][row][tap][chunk][slot][8]
+    flat = w.permute(0, 3, 2, 4, 1, 5).contiguous().view(-1)      # [tile][chunk][tap][slot][row][8]
+    return torch.cat([flat, torch.zeros(32, dtype=flat.dtype)])   # + 64 B of zeros: the kernel's zero page
+
+
+def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=True, device="cuda"):
+    """3x3 stride-1 conv with C0, C1 multiples of 32 and Cout a multiple of 64, for conv_stream.hip."""
+    lib = _lib.load()
+    w = weight.detach().float().cpu()
+    cout, cin, k, _ = w.shape
+    if C0 is None:
+        C0 = cin
+    tile = lib.v2x_conv_stream_tile_rows(cout, V2X_EPI_BF16)
+    if k != 3 or C0 + C1 != cin or C0 % 32 or C1 % 32 or tile == 0:
+        raise ValueError("%s: not a shape the streamed kernel covers" % name)
+    wk = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
+    return PackedConv(name=name, weight=_stream_layout(wk, tile, cin).to(torch.bfloat16).to(device).contiguous(),
+                      scale=scale.detach().float().to(device).contiguous(),
+                      shift=shift.detach().float().to(device).contiguous(), C0=C0, C1=C1, Cout=cout, ksize=3,
+                      stride=1, pad=1, up0=up0, epilogue=V2X_EPI_BF16, relu=relu, w_rows=cout, w_kpad=9 * cin,
+                      w_layout=2, Cout2=0)
+
+
+def pack_gru_stream(name, weight_ih, bias_ih, bias_hh, *, C0, C1, device="cuda"):
+    """ConvGRU (h0 = 0) for conv_stream.hip: (r,z,n) row triples as pack_gru, streamed-slice layout."""
+    w = weight_ih.detach().float().cpu()
+    three_h, cin, k, _ = w.shape
+    hid = three_h // 3
+    if hid % 32 != 0 or cin != C0 + C1 or C0 % 32 or C1 % 32 or k != 3:
+        raise ValueError("%s: not a shape the streamed GRU kernel covers" % name)
+    K = 9 * cin
+    wk = w.permute(0, 2, 3, 1).reshape(three_h, K)
+    groups = hid // 16
+    wk = wk.view(3, groups, 16, K).permute(1, 0, 2, 3).reshape(groups * 48, K)
+    bi, bh = bias_ih.detach().float().cpu().view(3, hid), bias_hh.detach().float().cpu().view(3, hid)
+    bias4 = torch.stack([bi[0] + bh[0], bi[1] + bh[1], bi[2], bh[2]], dim=1).contiguous()
+    return PackedConv(name=name, weight=_stream_layout(wk, 96, cin).to(torch.bfloat16).to(device).contiguous(),
+                      scale=bias4.to(device), shift=None, C0=C0, C1=C1, Cout=hid, ksize=3, stride=1, pad=1, up0=0,
+                      epilogue=V2X_EPI_GRU, relu=False, w_rows=three_h, w_kpad=K, w_layout=2, Cout2=0)

@@ -92,7 +92,7 @@ class ShardedV2VNet:
             mean = ops.warp_fuse(src, sh.A, sh.Bt, trans, plan["items"], plan["coef"], V2X_FUSE_MEAN)
             rows = plan["local_rows"]
             ego = cur if rows is None else cur.index_select(0, rows)
-            h = ops.conv2d(pk["gru"], ego, mean)
+            h = ops.run_layer(pk["gru"], ego, mean)
             if rows is None:
                 cur = h
             else:
