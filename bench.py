@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-gpu", type=int, default=8)
+    ap.add_argument("--frames-per-gpu", type=int, default=32)
     ap.add_argument("--gnn-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -187,6 +187,14 @@ def main():
             achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBS, "traffic": None}
+        # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
+        # WRITE_SIZE, gfx950-corrected by tools/pmc_traffic.py); valid for the default 32 frames/GPU workload only
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile) and args.frames_per_gpu == 32 and world == 1:
+            with open(tfile) as fh:
+                tk = json.load(fh)["kernels"].get(dom)
+            if tk:
+                roofline["traffic"] = tk["hbm_bytes_per_launch"]
         roofline.update({"kernel": dom, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                          "launches_per_step": d["launches"] // n_inst,
                          "share_of_kernel_time": d["ms"] / total_ms,

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (two separate runs, csv output) into per-kernel
+HBM bytes per launch.  Corrections per /opt/skills/guides/MI355X_MICROARCH.md section HBM: counters are in KiB;
+on gfx950 FETCH_SIZE reports exactly half of a wide coalesced read stream -> doubled; WRITE_SIZE as is
+(both calibrated here on bits_to_nhwc_bf16_kernel: known 10.5 MB read / 167.8 MB written per launch).
+usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
+import collections
+import csv
+import json
+import sys
+
+
+def agg(path, counter):
+    d = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] == counter:
+            d[r["Kernel_Name"]][0] += 1
+            d[r["Kernel_Name"]][1] += float(r["Counter_Value"])
+    return d
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name[:name.index("(")] if "(" in name else name
+
+
+def main():
+    f, w = agg(sys.argv[1], "FETCH_SIZE"), agg(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in f:
+        if k not in w or f[k][0] == 0 or w[k][0] == 0:
+            continue
+        fetch = 2.0 * 1024.0 * f[k][1] / f[k][0]
+        write = 1024.0 * w[k][1] / w[k][0]
+        out[short(k)] = {"launches_profiled": f[k][0], "hbm_read_bytes_per_launch": fetch,
+                         "hbm_write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --graph 0, 32 frames/step (default workload)",
+               "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE x1",
+               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):
+        print("%-60s read %8.1f MB  write %8.1f MB" % (k[:60], v["hbm_read_bytes_per_launch"] / 1e6, v["hbm_write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main()

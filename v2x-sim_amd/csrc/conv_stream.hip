@@ -170,9 +170,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // 4. MFMAs of (chunk kc, tap)
             const char *ws = s_ring + (s & (RING - 1)) * SLICE_BYTES;
             bf16x8_t fa[TCO], fb[4];
-#pragma unroll
-            for (int i = 0; i < TCO; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
             const int sh = half ? 1 : 0, pw = half ? PW0 : PW;  // wave-uniform: no branches in the step body
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
@@ -181,15 +178,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int pc = ((fcol[f] + kx - sh) >> sh) + sh;
                 fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + (((pr * pw + pc) << 2) + (fq ^ ((pc >> 1) & 3))) * 16);
             }
-            // all fragment reads are ISSUED before the first MFMA (hipcc otherwise recycles one A register set
-            // and exposes the LDS latency 8x per step); the MFMAs then wait on counted lgkmcnt as data arrives
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+                fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
 #pragma unroll
             for (int i = 0; i < TCO; ++i)
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
                     acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TCO + 4, 0);  // DS reads: all of them first ...
-            __builtin_amdgcn_sched_group_barrier(0x008, TCO * 4, 0);  // ... then the MFMA block
+
+            // schedule (measured): ALL fragment reads first, one wait, then the 32-MFMA block.  hipcc on its own
+            // recycles a single A register set and exposes the LDS latency TCO times per step (-15 %); a finer
+            // read/MFMA interleave (-4 %) and s_setprio around the block (-6 %) were both slower: the co-resident
+            // wave of the other workgroup is what hides this wave's read phase.
+            __builtin_amdgcn_sched_group_barrier(0x100, TCO + 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TCO * 4, 0);
         }
     }
 
