@@ -96,8 +96,13 @@ def main():
         raise SystemExit("bench.py needs the MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # V2X_FORCE_DIST=1: exercise the RCCL code path (process group, bf16 all-gather, barrier, all-reduce) even with
+    # one rank -- the only way to smoke-test it on a 1-GPU box
+    force_dist = os.environ.get("V2X_FORCE_DIST") == "1"
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from v2x_sim_amd import ops
@@ -112,6 +117,14 @@ def main():
     model = model.to(dev)
     shard = AgentShard(AGENTS, Bt, rank, world)
     runner = ShardedV2VNet(model, shard)
+    if force_dist and world == 1:
+        from v2x_sim_amd.parallel import exchange_features
+
+        def _forced(t):
+            out = torch.empty_like(t)
+            dist.all_gather_into_tensor(out, t.contiguous())
+            return out
+        runner.exchange = _forced
     # synthetic sweeps of this rank's (agent, frame) items, resident in HBM
     pts = np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=1000 + r) for r in shard.rows])
     points = torch.from_numpy(pts).to(dev)
@@ -125,14 +138,14 @@ def main():
             return runner.forward_points(points, n_pts, trans, plan)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
-    for _ in range(max(args.warmup, 1) if args.graph and world == 1 else args.warmup):
+    for _ in range(max(args.warmup, 1) if args.graph and not use_dist else args.warmup):
         out = step()
     torch.cuda.synchronize()
 
-    use_graph = bool(args.graph) and world == 1
+    use_graph = bool(args.graph) and not use_dist
     if use_graph:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -153,7 +166,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -224,9 +237,17 @@ def main():
                        "hip_graph": use_graph},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
-        print(json.dumps(rec))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
+    # RCCL prints its version banner through C stdio, which (on a pipe) is only flushed at exit and would land
+    # AFTER our JSON line: flush C stdio first so that the JSON record is the last line of stdout.
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
 
 
 if __name__ == "__main__":

@@ -70,6 +70,12 @@ int v2x_dense_f32_to_nhwc_bf16(const float *bev, int n, int X, int Y, int Z, int
 int v2x_bits_to_indices(const uint32_t *bits, int n, int X, int Y, int Z, int32_t *idx, int cap, int32_t *counts,
                         int32_t *scratch, v2x_stream_t stream);
 
+/* Densify: the parsed dataset stores each sweep as sparse voxel indices (README.md:66-79 layout;
+ * upstream V2XSimDet.__getitem__: curr_voxels[idx[:,0], idx[:,1], idx[:,2]] = 1).  idx: [n][cap][3] int32,
+ * counts: [n]; bits as v2x_voxelize_bits (cleared by the call). */
+int v2x_indices_to_bits(const int32_t *idx, const int32_t *counts, int n, int cap, int X, int Y, int Z,
+                        uint32_t *bits, v2x_stream_t stream);
+
 /* ---------------------------------------------------------------- a2/a4/a6/a7/a8: convolutions
  * One implicit-GEMM MFMA kernel family covers
  *   - coperception/models/det/backbone/Backbone.py::LidarEncoder / LidarDecoder

@@ -1,0 +1,57 @@
+"""CPU tests of the parsed-dataset reader/writer: README.md:66-79 layout, densify,
+agent-major collation."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import voxelize_ref as VR
+from v2x_sim_amd.configs import Config
+from v2x_sim_amd.datasets import V2XSimDet, collate_dense, write_sample
+from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
+
+
+def make_tree(tmp, A=3, frames=2, n_pts=3000):
+    pts = synthetic_points(A * frames, n_pts, seed=3)
+    T = synthetic_poses(frames, A, seed=4)
+    grids = {}
+    for f in range(frames):
+        for a in range(A):
+            grid, idx = VR.voxelize_occupy(pts[a * frames + f], return_indices=True)
+            grids[(a, f)] = grid
+            # agent0 = RSU directory exists too (README.md:70); scene 7, frames 0..
+            write_sample(str(tmp), "test", a, 7, f, idx[::-1], T[f, a], A)   # unsorted on purpose
+    roots = [os.path.join(str(tmp), "test", "agent%d" % a) for a in range(A)]
+    return roots, grids, T
+
+
+def test_layout_and_roundtrip(tmp_path):
+    roots, grids, T = make_tree(tmp_path)
+    assert os.path.isfile(os.path.join(str(tmp_path), "test", "agent0", "7_1", "0.npy"))   # README.md:66-79 layout
+    ds = V2XSimDet(dataset_roots=roots, config=Config("test"), split="test", val=True)
+    assert len(ds) == 2 and ds.seq_names == ["7_0", "7_1"]
+    s = ds[1]
+    assert len(s) == 3 and len(s[0]) == 12
+    for a in range(3):
+        bev = s[a][0]
+        assert bev.shape == (1, 256, 256, 13) and bev.dtype == np.float32
+        assert np.array_equal(bev[0], grids[(a, 1)])                      # densify == voxelize_occupy's grid
+        assert s[a][9] == a and s[a][10] == 3 and np.allclose(s[a][11], T[1, a])
+    bevs, trans, nat = collate_dense([ds[0], ds[1]])
+    assert bevs.shape == (6, 1, 256, 256, 13) and trans.shape == (2, 3, 3, 4, 4) and nat.tolist() == [[3] * 3] * 2
+    assert torch.equal(bevs[2 * 1 + 1, 0], torch.from_numpy(grids[(1, 1)]))   # row = agent*B + frame
+    sp = V2XSimDet(dataset_roots=roots, config=Config("test"), split="test", densify="none")[0]
+    idx = sp[0][0]
+    assert idx.dtype == np.int32 and np.array_equal(VR.densify(idx, (256, 256, 13)), grids[(0, 0)].astype(bool))
+    assert np.array_equal(idx, idx[np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))])  # stored sorted
+
+
+def test_errors(tmp_path):
+    with pytest.raises(ValueError):
+        V2XSimDet(dataset_roots=None, config=Config("test"), split="test")
+    with pytest.raises(FileNotFoundError):
+        V2XSimDet(dataset_roots=[str(tmp_path / "nope")], config=Config("test"), split="test")
+    os.makedirs(tmp_path / "empty")
+    with pytest.raises(RuntimeError):
+        V2XSimDet(dataset_roots=[str(tmp_path / "empty")], config=Config("test"), split="test")

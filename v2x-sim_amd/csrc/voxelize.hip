@@ -171,6 +171,22 @@ __global__ void row_emit_kernel(const uint32_t *__restrict__ bits, int X, int Y,
     }
 }
 
+// ---- densify: sparse voxel indices (the parsed dataset's storage format) -> bit grid -------------
+__global__ __launch_bounds__(256) void indices_to_bits_kernel(const int32_t *__restrict__ idx,
+                                                              const int32_t *__restrict__ counts, int cap, int X,
+                                                              int Y, int Z, uint32_t *__restrict__ bits) {
+    const int cloud = blockIdx.y;
+    const int n = min(counts[cloud], cap);
+    const int32_t *src = idx + (size_t)cloud * cap * 3;
+    uint32_t *grid = bits + (size_t)cloud * X * Y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int x = src[3 * i + 0], y = src[3 * i + 1], z = src[3 * i + 2];
+        // numpy fancy indexing would raise IndexError on an out-of-range index; we drop it
+        if ((unsigned)x < (unsigned)X && (unsigned)y < (unsigned)Y && (unsigned)z < (unsigned)Z)
+            atomicOr(&grid[(size_t)x * Y + y], 1u << z);
+    }
+}
+
 static inline int grid_for(size_t total, int block) {
     size_t g = (total + block - 1) / block;
     if (g > 256 * 8) g = 256 * 8;  // grid-stride the rest (guide: cap at ~2048 blocks)
@@ -259,5 +275,23 @@ extern "C" int v2x_bits_to_indices(const uint32_t *bits, int n, int X, int Y, in
     V2X_CHECK_LAUNCH("row_count_kernel");
     hipLaunchKernelGGL(row_emit_kernel, dim3(X, n), dim3(block), 0, s, bits, X, Y, Z, scratch, idx, cap, counts);
     V2X_CHECK_LAUNCH("row_emit_kernel");
+    return V2X_OK;
+}
+
+extern "C" int v2x_indices_to_bits(const int32_t *idx, const int32_t *counts, int n, int cap, int X, int Y, int Z,
+                                   uint32_t *bits, v2x_stream_t stream) {
+    V2X_REQUIRE(idx && counts && bits, "v2x_indices_to_bits: null pointer");
+    V2X_REQUIRE(n >= 0 && cap >= 0 && X > 0 && Y > 0 && Z > 0 && Z <= 32, "v2x_indices_to_bits: bad dims");
+    if (n == 0) return V2X_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(bits, 0, (size_t)n * X * Y * sizeof(uint32_t), s) != hipSuccess) {
+        v2x_set_error("v2x_indices_to_bits: memset failed");
+        return V2X_EIO;
+    }
+    if (cap == 0) return V2X_OK;
+    dim3 grid((cap + 255) / 256, n);
+    if (grid.x > 512) grid.x = 512;
+    hipLaunchKernelGGL(indices_to_bits_kernel, grid, dim3(256), 0, s, idx, counts, cap, X, Y, Z, bits);
+    V2X_CHECK_LAUNCH("indices_to_bits_kernel");
     return V2X_OK;
 }

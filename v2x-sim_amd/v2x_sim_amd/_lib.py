@@ -46,6 +46,8 @@ SIGNATURES = {
                                               C.c_void_p]),
     "v2x_bits_to_indices": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_indices_to_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_void_p, C.c_void_p]),
     "v2x_conv_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "v2x_conv_stream_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "v2x_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

@@ -1,0 +1,121 @@
+"""Parsed-dataset reader -- mirror of upstream
+coperception/datasets/V2XSimDet.py, which is not in /root/reference.
+
+On-disk layout is the one the reference documents (/root/reference/README.md:66-79):
+
+    V2X-Sim-det/{train,val,test}/agent{0..5}/{scene}_{frame}/0.npy          agent0 = RSU (README.md:70)
+
+The *content* of 0.npy cannot be read off the reference tree; from recollection upstream's
+create_data_det.py stores one pickled dict per (agent, scene, frame) with the sweep as SPARSE voxel indices
+(the output of voxelize_occupy(return_indices=True)) plus the pairwise poses.  This module freezes that as the
+build-owned format below and provides both the writer (a create_data stand-in for synthetic scenes and tests)
+and the reader:
+
+    {"voxel_indices_0": int32 (M, 3)   lexicographically sorted occupied voxels (x, y, z),
+     "trans_matrices":   float32 (A, 4, 4)  pose of every agent w.r.t. this one (row j -> feature_transformation),
+     "target_agent_id":  int,  "num_sensor": int   (number of real agents in the frame)}
+
+__getitem__ keeps upstream's per-agent tuple order for the fields the inference path consumes
+(padded_voxel_points, trans_matrices, target_agent_id, num_sensor); training targets (label_one_hot,
+reg_target, anchors_map, ...) belong to row f-3 and are returned as None.
+
+Densify (the CPU fancy-index scatter of upstream __getitem__) is available two ways:
+  * `densify="cpu"`  -- numpy, exactly what upstream does in the DataLoader worker -> dense (1, X, Y, Z) float32;
+  * `densify="none"` -- return the sparse indices; `collate_to_device` then scatters them ON THE GPU with
+    ops.indices_to_bits (v2x_indices_to_bits) straight into the network's NHWC bf16 input, skipping the dense
+    fp32 tensor and its PCIe copy (13x fewer bytes over the host link for a typical sweep).
+"""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import Dataset
+
+
+def write_sample(root, split, agent, scene, frame, voxel_indices, trans_matrices, num_sensor):
+    """Writes one (agent, scene, frame) sample in the layout of README.md:66-79."""
+    d = os.path.join(root, split, "agent%d" % agent, "%d_%d" % (scene, frame))
+    os.makedirs(d, exist_ok=True)
+    idx = np.ascontiguousarray(voxel_indices, dtype=np.int32).reshape(-1, 3)
+    order = np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))
+    sample = {"voxel_indices_0": idx[order], "trans_matrices": np.asarray(trans_matrices, dtype=np.float32),
+              "target_agent_id": int(agent), "num_sensor": int(num_sensor)}
+    np.save(os.path.join(d, "0.npy"), sample, allow_pickle=True)
+    return d
+
+
+class V2XSimDet(Dataset):
+    def __init__(self, dataset_roots=None, config=None, config_global=None, agent_list=None, split=None, val=False,
+                 bound=None, kd_flag=False, rsu=False, densify="cpu"):
+        if split is None or dataset_roots is None or config is None:
+            raise ValueError("dataset_roots, config and split are required")
+        if kd_flag:
+            raise NotImplementedError("teacher inputs (knowledge distillation) are out of scope")
+        if densify not in ("cpu", "none"):
+            raise ValueError("densify must be 'cpu' or 'none'")
+        self.dataset_roots = list(dataset_roots)  # one directory per agent: .../{split}/agent{k}
+        self.config, self.config_global = config, config_global
+        self.split, self.val, self.bound, self.rsu = split, val, bound, rsu
+        self.densify = densify
+        self.dims = tuple(config.map_dims)
+        self.num_agent = len(self.dataset_roots)
+        # frames present for EVERY agent, in (scene, frame) order
+        names = None
+        for root in self.dataset_roots:
+            if not os.path.isdir(root):
+                raise FileNotFoundError(root)
+            here = {n for n in os.listdir(root) if os.path.isfile(os.path.join(root, n, "0.npy"))}
+            names = here if names is None else names & here
+        self.seq_names = sorted(names, key=lambda s: tuple(int(t) for t in s.split("_")))
+        if not self.seq_names:
+            raise RuntimeError("no common {scene}_{frame} samples under %s" % (self.dataset_roots,))
+
+    def __len__(self):
+        return len(self.seq_names)
+
+    def __getitem__(self, idx):
+        """-> list with one tuple per agent (upstream returns the per-agent tuples the same way)."""
+        name = self.seq_names[idx]
+        res = []
+        for root in self.dataset_roots:
+            gt = np.load(os.path.join(root, name, "0.npy"), allow_pickle=True).item()
+            indices = np.asarray(gt["voxel_indices_0"], dtype=np.int32).reshape(-1, 3)
+            if self.densify == "cpu":
+                vox = np.zeros(self.dims, dtype=bool)
+                vox[indices[:, 0], indices[:, 1], indices[:, 2]] = 1      # upstream's densify scatter
+                padded_voxel_points = vox[None].astype(np.float32)         # (1, X, Y, Z)
+            else:
+                padded_voxel_points = indices
+            res.append((padded_voxel_points, None, None, None, None, None, None, None,
+                        os.path.join(root, name), int(gt["target_agent_id"]), int(gt["num_sensor"]),
+                        np.asarray(gt["trans_matrices"], dtype=np.float32)))
+        return res
+
+
+def collate_dense(samples):
+    """samples: list (batch) of __getitem__ results with densify='cpu'  ->  the tensors upstream's
+    train/test scripts build: bevs (A*B, 1, X, Y, Z) agent-major, trans_matrices (B, A, A, 4, 4), num_agent (B, A)."""
+    B, A = len(samples), len(samples[0])
+    bevs = torch.from_numpy(np.stack([samples[b][a][0] for a in range(A) for b in range(B)]))
+    trans = torch.from_numpy(np.stack([np.stack([samples[b][a][11] for a in range(A)]) for b in range(B)]))
+    nat = torch.tensor([[samples[b][a][10] for a in range(A)] for b in range(B)])
+    return bevs, trans, nat
+
+
+def collate_to_device(samples, grid, device, c_pad=32):
+    """densify='none' path: ship the sparse indices, scatter on the GPU.  -> (x0 NHWC bf16 (A*B, X, Y, c_pad),
+    trans_matrices (B, A, A, 4, 4) on device, num_agent (B, A) on host)."""
+    from .. import ops
+    B, A = len(samples), len(samples[0])
+    items = [samples[b][a][0] for a in range(A) for b in range(B)]  # agent-major
+    cap = max(1, max(it.shape[0] for it in items))
+    idx = np.zeros((len(items), cap, 3), dtype=np.int32)
+    cnt = np.zeros((len(items),), dtype=np.int32)
+    for i, it in enumerate(items):
+        idx[i, :it.shape[0]] = it
+        cnt[i] = it.shape[0]
+    bits = ops.indices_to_bits(torch.from_numpy(idx).to(device), torch.from_numpy(cnt).to(device), grid)
+    x0 = ops.bits_to_nhwc(bits, grid.dims[2], c_pad)
+    trans = torch.from_numpy(np.stack([np.stack([samples[b][a][11] for a in range(A)]) for b in range(B)])).to(device)
+    nat = torch.tensor([[samples[b][a][10] for a in range(A)] for b in range(B)])
+    return x0, trans, nat

@@ -1,0 +1,1 @@
+from .V2XSimDet import V2XSimDet, collate_dense, collate_to_device, write_sample  # noqa: F401

@@ -146,6 +146,20 @@ def bits_to_indices(bits, Z, cap):
     return idx, counts
 
 
+def indices_to_bits(idx, counts, grid):
+    """idx (n, cap, 3) int32 sparse voxel indices, counts (n,) int32 -> bits (n, X, Y) int32 (the densify
+    scatter of the parsed-dataset reader, on the GPU)."""
+    lib = _lib.load()
+    n, cap, three = idx.shape
+    if three != 3:
+        raise ValueError("idx must be (n, cap, 3)")
+    X, Y, Z = grid.dims
+    out = torch.empty((n, X, Y), dtype=torch.int32, device=idx.device)
+    _lib.check(lib.v2x_indices_to_bits(_dev(idx, torch.int32, "idx"), _dev(counts, torch.int32, "counts"), n, cap,
+                                       X, Y, Z, _dev(out, torch.int32, "bits"), _stream()), "v2x_indices_to_bits")
+    return out
+
+
 # ------------------------------------------------------------------ a2/a4/a6/a7/a8
 class PackedConv:
     """Device-resident packed parameters of one conv layer (see packing.py)."""
