@@ -90,38 +90,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // zero page for out-of-image patch pixels and count-keeping dummy DMAs: the packer appends 64 B of zeros
     const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
 
+    // ---- per-lane tables, computed once (the step body then only adds and selects) ---------------------
+    // (a) DMA source descriptors of this lane's 6 patch pieces (piece = wave + 4t), for a full-resolution and a
+    //     half-resolution source:  (source pixel index << 5) | (swizzled 16-B slot * 8 elements),  -1 = zero page
+    int pd_full[6], pd_half[6];
+#pragma unroll
+    for (int t = 0; t < 6; ++t) {
+        const int L = (wave + 4 * t) * 64 + lane;
+        const int pix = L >> 2, phys = L & 3;
+        {
+            const int pr = pix / PW, pc = pix - pr * PW;
+            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+            const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            pd_full[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+        }
+        {
+            const int Hs = a.H >> 1, Ws = a.W >> 1;
+            const int pr = pix / PW0, pc = pix - pr * PW0;
+            const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+            const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+            pd_half[t] = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+        }
+    }
+    // (b) byte offset inside a patch row of this lane's B fragment f for tap column kx (pixel slot + swizzled k-slot)
+    int frow[4], ct_full[4][3], ct_half[4][3];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int col = (TW == 32) ? (f & 1) * 16 + fj : fj;
+        frow[f] = (TW == 32) ? 2 * wave + (f >> 1) : 4 * wave + f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pcf = col + kx;                    // full res: column col + kx
+            const int pch = ((col + kx - 1) >> 1) + 1;   // half res: floor((col + kx - 1) / 2) + 1
+            ct_full[f][kx] = ((pcf << 2) + (fq ^ ((pcf >> 1) & 3))) * 16;
+            ct_half[f][kx] = ((pch << 2) + (fq ^ ((pch >> 1) & 3))) * 16;
+        }
+    }
+
     // ---- DMA issue helpers -------------------------------------------------------------------------
+    const uint16_t *wsrc = wbase + lane * 8 + wave * 512;  // this lane's element of slice 0, piece `wave`
     auto issue_weights = [&](int s) {  // slice of step s -> ring slot s % RING ; NW instructions
         char *dst = s_ring + (s & (RING - 1)) * SLICE_BYTES;
-        const uint16_t *src = wbase + (size_t)s * (BCO * 32) + lane * 8;
-        glds16s(src + wave * 512, dst + wave * 1024);
-        if (NW == 2) glds16s(src + (wave + 4) * 512, dst + (wave + 4) * 1024);
+        const uint16_t *src = wsrc + (size_t)s * (BCO * 32);
+        glds16s(src, dst + wave * 1024);
+        if (NW == 2) glds16s(src + 4 * 512, dst + (wave + 4) * 1024);
     };
-    auto issue_patch_piece = [&](int kc, int piece, int buf) {  // one 1-KiB piece of chunk kc's patch
-        // branch-free: every source / resolution choice is a wave-uniform select
-        char *dst = s_patch + buf * PATCH_BYTES + piece * 1024;
-        const int L = piece * 64 + lane;
-        const int pix = L >> 2, phys = L & 3;
+    auto issue_patch_piece = [&](int kc, int t, int buf) {  // piece wave+4t of chunk kc's patch
         const bool first = kc < nc0;
         const bool hf = first && a.up0;
-        const int sh = hf ? 1 : 0;
-        const int pw = hf ? PW0 : PW, npix = hf ? PH0 * PW0 : PH * PW;
-        const int pr = hf ? pix / PW0 : pix / PW;
-        const int pc = pix - pr * pw;
-        const int Hs = a.H >> sh, Ws = a.W >> sh;
-        const int y = (y0 >> sh) - 1 + pr, x = (x0 >> sh) - 1 + pc;
-        const bool ok = pix < npix && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        // 6-way select by the wave-uniform t (a runtime-indexed register array would go to scratch)
+        int d = hf ? pd_half[0] : pd_full[0];
+#pragma unroll
+        for (int u = 1; u < 6; ++u) d = (t == u) ? (hf ? pd_half[u] : pd_full[u]) : d;
         const uint16_t *src = first ? a.in0 : a.in1;
         const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
-        const unsigned coff = (unsigned)((first ? kc : kc - nc0) * 32 + ((phys ^ ((pc >> 1) & 3)) << 3));
-        const unsigned off = ((unsigned)(n * Hs + y) * (unsigned)Ws + (unsigned)x) * cs + coff;
-        glds16s(ok ? (const void *)(src + off) : zero_page, dst);
+        const unsigned off = (unsigned)(d >> 5) * cs + (unsigned)((first ? kc : kc - nc0) * 32 + (d & 31));
+        glds16s(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + buf * PATCH_BYTES + (wave + 4 * t) * 1024);
     };
     auto issue_dummy = [&]() { glds16s(zero_page, s_dummy); };
 
     // ---- prologue: whole patch of chunk 0 (6 pieces per wave), weight slices of steps 0..2 --------
 #pragma unroll
-    for (int t = 0; t < 6; ++t) issue_patch_piece(0, wave + 4 * t, 0);
+    for (int t = 0; t < 6; ++t) issue_patch_piece(0, t, 0);
     issue_weights(0);  // S = 9 * chunks >= 9, so steps 1 and 2 always exist
     issue_weights(1);
     issue_weights(2);
@@ -132,67 +162,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-    // per-lane pixel coordinates of the 4 fragments
-    int frow[4], fcol[4];
-#pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        if constexpr (TW == 32) {
-            frow[f] = 2 * wave + (f >> 1);
-            fcol[f] = (f & 1) * 16 + fj;
-        } else {
-            frow[f] = 4 * wave + f;
-            fcol[f] = fj;
-        }
-    }
-
     int s = 0;
     for (int kc = 0; kc < nchunks; ++kc) {
         const char *pb = s_patch + (kc & 1) * PATCH_BYTES;
         const bool half = (kc < nc0) && a.up0;
-#pragma unroll 1  // keep the 9 taps rolled: unrolling hoists 72 per-tap LDS offsets and spills (scratch traffic
-                  // would also corrupt the vmcnt bookkeeping below)
-        for (int tap = 0; tap < 9; ++tap, ++s) {
-            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-            // 1. wait for this step's weight slice (and, at tap 0, the chunk's patch): everything older than
-            //    the two most recent groups has landed.  group = NW weight DMAs + 1 patch/dummy DMA.
-            if (s + 3 >= S) wait_vmcnt<0>();                  // tail: nothing (or not everything) is issued below
-            else if (s < 2) { if (NW == 2) wait_vmcnt<4>(); else wait_vmcnt<2>(); }
-            else { if (NW == 2) wait_vmcnt<6>(); else wait_vmcnt<4>(); }
-            // 2. everyone's pieces have landed; everyone is done reading ring slot (s-1) and, at tap 0, the
-            //    other patch buffer
-            __builtin_amdgcn_s_barrier();
-            // 3. keep the pipe full: weight slice of step s+3, one piece of the next chunk's patch
-            if (s + 3 < S) {
-                issue_weights(s + 3);
-                if (tap < 6 && kc + 1 < nchunks) issue_patch_piece(kc + 1, wave + 4 * tap, (kc + 1) & 1);
-                else issue_dummy();
-            }
-            // 4. MFMAs of (chunk kc, tap)
-            const char *ws = s_ring + (s & (RING - 1)) * SLICE_BYTES;
-            bf16x8_t fa[TCO], fb[4];
-            const int sh = half ? 1 : 0, pw = half ? PW0 : PW;  // wave-uniform: no branches in the step body
+        const int sh = half ? 1 : 0, row_bytes = (half ? PW0 : PW) * 64;  // wave-uniform
+#pragma unroll 1  // ky stays rolled (full unrolling hoists per-tap offsets into ~70 registers and spills; scratch
+                  // traffic would also corrupt the vmcnt bookkeeping); kx is unrolled so the table indices are static
+        for (int ky = 0; ky < 3; ++ky) {
+            // patch row of each fragment for this ky: full res row+ky, half res floor((row+ky-1)/2)+1
+            int rowoff[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                // full res: (row+ky, col+kx);  half res: floor((row+ky-1)/2)+1, floor((col+kx-1)/2)+1
-                const int pr = ((frow[f] + ky - sh) >> sh) + sh;
-                const int pc = ((fcol[f] + kx - sh) >> sh) + sh;
-                fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + (((pr * pw + pc) << 2) + (fq ^ ((pc >> 1) & 3))) * 16);
-            }
+            for (int f = 0; f < 4; ++f) rowoff[f] = (((frow[f] + ky - sh) >> sh) + sh) * row_bytes;
 #pragma unroll
-            for (int i = 0; i < TCO; ++i)
-                fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
-#pragma unroll
-            for (int i = 0; i < TCO; ++i)
+            for (int kx = 0; kx < 3; ++kx, ++s) {
+                const int tap = ky * 3 + kx;
+                // 1. wait for this step's weight slice (and, at tap 0, the chunk's patch): everything older than
+                //    the two most recent groups has landed.  group = NW weight DMAs + 1 patch/dummy DMA.
+                if (s + 3 >= S) wait_vmcnt<0>();              // tail: nothing (or not everything) is issued below
+                else if (s < 2) { if (NW == 2) wait_vmcnt<4>(); else wait_vmcnt<2>(); }
+                else { if (NW == 2) wait_vmcnt<6>(); else wait_vmcnt<4>(); }
+                // 2. everyone's pieces have landed; everyone is done reading ring slot (s-1) and, at tap 0, the
+                //    other patch buffer
+                __builtin_amdgcn_s_barrier();
+                // 3. keep the pipe full: weight slice of step s+3, one piece of the next chunk's patch
+                if (s + 3 < S) {
+                    issue_weights(s + 3);
+                    if (tap < 6 && kc + 1 < nchunks) issue_patch_piece(kc + 1, tap, (kc + 1) & 1);
+                    else issue_dummy();
+                }
+                // 4. MFMAs of (chunk kc, tap)
+                const char *ws = s_ring + (s & (RING - 1)) * SLICE_BYTES;
+                bf16x8_t fa[TCO], fb[4];
 #pragma unroll
                 for (int f = 0; f < 4; ++f)
-                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                    fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + (half ? ct_half[f][kx] : ct_full[f][kx]));
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
 
-            // schedule (measured): ALL fragment reads first, one wait, then the 32-MFMA block.  hipcc on its own
-            // recycles a single A register set and exposes the LDS latency TCO times per step (-15 %); a finer
-            // read/MFMA interleave (-4 %) and s_setprio around the block (-6 %) were both slower: the co-resident
-            // wave of the other workgroup is what hides this wave's read phase.
-            __builtin_amdgcn_sched_group_barrier(0x100, TCO + 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, TCO * 4, 0);
+                // schedule (measured): ALL fragment reads first, one wait, then the 32-MFMA block.  hipcc on its own
+                // recycles a single A register set and exposes the LDS latency TCO times per step (-15 %); a finer
+                // read/MFMA interleave and s_setprio around the block were not faster: the co-resident wave of the
+                // other workgroup is what hides this wave's read phase.
+                __builtin_amdgcn_sched_group_barrier(0x100, TCO + 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TCO * 4, 0);
+            }
         }
     }
 
@@ -219,7 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 uint2 o;
                 o.x = pack_bf16x2(h[0], h[1]);
                 o.y = pack_bf16x2(h[2], h[3]);
-                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + fcol[f];
+                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + hc) = o;
             }
         }
@@ -243,7 +263,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 uint2 o;
                 o.x = pack_bf16x2(v0, v1);
                 o.y = pack_bf16x2(v2, v3);
-                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + fcol[f];
+                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
             }
         }
