@@ -124,6 +124,8 @@ typedef struct v2x_conv_desc {
     const float *scale2; /*   describe the FINAL output, scale/shift/relu the hidden layer and     */
     const float *shift2; /*   scale2/shift2/relu2 (fp32 [ceil16(Cout2)]) the chained one.          */
     int32_t relu2;       /*   weight rows must be in the chain order documented in conv_halo.hip.  */
+    int32_t in_format;   /* 0: in0 is bf16 NHWC.  1 (w_layout 1, C0 == 32, C1 == 0 only): in0 is the voxelizer's  */
+    int32_t in_zbits;    /*    uint32 bit grid [N][H][W]; bit z < in_zbits = channel z, expanded on the fly.      */
 } v2x_conv_desc;
 
 /* Rows-per-tile the kernel will use for (Cout, epilogue); the weight packer pads w_rows to a multiple. */

@@ -1,0 +1,57 @@
+"""GPU: conv_pre_1 reading the voxelizer's bit grid directly (halo kernel, BITS form) is bit-identical to the
+expanded NHWC bf16 input, for whole networks (points -> logits) and at the layer level incl. odd extents."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coperception_ref as R
+from oracle import voxelize_ref as VR
+
+pytestmark = pytest.mark.gpu
+
+
+def test_first_layer_from_bits_equals_expanded(device):
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.models.det.base import LidarEncoder
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points
+    pm = init_synthetic_weights(FaFNet(Config("test")), seed=2).to(device)
+    pk = pm.packed(device)
+    grid = ops.VoxelGrid()
+    pts = torch.from_numpy(synthetic_points(3, 30000, seed=4)).to(device)
+    cnt = torch.tensor([30000, 12345, 0], dtype=torch.int32, device=device)     # incl. an empty sweep
+    bits = ops.voxelize_bits(pts, cnt, grid)
+    a = LidarEncoder.run(pk["enc"], bits, zbits=13)
+    b = LidarEncoder.run(pk["enc"], ops.bits_to_nhwc(bits, 13, 32))
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # odd extent (not a multiple of 8 x 32): run_layer expands the bits and uses the gather kernel
+    small = bits[:, :40, :48].contiguous()
+    c = ops.run_layer(pk["enc"][0][0], small, zbits=13)
+    d = ops.run_layer(pk["enc"][0][0], ops.bits_to_nhwc(small, 13, 32))
+    assert torch.equal(c, d)
+    # zbits masks higher bits: garbage above the height bins must not leak into channels 13..31
+    dirty = bits | (1 << 20)
+    e = ops.run_layer(pk["enc"][0][0], dirty, zbits=13)
+    assert torch.equal(e, a[0] if False else ops.run_layer(pk["enc"][0][0], bits, zbits=13))
+
+
+def test_points_path_equals_dense_bev_path(device):
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
+    A, B = 5, 1
+    pm = init_synthetic_weights(V2VNet(Config("test")), seed=0).to(device)
+    pts = synthetic_points(A * B, 20000, seed=6)
+    bev = torch.from_numpy(np.stack([VR.voxelize_occupy(p) for p in pts])[:, None])
+    T = torch.from_numpy(synthetic_poses(B, A, seed=7)).to(device)
+    nat = torch.full((B, A), A)
+    shard = AgentShard(A, B, 0, 1)
+    with torch.no_grad():
+        dense = pm(bev.to(device), T, nat, batch_size=B)                         # upstream-style dense fp32 BEV
+        pts_out = ShardedV2VNet(pm, shard).forward_points(
+            torch.from_numpy(pts).to(device), torch.full((A * B,), 20000, dtype=torch.int32, device=device), T,
+            shard.fusion_plan(nat, device))                                      # points -> bits -> conv_pre_1
+    assert torch.equal(dense["cls"], pts_out["cls"]) and torch.equal(dense["loc"], pts_out["loc"])

@@ -36,7 +36,7 @@ with torch.no_grad():
         for name, fl, by, e0, e1 in recs:
             key = name
             if name.startswith("conv"):
-                key = names[ci] + "  " + name.replace("conv_igemm_kernel", "").replace("conv3x3_halo_kernel", "halo"); ci += 1
+                key = names[ci] + "  " + name.replace("conv_igemm_kernel", "").replace("conv3x3_halo_sb_kernel", "halo_sb").replace("conv3x3_halo_kernel", "halo"); ci += 1
             a = agg.setdefault(key, [0.0, 0.0, 0.0]); a[0] += e0.elapsed_time(e1) / reps; a[1] += fl / reps; a[2] += by / reps
 tot = sum(v[0] for v in agg.values())
 print("frames/step %d  total kernel time %.3f ms" % (Bt, tot))

@@ -37,6 +37,8 @@ __device__ __forceinline__ void glds16h(const void *g, char *lds_wave_base) {
 struct HaloArgs {
     const uint16_t *in0;  // [N][H/2][W/2][C0] (nearest-x2 upsampled on the fly) or nullptr
     const uint16_t *in1;  // [N][H][W][C1]
+    const uint32_t *bits; // BITS form: in1 is replaced by the occupancy words [N][H][W] (bit z = channel z)
+    int zbits;            // number of valid bits (BEV height bins)
     int N, H, W;
     const uint16_t *w;    // k-slot-major [9*(C0+C1)/8][COUT][8] bf16
     const float *scale, *shift;  // [COUT] (chain: in kappa order)
@@ -64,8 +66,17 @@ __device__ __forceinline__ int swz(int slot, int x) {
 constexpr int round64(int v) { return (v + 63) / 64 * 64; }
 
 // EPI2: 0 = none (plain epilogue, bf16 out), 1 = chained 1x1 with bf16 out, 2 = chained 1x1 with fp32 split out
-template <int C0, int C1, int COUT, int COUT2, int EPI2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const HaloArgs a) {
+// DB:   true  = two patch buffers, the next tile's patch streams in under this tile's MFMAs (MFMA-heavy variants);
+//       false = ONE patch buffer and a raw barrier after the output stores: the per-tile __syncthreads of the DB
+//               form drains vmcnt(0), i.e. also waits for the tile's own output stores, which serialises ~2 us of
+//               store latency into every tile of an HBM-bound layer.  The single-buffer form halves the LDS
+//               footprint instead (40 KiB for 32 -> 32) so 3-4 workgroups per CU hide each other's load AND store
+//               latency.
+// BITS: the full-resolution source is the voxelizer's bit grid; the patch fill expands bit z -> bf16 {0,1} channel z
+//       while writing LDS (ordinary loads + ds_write_b128), so the first layer reads 4 B instead of 64 B per pixel
+//       and the separate expansion kernel disappears from the points -> logits path.
+template <int C0, int C1, int COUT, int COUT2, int EPI2, bool DB, bool BITS = false>
+__device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     constexpr int SPP0 = C0 / 8, SPP1 = C1 / 8;
     constexpr int NS1 = round64(PH * PW * SPP1);            // 16-B slots of the full-res patch (padded to whole waves)
     constexpr int NS0 = C0 ? round64(PH0 * PW0 * SPP0) : 0; // ... of the half-res patch
@@ -80,7 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_w = smem;
-    char *s_patch = smem + W_BYTES;  // two buffers of PATCH_BYTES
+    char *s_patch = smem + W_BYTES;  // DB: two buffers of PATCH_BYTES, else one
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,6 +111,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int tx = r - ty * a.tiles_x;
         const int y0 = ty * TH, x0 = tx * TW;
         char *pb = s_patch + buf * PATCH_BYTES;
+        if constexpr (BITS) {
+            static_assert(!BITS || (C0 == 0 && SPP1 == 4), "bit-grid input: single 32-channel source");
+            const uint32_t zmask = (a.zbits >= 32) ? 0xffffffffu : ((1u << a.zbits) - 1u);
+            for (int p = tid; p < PH * PW; p += 256) {
+                const int pr = p / PW, pc = p - pr * PW;
+                const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+                const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                const uint32_t word = ok ? (a.bits[(size_t)(n * a.H + y) * a.W + x] & zmask) : 0u;
+#pragma unroll
+                for (int slot = 0; slot < 4; ++slot) {
+                    const uint32_t b = (word >> (8 * slot)) & 0xffu;
+                    const uint32_t one = 0x3f80u;  // bf16(1.0)
+                    uint4 v;
+                    v.x = ((b & 1u) ? one : 0u) | ((b & 2u) ? (one << 16) : 0u);
+                    v.y = ((b & 4u) ? one : 0u) | ((b & 8u) ? (one << 16) : 0u);
+                    v.z = ((b & 16u) ? one : 0u) | ((b & 32u) ? (one << 16) : 0u);
+                    v.w = ((b & 64u) ? one : 0u) | ((b & 128u) ? (one << 16) : 0u);
+                    *reinterpret_cast<uint4 *>(pb + NS0 * 16 + (p * 4 + swz<4>(slot, pc)) * 16) = v;
+                }
+            }
+            return;
+        }
         // full-resolution source: patch pixel (pr, pc) <- image pixel (y0-1+pr, x0-1+pc)
         for (int base = wave * 64; base < NS1; base += 256) {
             const int L = base + lane;
@@ -141,12 +174,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     int tile = blockIdx.x;
     int cur = 0;
-    if (tile < a.n_tiles) load_patch(tile, 0);
+    if (DB && tile < a.n_tiles) load_patch(tile, 0);
 
     for (; tile < a.n_tiles; tile += gridDim.x) {
-        __syncthreads();  // patch[cur] (and, first time, the weights) have landed; everyone left patch[cur^1]
-        const int next = tile + gridDim.x;
-        if (next < a.n_tiles) load_patch(next, cur ^ 1);
+        if constexpr (DB) {
+            __syncthreads();  // patch[cur] (and, first time, the weights) have landed; everyone left patch[cur^1]
+            const int next = tile + gridDim.x;
+            if (next < a.n_tiles) load_patch(next, cur ^ 1);
+        } else {
+            load_patch(tile, 0);
+            __syncthreads();  // this tile's patch (and, first time, the weights) have landed
+        }
 
         const char *pb = s_patch + cur * PATCH_BYTES;
         f32x4_t acc[TCO][4];
@@ -302,11 +340,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        cur ^= 1;
+        if constexpr (DB) {
+            cur ^= 1;
+        } else {
+            // everyone is done READING the patch (fragment reads were consumed by MFMAs); the output stores stay
+            // in flight across this raw barrier and drain under the next tile's patch load
+            __builtin_amdgcn_s_barrier();
+        }
     }
 }
 
+template <int C0, int C1, int COUT, int COUT2, int EPI2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const HaloArgs a) {
+    conv3x3_halo_body<C0, C1, COUT, COUT2, EPI2, true>(a);
+}
+
+// single-buffer form: up to 4 workgroups (16 waves) per CU
+template <int C0, int C1, int COUT, int COUT2, int EPI2, bool BITS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv3x3_halo_sb_kernel(const HaloArgs a) {
+    conv3x3_halo_body<C0, C1, COUT, COUT2, EPI2, false, BITS>(a);
+}
+
 // ---- host side ---------------------------------------------------------------------------------
+template <int C0, int C1, int COUT, int COUT2, int EPI2, bool BITS>
+static int launch_halo_sb(const HaloArgs &a, hipStream_t s) {
+    constexpr int NS1 = round64(PH * PW * (C1 / 8));
+    constexpr int NS0 = C0 ? round64(PH0 * PW0 * (C0 / 8)) : 0;
+    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + (NS0 + NS1) * 16;
+    static bool attr_done = false;
+    auto kern = &conv3x3_halo_sb_kernel<C0, C1, COUT, COUT2, EPI2, BITS>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    int per_cu = (160 * 1024 - 2048) / smem;  // leave a little LDS slack: exactly-full allocations may not co-reside
+    if (per_cu > 4) per_cu = 4;
+    if (per_cu < 1) per_cu = 1;
+    int grid = 256 * per_cu;
+    if (grid > a.n_tiles) grid = a.n_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_halo_sb_kernel");
+    return V2X_OK;
+}
+
 template <int C0, int C1, int COUT, int COUT2, int EPI2>
 static int launch_halo(const HaloArgs &a, hipStream_t s) {
     constexpr int NS1 = round64(PH * PW * (C1 / 8));
@@ -333,6 +409,8 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     HaloArgs a;
     a.in0 = d->C1 ? d->in0 : nullptr;
     a.in1 = d->C1 ? d->in1 : d->in0;
+    a.bits = d->in_format == 1 ? reinterpret_cast<const uint32_t *>(d->in0) : nullptr;
+    a.zbits = d->in_zbits;
     const int C0 = d->C1 ? d->C0 : 0, C1 = d->C1 ? d->C1 : d->C0;
     a.N = d->N;
     a.H = d->H;
@@ -359,7 +437,10 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     const int e2 = d->Cout2 > 0 ? (d->epilogue == V2X_EPI_F32 ? 2 : 1) : 0;
 #define HALO_CASE(c0, c1, co, c2, ep) \
     if (C0 == c0 && C1 == c1 && d->Cout == co && co2 == c2 && e2 == ep) return launch_halo<c0, c1, co, c2, ep>(a, s);
-    HALO_CASE(0, 32, 32, 0, 0)    // conv_pre_1 (13 -> 32 padded), conv_pre_2, conv8_2
+    // HBM-bound 32 -> 32 layers (conv_pre_1 (13 -> 32 padded), conv_pre_2, conv8_2): single-buffer form
+    if (C0 == 0 && C1 == 32 && d->Cout == 32 && co2 == 0 && e2 == 0)
+        return d->in_format == 1 ? launch_halo_sb<0, 32, 32, 0, 0, true>(a, s) : launch_halo_sb<0, 32, 32, 0, 0, false>(a, s);
+    if (d->in_format == 1) return 1;  // bit-grid input exists for the 32 -> 32 first layer only
     HALO_CASE(64, 32, 32, 0, 0)   // conv8_1: cat(up(x_7), x)
     HALO_CASE(0, 64, 64, 0, 0)    // conv7_2
     HALO_CASE(0, 64, 64, 64, 1)   // conv1_2 -> conv3d_1

@@ -341,6 +341,8 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
         V2X_REQUIRE((long long)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 32),
                     "v2x_conv2d(halo): tensor exceeds 32-bit element offsets");
         V2X_REQUIRE(d->epilogue == V2X_EPI_BF16 || d->epilogue == V2X_EPI_F32, "v2x_conv2d(halo): bad epilogue");
+        V2X_REQUIRE(d->in_format == 0 || (d->in_format == 1 && d->C0 == 32 && d->C1 == 0 && d->in_zbits >= 1 && d->in_zbits <= 32),
+                    "v2x_conv2d(halo): bit-grid input needs C0 == 32, C1 == 0 and 1 <= in_zbits <= 32");
         if (d->Cout2 > 0) {
             V2X_REQUIRE(d->weight2 && d->scale2 && d->shift2, "v2x_conv2d(halo): chained 1x1 needs weight2/scale2/shift2");
             const int cfin = d->Cout2;
@@ -360,6 +362,7 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
         return rc;
     }
     V2X_REQUIRE(d->Cout2 == 0, "v2x_conv2d: chained 1x1 needs the halo layout (w_layout=1)");
+    V2X_REQUIRE(d->in_format == 0, "v2x_conv2d: bit-grid input needs the halo layout (w_layout=1)");
     if (d->w_layout == 2) {
         V2X_REQUIRE(d->in0 && d->weight && d->scale && d->out, "v2x_conv2d(stream): null tensor pointer");
         V2X_REQUIRE(d->epilogue == V2X_EPI_GRU || d->shift, "v2x_conv2d(stream): null shift");

@@ -29,6 +29,7 @@ class ConvDesc(C.Structure):
         ("out2", C.c_void_p), ("split", C.c_int32), ("out2_cstride", C.c_int32),
         ("w_layout", C.c_int32), ("Cout2", C.c_int32),
         ("weight2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("relu2", C.c_int32),
+        ("in_format", C.c_int32), ("in_zbits", C.c_int32),
     ]
 
 

@@ -87,12 +87,13 @@ class LidarEncoder(_ParamsOnly):
         return levels
 
     @staticmethod
-    def run(levels, x):
-        """x: (N, 256, 256, INPUT_C_PAD) bf16 NHWC -> [x, x_1, x_2, x_3, x_4]."""
+    def run(levels, x, zbits=0):
+        """x: (N, X, Y, INPUT_C_PAD) bf16 NHWC, or the voxelizer's int32 bit grid (N, X, Y) with zbits height bins
+        (conv_pre_1 then expands the bits while filling its LDS patch) -> [x, x_1, x_2, x_3, x_4]."""
         feats = []
         for stage in levels:
             for layer in stage:
-                x = ops.run_layer(layer, x)
+                x = ops.run_layer(layer, x, zbits=zbits if x.dtype == torch.int32 else 0)
             feats.append(x)
         return feats
 

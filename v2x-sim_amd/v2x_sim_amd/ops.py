@@ -41,7 +41,7 @@ class _Prof:
 _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 128: (128, 128, 2, 2), 96: (96, 128, 2, 2)}
 
 
-def conv_kernel_name(pc, H=0, W=0):
+def conv_kernel_name(pc, H=0, W=0, bits=False):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
     if pc.w_layout == 2:
         rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
@@ -51,6 +51,8 @@ def conv_kernel_name(pc, H=0, W=0):
         c0, c1 = (pc.C0, pc.C1) if pc.C1 else (0, pc.C0)
         co2 = (pc.Cout2 + 15) // 16 * 16 if pc.Cout2 else 0
         e2 = 0 if not pc.Cout2 else (2 if pc.epilogue == V2X_EPI_F32 else 1)
+        if (c0, c1, pc.Cout, co2) == (0, 32, 32, 0):  # HBM-bound layers: single-buffer form (+ bit-grid input)
+            return "conv3x3_halo_sb_kernel<0, 32, 32, 0, 0, %s>" % ("true" if bits else "false")
         return "conv3x3_halo_kernel<%d, %d, %d, %d, %d>" % (c0, c1, pc.Cout, co2, e2)
     rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
     return "conv_igemm_kernel<%d, %d, %d, %d, %d>" % (_CONV_TILES[rows] + (pc.epilogue,))
@@ -178,13 +180,22 @@ def conv_out_hw(pc, H, W):
     return Ho, Wo
 
 
-def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0):
+def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0):
     """in0 (N, H>>up0, W>>up0, C0) bf16 NHWC [, in1 (N, H, W, C1)] -> out (N, Ho, Wo, Cout) NHWC.
 
     split > 0: returns (out[..., :split], out2[..., Cout-split]) as two contiguous tensors."""
     lib = _lib.load()
     d = ConvDesc()
-    d.in0 = _dev(in0, torch.bfloat16, "in0").value
+    from_bits = in0.dtype == torch.int32  # the voxelizer's bit grid (N, H, W): first layer, halo kernel only
+    if from_bits:
+        if pc.w_layout != 1 or in1 is not None or in0.dim() != 3 or not (1 <= zbits <= 32):
+            raise ValueError("bit-grid input needs a halo-packed single-source layer and 1 <= zbits <= 32")
+        d.in0 = _dev(in0, torch.int32, "in0").value
+        d.in_format, d.in_zbits = 1, zbits
+        in0_shape = (in0.shape[0], in0.shape[1], in0.shape[2], pc.C0)
+    else:
+        d.in0 = _dev(in0, torch.bfloat16, "in0").value
+        in0_shape = tuple(in0.shape)
     N = in0.shape[0]
     if in1 is not None:
         d.in1 = _dev(in1, torch.bfloat16, "in1").value
@@ -198,8 +209,8 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0):
             raise ValueError("layer %s expects a second source" % pc.name)
         d.in1 = None
         H, W = in0.shape[1] << pc.up0, in0.shape[2] << pc.up0
-    if in0.shape[3] != pc.C0:
-        raise ValueError("in0 has %d channels, layer %s expects %d" % (in0.shape[3], pc.name, pc.C0))
+    if in0_shape[3] != pc.C0:
+        raise ValueError("in0 has %d channels, layer %s expects %d" % (in0_shape[3], pc.name, pc.C0))
     Ho, Wo = conv_out_hw(pc, H, W)
     odt = torch.float32 if pc.epilogue == V2X_EPI_F32 else torch.bfloat16
     cfin = pc.Cout2 if pc.Cout2 else pc.Cout  # channels of the tensor that is actually written
@@ -232,10 +243,10 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0):
         rows_logical = 3 * pc.Cout if pc.epilogue == V2X_EPI_GRU else pc.Cout
         k_logical = pc.ksize * pc.ksize * (pc.C0 + pc.C1)
         M = N * Ho * Wo
-        nbytes = in0.numel() * 2 + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
+        nbytes = in0.numel() * (4 if from_bits else 2) + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
-        prof = _Prof(conv_kernel_name(pc, H, W), flops, nbytes)
+        prof = _Prof(conv_kernel_name(pc, H, W, from_bits), flops, nbytes)
     rc = lib.v2x_conv2d(C.byref(d), _stream())
     if prof is not None:
         prof.done()
@@ -316,7 +327,14 @@ def halo_eligible(H, W, w_layout=1):
     return w_layout == 2 and H % 16 == 0 and W % 16 == 0  # the streamed kernel also has 16x16 tiles
 
 
-def run_layer(layer, in0, in1=None):
+def run_layer(layer, in0, in1=None, zbits=0):
+    """zbits > 0: in0 is the voxelizer's int32 bit grid (N, H, W) -- only the first layer's halo packing reads it."""
+    if in0.dtype == torch.int32:
+        h = layer.halo
+        if h is None or not halo_eligible(in0.shape[1], in0.shape[2], 1) or h.w_layout != 1:
+            in0 = bits_to_nhwc(in0, zbits, layer.fallback[0].C0)  # odd extent: expand, then the gather kernel
+        else:
+            return conv2d(h, in0, zbits=zbits)
     if in1 is not None:
         H, W = in1.shape[1], in1.shape[2]
     else:

@@ -185,10 +185,10 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
         cin_h = _ceil_to(cin_p, 32)
         key = (fb.C0 if fb.C1 else 0, fb.C1 if fb.C1 else cin_h, conv.out_channels)
-        if key in ((0, 32, 32), (64, 32, 32), (0, 64, 64)):
+        if key in ((0, 32, 32), (64, 32, 32)) or (key == (0, 64, 64) and not STREAM_64):
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
-        elif (cin_p >= 128 and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
+        elif (cin_p >= (64 if STREAM_64 else 128) and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
               and STREAM_KERNEL):
             h = pack_conv_stream(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, up0=fb.up0, relu=relu,
                                  device=device)
@@ -196,6 +196,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
 
 
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
+STREAM_64 = False     # 64 -> 64 layers (conv7_2): streamed kernel instead of the resident-weights halo kernel
 
 
 # ------------------------------------------------------------------ streamed-weights kernel layout (conv_stream.hip)

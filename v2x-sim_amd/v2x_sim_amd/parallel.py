@@ -79,8 +79,7 @@ class ShardedV2VNet:
         """points (L, max_pts, stride) fp32 of this rank's items -> encoder pyramid."""
         X, Y, Z = self.grid.dims
         bits = ops.voxelize_bits(points, n_pts, self.grid)
-        x0 = ops.bits_to_nhwc(bits, Z, INPUT_C_PAD)
-        return LidarEncoder.run(pk["enc"], x0)
+        return LidarEncoder.run(pk["enc"], bits, zbits=Z)  # conv_pre_1 reads the bit grid directly
 
     def fuse_local(self, feats, trans, plan, pk):
         m, sh = self.model, self.shard
