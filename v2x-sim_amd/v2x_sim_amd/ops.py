@@ -343,11 +343,11 @@ def run_layer(layer, in0, in1=None, zbits=0):
     if h is not None and halo_eligible(H, W, h.w_layout):
         use = True
         if h.w_layout == 2:
-            # streamed kernel = one 256-pixel x <=128-channel tile per workgroup: with too few workgroups for the
-            # 256 CUs (small maps, small batch) the finer-grained gather kernel fills the chip better
-            # (the rule looks at the map extent only, never at the batch: kernel selection must not change with
-            #  the number of items a rank owns, or R-rank results would stop being bitwise equal to 1-rank results)
-            use = H * W >= 1024
+            # streamed kernel = one 256-pixel x <=128-channel tile per workgroup.  The choice looks at the map extent
+            # only, never at the batch: kernel selection must not change with the number of items a rank owns, or
+            # R-rank results would stop being bitwise equal to 1-rank results.  16x16 maps give Cout/128 workgroups
+            # per map, enough to fill 256 CUs from ~13 frames x 5 agents on; below 16x16 the gather kernel is used.
+            use = H * W >= 256
         if use:
             return conv2d(h, in0, in1, split=layer.split)
     y = conv2d(layer.fallback[0], in0, in1, split=layer.split if len(layer.fallback) == 1 else 0)
