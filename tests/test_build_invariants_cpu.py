@@ -1,0 +1,75 @@
+"""CPU (cross-compile) checks of code-generation invariants the kernels rely on.
+
+conv_stream.hip counts its own LDS-DMA operations with `s_waitcnt vmcnt(N)`: any compiler-inserted scratch
+(spill) load/store inside the kernel would join the same counter and silently corrupt the pipeline, so the
+build must keep every conv kernel spill-free.  The halo / gather kernels must really use LDS-DMA
+(global_load_lds) -- a silent fallback to register staging is how the first version lost 2x."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "v2x-sim_amd", "csrc")
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def _asm(src, tmp_path):
+    out = os.path.join(str(tmp_path), src + ".s")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only",
+                           os.path.join(CSRC, src), "-o", out], stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def _kernels(asm):
+    """name -> (body, metadata dict) for every amdhsa kernel in the file."""
+    res = {}
+    for m in re.finditer(r"^(_Z\w+):.*?s_endpgm", asm, flags=re.S | re.M):
+        res[m.group(1)] = m.group(0)
+    meta = {}
+    for m in re.finditer(r"\.name:\s+(_Z\w+)\n(.*?)\.wavefront_size", asm, flags=re.S):
+        meta[m.group(1)] = m.group(2)
+    return res, meta
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+@pytest.mark.parametrize("src,kernel_prefix,min_kernels", [
+    ("conv_stream.hip", "_Z21conv3x3_stream_kernel", 6),
+    ("conv_halo.hip", "_Z19conv3x3_halo_kernel", 4),
+    ("conv_halo.hip", "_Z22conv3x3_halo_sb_kernel", 2),
+    ("conv_igemm.hip", "_Z17conv_igemm_kernel", 9),
+])
+def test_conv_kernels_are_spill_free_and_use_lds_dma(tmp_path, src, kernel_prefix, min_kernels):
+    asm = _asm(src, tmp_path)
+    bodies, meta = _kernels(asm)
+    names = [n for n in bodies if n.startswith(kernel_prefix)]
+    assert len(names) >= min_kernels, names
+    for n in names:
+        body = bodies[n]
+        assert "scratch_" not in body, "%s touches scratch (spill) -- breaks the vmcnt bookkeeping" % n
+        assert "global_load_lds_dwordx4" in body, "%s lost its LDS-DMA loads" % n
+        assert "v_mfma_f32_16x16x32_bf16" in body
+        md = meta.get(n, "")
+        seg = re.search(r"\.private_segment_fixed_size:\s+(\d+)", md)
+        assert seg and int(seg.group(1)) == 0, (n, seg and seg.group(1))
+        vg = re.search(r"\.vgpr_count:\s+(\d+)", md)
+        assert vg and int(vg.group(1)) <= 256, (n, vg and vg.group(1))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_stream_kernel_waits_are_counted(tmp_path):
+    """Inside the streamed kernel the only vmcnt waits are the hand-placed counted ones (0/2/4/6); in particular the
+    step barrier is a bare s_barrier (a __syncthreads-style `s_waitcnt vmcnt(0)` right before it would drain the ring)."""
+    asm = _asm("conv_stream.hip", tmp_path)
+    bodies, _ = _kernels(asm)
+    name = [n for n in bodies if n.startswith("_Z21conv3x3_stream_kernelILi128ELi8ELi32")][0]
+    body = bodies[name]
+    waits = set(re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
+    assert {"6", "4", "0"} <= waits and waits <= {"0", "2", "4", "6"}, waits
+    # exactly one barrier in the step loop, and the instruction before it is not a vmcnt(0) drain
+    lines = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(";")]
+    idx = [i for i, ln in enumerate(lines) if ln.startswith("s_barrier")]
+    assert len(idx) >= 1
+    for i in idx:
+        assert "vmcnt(0)" not in lines[i - 1], lines[i - 3:i + 1]
