@@ -361,7 +361,7 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
                     d->Cout, d->Cout2, d->epilogue);
         return rc;
     }
-    V2X_REQUIRE(d->Cout2 == 0, "v2x_conv2d: chained 1x1 needs the halo layout (w_layout=1)");
+    V2X_REQUIRE(d->Cout2 == 0 || d->w_layout == 2, "v2x_conv2d: chained 1x1 needs the halo or streamed layout (w_layout 1/2)");
     V2X_REQUIRE(d->in_format == 0, "v2x_conv2d: bit-grid input needs the halo layout (w_layout=1)");
     if (d->w_layout == 2) {
         V2X_REQUIRE(d->in0 && d->weight && d->scale && d->out, "v2x_conv2d(stream): null tensor pointer");

@@ -35,13 +35,17 @@ struct StreamArgs {
     void *out;
     int out_cstride, out_coff, Cout;
     int tiles_x, tiles_y, n_px_tiles, n_co_tiles;
+    // chained 1x1 (SEPI_CHAIN, BCO == Cout == 64): hidden = relu(acc*scale+shift) never leaves the registers
+    const uint16_t *w2;   // bf16 [64][64] row-major, K in the chain (kappa) order of conv_halo.hip
+    const float *scale2, *shift2;
+    int relu2;
 };
 
 constexpr int PATCH_PIECES = 24;             // wave instructions (1 KiB each) per patch buffer
 constexpr int PATCH_BYTES = PATCH_PIECES * 1024;
 constexpr int RING = 4;                      // weight slices in flight + 1 being read
 
-enum { SEPI_BF16 = 0, SEPI_GRU = 2 };
+enum { SEPI_BF16 = 0, SEPI_CHAIN = 1, SEPI_GRU = 2 };
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -208,7 +212,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
                 // schedule (measured): ALL fragment reads first, one wait, then the 32-MFMA block.  hipcc on its own
                 // recycles a single A register set and exposes the LDS latency TCO times per step (-15 %); a finer
-                // read/MFMA interleave and s_setprio around the block were not faster: the co-resident wave of the
+                // read/MFMA interleave, s_setprio around the block, and issuing the reads before the DMA-issue block (in-process
+                // A/B: 433.9 vs 435.3 us) were not faster: the co-resident wave of the
                 // other workgroup is what hides this wave's read phase.
                 __builtin_amdgcn_sched_group_barrier(0x100, TCO + 4, 0);
                 __builtin_amdgcn_sched_group_barrier(0x008, TCO * 4, 0);
@@ -241,6 +246,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 o.y = pack_bf16x2(h[2], h[3]);
                 const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + hc) = o;
+            }
+        }
+    } else if constexpr (EPI == SEPI_CHAIN) {
+        // conv (BCO = all 64 channels, rows in kappa order) -> BN/ReLU -> bf16 -> 1x1 conv 64 -> 64 -> BN/ReLU.
+        // Same register-layout trick as conv_halo.hip: tiles (2s, 2s+1) of a lane ARE its B fragment of k-step s.
+        static_assert(EPI != SEPI_CHAIN || BCO == 64, "chain epilogue needs all channels in one workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // leave the counted-DMA regime before ordinary loads
+        bf16x8_t w2f[4][2];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                w2f[i2][ks] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * 64 + ks * 32 + fq * 8);
+        float4 sc[4], sf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
+            sc[i] = *reinterpret_cast<const float4 *>(a.scale + kappa);
+            sf[i] = *reinterpret_cast<const float4 *>(a.shift + kappa);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            bf16x8_t hb[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float h[8];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int i = 2 * ks + hf;
+                    h[hf * 4 + 0] = acc[i][f][0] * sc[i].x + sf[i].x;
+                    h[hf * 4 + 1] = acc[i][f][1] * sc[i].y + sf[i].y;
+                    h[hf * 4 + 2] = acc[i][f][2] * sc[i].z + sf[i].z;
+                    h[hf * 4 + 3] = acc[i][f][3] * sc[i].w + sf[i].w;
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = fmaxf(h[e], 0.f);
+                }
+                uint4 p;
+                p.x = pack_bf16x2(h[0], h[1]);
+                p.y = pack_bf16x2(h[2], h[3]);
+                p.z = pack_bf16x2(h[4], h[5]);
+                p.w = pack_bf16x2(h[6], h[7]);
+                hb[ks] = __builtin_bit_cast(bf16x8_t, p);
+            }
+            const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][0], hb[0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][1], hb[1], d, 0, 0, 0);
+                const int co = i2 * 16 + fq * 4;
+                const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
+                const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
+                float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
+                if (a.relu2) {
+                    v0 = fmaxf(v0, 0.f);
+                    v1 = fmaxf(v1, 0.f);
+                    v2 = fmaxf(v2, 0.f);
+                    v3 = fmaxf(v3, 0.f);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
             }
         }
     } else {
@@ -321,6 +391,14 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.tiles_y = d->H / (t16 ? 16 : 8);
     a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
     a.n_co_tiles = d->w_rows / rows;
+    a.w2 = d->weight2;
+    a.scale2 = d->scale2;
+    a.shift2 = d->shift2;
+    a.relu2 = d->relu2;
+    if (d->Cout2 > 0) {  // chained 1x1: only the 64 -> 64 -> 64 form (conv1_2 -> conv3d_1) exists
+        if (d->Cout != 64 || d->Cout2 != 64 || d->epilogue != V2X_EPI_BF16 || !d->weight2 || !d->scale2 || !d->shift2) return 1;
+        return t16 ? launch_stream<64, 16, 16, SEPI_CHAIN>(a, s) : launch_stream<64, 8, 32, SEPI_CHAIN>(a, s);
+    }
     if (d->epilogue == V2X_EPI_GRU) return t16 ? launch_stream<96, 16, 16, SEPI_GRU>(a, s) : launch_stream<96, 8, 32, SEPI_GRU>(a, s);
     if (rows == 128) return t16 ? launch_stream<128, 16, 16, SEPI_BF16>(a, s) : launch_stream<128, 8, 32, SEPI_BF16>(a, s);
     return t16 ? launch_stream<64, 16, 16, SEPI_BF16>(a, s) : launch_stream<64, 8, 32, SEPI_BF16>(a, s);

@@ -75,8 +75,9 @@ class LidarEncoder(_ParamsOnly):
                       packing.pack_conv_bn(prefix + "conv3d_1", c3.conv3d, c3.bn3d, device=device)]
                 s1, t1 = packing.fold_bn(c2.bias, b2, c2.out_channels)
                 s2, t2 = packing.fold_bn(c3.conv3d.bias, c3.bn3d, c3.conv3d.out_channels)
-                halo = packing.pack_conv_halo(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
-                                              chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
+                pack = packing.pack_conv_stream if packing.CHAIN_STREAM else packing.pack_conv_halo
+                halo = pack(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
+                            chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
                 stage.append(ops.Layer(fb, halo, name=prefix + "conv1_2+conv3d_1"))
             else:
                 stage.append(L(prefix + "conv%s_2" % lvl, c2, b2, device=device))

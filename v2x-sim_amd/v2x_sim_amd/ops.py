@@ -46,7 +46,8 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
     if pc.w_layout == 2:
         rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
         th, tw = (8, 32) if W % 32 == 0 else (16, 16)
-        return "conv3x3_stream_kernel<%d, %d, %d, %d>" % (rows, th, tw, 2 if pc.epilogue == V2X_EPI_GRU else 0)
+        epi = 2 if pc.epilogue == V2X_EPI_GRU else (1 if pc.Cout2 else 0)
+        return "conv3x3_stream_kernel<%d, %d, %d, %d>" % (rows, th, tw, epi)
     if pc.w_layout == 1:
         c0, c1 = (pc.C0, pc.C1) if pc.C1 else (0, pc.C0)
         co2 = (pc.Cout2 + 15) // 16 * 16 if pc.Cout2 else 0

@@ -196,6 +196,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
 
 
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
+CHAIN_STREAM = True   # conv1_2 -> conv3d_1: chained epilogue in the streamed kernel (2 WG/CU) instead of the halo kernel
 STREAM_64 = False     # 64 -> 64 layers (conv7_2): streamed kernel instead of the resident-weights halo kernel
 
 
@@ -209,8 +210,10 @@ def _stream_layout(wk, rows_tile, cin):
     return torch.cat([flat, torch.zeros(32, dtype=flat.dtype)])   # + 64 B of zeros: the kernel's zero page
 
 
-def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=True, device="cuda"):
-    """3x3 stride-1 conv with C0, C1 multiples of 32 and Cout a multiple of 64, for conv_stream.hip."""
+def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=True, chain=None, device="cuda"):
+    """3x3 stride-1 conv with C0, C1 multiples of 32 and Cout a multiple of 64, for conv_stream.hip.
+    chain = (weight2 [64, 64, 1, 1], scale2, shift2, relu2): 1x1 conv fused in the epilogue (Cout == 64 only);
+    the hidden rows are stored in the chain order of conv_halo.hip."""
     lib = _lib.load()
     w = weight.detach().float().cpu()
     cout, cin, k, _ = w.shape
@@ -220,11 +223,21 @@ def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=T
     if k != 3 or C0 + C1 != cin or C0 % 32 or C1 % 32 or tile == 0:
         raise ValueError("%s: not a shape the streamed kernel covers" % name)
     wk = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
-    return PackedConv(name=name, weight=_stream_layout(wk, tile, cin).to(torch.bfloat16).to(device).contiguous(),
-                      scale=scale.detach().float().to(device).contiguous(),
-                      shift=shift.detach().float().to(device).contiguous(), C0=C0, C1=C1, Cout=cout, ksize=3,
-                      stride=1, pad=1, up0=up0, epilogue=V2X_EPI_BF16, relu=relu, w_rows=cout, w_kpad=9 * cin,
-                      w_layout=2, Cout2=0)
+    if chain is not None:
+        if cout != 64 or chain[0].shape[0] != 64:
+            raise ValueError("%s: the streamed kernel chains only 64 -> 64 -> 64" % name)
+        wk = wk[_chain_row_order(cout)]
+    pc = PackedConv(name=name, weight=_stream_layout(wk, tile, cin).to(torch.bfloat16).to(device).contiguous(),
+                    scale=scale.detach().float().to(device).contiguous(),
+                    shift=shift.detach().float().to(device).contiguous(), C0=C0, C1=C1, Cout=cout, ksize=3,
+                    stride=1, pad=1, up0=up0, epilogue=V2X_EPI_BF16, relu=relu, w_rows=cout, w_kpad=9 * cin,
+                    w_layout=2, Cout2=0)
+    if chain is not None:
+        w2, s2, t2, relu2 = chain
+        pc.Cout2, pc.relu2 = 64, relu2
+        pc.weight2 = w2.detach().float().cpu().reshape(64, 64).to(torch.bfloat16).to(device).contiguous()
+        pc.scale2, pc.shift2 = s2.detach().float().to(device).contiguous(), t2.detach().float().to(device).contiguous()
+    return pc
 
 
 def pack_gru_stream(name, weight_ih, bias_ih, bias_hh, *, C0, C1, device="cuda"):
