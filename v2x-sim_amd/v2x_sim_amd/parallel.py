@@ -106,3 +106,61 @@ class ShardedV2VNet:
         feats[m.layer] = self.fuse_local(feats, trans, plan, pk)
         x = LidarDecoder.run(pk["dec"], *feats)
         return m.get_cls_loc_result(x, pk["heads"])
+
+
+class ShardedWhen2com:
+    """when2com / who2com over an agent shard (BASELINE.json config 4).
+
+    Exchange = (1) the per-item key (1024 fp32) and query (32 fp32) vectors -- 4 KiB per item, every rank then runs the
+    5x5 handshake of every frame itself (it is ~5 kFLOP) -- and (2) the fusion-layer maps.  `sparse_fetch` names the
+    communication-sparsity idea of when2com: only maps with a non-zero coefficient for one of this rank's items are
+    needed; with an all-gather transport every map travels anyway, so the saving here is the skipped warps
+    (warp_fuse never touches a source whose coefficient is 0).  A point-to-point fetch of just the needed maps is
+    the natural next step on xGMI and is left for a later round."""
+
+    def __init__(self, model, shard, exchange=None, group=None):
+        self.model, self.shard, self.group = model, shard, group
+        self.exchange = exchange or (lambda t: exchange_features(t, shard.world, group))
+        self.grid = ops.VoxelGrid()
+
+    def plan(self, num_agent_tensor, device):
+        sh = self.shard
+        nat = num_agent_tensor.detach().to("cpu") if isinstance(num_agent_tensor, torch.Tensor) else num_agent_tensor
+        counts = [int(nat[f][0]) for f in range(sh.Bt)]
+        sel = [i for i, (a, f) in enumerate(sh.items) if a < counts[f]]
+        items = [sh.items[i] for i in sel]
+        mask = torch.zeros((len(items), sh.A), dtype=torch.float32)
+        for m, (a, f) in enumerate(items):
+            mask[m, :counts[f]] = 1.0
+        it = torch.tensor(items, dtype=torch.int64).view(-1, 2)
+        return {"items": torch.tensor(items, dtype=torch.int32, device=device).view(-1, 2), "mask": mask.to(device),
+                "local_rows": None if len(sel) == sh.per_rank else torch.tensor(sel, device=device),
+                "q_idx": it[:, 0].to(device), "f_idx": it[:, 1].to(device)}
+
+    def forward_bits(self, bits, zbits, trans, plan, training=False, inference="activated"):
+        """bits: this rank's (L, X, Y) int32 occupancy words."""
+        from ._lib import V2X_FUSE_WSUM
+        from .models.det.When2com import KmGenerator
+        m, sh = self.model, self.shard
+        pk = m.packed(bits.device)
+        feats = LidarEncoder.run(pk["enc"], bits, zbits=zbits)
+        y = LidarEncoder.run(pk["tower"]["enc"], bits, zbits=zbits)[4]
+        for layer in pk["tower"]["convs"]:
+            y = ops.run_layer(layer, y)
+        keys = self.exchange(KmGenerator.run(pk["key"], y).contiguous())       # (A*Bt, 1024) on every rank
+        querys = self.exchange(KmGenerator.run(pk["query"], y).contiguous())   # (A*Bt, 32)
+        mode = "softmax" if (training or inference == "softmax") else inference
+        prob, coef = ops.attn_handshake(keys, querys, pk["w_lin"], pk["b_lin"], sh.A, sh.Bt, mode)
+        coef_items = coef[plan["f_idx"], :, plan["q_idx"]].contiguous() * plan["mask"]
+        gathered = self.exchange(feats[m.layer])
+        fused_items = ops.warp_fuse(gathered, sh.A, sh.Bt, trans, plan["items"], coef_items, V2X_FUSE_WSUM)
+        if plan["local_rows"] is None:
+            fused = fused_items
+        else:
+            fused = torch.zeros_like(feats[m.layer])
+            fused.index_copy_(0, plan["local_rows"], fused_items)
+        feats[m.layer] = fused
+        x = LidarDecoder.run(pk["dec"], *feats)
+        res = m.get_cls_loc_result(x, pk["heads"])
+        res["prob_action"], res["coef"] = prob, coef
+        return res
