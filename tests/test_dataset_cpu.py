@@ -32,7 +32,7 @@ def test_layout_and_roundtrip(tmp_path):
     ds = V2XSimDet(dataset_roots=roots, config=Config("test"), split="test", val=True)
     assert len(ds) == 2 and ds.seq_names == ["7_0", "7_1"]
     s = ds[1]
-    assert len(s) == 3 and len(s[0]) == 12
+    assert len(s) == 3 and len(s[0]) == 13 and s[0][12].shape == (0, 5)
     for a in range(3):
         bev = s[a][0]
         assert bev.shape == (1, 256, 256, 13) and bev.dtype == np.float32

@@ -53,3 +53,34 @@ def test_dataset_dense_and_sparse_paths_agree(device, tmp_path):
         a = pm(bevs.to(device), trans.to(device), nat, batch_size=1)
         b = pm.forward_nhwc(x0, trans_d, nat2, batch_size=1)
     assert torch.equal(a["cls"], b["cls"]) and torch.equal(a["loc"], b["loc"])
+
+
+@pytest.mark.parametrize("com", ["v2v", "lowerbound", "who2com"])
+def test_test_codet_driver_runs_on_a_parsed_tree(device, tmp_path, com, capsys):
+    """tools/det/test_codet.py (upstream flag surface) end to end on a synthetic parsed dataset + a saved checkpoint."""
+    import importlib.util
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.datasets import write_sample
+    from v2x_sim_amd.models.det import FaFNet, V2VNet, When2com
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
+    A, frames = 3, 2
+    pts = synthetic_points(A * frames, 15000, seed=31)
+    T = synthetic_poses(frames, A, seed=32)
+    rng = np.random.default_rng(1)
+    for f in range(frames):
+        for a in range(A):
+            _, idx = VR.voxelize_occupy(pts[a * frames + f], return_indices=True)
+            gt = np.concatenate([rng.uniform(-25, 25, (6, 2)), np.tile([2.0, 4.0], (6, 1)), rng.uniform(-1, 1, (6, 1))], 1)
+            write_sample(str(tmp_path), "test", a, 3, f, idx, T[f, a], A, gt_boxes=gt)
+    cls = {"v2v": V2VNet, "lowerbound": FaFNet, "who2com": When2com}[com]
+    kw = {"kd_flag": 0} if com == "lowerbound" else {}
+    ckpt = os.path.join(str(tmp_path), "ckpt.pth")
+    torch.save({"epoch": 1, "model_state_dict": init_synthetic_weights(cls(Config("test"), num_agent=A, **kw), seed=4).state_dict()}, ckpt)
+    spec = importlib.util.spec_from_file_location("test_codet", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "det", "test_codet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    res = mod.main(["--data", os.path.join(str(tmp_path), "test"), "--com", com, "--resume", ckpt, "--num_agent", str(A),
+                    "--batch", "2", "--score_thr", "0.55"])
+    out = capsys.readouterr().out
+    assert "average local mAP@0.5" in out and out.count("agent") >= A
+    assert 0.0 <= res[0.5] <= 1.0 and 0.0 <= res[0.7] <= 1.0

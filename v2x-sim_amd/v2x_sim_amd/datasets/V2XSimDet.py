@@ -13,7 +13,8 @@ and the reader:
 
     {"voxel_indices_0": int32 (M, 3)   lexicographically sorted occupied voxels (x, y, z),
      "trans_matrices":   float32 (A, 4, 4)  pose of every agent w.r.t. this one (row j -> feature_transformation),
-     "target_agent_id":  int,  "num_sensor": int   (number of real agents in the frame)}
+     "target_agent_id":  int,  "num_sensor": int   (number of real agents in the frame),
+     "gt_boxes":         float32 (G, 5) optional   [x, y, w, h, yaw] ground truth for test-time mAP}
 
 __getitem__ keeps upstream's per-agent tuple order for the fields the inference path consumes
 (padded_voxel_points, trans_matrices, target_agent_id, num_sensor); training targets (label_one_hot,
@@ -32,14 +33,17 @@ import torch
 from torch.utils.data import Dataset
 
 
-def write_sample(root, split, agent, scene, frame, voxel_indices, trans_matrices, num_sensor):
-    """Writes one (agent, scene, frame) sample in the layout of README.md:66-79."""
+def write_sample(root, split, agent, scene, frame, voxel_indices, trans_matrices, num_sensor, gt_boxes=None):
+    """Writes one (agent, scene, frame) sample in the layout of README.md:66-79.
+    gt_boxes: optional (G, 5) [x, y, w, h, yaw] ground-truth vehicles in this agent's frame (for test-time mAP)."""
     d = os.path.join(root, split, "agent%d" % agent, "%d_%d" % (scene, frame))
     os.makedirs(d, exist_ok=True)
     idx = np.ascontiguousarray(voxel_indices, dtype=np.int32).reshape(-1, 3)
     order = np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))
     sample = {"voxel_indices_0": idx[order], "trans_matrices": np.asarray(trans_matrices, dtype=np.float32),
               "target_agent_id": int(agent), "num_sensor": int(num_sensor)}
+    if gt_boxes is not None:
+        sample["gt_boxes"] = np.asarray(gt_boxes, dtype=np.float32).reshape(-1, 5)
     np.save(os.path.join(d, "0.npy"), sample, allow_pickle=True)
     return d
 
@@ -88,7 +92,8 @@ class V2XSimDet(Dataset):
                 padded_voxel_points = indices
             res.append((padded_voxel_points, None, None, None, None, None, None, None,
                         os.path.join(root, name), int(gt["target_agent_id"]), int(gt["num_sensor"]),
-                        np.asarray(gt["trans_matrices"], dtype=np.float32)))
+                        np.asarray(gt["trans_matrices"], dtype=np.float32),
+                        np.asarray(gt.get("gt_boxes", np.zeros((0, 5), np.float32)), dtype=np.float32)))
         return res
 
 
