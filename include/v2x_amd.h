@@ -53,6 +53,16 @@ int v2x_voxelize_bits(const float *pts, const int32_t *n_pts, int n_clouds, int 
                       const double *extents, const double *voxel, const int32_t *dims_xyz,
                       uint32_t *bits, v2x_stream_t stream);
 
+/* Early fusion (the "upperbound" baseline, README.md:101): upstream merges the clouds of all agents into the
+ * ego frame at data-preparation time (create_data_det.py, CPU) and voxelizes the union.  Here job j moves source
+ * cloud src_cloud[j] by the rigid transform xform[j] (device fp32 [n_jobs][3][4], row-major) and scatters it into
+ * target grid dst_grid[j]; several jobs may share a target.  fp32 transform with separately rounded ops in the
+ * order ((x*m0 + y*m1) + z*m2) + m3, then the a1 index spec.  bits: [n_grids][X][Y], cleared by the call. */
+int v2x_voxelize_fused_bits(const float *pts, const int32_t *n_pts, int n_clouds, int max_pts, int pt_stride,
+                            const float *xform, const int32_t *src_cloud, const int32_t *dst_grid, int n_jobs,
+                            int n_grids, const double *extents, const double *voxel, const int32_t *dims_xyz,
+                            uint32_t *bits, v2x_stream_t stream);
+
 /* bits -> the reference's dense padded_voxel_points layout [n][X][Y][Z] fp32 {0,1}. */
 int v2x_bits_to_dense_f32(const uint32_t *bits, int n, int X, int Y, int Z, float *out, v2x_stream_t stream);
 

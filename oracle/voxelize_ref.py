@@ -120,3 +120,23 @@ def synthetic_points(n, seed, n_dup_frac=0.01, n_edge=64):
         e[i, 2] = zs[rng.integers(0, len(zs))]
     pts[n_rand + n_dup:] = e
     return pts
+
+
+def transform_points_f32(pts, T):
+    """Early-fusion spec: rigid transform of fp32 points by the fp32 matrix T (3x4 or 4x4),
+    every product and sum rounded to fp32, in the order ((x*m0 + y*m1) + z*m2) + m3."""
+    p = np.asarray(pts, dtype=np.float32)
+    m = np.asarray(T, dtype=np.float32)
+    out = p.copy()
+    for r in range(3):
+        acc = (p[:, 0] * m[r, 0]).astype(np.float32)
+        acc = (acc + (p[:, 1] * m[r, 1]).astype(np.float32)).astype(np.float32)
+        acc = (acc + (p[:, 2] * m[r, 2]).astype(np.float32)).astype(np.float32)
+        out[:, r] = (acc + m[r, 3]).astype(np.float32)
+    return out
+
+
+def voxelize_early_fusion(clouds, transforms, voxel_size=VOXEL_SIZE, extents=AREA_EXTENTS):
+    """Upperbound input of one ego: union of all agents' sweeps moved into the ego frame, then voxelize_occupy."""
+    merged = np.concatenate([transform_points_f32(c, T) for c, T in zip(clouds, transforms)], axis=0)
+    return voxelize_occupy(merged, voxel_size, extents)

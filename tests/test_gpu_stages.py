@@ -416,3 +416,35 @@ def test_halo_chain_heads_split_f32(device):
     got = torch.cat([from_nhwc(cls), from_nhwc(loc)], 1)
     assert torch.allclose(got, ref, atol=2e-2, rtol=1e-2), float((got - ref).abs().max())
     assert float((got - ref).abs().mean()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------- a1, early fusion (upperbound)
+def test_voxelize_early_fusion_bit_exact(device):
+    """BASELINE.json config 1: every ego grid = union of all agents' sweeps moved into the ego frame.  Bit-exact vs the
+    oracle's fp32 transform (separately rounded ops) + voxelize_occupy; also checks jobs sharing a target grid."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.utils.synthetic import synthetic_poses
+    A, n = 5, 30000
+    clouds = [VR.synthetic_points(n, seed=70 + a, n_edge=32) for a in range(A)]
+    T = synthetic_poses(1, A, seed=5)[0]                      # T[i, j]: agent j's frame -> agent i's frame
+    pts = torch.from_numpy(np.stack(clouds)).to(device)
+    cnt = torch.full((A,), n, dtype=torch.int32, device=device)
+    xf, src, dst = [], [], []
+    for i in range(A):
+        for j in range(A):
+            xf.append(T[i, j][:3])
+            src.append(j)
+            dst.append(i)
+    grid = ops.VoxelGrid()
+    bits = ops.voxelize_fused_bits(pts, cnt, torch.tensor(np.stack(xf), dtype=torch.float32, device=device),
+                                   torch.tensor(src, dtype=torch.int32, device=device),
+                                   torch.tensor(dst, dtype=torch.int32, device=device), A, grid)
+    dense = ops.bits_to_dense(bits, 13).cpu().numpy()
+    for i in range(A):
+        ref = VR.voxelize_early_fusion(clouds, [T[i, j] for j in range(A)])
+        assert np.array_equal(dense[i], ref), "ego %d" % i
+    # identity transform on a single job == plain voxelizer
+    eye = torch.eye(4)[:3].unsqueeze(0).contiguous().to(device)
+    one = ops.voxelize_fused_bits(pts, cnt, eye, torch.tensor([2], dtype=torch.int32, device=device),
+                                  torch.tensor([0], dtype=torch.int32, device=device), 1, grid)
+    assert torch.equal(one[0], ops.voxelize_bits(pts, cnt, grid)[2])

@@ -197,3 +197,23 @@ def test_confusion_matrix():
     label = torch.tensor([0, 1, 2, 7, 3])
     cm = R.confusion_matrix(pred, label)
     assert cm.sum() == 5 and cm[2, 1] == 1 and cm[7, 7] == 1
+
+
+def test_early_fusion_transform_spec():
+    """fp32 transform with separately rounded ops: identity is exact, a generic pose agrees with the
+    fp64 product to fp32 round-off, and the merged grid is the union of the individually voxelized moved clouds."""
+    pts = VR.synthetic_points(5000, seed=11)
+    eye = np.eye(4, dtype=np.float32)
+    assert np.array_equal(VR.transform_points_f32(pts, eye)[:, :3], pts[:, :3])
+    from v2x_sim_amd.utils.synthetic import synthetic_poses
+    T = synthetic_poses(1, 3, seed=2)[0]
+    moved = VR.transform_points_f32(pts, T[0, 1])
+    ref = pts[:, :3].astype(np.float64) @ T[0, 1][:3, :3].astype(np.float64).T + T[0, 1][:3, 3].astype(np.float64)
+    assert np.abs(moved[:, :3] - ref).max() < 2e-5
+    assert np.array_equal(moved[:, 3], pts[:, 3])
+    clouds = [VR.synthetic_points(3000, seed=20 + a) for a in range(3)]
+    merged = VR.voxelize_early_fusion(clouds, [T[0, j] for j in range(3)])
+    union = np.zeros_like(merged)
+    for j in range(3):
+        union = np.maximum(union, VR.voxelize_occupy(VR.transform_points_f32(clouds[j], T[0, j])))
+    assert np.array_equal(merged, union)

@@ -46,6 +46,43 @@ __global__ __launch_bounds__(256) void voxelize_scatter_kernel(const float *__re
     }
 }
 
+// Early fusion (upperbound): job j scatters source cloud src[j], moved by the rigid transform xform[j] (row-major
+// 3x4, fp32), into target grid dst[j].  The transform is evaluated in fp32 with every multiply and add rounded
+// separately, in the fixed order ((x*m0 + y*m1) + z*m2) + m3 (no FMA contraction), so the oracle can restate it
+// bit for bit; the voxel index of the moved point then follows the a1 spec (fp64 compare / divide).
+__global__ __launch_bounds__(256) void voxelize_fused_scatter_kernel(const float *__restrict__ pts,
+                                                                     const int32_t *__restrict__ n_pts, int max_pts,
+                                                                     int pt_stride, const float *__restrict__ xform,
+                                                                     const int32_t *__restrict__ src,
+                                                                     const int32_t *__restrict__ dst, VoxParams vp,
+                                                                     uint32_t *__restrict__ bits) {
+    const int job = blockIdx.y;
+    const int cloud = src[job];
+    const int n = n_pts[cloud];
+    const float *base = pts + (size_t)cloud * max_pts * pt_stride;
+    const float *m = xform + (size_t)job * 12;
+    uint32_t *grid = bits + (size_t)dst[job] * vp.X * vp.Y;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const float px = base[(size_t)i * pt_stride + 0], py = base[(size_t)i * pt_stride + 1],
+                    pz = base[(size_t)i * pt_stride + 2];
+        float t[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+            t[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(px, m[4 * r + 0]), __fmul_rn(py, m[4 * r + 1])),
+                                       __fmul_rn(pz, m[4 * r + 2])), m[4 * r + 3]);
+        const double x = (double)t[0], y = (double)t[1], z = (double)t[2];
+        const bool keep = (vp.lo[0] < x) && (x < vp.hi[0]) && (vp.lo[1] < y) && (y < vp.hi[1]) &&
+                          (vp.lo[2] < z) && (z < vp.hi[2]);
+        if (!keep) continue;
+        const int ix = (int)(floor(x / vp.vs[0]) - vp.mn[0]);
+        const int iy = (int)(floor(y / vp.vs[1]) - vp.mn[1]);
+        const int iz = (int)(floor(z / vp.vs[2]) - vp.mn[2]);
+        if ((unsigned)ix >= (unsigned)vp.X || (unsigned)iy >= (unsigned)vp.Y || (unsigned)iz >= (unsigned)vp.Z)
+            continue;
+        atomicOr(&grid[(size_t)ix * vp.Y + iy], 1u << iz);
+    }
+}
+
 // [n][X][Y] words -> [n][X][Y][Z] fp32, one thread per output element (coalesced 4-B stores)
 __global__ __launch_bounds__(256) void bits_to_dense_f32_kernel(const uint32_t *__restrict__ bits, size_t n_pix,
                                                                 int Z, float *__restrict__ out) {
@@ -293,5 +330,41 @@ extern "C" int v2x_indices_to_bits(const int32_t *idx, const int32_t *counts, in
     if (grid.x > 512) grid.x = 512;
     hipLaunchKernelGGL(indices_to_bits_kernel, grid, dim3(256), 0, s, idx, counts, cap, X, Y, Z, bits);
     V2X_CHECK_LAUNCH("indices_to_bits_kernel");
+    return V2X_OK;
+}
+
+extern "C" int v2x_voxelize_fused_bits(const float *pts, const int32_t *n_pts, int n_clouds, int max_pts, int pt_stride,
+                                       const float *xform, const int32_t *src_cloud, const int32_t *dst_grid, int n_jobs,
+                                       int n_grids, const double *extents, const double *voxel,
+                                       const int32_t *dims_xyz, uint32_t *bits, v2x_stream_t stream) {
+    V2X_REQUIRE(pts && n_pts && xform && src_cloud && dst_grid && extents && voxel && dims_xyz && bits,
+                "v2x_voxelize_fused_bits: null pointer");
+    V2X_REQUIRE(n_clouds >= 0 && max_pts >= 0 && pt_stride >= 3 && n_jobs >= 0 && n_grids >= 0 && n_jobs <= 65535,
+                "v2x_voxelize_fused_bits: bad sizes");
+    V2X_REQUIRE(dims_xyz[2] >= 1 && dims_xyz[2] <= 32 && dims_xyz[0] >= 1 && dims_xyz[1] >= 1,
+                "v2x_voxelize_fused_bits: bad grid dims");
+    if (n_grids == 0) return V2X_OK;
+    hipStream_t s = (hipStream_t)stream;
+    VoxParams vp;
+    for (int a = 0; a < 3; ++a) {
+        vp.lo[a] = extents[2 * a];
+        vp.hi[a] = extents[2 * a + 1];
+        vp.vs[a] = voxel[a];
+        V2X_REQUIRE(voxel[a] > 0.0, "v2x_voxelize_fused_bits: voxel size must be > 0");
+        vp.mn[a] = floor(extents[2 * a] / voxel[a]);
+    }
+    vp.X = dims_xyz[0];
+    vp.Y = dims_xyz[1];
+    vp.Z = dims_xyz[2];
+    if (hipMemsetAsync(bits, 0, (size_t)n_grids * vp.X * vp.Y * sizeof(uint32_t), s) != hipSuccess) {
+        v2x_set_error("v2x_voxelize_fused_bits: memset failed");
+        return V2X_EIO;
+    }
+    if (max_pts == 0 || n_jobs == 0) return V2X_OK;
+    dim3 grid((max_pts + 255) / 256, n_jobs);
+    if (grid.x > 256) grid.x = 256;
+    hipLaunchKernelGGL(voxelize_fused_scatter_kernel, grid, dim3(256), 0, s, pts, n_pts, max_pts, pt_stride, xform,
+                       src_cloud, dst_grid, vp, bits);
+    V2X_CHECK_LAUNCH("voxelize_fused_scatter_kernel");
     return V2X_OK;
 }

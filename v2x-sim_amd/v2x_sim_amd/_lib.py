@@ -40,6 +40,9 @@ SIGNATURES = {
     "v2x_voxelize_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                      C.c_void_p, C.c_void_p]),
+    "v2x_voxelize_fused_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                           C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_int32), C.c_void_p, C.c_void_p]),
     "v2x_bits_to_dense_f32": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_bits_to_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_void_p]),

@@ -102,6 +102,24 @@ def voxelize_bits(points, n_pts, grid, out=None):
     return out
 
 
+def voxelize_fused_bits(points, n_pts, xform, src_cloud, dst_grid, n_grids, grid):
+    """Early fusion: job j scatters cloud src_cloud[j], moved by xform[j] (n_jobs, 3, 4) fp32, into grid dst_grid[j].
+    -> bits (n_grids, X, Y) int32."""
+    lib = _lib.load()
+    n, mp, st = points.shape
+    n_jobs = xform.shape[0]
+    if tuple(xform.shape) != (n_jobs, 3, 4) or src_cloud.shape[0] != n_jobs or dst_grid.shape[0] != n_jobs:
+        raise ValueError("xform (n_jobs, 3, 4), src_cloud (n_jobs,), dst_grid (n_jobs,) expected")
+    X, Y, Z = grid.dims
+    out = torch.empty((n_grids, X, Y), dtype=torch.int32, device=points.device)
+    rc = lib.v2x_voxelize_fused_bits(_dev(points, torch.float32, "points"), _dev(n_pts, torch.int32, "n_pts"), n, mp, st,
+                                     _dev(xform, torch.float32, "xform"), _dev(src_cloud, torch.int32, "src_cloud"),
+                                     _dev(dst_grid, torch.int32, "dst_grid"), n_jobs, n_grids, grid._ext, grid._vox,
+                                     grid._dims, _dev(out, torch.int32, "bits"), _stream())
+    _lib.check(rc, "v2x_voxelize_fused_bits")
+    return out
+
+
 def bits_to_dense(bits, Z):
     lib = _lib.load()
     n, X, Y = bits.shape
