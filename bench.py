@@ -7,7 +7,8 @@ One step = one pass of the whole hot path over one batch of synthetic frames, in
 resident in HBM:  LiDAR points -> voxel scatter (a1) -> encoder (a2) -> [RCCL all-gather of the
 fusion-layer maps when N > 1] -> warp + ConvGRU (a3, a4) -> decoder (a6) -> det heads (a7).
 Work items are (agent, frame) maps sharded agent-major over the ranks (v2x_sim_amd/parallel.py);
-per-GPU work is fixed as N grows (weak scaling): frames = frames_per_gpu * N.
+per-GPU work is fixed as N grows (weak scaling): frames = frames_per_gpu * N, run as two half-batches whose
+all-gathers are asynchronous and hidden under the other half's compute.
 
 Prints ONE JSON line (rank 0).  `roofline` is computed from HIP events recorded live around every
 kernel launch of an instrumented pass on the launch stream; `cpu_baseline` times the CPU oracle
@@ -40,7 +41,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-gpu", type=int, default=32)
+    ap.add_argument("--frames-per-gpu", type=int, default=64)
     ap.add_argument("--gnn-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -111,31 +112,45 @@ def main():
     from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
     from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
 
-    Bt = args.frames_per_gpu * world
+    if args.frames_per_gpu % 2:
+        raise SystemExit("--frames-per-gpu must be even (the step runs as two half-batches)")
+    Bt = args.frames_per_gpu * world            # frames per step, whole job
+    Bh = Bt // 2                                # frames per half-batch
     model = init_synthetic_weights(V2VNet(Config("test"), gnn_iter_times=args.gnn_iters, num_agent=AGENTS), seed=0)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    shard = AgentShard(AGENTS, Bt, rank, world)
+    # The step is two independent half-batches of Bh frames, each agent-sharded over all ranks.  Half A's all-gather
+    # is started asynchronously and flies under half B's encoder; half B's flies under half A's fusion/decoder/heads.
+    # The decomposition is the same for every N (at N = 1 there is simply nothing to gather): weak scaling.
+    shard = AgentShard(AGENTS, Bh, rank, world)
     runner = ShardedV2VNet(model, shard)
     if force_dist and world == 1:
-        from v2x_sim_amd.parallel import exchange_features
-
-        def _forced(t):
-            out = torch.empty_like(t)
-            dist.all_gather_into_tensor(out, t.contiguous())
-            return out
-        runner.exchange = _forced
-    # synthetic sweeps of this rank's (agent, frame) items, resident in HBM
-    pts = np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=1000 + r) for r in shard.rows])
-    points = torch.from_numpy(pts).to(dev)
-    n_pts = torch.full((shard.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=dev)
-    trans = torch.from_numpy(synthetic_poses(Bt, AGENTS, seed=99)).to(dev)
-    plan = shard.fusion_plan(torch.full((Bt, AGENTS), AGENTS), dev)
+        class _ForcedWorld1(ShardedV2VNet):     # take the world > 1 code path (async RCCL all-gather) on one rank
+            def begin(self, points, n_pts):
+                pk = self.model.packed(points.device)
+                feats = self.encode_points(points, n_pts, pk)
+                local = feats[self.model.layer].contiguous()
+                out = torch.empty_like(local)
+                return feats, out, dist.all_gather_into_tensor(out, local, async_op=True)
+        runner = _ForcedWorld1(model, shard)
+    halves = []
+    for h in range(2):
+        # synthetic sweeps of this rank's (agent, frame) items of half h, resident in HBM
+        pts = np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=1000 + 100000 * h + r) for r in shard.rows])
+        halves.append({"points": torch.from_numpy(pts).to(dev),
+                       "n_pts": torch.full((shard.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=dev),
+                       "trans": torch.from_numpy(synthetic_poses(Bh, AGENTS, seed=99 + h)).to(dev),
+                       "plan": shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), dev)})
     model.packed(dev)
 
     def step():
         with torch.no_grad():
-            return runner.forward_points(points, n_pts, trans, plan)
+            a, b = halves
+            fa = runner.begin(a["points"], a["n_pts"])
+            fb = runner.begin(b["points"], b["n_pts"])
+            out_a = runner.finish(*fa, a["trans"], a["plan"])
+            out_b = runner.finish(*fb, b["trans"], b["plan"])
+            return out_a, out_b
 
     def barrier():
         if use_dist:
@@ -203,7 +218,7 @@ def main():
         # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, gfx950-corrected by tools/pmc_traffic.py); valid for the default 32 frames/GPU workload only
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and args.frames_per_gpu == 32 and world == 1:
+        if os.path.exists(tfile) and args.frames_per_gpu == 64 and world == 1:  # 2 half-batches of 32 = the profiled launches
             with open(tfile) as fh:
                 tk = json.load(fh)["kernels"].get(dom)
             if tk:
@@ -231,8 +246,10 @@ def main():
             "data": "synthetic (seeded 65536-pt sweeps per agent, random SE(2) poses, He-init weights)",
             "config": {"workload": "V2VNet 5-agent detection, points->logits (a1-a7), gnn_iter=%d" % args.gnn_iters,
                        "agents": AGENTS, "frames_per_step": Bt, "frames_per_gpu": args.frames_per_gpu,
+                       "half_batches": 2,
                        "points_per_agent": POINTS_PER_SWEEP, "bev": [256, 256, 13],
-                       "sharding": "agent-major (agent,frame) items, contiguous slices; all-gather of fusion maps"
+                       "sharding": "agent-major (agent,frame) items, contiguous slices; async RCCL all-gather of the fusion "
+                                   "maps of one half-batch overlapped with the other half's compute"
                                    if world > 1 else "single GPU, no collective",
                        "hip_graph": use_graph},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,

@@ -241,6 +241,33 @@ def test_sharded_equals_unsharded_bitwise(device, world):
     assert torch.equal(torch.cat([o["loc"] for o in outs]), ref["loc"])
 
 
+def test_begin_finish_interleaved_equals_forward_points(device):
+    """bench.py's step: two half-batches, begin(A) begin(B) finish(A) finish(B).  Interleaving must not change a bit
+    of either half (separate buffers, no shared state between begin and finish)."""
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+    from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
+    A, Bt = 5, 2
+    pm, _ = build(V2VNet, R.V2VNet, device)
+    sh = AgentShard(A, Bt, 0, 1)
+    rn = ShardedV2VNet(pm, sh)
+    nat = torch.full((Bt, A), A)
+    plan = sh.fusion_plan(nat, device)
+    halves = []
+    for h in range(2):
+        pts = torch.from_numpy(synthetic_points(A * Bt, 16384, seed=70 + h)).to(device)
+        cnt = torch.full((A * Bt,), 16384, dtype=torch.int32, device=device)
+        trans = torch.from_numpy(synthetic_poses(Bt, A, seed=80 + h)).to(device)
+        halves.append((pts, cnt, trans))
+    with torch.no_grad():
+        ref = [rn.forward_points(p, c, t, plan) for p, c, t in halves]
+        fa = rn.begin(halves[0][0], halves[0][1])
+        fb = rn.begin(halves[1][0], halves[1][1])
+        got = [rn.finish(*fa, halves[0][2], plan), rn.finish(*fb, halves[1][2], plan)]
+    for g, r in zip(got, ref):
+        assert torch.equal(g["cls"], r["cls"]) and torch.equal(g["loc"], r["loc"])
+
+
 def test_sharded_when2com_equals_unsharded_bitwise(device):
     """BASELINE.json config 4: when2com agent-sharded.  Two virtual ranks on one GPU (the all-gathers are emulated by
     concatenating the ranks' tensors) must reproduce the unsharded model bit for bit, incl. a ragged frame."""

@@ -72,6 +72,7 @@ class ShardedV2VNet:
 
     def __init__(self, model, shard, exchange=None, group=None):
         self.model, self.shard, self.group = model, shard, group
+        self._custom_exchange = exchange is not None
         self.exchange = exchange or (lambda t: exchange_features(t, shard.world, group))
         self.grid = ops.VoxelGrid()
 
@@ -81,11 +82,36 @@ class ShardedV2VNet:
         bits = ops.voxelize_bits(points, n_pts, self.grid)
         return LidarEncoder.run(pk["enc"], bits, zbits=Z)  # conv_pre_1 reads the bit grid directly
 
-    def fuse_local(self, feats, trans, plan, pk):
+    def begin(self, points, n_pts):
+        """Encoder of this rank's items, then START the exchange of the fusion-layer maps without waiting for it:
+        -> (feats, gathered, work).  With world > 1 and the default transport the all-gather runs asynchronously on
+        RCCL's stream (`async_op=True`), so the caller can launch more encoder work before calling finish()."""
+        m, sh = self.model, self.shard
+        pk = m.packed(points.device)
+        feats = self.encode_points(points, n_pts, pk)
+        local = feats[m.layer]
+        if sh.world == 1 or self._custom_exchange:
+            return feats, self.exchange(local), None
+        out = torch.empty((sh.world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        work = dist.all_gather_into_tensor(out, local.contiguous(), group=self.group, async_op=True)
+        return feats, out, work
+
+    def finish(self, feats, gathered, work, trans, plan):
+        """Wait for the exchange started by begin(), then warp + ConvGRU + decoder + heads for this rank's items."""
+        if work is not None:
+            work.wait()  # makes the current stream wait for the collective; the host does not block
+        m = self.model
+        pk = m.packed(gathered.device)
+        feats[m.layer] = self.fuse_local(feats, trans, plan, pk, gathered0=gathered)
+        x = LidarDecoder.run(pk["dec"], *feats)
+        return m.get_cls_loc_result(x, pk["heads"])
+
+    def fuse_local(self, feats, trans, plan, pk, gathered0=None):
         m, sh = self.model, self.shard
         local = feats[m.layer]
         cur = local
-        gathered0 = self.exchange(local)
+        if gathered0 is None:
+            gathered0 = self.exchange(local)
         for it in range(m.gnn_iter_num):
             src = gathered0 if (m.neighbor_source == "initial" or it == 0) else self.exchange(cur)
             mean = ops.warp_fuse(src, sh.A, sh.Bt, trans, plan["items"], plan["coef"], V2X_FUSE_MEAN)
