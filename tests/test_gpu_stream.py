@@ -106,3 +106,43 @@ def test_stream_chain_conv1x1(device, hw):
     if W % 32 == 0:
         alt = back(ops.conv2d(ph, nhwc(x, device)))
         assert torch.allclose(got, alt, atol=3e-2, rtol=2 ** -6)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (C_up, C, Cout, N, H, W, gru)
+    (0, 256, 256, 3, 32, 32, False),    # conv3_2 class
+    (512, 256, 256, 2, 32, 32, False),  # conv5_1: half-resolution source + skip
+    (256, 128, 128, 1, 64, 64, False),  # conv6_1
+    (0, 128, 128, 2, 16, 32, False),    # a single 16x32 tile per map
+    (256, 256, 256, 2, 32, 32, True),   # ConvGRU (two plain sources)
+])
+def test_stream8_equals_stream4_bitwise(device, cfg, monkeypatch):
+    """The 8-wave ping-pong kernel walks K in the same order with the same fragment mapping as the 4-wave kernel:
+    outputs must be identical bit for bit (and stable over repeated launches: its barrier/vmcnt protocol is new)."""
+    from v2x_sim_amd import ops, packing
+    cup, c, cout, N, H, W, gru = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:6]))
+    x = nhwc(bf16r(torch.randn(N, c, H, W, generator=g)), device)
+    if gru:
+        x0 = nhwc(bf16r(torch.randn(N, cup, H, W, generator=g)), device)
+        w = torch.randn(3 * cout, cup + c, 3, 3, generator=g) * 0.02
+        b1, b2 = torch.randn(3 * cout, generator=g) * 0.1, torch.randn(3 * cout, generator=g) * 0.1
+        pc = packing.pack_gru_stream("g", w, b1, b2, C0=cup, C1=c, device=device)
+        run = lambda: ops.conv2d(pc, x0, x)
+    else:
+        w = torch.randn(cout, cup + c, 3, 3, generator=g) * (2.0 / ((cup + c) * 9)) ** 0.5
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+        pc = packing.pack_conv_stream("t", w, scale, shift, C0=cup if cup else c, C1=c if cup else 0,
+                                      up0=1 if cup else 0, device=device)
+        if cup:
+            x0 = nhwc(bf16r(torch.randn(N, cup, H // 2, W // 2, generator=g)), device)
+            run = lambda: ops.conv2d(pc, x0, x)
+        else:
+            run = lambda: ops.conv2d(pc, x)
+    monkeypatch.setenv("V2X_STREAM_WAVES", "4")
+    y4 = run()
+    monkeypatch.delenv("V2X_STREAM_WAVES")
+    y8 = run()
+    assert torch.equal(y4, y8)
+    for _ in range(10):
+        assert torch.equal(run(), y8)

@@ -17,6 +17,7 @@
 // LDS: 4 x 8 KiB ring + 2 x 24 KiB patch buffers = 80 KiB -> two workgroups per CU (160 KiB).
 // LDS layouts as conv_halo.hip (conflict-free: patch slot ^ ((x>>1)&3), weights k-slot-major).
 #include "common.h"
+#include <cstdlib>
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -50,6 +51,129 @@ enum { SEPI_BF16 = 0, SEPI_CHAIN = 1, SEPI_GRU = 2 };
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// ---- epilogue shared by the 4-wave and the 8-wave kernels -------------------------------------------
+template <int BCO, int TW, int EPI>
+__device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&acc)[BCO / 16][4], int co_tile, int n, int y0,
+                                                int x0, const int (&frow)[4], int fj, int fq) {
+    constexpr int TCO = BCO / 16;
+    if constexpr (EPI == SEPI_GRU) {
+        // rows are (r,z,n) triples of 16 hidden channels: tiles 3g, 3g+1, 3g+2  (packing.pack_gru_stream)
+#pragma unroll
+        for (int g = 0; g < TCO / 3; ++g) {
+            const int hc = (co_tile * (TCO / 3) + g) * 16 + fq * 4;
+            if (hc >= a.Cout) continue;
+            float4 bias[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias[r] = reinterpret_cast<const float4 *>(a.scale)[hc + r];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float h[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float rg = 1.0f / (1.0f + __expf(-(acc[3 * g][f][r] + bias[r].x)));
+                    const float zg = 1.0f / (1.0f + __expf(-(acc[3 * g + 1][f][r] + bias[r].y)));
+                    const float ng = tanhf(acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w);
+                    h[r] = ng + zg * (0.0f - ng);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(h[0], h[1]);
+                o.y = pack_bf16x2(h[2], h[3]);
+                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + hc) = o;
+            }
+        }
+    } else if constexpr (EPI == SEPI_CHAIN) {
+        // conv (BCO = all 64 channels, rows in kappa order) -> BN/ReLU -> bf16 -> 1x1 conv 64 -> 64 -> BN/ReLU.
+        // Same register-layout trick as conv_halo.hip: tiles (2s, 2s+1) of a lane ARE its B fragment of k-step s.
+        static_assert(EPI != SEPI_CHAIN || BCO == 64, "chain epilogue needs all channels in one workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // leave the counted-DMA regime before ordinary loads
+        bf16x8_t w2f[4][2];
+#pragma unroll
+        for (int i2 = 0; i2 < 4; ++i2)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                w2f[i2][ks] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * 64 + ks * 32 + fq * 8);
+        float4 sc[4], sf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
+            sc[i] = *reinterpret_cast<const float4 *>(a.scale + kappa);
+            sf[i] = *reinterpret_cast<const float4 *>(a.shift + kappa);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            bf16x8_t hb[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float h[8];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf) {
+                    const int i = 2 * ks + hf;
+                    h[hf * 4 + 0] = acc[i][f][0] * sc[i].x + sf[i].x;
+                    h[hf * 4 + 1] = acc[i][f][1] * sc[i].y + sf[i].y;
+                    h[hf * 4 + 2] = acc[i][f][2] * sc[i].z + sf[i].z;
+                    h[hf * 4 + 3] = acc[i][f][3] * sc[i].w + sf[i].w;
+                }
+                if (a.relu) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) h[e] = fmaxf(h[e], 0.f);
+                }
+                uint4 p;
+                p.x = pack_bf16x2(h[0], h[1]);
+                p.y = pack_bf16x2(h[2], h[3]);
+                p.z = pack_bf16x2(h[4], h[5]);
+                p.w = pack_bf16x2(h[6], h[7]);
+                hb[ks] = __builtin_bit_cast(bf16x8_t, p);
+            }
+            const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+#pragma unroll
+            for (int i2 = 0; i2 < 4; ++i2) {
+                f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][0], hb[0], d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][1], hb[1], d, 0, 0, 0);
+                const int co = i2 * 16 + fq * 4;
+                const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
+                const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
+                float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
+                if (a.relu2) {
+                    v0 = fmaxf(v0, 0.f);
+                    v1 = fmaxf(v1, 0.f);
+                    v2 = fmaxf(v2, 0.f);
+                    v3 = fmaxf(v3, 0.f);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int co = co_tile * BCO + i * 16 + fq * 4;
+            if (co >= a.Cout) continue;
+            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
+            const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
+                float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
+                if (a.relu) {
+                    v0 = fmaxf(v0, 0.f);
+                    v1 = fmaxf(v1, 0.f);
+                    v2 = fmaxf(v2, 0.f);
+                    v3 = fmaxf(v3, 0.f);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
+            }
+        }
+    }
 }
 
 template <int BCO, int TH, int TW, int EPI>
@@ -221,123 +345,199 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
 
-    // ---- epilogue ------------------------------------------------------------------------------------
-    if constexpr (EPI == SEPI_GRU) {
-        // rows are (r,z,n) triples of 16 hidden channels: tiles 3g, 3g+1, 3g+2  (packing.pack_gru_stream)
+    stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+}
+
+// ---- 8-wave "ping-pong" form --------------------------------------------------------------------------
+// One 512-thread workgroup per CU owns a 16x32-pixel tile: wave group g (waves 4g..4g+3) computes pixel rows
+// [8g, 8g+8) with exactly the fragment mapping of the 4-wave kernel, and both groups share ONE weight ring and ONE
+// patch, so a weight slice is fetched L2->LDS once per 512 pixels (half the DMA instructions per MFMA: 1 weight piece
+// + 1 patch piece per wave and step; an LDS-DMA instruction costs 60-185 issue cycles next to MFMAs,
+// MI355X_MICROARCH.md).  The two groups run half a step out of phase:
+//
+//      interval   2s          2s+1        2s+2
+//      group 0    L(s)        M(s)        L(s+1)        L(s) = issue the DMAs of step s+3, read the 12 fragments
+//      group 1    M(s-1)      L(s)        M(s)                 of step s, wait for own pieces of slice s+1
+//                                                       M(s) = the 32 MFMAs of step s
+// with one s_barrier between intervals (group 1 takes one extra barrier up front, group 0 one at the end), so on
+// every SIMD the MFMA block of one wave always runs beside the load phase of the other -- the overlap the two
+// independent 4-wave workgroups per CU only get by chance.
+// Hazards: (R1) a wave waits for its own pieces of slice s+1 (vmcnt(4): two newer 2-DMA groups may be in flight)
+// before the barrier closing its L(s); both groups' L(s) close before interval 2s+2, where slice s+1 is first read.
+// (R2) slice s+3 overwrites the ring slot of slice s-1, last read in group 1's L(s-1) (interval 2s-1, lgkmcnt(0)
+// before its barrier); the first overwrite is issued in interval 2s.  (R3) the next chunk's patch goes to the
+// other buffer, last read in L(9kc-1), first written in L(9kc); its last piece is issued at tap 4, five steps
+// before it is read.  Every wave issues exactly 2 DMAs per step (dummies keep the count), so the counts are static.
+constexpr int PATCH8_PIECES = 40;            // 18 x 34 pixels x 64 B = 38.25 KiB; piece 39 is padding / dummy target
+constexpr int PATCH8_BYTES = PATCH8_PIECES * 1024;
+
+template <int BCO, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8_kernel(const StreamArgs a) {
+    constexpr int TH = 16, TW = 32;
+    constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
+    constexpr int TCO = BCO / 16;
+    constexpr int W_PIECES = BCO / 16;
+    constexpr int SLICE_BYTES = BCO * 64;
+    static_assert(PH * PW * 4 <= (PATCH8_PIECES - 1) * 64, "patch must leave the last piece as padding");
+    static_assert(W_PIECES <= 8, "at most one weight DMA per wave per step");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_ring = smem;
+    char *s_patch = smem + RING * SLICE_BYTES;
+    char *s_dummy = s_patch + (PATCH8_PIECES - 1) * 1024;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int grp = wave >> 2, wv = wave & 3;
+    const int fj = lane & 15, fq = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int co_tile = bid % a.n_co_tiles;
+    const int px_tile = bid / a.n_co_tiles;
+    const int txy = a.tiles_x * a.tiles_y;
+    const int n = px_tile / txy;
+    const int trem = px_tile - n * txy;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    const int nc0 = a.C0 >> 5, nchunks = (a.C0 + a.C1) >> 5;
+    const int S = nchunks * 9;
+    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+
+    // per-lane tables (as in the 4-wave kernel): 5 patch pieces per wave (piece = wave + 8t)
+    int pd_full[5], pd_half[5];
 #pragma unroll
-        for (int g = 0; g < TCO / 3; ++g) {
-            const int hc = (co_tile * (TCO / 3) + g) * 16 + fq * 4;
-            if (hc >= a.Cout) continue;
-            float4 bias[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bias[r] = reinterpret_cast<const float4 *>(a.scale)[hc + r];
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                float h[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float rg = 1.0f / (1.0f + __expf(-(acc[3 * g][f][r] + bias[r].x)));
-                    const float zg = 1.0f / (1.0f + __expf(-(acc[3 * g + 1][f][r] + bias[r].y)));
-                    const float ng = tanhf(acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w);
-                    h[r] = ng + zg * (0.0f - ng);
-                }
-                uint2 o;
-                o.x = pack_bf16x2(h[0], h[1]);
-                o.y = pack_bf16x2(h[2], h[3]);
-                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + hc) = o;
-            }
+    for (int t = 0; t < 5; ++t) {
+        const int L = (wave + 8 * t) * 64 + lane;
+        const int pix = L >> 2, phys = L & 3;
+        {
+            const int pr = pix / PW, pc = pix - pr * PW;
+            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+            const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            pd_full[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
         }
-    } else if constexpr (EPI == SEPI_CHAIN) {
-        // conv (BCO = all 64 channels, rows in kappa order) -> BN/ReLU -> bf16 -> 1x1 conv 64 -> 64 -> BN/ReLU.
-        // Same register-layout trick as conv_halo.hip: tiles (2s, 2s+1) of a lane ARE its B fragment of k-step s.
-        static_assert(EPI != SEPI_CHAIN || BCO == 64, "chain epilogue needs all channels in one workgroup");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // leave the counted-DMA regime before ordinary loads
-        bf16x8_t w2f[4][2];
-#pragma unroll
-        for (int i2 = 0; i2 < 4; ++i2)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                w2f[i2][ks] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * 64 + ks * 32 + fq * 8);
-        float4 sc[4], sf[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
-            sc[i] = *reinterpret_cast<const float4 *>(a.scale + kappa);
-            sf[i] = *reinterpret_cast<const float4 *>(a.shift + kappa);
+        {
+            const int Hs = a.H >> 1, Ws = a.W >> 1;
+            const int pr = pix / PW0, pc = pix - pr * PW0;
+            const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+            const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+            pd_half[t] = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
         }
+    }
+    int frow[4], ct_full[4][3], ct_half[4][3];
 #pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            bf16x8_t hb[2];
+    for (int f = 0; f < 4; ++f) {
+        const int col = (f & 1) * 16 + fj;
+        frow[f] = 8 * grp + 2 * wv + (f >> 1);
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float h[8];
-#pragma unroll
-                for (int hf = 0; hf < 2; ++hf) {
-                    const int i = 2 * ks + hf;
-                    h[hf * 4 + 0] = acc[i][f][0] * sc[i].x + sf[i].x;
-                    h[hf * 4 + 1] = acc[i][f][1] * sc[i].y + sf[i].y;
-                    h[hf * 4 + 2] = acc[i][f][2] * sc[i].z + sf[i].z;
-                    h[hf * 4 + 3] = acc[i][f][3] * sc[i].w + sf[i].w;
-                }
-                if (a.relu) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) h[e] = fmaxf(h[e], 0.f);
-                }
-                uint4 p;
-                p.x = pack_bf16x2(h[0], h[1]);
-                p.y = pack_bf16x2(h[2], h[3]);
-                p.z = pack_bf16x2(h[4], h[5]);
-                p.w = pack_bf16x2(h[6], h[7]);
-                hb[ks] = __builtin_bit_cast(bf16x8_t, p);
-            }
-            const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
-#pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
-                f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][0], hb[0], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][1], hb[1], d, 0, 0, 0);
-                const int co = i2 * 16 + fq * 4;
-                const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
-                const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
-                float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
-                if (a.relu2) {
-                    v0 = fmaxf(v0, 0.f);
-                    v1 = fmaxf(v1, 0.f);
-                    v2 = fmaxf(v2, 0.f);
-                    v3 = fmaxf(v3, 0.f);
-                }
-                uint2 o;
-                o.x = pack_bf16x2(v0, v1);
-                o.y = pack_bf16x2(v2, v3);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
-            }
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pcf = col + kx;
+            const int pch = ((col + kx - 1) >> 1) + 1;
+            ct_full[f][kx] = ((pcf << 2) + (fq ^ ((pcf >> 1) & 3))) * 16;
+            ct_half[f][kx] = ((pch << 2) + (fq ^ ((pch >> 1) & 3))) * 16;
         }
-    } else {
+    }
+
+    const bool has_w = wave < W_PIECES;                       // wave-uniform
+    const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
+    auto issue_dummy = [&]() { glds16s(zero_page, s_dummy); };
+    auto issue_weights = [&](int s) {                         // exactly one DMA
+        if (has_w && s < S) glds16s(wsrc + (size_t)s * (BCO * 32), s_ring + (s & (RING - 1)) * SLICE_BYTES + wave * 1024);
+        else issue_dummy();
+    };
+    auto issue_patch_piece = [&](int kc, int t, int buf) {    // exactly one DMA
+        const bool first = kc < nc0;
+        const bool hf = first && a.up0;
+        int d = hf ? pd_half[0] : pd_full[0];
 #pragma unroll
-        for (int i = 0; i < TCO; ++i) {
-            const int co = co_tile * BCO + i * 16 + fq * 4;
-            if (co >= a.Cout) continue;
-            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
-            const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+        for (int u = 1; u < 5; ++u) d = (t == u) ? (hf ? pd_half[u] : pd_full[u]) : d;
+        const uint16_t *src = first ? a.in0 : a.in1;
+        const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
+        const unsigned off = (unsigned)(d >> 5) * cs + (unsigned)((first ? kc : kc - nc0) * 32 + (d & 31));
+        glds16s(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + buf * PATCH8_BYTES + (wave + 8 * t) * 1024);
+    };
+
+    // prologue: patch of chunk 0 (5 pieces per wave), then the 2-DMA groups of steps 0, 1, 2
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
-                float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
-                if (a.relu) {
-                    v0 = fmaxf(v0, 0.f);
-                    v1 = fmaxf(v1, 0.f);
-                    v2 = fmaxf(v2, 0.f);
-                    v3 = fmaxf(v3, 0.f);
-                }
-                uint2 o;
-                o.x = pack_bf16x2(v0, v1);
-                o.y = pack_bf16x2(v2, v3);
-                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
+    for (int t = 0; t < 5; ++t) issue_patch_piece(0, t, 0);
+    issue_weights(0); issue_dummy();
+    issue_weights(1); issue_dummy();
+    issue_weights(2); issue_dummy();
+    wait_vmcnt<4>();                       // patch 0 and slice 0 have landed (groups 1 and 2 may be in flight)
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // half-step offset
+
+    f32x4_t acc[TCO][4];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    int s = 0;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const char *pb = s_patch + (kc & 1) * PATCH8_BYTES;
+        const bool half = (kc < nc0) && a.up0;
+        const int sh = half ? 1 : 0, row_bytes = (half ? PW0 : PW) * 64;
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            int rowoff[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) rowoff[f] = (((frow[f] + ky - sh) >> sh) + sh) * row_bytes;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx, ++s) {
+                const int tap = ky * 3 + kx;
+                // ---- L(s): DMAs of step s+3, fragments of step s
+                issue_weights(s + 3);
+                if (tap < 5 && kc + 1 < nchunks) issue_patch_piece(kc + 1, tap, (kc + 1) & 1);
+                else issue_dummy();
+                const char *ws = s_ring + (s & (RING - 1)) * SLICE_BYTES;
+                bf16x8_t fa[TCO], fb[4];
+#pragma unroll
+                for (int f = 0; f < 4; ++f)
+                    fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + (half ? ct_half[f][kx] : ct_full[f][kx]));
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+                wait_vmcnt<4>();                                   // own pieces of slice s+1 (and older) have landed
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers (R2)
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- M(s)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the offset barrier of group 1
+    stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+}
+
+template <int BCO, int EPI>
+static int launch_stream8(const StreamArgs &a, hipStream_t s) {
+    constexpr int smem = RING * BCO * 64 + 2 * PATCH8_BYTES;  // 112 KiB at BCO=128: one 8-wave workgroup per CU
+    static bool attr_done = false;
+    auto kern = &conv3x3_stream8_kernel<BCO, EPI>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(512), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_stream8_kernel");
+    return V2X_OK;
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -395,6 +595,17 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.scale2 = d->scale2;
     a.shift2 = d->shift2;
     a.relu2 = d->relu2;
+    // 8-wave ping-pong form: 16x32 tiles, the wide channel tiles.  V2X_STREAM_WAVES=4 forces the 4-wave kernel
+    // (A/B runs and the bitwise-equality test; the choice never depends on the batch size).
+    if (!t16 && d->H % 16 == 0 && d->Cout2 == 0 && (rows == 128 || rows == 96)) {
+        const char *e = getenv("V2X_STREAM_WAVES");
+        if (!(e && e[0] == '4')) {
+            a.tiles_y = d->H / 16;
+            a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
+            if (d->epilogue == V2X_EPI_GRU) return launch_stream8<96, SEPI_GRU>(a, s);
+            return launch_stream8<128, SEPI_BF16>(a, s);
+        }
+    }
     if (d->Cout2 > 0) {  // chained 1x1: only the 64 -> 64 -> 64 form (conv1_2 -> conv3d_1) exists
         if (d->Cout != 64 || d->Cout2 != 64 || d->epilogue != V2X_EPI_BF16 || !d->weight2 || !d->scale2 || !d->shift2) return 1;
         return t16 ? launch_stream<64, 16, 16, SEPI_CHAIN>(a, s) : launch_stream<64, 8, 32, SEPI_CHAIN>(a, s);
