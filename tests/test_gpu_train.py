@@ -1,0 +1,133 @@
+"""Row f-3 (training path) and the mAP half of BASELINE.json's metric with a TRAINED detector.
+
+1. The product's training graph (v2x_sim_amd/train/graph.py, PyTorch-ROCm autograd on the MI355X) computes the same
+   loss (1e-3, both BN modes) as the oracle's autograd graph on the CPU, and with running-statistics BN the same
+   gradients within 2e-2 of each tensor's largest entry.  The tolerance is set by measurement: every individual op (conv
+   fwd/dgrad/wgrad at the network's shapes, grid_sample, BN, index_add) agrees GPU-vs-CPU-vs-fp64 to ~1e-6, but a ReLU
+   network's gradient is discontinuous in its activations -- 1e-7 forward differences flip a few ReLUs -- and
+   batch-statistics BN amplifies that further (printed, not asserted; even CPU-vs-CPU the two graphs differ by 1e-3..1e-2
+   there, tests/test_train_graph_cpu.py, which also shows the lowerbound graph is identical to rounding).
+2. A V2VNet trained for a few hundred steps on synthetic scenes (utils/synthetic_scene.py) has separated scores, so
+   mAP stops being chaotic in the rounding noise (contrast tests/test_gpu_map.py): the HIP inference path (bf16
+   kernels) and the fp32 CPU oracle, loaded with the SAME trained weights, must agree on mAP@0.5 and mAP@0.7 within
+   +-0.2 points -- the tolerance BASELINE.json's north_star states -- on held-out scenes.
+PARITY UNPINNED w.r.t. the reference (no reference code or checkpoints in /root/reference); the oracle is build-owned.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import coperception_ref as R
+
+pytestmark = pytest.mark.gpu
+
+TRAIN_STEPS = 300
+EVAL_FRAMES = 6
+
+
+def test_train_graph_loss_and_grads_match_oracle(device):
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.loop import synthetic_batch_on_device
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    A = 2
+    cfg = Config("train")
+    # random biases / BN statistics: with zero biases every empty BEV region sits EXACTLY on the ReLU kink
+    # (pre-activation 0.0), where the subgradient is a convention and 1e-9 of kernel noise flips it
+    pm = init_synthetic_weights(V2VNet(cfg, num_agent=A), seed=3)
+    om = R.V2VNet(num_agent=A)
+    om.load_state_dict(pm.state_dict())
+    pm = pm.to(device)
+    data = synthetic_batch_on_device(cfg, 1, A, seed=5, device=device)
+    cpu = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+    for mode, gtol in (("eval", 2e-2), ("train", None)):
+        getattr(pm, mode)()
+        getattr(om, mode)()
+        pm.zero_grad()
+        om.zero_grad()
+        res = train_forward(pm, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
+        loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])
+        loss[0].backward()
+        ref = om(cpu["bev_seq"], cpu["trans_matrices"], cpu["num_agent"], batch_size=1)
+        rloss = detection_loss(ref, cpu["labels"], cpu["reg_targets"], cpu["reg_loss_mask"])
+        rloss[0].backward()
+        for a, b in zip(loss, rloss):
+            assert abs(float(a.detach()) - float(b.detach())) <= 1e-3 * abs(float(b.detach())) + 1e-5, mode
+        og = dict(om.named_parameters())
+        gmax = max(float(g.grad.abs().max()) for g in og.values() if g.grad is not None)
+        worst, worst_k = 0.0, ""
+        for k, p in pm.named_parameters():
+            if p.grad is None:              # convgru.weight_hh_l0: h0 = 0, never multiplied -> the oracle's gradient is 0
+                assert k == "convgru.weight_hh_l0" and (og[k].grad is None or float(og[k].grad.abs().max()) == 0.0), k
+                continue
+            d = float((p.grad.cpu() - og[k].grad).abs().max()) / max(float(og[k].grad.abs().max()), 1e-3 * gmax)
+            if d >= worst:
+                worst, worst_k = d, k
+        print("%s-mode BN: loss %.5f (oracle %.5f), worst relative gradient difference %.2e (%s)" % (
+            mode, float(loss[0].detach()), float(rloss[0].detach()), worst, worst_k))
+        if gtol is not None:
+            assert worst < gtol, (mode, worst, worst_k)
+
+
+@pytest.fixture(scope="module")
+def trained(device):
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.train.loop import init_for_training, train_synthetic
+    cfg = Config("train")
+    model = init_for_training(V2VNet(cfg), seed=0)
+    hist = train_synthetic(model, cfg, TRAIN_STEPS, frames_per_step=2, lr=1e-3, seed=7, device=device, log=50)
+    return cfg, model, hist
+
+
+def test_loss_decreases(trained):
+    _, _, hist = trained
+    first, last = np.mean([h[0] for h in hist[:10]]), np.mean([h[0] for h in hist[-10:]])
+    print("loss: first 10 steps %.4f -> last 10 steps %.4f" % (first, last))
+    assert last < 0.2 * first
+
+
+def test_trained_detector_map_parity(trained, device):
+    from v2x_sim_amd.train.loop import synthetic_batch_on_device
+    from v2x_sim_amd.utils import postprocess as P
+    from v2x_sim_amd.utils.CoDetModule import FaFModule
+    cfg, model, _ = trained
+    A, B = model.agent_num, EVAL_FRAMES
+    data = synthetic_batch_on_device(cfg, B, A, seed=424242, device=device, with_targets=False)
+    module = FaFModule(model, None, cfg, None, 0)
+    _, _, _, seq = module.predict_all(data, B, validation=False, num_agent=A)          # HIP engine, bf16 kernels
+    om = R.V2VNet().eval()
+    om.load_state_dict(model.state_dict())
+    with torch.no_grad():
+        ref = om(data["bev_seq"].cpu(), data["trans_matrices"].cpu(), data["num_agent"], batch_size=B)
+    det_hip, det_ref, gts = [], [], []
+    for k in range(A):
+        for b in range(B):
+            row = k * B + b
+            det_hip.append(seq[k][b])
+            det_ref.append(P.apply_nms_det(ref["loc"][row].numpy(), ref["cls"][row].numpy(), module.anchors,
+                                           module.score_thr, module.nms_thr))
+            gts.append(P.box_corners(data["gt_boxes"][k][b].astype(np.float64)))
+    n_gt = sum(g.shape[0] for g in gts)
+    out = {}
+    for iou in (0.5, 0.7):
+        ap_ref, info = P.eval_map(det_ref, gts, iou)
+        ap_hip, info_h = P.eval_map(det_hip, gts, iou)
+        out[iou] = (100 * ap_ref, 100 * ap_hip)
+        print("trained V2VNet, %d held-out agent-frames, %d gt boxes: mAP@%.1f  oracle-fp32 %.2f (%d det)  HIP %.2f (%d det)"
+              % (A * B, n_gt, iou, 100 * ap_ref, info["num_det"], 100 * ap_hip, info_h["num_det"]))
+    # detection-level agreement: same number of boxes per agent-frame (+-1) and, for boxes that pair up, centimetre agreement
+    worst_xy, n_pair, n_diff = 0.0, 0, 0
+    for dh, dr in zip(det_hip, det_ref):
+        n_diff += abs(dh["boxes"].shape[0] - dr["boxes"].shape[0])
+        for bx in dh["boxes"]:
+            if dr["boxes"].shape[0]:
+                d = np.hypot(dr["boxes"][:, 0] - bx[0], dr["boxes"][:, 1] - bx[1])
+                if d.min() < 1.0:
+                    worst_xy, n_pair = max(worst_xy, float(d.min())), n_pair + 1
+    print("detections: %d paired HIP/oracle boxes, worst centre distance %.3f m, %d unpaired" % (n_pair, worst_xy, n_diff))
+    assert n_diff <= 0.02 * n_pair and worst_xy < 0.05
+    assert out[0.5][0] > 30.0, "the detector did not train"
+    for iou in (0.5, 0.7):
+        assert abs(out[iou][0] - out[iou][1]) <= 0.2, out

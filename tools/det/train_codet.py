@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Detection training driver -- the flag surface of upstream coperception/tools/det/train_codet.py
+(/root/reference/README.md:101 points at it; the script itself is not in the reference tree).
+
+    python tools/det/train_codet.py --data synthetic --com v2v --nepoch 1 --steps 400 --batch 2 --logpath out/
+
+Training = PyTorch-ROCm autograd graph over the parameter tree of the HIP engine (v2x_sim_amd/train/); the sweeps are
+voxelised by the HIP voxeliser.  `--data synthetic` draws fresh synthetic scenes (the V2X-Sim download is not
+available offline, README.md:42-48).  Writes epoch_{n}.pth with 'model_state_dict' (upstream's checkpoint key), which
+tools/det/test_codet.py --resume loads into the HIP inference path."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for _p in (ROOT, os.path.join(ROOT, "v2x-sim_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-d", "--data", default="synthetic", type=str)
+    ap.add_argument("--com", default="v2v", choices=["lowerbound", "upperbound", "v2v"])
+    ap.add_argument("--batch", default=2, type=int, help="frames per step")
+    ap.add_argument("--nepoch", default=1, type=int)
+    ap.add_argument("--steps", default=400, type=int, help="steps per epoch (synthetic data has no natural epoch)")
+    ap.add_argument("--lr", default=1e-3, type=float)
+    ap.add_argument("--num_agent", default=5, type=int)
+    ap.add_argument("--layer", default=3, type=int)
+    ap.add_argument("--gnn_iter_times", default=1, type=int)
+    ap.add_argument("--resume", default="", type=str)
+    ap.add_argument("--logpath", default="", type=str)
+    ap.add_argument("--seed", default=0, type=int)
+    ap.add_argument("--log", action="store_true")
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet, V2VNet
+    from v2x_sim_amd.train.loop import init_for_training, train_synthetic
+    if not torch.cuda.is_available():
+        raise SystemExit("train_codet.py needs the MI355X")
+    if args.data != "synthetic":
+        raise SystemExit("only --data synthetic is wired up (parsed V2X-Sim-det training targets: DESIGN.md section 9)")
+    config = Config("train", binary=True, only_det=True)
+    A = args.num_agent
+    model = (V2VNet(config, gnn_iter_times=args.gnn_iter_times, layer=args.layer, num_agent=A) if args.com == "v2v"
+             else FaFNet(config, layer=args.layer, kd_flag=0, num_agent=A))
+    if args.resume:
+        ckpt = torch.load(args.resume, map_location="cpu")
+        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=False)
+    else:
+        init_for_training(model, seed=args.seed)
+    for epoch in range(1, args.nepoch + 1):
+        hist = train_synthetic(model, config, args.steps, args.batch, args.lr, seed=args.seed + epoch, log=20 if args.log else None)
+        tail = hist[-20:]
+        print("epoch %d: mean loss of the last %d steps %.4f" % (epoch, len(tail), sum(h[0] for h in tail) / len(tail)))
+        if args.logpath:
+            os.makedirs(args.logpath, exist_ok=True)
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict()}, os.path.join(args.logpath, "epoch_%d.pth" % epoch))
+    return model
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,116 @@
+"""Differentiable graph of the detection baselines for TRAINING.
+
+Inference runs the hand-written HIP kernels (models/det/*.forward).  Training needs batch-statistics BatchNorm and
+gradients; SURVEY.md section 8(b) allows the backward to "stay in PyTorch-ROCm ops", and that is what this module is:
+the same graph written with torch ops on the MI355X (MIOpen convolutions, autograd), over the SAME parameter tree --
+the nn.Conv2d / nn.BatchNorm2d containers that models/det/base.py holds under the upstream names -- so an optimizer
+steps the very tensors the HIP engine packs (DetModelBase.packed() notices the version bump and re-packs).
+
+Graph = upstream Backbone.py / DetModelBase.py / V2VNet.py semantics (PyTorch 1.8 per README.md:88-95): nearest x2
+upsample, concat (up, skip), two-step affine_grid/grid_sample warp with align_corners=False, ConvGRU step with h0 = 0.
+It is NOT a fallback for inference: models refuse to run forward() off the GPU library, and this graph is only
+reached through FaFModule.step() / train_forward().
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _cbr(x, conv, bn):
+    return F.relu(bn(conv(x)))
+
+
+def _conv3d_1x1(x, m):
+    """upstream Conv3D on a length-1 sequence: (N, C, H, W) -> 1x1x1 conv3d + BN3d + ReLU."""
+    return F.relu(m.bn3d(m.conv3d(x.unsqueeze(2)))).squeeze(2)
+
+
+def encoder(e, x):
+    """x (N, Z, X, Y) fp32 -> [x, x_1, x_2, x_3, x_4]."""
+    x = _cbr(x, e.conv_pre_1, e.bn_pre_1)
+    x = _cbr(x, e.conv_pre_2, e.bn_pre_2)
+    x_1 = _cbr(x, e.conv1_1, e.bn1_1)
+    x_1 = _conv3d_1x1(_cbr(x_1, e.conv1_2, e.bn1_2), e.conv3d_1)
+    x_2 = _cbr(x_1, e.conv2_1, e.bn2_1)
+    x_2 = _conv3d_1x1(_cbr(x_2, e.conv2_2, e.bn2_2), e.conv3d_2)
+    x_3 = _cbr(_cbr(x_2, e.conv3_1, e.bn3_1), e.conv3_2, e.bn3_2)
+    x_4 = _cbr(_cbr(x_3, e.conv4_1, e.bn4_1), e.conv4_2, e.bn4_2)
+    return [x, x_1, x_2, x_3, x_4]
+
+
+def decoder(d, x, x_1, x_2, x_3, x_4):
+    up = lambda t: F.interpolate(t, scale_factor=(2, 2))  # noqa: E731  (nearest)
+    y = _cbr(_cbr(torch.cat((up(x_4), x_3), 1), d.conv5_1, d.bn5_1), d.conv5_2, d.bn5_2)
+    y = _cbr(_cbr(torch.cat((up(y), x_2), 1), d.conv6_1, d.bn6_1), d.conv6_2, d.bn6_2)
+    y = _cbr(_cbr(torch.cat((up(y), x_1), 1), d.conv7_1, d.bn7_1), d.conv7_2, d.bn7_2)
+    return _cbr(_cbr(torch.cat((up(y), x), 1), d.conv8_1, d.bn8_1), d.conv8_2, d.bn8_2)
+
+
+def heads(model, x):
+    c, bp = model.classification, model.regression.box_prediction
+    cls = c.conv2(_cbr(x, c.conv1, c.bn1)).permute(0, 2, 3, 1).contiguous()
+    loc = bp[3](_cbr(x, bp[0], bp[1])).permute(0, 2, 3, 1).contiguous()
+    return {"cls": cls.view(cls.shape[0], -1, model.category_num),
+            "loc": loc.view(-1, loc.size(1), loc.size(2), model.anchor_num_per_loc, model.out_seq_len,
+                            model.box_code_size)}
+
+
+def warp_batch(feat, T):
+    """feat (P, C, H, W); T (P, 4, 4) pose of the source w.r.t. the ego -> maps in the ego frame
+    (upstream feature_transformation: rotate about the map centre, then translate by (4*T03/128, -4*T13/128))."""
+    P = feat.shape[0]
+    z = torch.zeros(P, device=feat.device, dtype=feat.dtype)
+    o = torch.ones(P, device=feat.device, dtype=feat.dtype)
+    rot = torch.stack([torch.stack([T[:, 0, 0], T[:, 0, 1], z], 1), torch.stack([T[:, 1, 0], T[:, 1, 1], z], 1)], 1)
+    tr = torch.stack([torch.stack([o, z, 4 * T[:, 0, 3] / 128], 1), torch.stack([z, o, -4 * T[:, 1, 3] / 128], 1)], 1)
+    g1 = F.affine_grid(rot, feat.shape, align_corners=False)
+    g2 = F.affine_grid(tr, feat.shape, align_corners=False)
+    y = F.grid_sample(feat, g1, mode="bilinear", padding_mode="zeros", align_corners=False)
+    return F.grid_sample(y, g2, mode="bilinear", padding_mode="zeros", align_corners=False)
+
+
+def _gru_step(g, x):
+    """convolutional_rnn.Conv2dGRU cell with hidden=None (h0 = 0): gh = b_hh exactly, h = n + z*(0 - n)."""
+    gi = F.conv2d(x, g.weight_ih_l0, g.bias_ih_l0, 1, g.kernel_size // 2)
+    i_r, i_z, i_n = gi.chunk(3, 1)
+    h_r, h_z, h_n = g.bias_hh_l0.view(1, -1, 1, 1).chunk(3, 1)
+    r = torch.sigmoid(i_r + h_r)
+    zg = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    return n - zg * n
+
+
+def v2v_fuse(model, feat, trans, num_agent_tensor, B):
+    """feat (A*B, C, H, W) agent-major -> updated maps (same shape)."""
+    A = model.agent_num
+    counts, items, rows = model.frame_plan(num_agent_tensor, B, A)
+    if min(counts) < 2:
+        raise RuntimeError("V2VNet needs >= 2 agents in every frame (stack expects a non-empty TensorList)")
+    pairs = [(m, j * B + f, f, a, j) for m, (a, f) in enumerate(items) for j in range(counts[f]) if j != a]
+    dev = feat.device
+    src = torch.tensor([p[1] for p in pairs], device=dev)
+    dst = torch.tensor([p[0] for p in pairs], device=dev)
+    Tp = torch.stack([trans[f, a, j] for (_, _, f, a, j) in pairs]).to(feat.dtype)
+    cnt = torch.tensor([counts[f] - 1 for (_, f) in items], device=dev, dtype=feat.dtype).view(-1, 1, 1, 1)
+    rows_t = torch.tensor(rows, device=dev)
+    cur = feat
+    for _ in range(model.gnn_iter_num):
+        base = feat if model.neighbor_source == "initial" else cur
+        warped = warp_batch(base.index_select(0, src), Tp)
+        mean = torch.zeros((len(items),) + tuple(feat.shape[1:]), device=dev, dtype=feat.dtype).index_add_(0, dst, warped) / cnt
+        h = _gru_step(model.convgru, torch.cat([cur.index_select(0, rows_t), mean], 1))
+        cur = cur.index_copy(0, rows_t, h)
+    return cur
+
+
+def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1):
+    """bevs (A*B, 1, X, Y, Z) dense occupancy (the Dataset format) -> {'loc', 'cls'} with the shapes of the HIP path.
+    Uses batch-statistics BN when model.training, running statistics otherwise."""
+    x = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)
+    if hasattr(model, "stpn"):                      # FaFNet: lowerbound / upperbound
+        feats = encoder(model.stpn.encoder, x)
+        return heads(model, decoder(model.stpn.decoder, *feats))
+    if hasattr(model, "convgru"):                   # V2VNet
+        feats = encoder(model.u_encoder, x)
+        feats[model.layer] = v2v_fuse(model, feats[model.layer], trans_matrices.to(x.device), num_agent_tensor, batch_size)
+        return heads(model, decoder(model.decoder, *feats))
+    raise NotImplementedError("training graph exists for FaFNet and V2VNet (when2com training: DESIGN.md section 9)")

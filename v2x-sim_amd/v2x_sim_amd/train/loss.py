@@ -1,0 +1,33 @@
+"""Detection losses of upstream coperception/utils/loss.py + CoDetModule.FaFModule.loss_calculator (absent from
+/root/reference; README.md:101 names the training scripts that use them).  Build-owned restatement:
+
+  classification: softmax focal loss (alpha = 0.25 on the foreground class, gamma = 2) over every anchor,
+  localisation:   smooth-L1 (sigma = 3  ->  beta = 1/9) over the anchors selected by reg_loss_mask,
+  both summed and divided by the number of positive anchors (at least 1);  loss = cls + loc.
+"""
+import torch
+import torch.nn.functional as F
+
+ALPHA, GAMMA, SIGMA = 0.25, 2.0, 3.0
+
+
+def focal_loss(cls_logits, label_one_hot):
+    """cls_logits (N, M, 2) fp32, label_one_hot (N, M, 2) -> per-anchor loss (N, M)."""
+    logp = F.log_softmax(cls_logits, dim=-1)
+    p_t = (logp.exp() * label_one_hot).sum(-1)
+    alpha_t = label_one_hot[..., 1] * ALPHA + label_one_hot[..., 0] * (1.0 - ALPHA)
+    return -alpha_t * (1.0 - p_t).pow(GAMMA) * (logp * label_one_hot).sum(-1)
+
+
+def detection_loss(result, labels, reg_targets, reg_loss_mask):
+    """result: {'cls' (N, X*Y*A, 2), 'loc' (N, X, Y, A, 1, 6)};  labels (N, X, Y, A, 2);  reg_targets (N, X, Y, A, 1, 6);
+    reg_loss_mask (N, X, Y, A, 1) bool  ->  (loss, cls_loss, loc_loss) scalars."""
+    n = result["cls"].shape[0]
+    lab = labels.reshape(n, -1, 2).to(result["cls"].dtype)
+    n_pos = lab[..., 1].sum().clamp(min=1.0)
+    cls_loss = focal_loss(result["cls"], lab).sum() / n_pos
+    m = reg_loss_mask.reshape(n, -1)
+    pred = result["loc"].reshape(n, -1, 6)[m]
+    tgt = reg_targets.reshape(n, -1, 6)[m]
+    loc_loss = F.smooth_l1_loss(pred, tgt, reduction="sum", beta=1.0 / (SIGMA * SIGMA)) / n_pos
+    return cls_loss + loc_loss, cls_loss, loc_loss

@@ -1,9 +1,10 @@
-"""Inference half of upstream coperception/utils/CoDetModule.py::FaFModule (absent from
-/root/reference; README.md:101 points at tools/det/test_codet.py which drives it).
+"""Mirror of upstream coperception/utils/CoDetModule.py::FaFModule (absent from /root/reference; README.md:101
+points at tools/det/{train,test}_codet.py which drive it).
 
-`predict_all` keeps the upstream call shape: run the model on the agent-major batch, then per
+`predict_all` keeps the upstream call shape: run the model (HIP engine) on the agent-major batch, then per
 agent apply the 'faf' decode + NMS (utils/postprocess.py) unless that agent's BEV is empty.
-`step` (training: losses, backward, optimiser) is SURVEY.md row f-3 and not built this round.
+`step` is the training step: PyTorch-ROCm autograd graph (train/graph.py) over the same
+parameter tree, focal + smooth-L1 losses (train/loss.py), optimizer step; the HIP engine re-packs lazily afterwards.
 """
 import numpy as np
 import torch
@@ -23,7 +24,22 @@ class FaFModule(object):
         self.nms_thr = 0.01
 
     def step(self, data, batch_size, num_agent=5):
-        raise NotImplementedError("training step (losses/backward/Adam) is SURVEY.md row f-3: not built yet")
+        """One optimisation step.  data: 'bev_seq' (A*B, 1, X, Y, Z), 'labels' (A*B, X, Y, A', 2), 'reg_targets'
+        (A*B, X, Y, A', 1, 6), 'reg_loss_mask' (A*B, X, Y, A', 1), 'trans_matrices' (B, A, A, 4, 4), 'num_agent' (B, A)
+        -> (loss, cls_loss, loc_loss) python floats, as upstream."""
+        from ..train import detection_loss, train_forward
+        if self.optimizer is None:
+            raise RuntimeError("FaFModule.step needs an optimizer")
+        bev = data["bev_seq"]
+        if not bev.is_cuda or next(self.model.parameters()).device != bev.device:
+            raise RuntimeError("FaFModule.step trains on the MI355X: move the model and the batch to 'cuda'")
+        self.model.train()
+        result = train_forward(self.model, bev, data.get("trans_matrices"), data.get("num_agent"), batch_size)
+        loss, cls_loss, loc_loss = detection_loss(result, data["labels"], data["reg_targets"], data["reg_loss_mask"])
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        return loss.item(), cls_loss.item(), loc_loss.item()
 
     def predict_all(self, data, batch_size, validation=True, num_agent=5):
         """data: dict with 'bev_seq' (A*B, 1, X, Y, Z), 'trans_matrices' (B, A, A, 4, 4),
