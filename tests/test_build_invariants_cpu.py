@@ -36,6 +36,7 @@ def _kernels(asm):
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 @pytest.mark.parametrize("src,kernel_prefix,min_kernels", [
     ("conv_stream.hip", "_Z21conv3x3_stream_kernel", 6),
+    ("conv_stream.hip", "_Z22conv3x3_stream8_kernel", 3),
     ("conv_halo.hip", "_Z19conv3x3_halo_kernel", 4),
     ("conv_halo.hip", "_Z22conv3x3_halo_sb_kernel", 2),
     ("conv_igemm.hip", "_Z17conv_igemm_kernel", 9),
@@ -63,7 +64,7 @@ def test_stream_kernel_waits_are_counted(tmp_path):
     step barrier is a bare s_barrier (a __syncthreads-style `s_waitcnt vmcnt(0)` right before it would drain the ring)."""
     asm = _asm("conv_stream.hip", tmp_path)
     bodies, _ = _kernels(asm)
-    name = [n for n in bodies if n.startswith("_Z21conv3x3_stream_kernelILi128ELi8ELi32")][0]
+    name = [n for n in bodies if n.startswith("_Z21conv3x3_stream_kernelILi128ELi8ELi32ELi0E")][0]
     body = bodies[name]
     waits = set(re.findall(r"s_waitcnt vmcnt\((\d+)\)", body))
     assert {"6", "4", "0"} <= waits and waits <= {"0", "2", "4", "6"}, waits

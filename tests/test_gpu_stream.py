@@ -85,27 +85,33 @@ def test_stream_gru_vs_oracle(device, hw):
     assert torch.allclose(h, h2, atol=2 ** -7, rtol=2 ** -7)
 
 
-@pytest.mark.parametrize("hw", [(16, 32), (16, 16)])
-def test_stream_chain_conv1x1(device, hw):
-    """conv1_2 -> conv3d_1 in the streamed kernel: 3x3 64->64 +BN+ReLU (bf16 hidden, never stored) then 1x1 64->64 +BN+ReLU."""
+@pytest.mark.parametrize("hw", [(16, 32), (16, 16), (8, 32)])
+@pytest.mark.parametrize("ch", [64, 128])
+def test_stream_chain_conv1x1(device, hw, ch, monkeypatch):
+    """conv1_2 -> conv3d_1 (64 ch) and conv2_2 -> conv3d_2 (128 ch) in the streamed kernel: 3x3 C->C +BN+ReLU (bf16 hidden,
+    never stored) then 1x1 C->C +BN+ReLU.  16x32 maps take the 8-wave kernel at 128 channels, 8x32 / 16x16 the 4-wave one."""
     from v2x_sim_amd import ops, packing
     H, W = hw
-    g = torch.Generator().manual_seed(15)
-    x = bf16r(torch.randn(2, 64, H, W, generator=g))
-    w1 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
-    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
-    w2 = torch.randn(64, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5
-    s2, t2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    g = torch.Generator().manual_seed(15 + ch)
+    x = bf16r(torch.randn(2, ch, H, W, generator=g))
+    w1 = torch.randn(ch, ch, 3, 3, generator=g) * (2.0 / (ch * 9)) ** 0.5
+    s1, t1 = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g) * 0.2
+    w2 = torch.randn(ch, ch, 1, 1, generator=g) * (2.0 / ch) ** 0.5
+    s2, t2 = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g) * 0.2
     hid = bf16r(F.relu(F.conv2d(x, bf16r(w1), None, 1, 1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1)))
     ref = F.relu(F.conv2d(hid, bf16r(w2)) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1))
     pc = packing.pack_conv_stream("c", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
     got = back(ops.conv2d(pc, nhwc(x, device)))
     assert torch.allclose(got, ref, atol=3e-2, rtol=2 ** -6), float((got - ref).abs().max())
     assert float((got - ref).abs().mean()) < 2e-3
-    ph = packing.pack_conv_halo("h", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
-    if W % 32 == 0:
+    if ch == 64 and W % 32 == 0:
+        ph = packing.pack_conv_halo("h", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
         alt = back(ops.conv2d(ph, nhwc(x, device)))
         assert torch.allclose(got, alt, atol=3e-2, rtol=2 ** -6)
+    if ch == 128 and H % 16 == 0 and W % 32 == 0:   # 8-wave and 4-wave kernels: same K order, same epilogue -> same bits
+        monkeypatch.setenv("V2X_STREAM_WAVES", "4")
+        y4 = back(ops.conv2d(pc, nhwc(x, device)))
+        assert torch.equal(got, y4)
 
 
 @pytest.mark.parametrize("cfg", [

@@ -85,36 +85,35 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             }
         }
     } else if constexpr (EPI == SEPI_CHAIN) {
-        // conv (BCO = all 64 channels, rows in kappa order) -> BN/ReLU -> bf16 -> 1x1 conv 64 -> 64 -> BN/ReLU.
+        // conv (BCO = ALL channels of the layer, rows in kappa order) -> BN/ReLU -> bf16 -> 1x1 conv BCO -> BCO -> BN/ReLU.
         // Same register-layout trick as conv_halo.hip: tiles (2s, 2s+1) of a lane ARE its B fragment of k-step s.
-        static_assert(EPI != SEPI_CHAIN || BCO == 64, "chain epilogue needs all channels in one workgroup");
+        // BCO = 64: conv1_2 -> conv3d_1;  BCO = 128: conv2_2 -> conv3d_2.
+        static_assert(EPI != SEPI_CHAIN || BCO == 64 || BCO == 128, "chain epilogue needs all channels in one workgroup");
+        constexpr int NKS = BCO / 32;   // k-steps of the second GEMM
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // leave the counted-DMA regime before ordinary loads
-        bf16x8_t w2f[4][2];
+        // hidden activations of all 4 pixel fragments as B fragments (bf16): NKS x 4 registers each.  k-step outermost so
+        // that only two tiles' scale/shift are live and the accumulator tiles die as they are consumed (register pressure).
+        bf16x8_t hb[4][NKS];
 #pragma unroll
-        for (int i2 = 0; i2 < 4; ++i2)
+        for (int ks = 0; ks < NKS; ++ks) {
+            float4 sc[2], sf[2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                w2f[i2][ks] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * 64 + ks * 32 + fq * 8);
-        float4 sc[4], sf[4];
+            for (int hf = 0; hf < 2; ++hf) {
+                const int i = 2 * ks + hf;
+                const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
+                sc[hf] = *reinterpret_cast<const float4 *>(a.scale + kappa);
+                sf[hf] = *reinterpret_cast<const float4 *>(a.shift + kappa);
+            }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
-            sc[i] = *reinterpret_cast<const float4 *>(a.scale + kappa);
-            sf[i] = *reinterpret_cast<const float4 *>(a.shift + kappa);
-        }
-#pragma unroll
-        for (int f = 0; f < 4; ++f) {
-            bf16x8_t hb[2];
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
+            for (int f = 0; f < 4; ++f) {
                 float h[8];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
                     const int i = 2 * ks + hf;
-                    h[hf * 4 + 0] = acc[i][f][0] * sc[i].x + sf[i].x;
-                    h[hf * 4 + 1] = acc[i][f][1] * sc[i].y + sf[i].y;
-                    h[hf * 4 + 2] = acc[i][f][2] * sc[i].z + sf[i].z;
-                    h[hf * 4 + 3] = acc[i][f][3] * sc[i].w + sf[i].w;
+                    h[hf * 4 + 0] = acc[i][f][0] * sc[hf].x + sf[hf].x;
+                    h[hf * 4 + 1] = acc[i][f][1] * sc[hf].y + sf[hf].y;
+                    h[hf * 4 + 2] = acc[i][f][2] * sc[hf].z + sf[hf].z;
+                    h[hf * 4 + 3] = acc[i][f][3] * sc[hf].w + sf[hf].w;
                 }
                 if (a.relu) {
 #pragma unroll
@@ -125,17 +124,29 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
                 p.y = pack_bf16x2(h[2], h[3]);
                 p.z = pack_bf16x2(h[4], h[5]);
                 p.w = pack_bf16x2(h[6], h[7]);
-                hb[ks] = __builtin_bit_cast(bf16x8_t, p);
+                hb[f][ks] = __builtin_bit_cast(bf16x8_t, p);
             }
-            const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+        }
+        size_t pix[4];
 #pragma unroll
-            for (int i2 = 0; i2 < 4; ++i2) {
+        for (int f = 0; f < 4; ++f)
+            pix[f] = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+        // second GEMM: one output-channel tile at a time; its NKS weight fragments (L1/L2-resident, BCO*BCO*2 bytes in
+        // all) are loaded once and serve the 4 pixel fragments
+#pragma unroll
+        for (int i2 = 0; i2 < TCO; ++i2) {
+            bf16x8_t w2f[NKS];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                w2f[ks] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * BCO + ks * 32 + fq * 8);
+            const int co = i2 * 16 + fq * 4;
+            const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
+            const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
                 f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][0], hb[0], d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][1], hb[1], d, 0, 0, 0);
-                const int co = i2 * 16 + fq * 4;
-                const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
-                const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
+#pragma unroll
+                for (int ks = 0; ks < NKS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hb[f][ks], d, 0, 0, 0);
                 float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
                 if (a.relu2) {
                     v0 = fmaxf(v0, 0.f);
@@ -146,7 +157,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
                 uint2 o;
                 o.x = pack_bf16x2(v0, v1);
                 o.y = pack_bf16x2(v2, v3);
-                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix[f] * a.out_cstride + a.out_coff + co) = o;
             }
         }
     } else {
@@ -595,19 +606,26 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.scale2 = d->scale2;
     a.shift2 = d->shift2;
     a.relu2 = d->relu2;
+    const bool chain = d->Cout2 > 0;
+    if (chain) {  // chained 1x1: 64 -> 64 -> 64 (conv1_2 -> conv3d_1) and 128 -> 128 -> 128 (conv2_2 -> conv3d_2)
+        if ((d->Cout != 64 && d->Cout != 128) || d->Cout2 != d->Cout || d->w_rows != d->Cout || d->epilogue != V2X_EPI_BF16 ||
+            !d->weight2 || !d->scale2 || !d->shift2)
+            return 1;
+    }
     // 8-wave ping-pong form: 16x32 tiles, the wide channel tiles.  V2X_STREAM_WAVES=4 forces the 4-wave kernel
     // (A/B runs and the bitwise-equality test; the choice never depends on the batch size).
-    if (!t16 && d->H % 16 == 0 && d->Cout2 == 0 && (rows == 128 || rows == 96)) {
+    if (!t16 && d->H % 16 == 0 && (rows == 128 || rows == 96)) {
         const char *e = getenv("V2X_STREAM_WAVES");
         if (!(e && e[0] == '4')) {
             a.tiles_y = d->H / 16;
             a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
             if (d->epilogue == V2X_EPI_GRU) return launch_stream8<96, SEPI_GRU>(a, s);
+            if (chain) return launch_stream8<128, SEPI_CHAIN>(a, s);
             return launch_stream8<128, SEPI_BF16>(a, s);
         }
     }
-    if (d->Cout2 > 0) {  // chained 1x1: only the 64 -> 64 -> 64 form (conv1_2 -> conv3d_1) exists
-        if (d->Cout != 64 || d->Cout2 != 64 || d->epilogue != V2X_EPI_BF16 || !d->weight2 || !d->scale2 || !d->shift2) return 1;
+    if (chain) {
+        if (d->Cout == 128) return t16 ? launch_stream<128, 16, 16, SEPI_CHAIN>(a, s) : launch_stream<128, 8, 32, SEPI_CHAIN>(a, s);
         return t16 ? launch_stream<64, 16, 16, SEPI_CHAIN>(a, s) : launch_stream<64, 8, 32, SEPI_CHAIN>(a, s);
     }
     if (d->epilogue == V2X_EPI_GRU) return t16 ? launch_stream<96, 16, 16, SEPI_GRU>(a, s) : launch_stream<96, 8, 32, SEPI_GRU>(a, s);

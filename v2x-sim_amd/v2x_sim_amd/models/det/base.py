@@ -79,6 +79,17 @@ class LidarEncoder(_ParamsOnly):
                 halo = pack(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
                             chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
                 stage.append(ops.Layer(fb, halo, name=prefix + "conv1_2+conv3d_1"))
+            elif lvl == "2" and packing.CHAIN_STREAM and packing.STREAM_KERNEL:
+                # 128 -> 128 3x3, then the 1x1x1 "Conv3D" 128 -> 128: chained in the streamed kernel's epilogue (the
+                # intermediate map never reaches HBM: -2 x 1 MB per map and one launch less)
+                c3 = self.conv3d_2
+                fb = [packing.pack_conv_bn(prefix + "conv2_2", c2, b2, device=device),
+                      packing.pack_conv_bn(prefix + "conv3d_2", c3.conv3d, c3.bn3d, device=device)]
+                s1, t1 = packing.fold_bn(c2.bias, b2, c2.out_channels)
+                s2, t2 = packing.fold_bn(c3.conv3d.bias, c3.bn3d, c3.conv3d.out_channels)
+                halo = packing.pack_conv_stream(prefix + "conv2_2+conv3d_2", c2.weight, s1, t1, relu=True,
+                                                chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
+                stage.append(ops.Layer(fb, halo, name=prefix + "conv2_2+conv3d_2"))
             else:
                 stage.append(L(prefix + "conv%s_2" % lvl, c2, b2, device=device))
                 if lvl == "2":

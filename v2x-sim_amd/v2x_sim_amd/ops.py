@@ -48,7 +48,7 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
         th, tw = (8, 32) if W % 32 == 0 else (16, 16)
         epi = 2 if pc.epilogue == V2X_EPI_GRU else (1 if pc.Cout2 else 0)
-        if W % 32 == 0 and H % 16 == 0 and not pc.Cout2 and rows in (96, 128) \
+        if W % 32 == 0 and H % 16 == 0 and rows in (96, 128) \
                 and not os.environ.get("V2X_STREAM_WAVES", "").startswith("4"):
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
         return "conv3x3_stream_kernel<%d, %d, %d, %d>" % (rows, th, tw, epi)

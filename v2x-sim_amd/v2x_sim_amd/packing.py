@@ -212,8 +212,8 @@ def _stream_layout(wk, rows_tile, cin):
 
 def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=True, chain=None, device="cuda"):
     """3x3 stride-1 conv with C0, C1 multiples of 32 and Cout a multiple of 64, for conv_stream.hip.
-    chain = (weight2 [64, 64, 1, 1], scale2, shift2, relu2): 1x1 conv fused in the epilogue (Cout == 64 only);
-    the hidden rows are stored in the chain order of conv_halo.hip."""
+    chain = (weight2 [Cout, Cout, 1, 1], scale2, shift2, relu2): 1x1 conv fused in the epilogue (Cout == 64 or 128: all
+    channels in one workgroup); the hidden rows are stored in the chain order of conv_halo.hip."""
     lib = _lib.load()
     w = weight.detach().float().cpu()
     cout, cin, k, _ = w.shape
@@ -224,8 +224,8 @@ def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=T
         raise ValueError("%s: not a shape the streamed kernel covers" % name)
     wk = w.permute(0, 2, 3, 1).reshape(cout, 9 * cin)
     if chain is not None:
-        if cout != 64 or chain[0].shape[0] != 64:
-            raise ValueError("%s: the streamed kernel chains only 64 -> 64 -> 64" % name)
+        if cout not in (64, 128) or chain[0].shape[0] != cout:
+            raise ValueError("%s: the streamed kernel chains only 64 -> 64 -> 64 and 128 -> 128 -> 128" % name)
         wk = wk[_chain_row_order(cout)]
     pc = PackedConv(name=name, weight=_stream_layout(wk, tile, cin).to(torch.bfloat16).to(device).contiguous(),
                     scale=scale.detach().float().to(device).contiguous(),
@@ -234,8 +234,8 @@ def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=T
                     w_layout=2, Cout2=0)
     if chain is not None:
         w2, s2, t2, relu2 = chain
-        pc.Cout2, pc.relu2 = 64, relu2
-        pc.weight2 = w2.detach().float().cpu().reshape(64, 64).to(torch.bfloat16).to(device).contiguous()
+        pc.Cout2, pc.relu2 = cout, relu2
+        pc.weight2 = w2.detach().float().cpu().reshape(cout, cout).to(torch.bfloat16).to(device).contiguous()
         pc.scale2, pc.shift2 = s2.detach().float().to(device).contiguous(), t2.detach().float().to(device).contiguous()
     return pc
 
