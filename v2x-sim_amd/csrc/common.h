@@ -39,6 +39,12 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
+// two fp32 -> packed bf16 pair, round-to-nearest-even, in ONE instruction (v_cvt_pk_bf16_f32, new on gfx950).  The
+// software form above costs ~12 instructions and two exec-mask round trips (its NaN branch) per value -- measured as
+// ~85 instructions per 8-byte output store, more than the MFMA loop of the small-channel layers.
+typedef __attribute__((ext_vector_type(2))) __bf16 v2x_bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float v2x_f32x2_t;
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16_rne(lo) | ((uint32_t)f32_to_bf16_rne(hi) << 16);
+    const v2x_f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v2x_bf16x2_t));
 }

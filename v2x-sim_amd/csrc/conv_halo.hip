@@ -174,11 +174,28 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
 
     int tile = blockIdx.x;
     int cur = 0;
+    bool first_tile = true;
+    // output-store instructions a wave issues per tile (static: every channel tile is written; the det heads' 48 real
+    // channels fill their 3 tiles exactly -- other padded widths fall back to the full drain)
+    constexpr int N_STORES = COUT2 == 0 ? TCO * 4 : ((COUT2 == 48 || COUT2 == 64) ? TCO2 * 4 : 0);
     if (DB && tile < a.n_tiles) load_patch(tile, 0);
 
     for (; tile < a.n_tiles; tile += gridDim.x) {
         if constexpr (DB) {
-            __syncthreads();  // patch[cur] (and, first time, the weights) have landed; everyone left patch[cur^1]
+            // patch[cur] (and, first time, the weights) have landed; everyone left patch[cur^1].  After the first tile
+            // this is a COUNTED wait + raw barrier: the only vector-memory operations younger than patch[cur]'s DMA are
+            // the previous tile's output stores (the epilogue's scale/shift loads were consumed before the stores were
+            // issued), and a __syncthreads (vmcnt(0)) would serialise their ~1-2 us HBM write latency into every tile.
+            if (first_tile) {
+                __syncthreads();
+                first_tile = false;
+            } else {
+                if constexpr (N_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if constexpr (N_STORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if constexpr (N_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
             const int next = tile + gridDim.x;
             if (next < a.n_tiles) load_patch(next, cur ^ 1);
         } else {
@@ -193,50 +210,90 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
-        // wave w owns tile rows 2w, 2w+1; fragment f = (row f>>1, columns (f&1)*16 .. +15)
+        // wave w owns tile rows 2w, 2w+1; fragment f = (row r = f>>1, column half ch = f&1).
+        // K is walked in GROUPS = (tap column kx, 32-channel chunk); a group covers the three tap rows ky.  Its pixel
+        // operands are read ONCE: the three ky shifts of the wave's two rows touch only 4 distinct patch rows (3 for the
+        // half-resolution source, where rows 2w+r+ky-1 fold pairwise), so a group reads 8 (6) B fragments instead of 12,
+        // plus its 3 x TCO weight fragments: 114 instead of 162 ds_read_b128 per tile for conv8_1, in batches of 12-20
+        // reads per wait (the LDS reaches its rate only with >= 16 reads in flight per wave, MI355X_MICROARCH.md).
+        // With TCO == 2 the fragments of group g+1 are read into a second register set before the 24 MFMAs of group g
+        // are issued (hard scheduling fences keep that order), so the LDS latency runs under the matrix work even with
+        // one wave per SIMD (conv8_1: 129 KiB of LDS -> 4 waves per CU).
+        constexpr int KC0 = C0 / 32, KC1 = C1 / 32, KC = KC0 + KC1, NG = 3 * KC;
+        constexpr bool PIPE = (TCO == 2) && DB;   // the single-buffer form runs 4 workgroups per CU on a 128-VGPR budget
+        struct Frags {
+            bf16x8_t A[3][TCO];
+            bf16x8_t B[8];
+        };
+        Frags fr[PIPE ? 2 : 1];
+        auto load_group = [&](int g, Frags &F) {
+            const int kx = g / KC, kk = g - kx * KC;
+            if (kk < KC0) {   // half-resolution (x2 upsampled) source, chunk kk
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap % 3;
-            if constexpr (C0 > 0) {
-#pragma unroll
-                for (int kc = 0; kc < C0 / 32; ++kc) {
-                    bf16x8_t fa[TCO], fb[4];
-                    const int kslot = tap * (SPP0 + SPP1) + kc * 4 + fq;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int kslot = (ky * 3 + kx) * (SPP0 + SPP1) + kk * 4 + fq;
 #pragma unroll
                     for (int i = 0; i < TCO; ++i)
-                        fa[i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+                        F.A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+                }
+#pragma unroll
+                for (int hr = 0; hr < 3; ++hr)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int pr = wave + hr;                           // = ((2w + r + ky - 1) >> 1) + 1
+                        const int pc = ((ch * 16 + fj + kx - 1) >> 1) + 1;
+                        F.B[hr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(
+                            pb + ((pr * PW0 + pc) * (SPP0 ? SPP0 : 1) + swz<(SPP0 ? SPP0 : 4)>(kk * 4 + fq, pc)) * 16);
+                    }
+            } else {
+                const int kc = kk - KC0;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int kslot = (ky * 3 + kx) * (SPP0 + SPP1) + SPP0 + kc * 4 + fq;
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+                        F.A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+                }
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int pr = 2 * wave + rr;                       // = 2w + r + ky
+                        const int pc = ch * 16 + fj + kx;
+                        F.B[rr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(
+                            pb + NS0 * 16 + ((pr * PW + pc) * SPP1 + swz<SPP1>(kc * 4 + fq, pc)) * 16);
+                    }
+            }
+        };
+        auto mma_group = [&](int g, const Frags &F) {
+            const bool half = (g % KC) < KC0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
 #pragma unroll
                     for (int f = 0; f < 4; ++f) {
-                        const int ly = 2 * wave + (f >> 1), lx = (f & 1) * 16 + fj;
-                        const int pr = ((ly + ky - 1) >> 1) + 1;  // floor((y0+ly+ky-1)/2) - (y0/2-1), y0 even
-                        const int pc = ((lx + kx - 1) >> 1) + 1;
-                        fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + ((pr * PW0 + pc) * SPP0 + swz<SPP0>(kc * 4 + fq, pc)) * 16);
+                        const int r = f >> 1, ch = f & 1;
+                        const int row = half ? (((r + ky - 1) >> 1) + 1) : (r + ky);
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.A[ky][i], F.B[row * 2 + ch], acc[i][f], 0, 0, 0);
                     }
+        };
+        if constexpr (PIPE) {
+            load_group(0, fr[0]);
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-                        for (int f = 0; f < 4; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
-                }
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1, fr[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);   // reads of group g+1 stay above the MFMA block of group g
+                mma_group(g, fr[g & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        } else {
 #pragma unroll
-            for (int kc = 0; kc < C1 / 32; ++kc) {
-                bf16x8_t fa[TCO], fb[4];
-                const int kslot = tap * (SPP0 + SPP1) + SPP0 + kc * 4 + fq;
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-                    fa[i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    const int pr = 2 * wave + (f >> 1) + ky;
-                    const int pc = (f & 1) * 16 + fj + kx;
-                    fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + NS0 * 16 + ((pr * PW + pc) * SPP1 + swz<SPP1>(kc * 4 + fq, pc)) * 16);
-                }
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+            for (int g = 0; g < NG; ++g) {
+                load_group(g, fr[0]);
+                __builtin_amdgcn_sched_barrier(0);   // all reads of the group in one batch, then its 12 x TCO MFMAs
+                mma_group(g, fr[0]);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 
