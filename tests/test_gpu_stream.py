@@ -104,10 +104,6 @@ def test_stream_chain_conv1x1(device, hw, ch, monkeypatch):
     got = back(ops.conv2d(pc, nhwc(x, device)))
     assert torch.allclose(got, ref, atol=3e-2, rtol=2 ** -6), float((got - ref).abs().max())
     assert float((got - ref).abs().mean()) < 2e-3
-    if ch == 64 and W % 32 == 0:
-        ph = packing.pack_conv_halo("h", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
-        alt = back(ops.conv2d(ph, nhwc(x, device)))
-        assert torch.allclose(got, alt, atol=3e-2, rtol=2 ** -6)
     if ch == 128 and H % 16 == 0 and W % 32 == 0:   # 8-wave and 4-wave kernels: same K order, same epilogue -> same bits
         monkeypatch.setenv("V2X_STREAM_WAVES", "4")
         y4 = back(ops.conv2d(pc, nhwc(x, device)))

@@ -103,6 +103,35 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     for (int off = wave * 1024; off < W_BYTES; off += 4096)
         glds16h(reinterpret_cast<const char *>(a.w) + off + lane * 16, s_w + off);
 
+    // ---- per-lane DMA tables, computed once (the per-tile patch fill is then ~14 instructions per 1-KiB piece instead
+    // of ~60: two integer divisions by constants, the swizzle and the 64-bit address used to be redone for every piece
+    // of every tile -- ~560 of the ~1200 instructions a wave executed per conv8_1 tile).  Piece t of this wave covers
+    // LDS slots [wave*64 + t*256, +64); one packed word per piece: bits 0-19 = element offset of the lane's 16 B relative
+    // to the patch origin pixel (the dispatcher bounds W so that it fits), bits 20-23 = patch row, bits 24-29 = patch
+    // column (for the image-bounds test), negative = padding slot behind the patch.
+    constexpr bool TABLES = DB && !BITS;   // the single-buffer form lives on a 128-VGPR budget: it keeps the per-piece arithmetic
+    constexpr int NP1 = TABLES ? (NS1 + 255) / 256 : 0, NP0 = TABLES ? (NS0 + 255) / 256 : 0;
+    int tb1[NP1 ? NP1 : 1], tb0[NP0 ? NP0 : 1];
+    if constexpr (TABLES) {
+#pragma unroll
+        for (int t = 0; t < NP1; ++t) {
+            const int L = wave * 64 + t * 256 + lane;
+            const int pix = L / SPP1, phys = L - pix * SPP1;
+            const int pr = pix / PW, pc = pix - pr * PW;
+            tb1[t] = pix < PH * PW ? (((pr * a.W + pc) * C1 + swz<SPP1>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
+        }
+        if constexpr (C0 > 0) {
+            constexpr int S0 = SPP0 ? SPP0 : 1;
+#pragma unroll
+            for (int t = 0; t < NP0; ++t) {
+                const int L = wave * 64 + t * 256 + lane;
+                const int pix = L / S0, phys = L - pix * S0;
+                const int pr = pix / PW0, pc = pix - pr * PW0;
+                tb0[t] = pix < PH0 * PW0 ? (((pr * (a.W >> 1) + pc) * C0 + swz<(SPP0 ? SPP0 : 4)>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
+            }
+        }
+    }
+
     auto load_patch = [&](int tile, int buf) {
         const int txy = a.tiles_x * a.tiles_y;
         const int n = tile / txy;
@@ -133,31 +162,45 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
             }
             return;
         }
+        if constexpr (!TABLES) {
+            // full-resolution source: patch pixel (pr, pc) <- image pixel (y0-1+pr, x0-1+pc)
+            for (int base = wave * 64; base < NS1; base += 256) {
+                const int L = base + lane;
+                const int pix = L / SPP1;
+                const int phys = L - pix * SPP1;
+                const int pr = pix / PW;
+                const int pc = pix - pr * PW;
+                const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+                const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                const unsigned off = ((unsigned)(n * a.H + y) * (unsigned)a.W + (unsigned)x) * (unsigned)C1 + swz<SPP1>(phys, pc) * 8;
+                glds16h(ok ? (const void *)(a.in1 + off) : (const void *)g_zero_page_h, pb + NS0 * 16 + base * 16);
+            }
+            static_assert(TABLES || C0 == 0, "the single-buffer form has one source");
+            return;
+        }
         // full-resolution source: patch pixel (pr, pc) <- image pixel (y0-1+pr, x0-1+pc)
-        for (int base = wave * 64; base < NS1; base += 256) {
-            const int L = base + lane;
-            const int pix = L / SPP1;
-            const int phys = L - pix * SPP1;
-            const int pr = pix / PW;
-            const int pc = pix - pr * PW;
-            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-            const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            const unsigned off = ((unsigned)(n * a.H + y) * (unsigned)a.W + (unsigned)x) * (unsigned)C1 + swz<SPP1>(phys, pc) * 8;
-            glds16h(ok ? (const void *)(a.in1 + off) : (const void *)g_zero_page_h, pb + NS0 * 16 + base * 16);
+        {
+            const unsigned base = ((unsigned)(n * a.H + y0 - 1) * (unsigned)a.W + (unsigned)(x0 - 1)) * (unsigned)C1;  // may wrap: only used in-bounds
+#pragma unroll
+            for (int t = 0; t < NP1; ++t) {
+                if (wave * 64 + t * 256 >= NS1) break;   // wave-uniform
+                const int y = y0 - 1 + ((tb1[t] >> 20) & 15), x = x0 - 1 + ((tb1[t] >> 24) & 63);
+                const bool ok = tb1[t] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                const unsigned off = base + (unsigned)(tb1[t] & 0xfffff);
+                glds16h(ok ? (const void *)(a.in1 + off) : (const void *)g_zero_page_h, pb + NS0 * 16 + (wave * 64 + t * 256) * 16);
+            }
         }
         if constexpr (C0 > 0) {
             // half-resolution source: patch pixel (pr, pc) <- source pixel (y0/2-1+pr, x0/2-1+pc)
             const int Hs = a.H >> 1, Ws = a.W >> 1;
-            for (int base = wave * 64; base < NS0; base += 256) {
-                const int L = base + lane;
-                const int pix = L / SPP0;
-                const int phys = L - pix * SPP0;
-                const int pr = pix / PW0;
-                const int pc = pix - pr * PW0;
-                const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
-                const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-                const unsigned off = ((unsigned)(n * Hs + y) * (unsigned)Ws + (unsigned)x) * (unsigned)C0 + swz<SPP0>(phys, pc) * 8;
-                glds16h(ok ? (const void *)(a.in0 + off) : (const void *)g_zero_page_h, pb + base * 16);
+            const unsigned base = ((unsigned)(n * Hs + (y0 >> 1) - 1) * (unsigned)Ws + (unsigned)((x0 >> 1) - 1)) * (unsigned)C0;
+#pragma unroll
+            for (int t = 0; t < NP0; ++t) {
+                if (wave * 64 + t * 256 >= NS0) break;   // wave-uniform
+                const int y = (y0 >> 1) - 1 + ((tb0[t] >> 20) & 15), x = (x0 >> 1) - 1 + ((tb0[t] >> 24) & 63);
+                const bool ok = tb0[t] >= 0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+                const unsigned off = base + (unsigned)(tb0[t] & 0xfffff);
+                glds16h(ok ? (const void *)(a.in0 + off) : (const void *)g_zero_page_h, pb + (wave * 64 + t * 256) * 16);
             }
         }
     };
@@ -487,6 +530,10 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.split = d->split;
     a.out2 = d->out2;
     a.out2_cstride = d->out2_cstride;
+    {   // the packed DMA tables hold the lane's element offset inside the patch in 20 bits
+        const int cmax = d->C1 ? (d->C0 > d->C1 ? d->C0 : d->C1) : d->C0;
+        if ((long long)(PH * d->W + PW) * cmax >= (1 << 20)) return 1;
+    }
     a.tiles_x = d->W / TW;
     a.tiles_y = d->H / TH;
     a.n_tiles = d->N * a.tiles_x * a.tiles_y;
@@ -500,7 +547,6 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     if (d->in_format == 1) return 1;  // bit-grid input exists for the 32 -> 32 first layer only
     HALO_CASE(64, 32, 32, 0, 0)   // conv8_1: cat(up(x_7), x)
     HALO_CASE(0, 64, 64, 0, 0)    // conv7_2
-    HALO_CASE(0, 64, 64, 64, 1)   // conv1_2 -> conv3d_1
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
 #undef HALO_CASE
     return 1;

@@ -69,15 +69,14 @@ class LidarEncoder(_ParamsOnly):
             c2, b2 = getattr(self, "conv%s_2" % lvl), getattr(self, "bn%s_2" % lvl)
             stage = [L(prefix + "conv%s_1" % lvl, c1, b1, device=device)]
             if lvl == "1":
-                # 64 -> 64 3x3, then the 1x1x1 "Conv3D" 64 -> 64: chained in the halo kernel's epilogue
+                # 64 -> 64 3x3, then the 1x1x1 "Conv3D" 64 -> 64: chained in the streamed kernel's epilogue
                 c3 = self.conv3d_1
                 fb = [packing.pack_conv_bn(prefix + "conv1_2", c2, b2, device=device),
                       packing.pack_conv_bn(prefix + "conv3d_1", c3.conv3d, c3.bn3d, device=device)]
                 s1, t1 = packing.fold_bn(c2.bias, b2, c2.out_channels)
                 s2, t2 = packing.fold_bn(c3.conv3d.bias, c3.bn3d, c3.conv3d.out_channels)
-                pack = packing.pack_conv_stream if packing.CHAIN_STREAM else packing.pack_conv_halo
-                halo = pack(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
-                            chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
+                halo = packing.pack_conv_stream(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
+                                                chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
                 stage.append(ops.Layer(fb, halo, name=prefix + "conv1_2+conv3d_1"))
             elif lvl == "2" and packing.CHAIN_STREAM and packing.STREAM_KERNEL:
                 # 128 -> 128 3x3, then the 1x1x1 "Conv3D" 128 -> 128: chained in the streamed kernel's epilogue (the

@@ -196,7 +196,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
 
 
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
-CHAIN_STREAM = True   # conv1_2 -> conv3d_1: chained epilogue in the streamed kernel (2 WG/CU) instead of the halo kernel
+CHAIN_STREAM = True   # conv1_2 -> conv3d_1 and conv2_2 -> conv3d_2: 1x1 chained in the streamed kernel's epilogue (False: separate launches for conv3d_2)
 STREAM_64 = False     # 64 -> 64 layers (conv7_2): streamed kernel instead of the resident-weights halo kernel
 
 
