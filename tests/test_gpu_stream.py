@@ -148,3 +148,39 @@ def test_stream8_equals_stream4_bitwise(device, cfg, monkeypatch):
     assert torch.equal(y4, y8)
     for _ in range(10):
         assert torch.equal(run(), y8)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (C_up, C, Cout, N, H, W, gru): enough tiles (> 256 workgroups) for the persistent form to take several tiles each
+    (0, 256, 256, 160, 32, 32, False),   # conv3_2 at the bench batch: 640 tiles, 2.5 per workgroup (uneven tail)
+    (256, 128, 128, 40, 64, 64, False),  # conv6_1: half-resolution source first -> descriptor tables switch resolution
+    (256, 256, 256, 40, 32, 32, True),   # ConvGRU: 8 channel tiles
+    (0, 128, 128, 33, 64, 64, False),    # 264 tiles: 8 workgroups take a second tile, 248 do not
+])
+def test_stream8_persistent_equals_one_tile_per_workgroup_bitwise(device, cfg, monkeypatch):
+    """The persistent 8-wave kernel (tiles bid, bid + grid, ...; next tile's patch and weight slices prefetched across the
+    tile boundary, relaxed vmcnt after the epilogue) must produce exactly the bits of the one-tile-per-workgroup launch."""
+    from v2x_sim_amd import ops, packing
+    cup, c, cout, N, H, W, gru = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:6]))
+    x = torch.randn(N, H, W, c, generator=g).to(torch.bfloat16).to(device)
+    if gru:
+        x0 = torch.randn(N, H, W, cup, generator=g).to(torch.bfloat16).to(device)
+        w = torch.randn(3 * cout, cup + c, 3, 3, generator=g) * 0.02
+        pc = packing.pack_gru_stream("g", w, torch.randn(3 * cout, generator=g) * 0.1, torch.randn(3 * cout, generator=g) * 0.1,
+                                     C0=cup, C1=c, device=device)
+        run = lambda: ops.conv2d(pc, x0, x)
+    else:
+        w = torch.randn(cout, cup + c, 3, 3, generator=g) * (2.0 / ((cup + c) * 9)) ** 0.5
+        pc = packing.pack_conv_stream("t", w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2,
+                                      C0=cup if cup else c, C1=c if cup else 0, up0=1 if cup else 0, device=device)
+        if cup:
+            x0 = torch.randn(N, H // 2, W // 2, cup, generator=g).to(torch.bfloat16).to(device)
+            run = lambda: ops.conv2d(pc, x0, x)
+        else:
+            run = lambda: ops.conv2d(pc, x)
+    monkeypatch.setenv("V2X_STREAM_PERSIST", "0")
+    ref = run()
+    monkeypatch.delenv("V2X_STREAM_PERSIST")
+    for _ in range(5):
+        assert torch.equal(run(), ref)

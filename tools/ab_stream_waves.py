@@ -50,12 +50,14 @@ for name, cup, c, cout, hw, gru in SHAPES:
         flops = 2.0 * N * hw * hw * cout * (cup + c) * 9
     res = {}
     for rnd in range(2):
-        for waves in ("4", "8"):
+        for waves in ("4", "8", "8p"):
+            os.environ.pop("V2X_STREAM_WAVES", None)
+            os.environ.pop("V2X_STREAM_PERSIST", None)
             if waves == "4":
                 os.environ["V2X_STREAM_WAVES"] = "4"
-            else:
-                os.environ.pop("V2X_STREAM_WAVES", None)
+            elif waves == "8":
+                os.environ["V2X_STREAM_PERSIST"] = "0"
             res.setdefault(waves, []).append(timed(fn))
-    t4, t8 = min(res["4"]), min(res["8"])
-    print("%-8s 4-wave %7.1f us (%6.0f TF/s)   8-wave %7.1f us (%6.0f TF/s)   x%.3f" % (
-        name, t4, flops / t4 / 1e6, t8, flops / t8 / 1e6, t4 / t8), flush=True)
+    t4, t8, t8p = min(res["4"]), min(res["8"]), min(res["8p"])
+    print("%-8s 4-wave %7.1f us (%6.0f TF/s)   8-wave %7.1f us (%6.0f TF/s)   8-wave persistent %7.1f us (%6.0f TF/s)  x%.3f" % (
+        name, t4, flops / t4 / 1e6, t8, flops / t8 / 1e6, t8p, flops / t8p / 1e6, t8 / t8p), flush=True)

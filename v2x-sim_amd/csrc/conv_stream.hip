@@ -382,15 +382,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 constexpr int PATCH8_PIECES = 40;            // 18 x 34 pixels x 64 B = 38.25 KiB; piece 39 is padding / dummy target
 constexpr int PATCH8_BYTES = PATCH8_PIECES * 1024;
 
+// PERSISTENT over tiles: a workgroup walks tiles bid, bid + gridDim.x, ... of ONE channel tile (the host makes gridDim.x a
+// multiple of n_co_tiles), and the K pipeline never drains between tiles: during the last chunk of a tile the idle patch
+// buffer receives chunk 0 of the NEXT tile and the weight ring simply wraps to slice 0 (same channel tile = same weights),
+// so the next tile's first step finds its operands in LDS.  With one 112-KiB workgroup per CU nothing else could hide the
+// per-tile prologue (patch + 3 slices from L2/HBM, ~3-5k cycles) and the workgroup re-dispatch; the short-K layers
+// (36-72 steps per tile) lost 20-30 % to it.  The epilogue's output stores are younger than the DMA groups the next two
+// steps wait for, so those two steps allow N_ST more operations in flight (vmcnt(4 + N_ST)) instead of stalling on the
+// HBM write latency; from the third step on the stores are older than the awaited group and vmcnt(4) is exact again.
 template <int BCO, int EPI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8_kernel(const StreamArgs a) {
+    // the chained-1x1 epilogue needs ~250 VGPRs on its own: it stays one tile per workgroup (the tile loop below then
+    // runs once and the compiler drops everything that would have to live across the epilogue)
+    constexpr bool PERSIST = (EPI != SEPI_CHAIN);
     constexpr int TH = 16, TW = 32;
     constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
     constexpr int TCO = BCO / 16;
     constexpr int W_PIECES = BCO / 16;
     constexpr int SLICE_BYTES = BCO * 64;
+    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;   // output-store instructions per wave and tile
     static_assert(PH * PW * 4 <= (PATCH8_PIECES - 1) * 64, "patch must leave the last piece as padding");
     static_assert(W_PIECES <= 8, "at most one weight DMA per wave per step");
+    static_assert(4 + N_ST <= 63, "vmcnt is a 6-bit counter");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_ring = smem;
@@ -403,138 +416,213 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int grp = wave >> 2, wv = wave & 3;
     const int fj = lane & 15, fq = lane >> 4;
 
+    const int nwg = gridDim.x;
     int bid = blockIdx.x;
     {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
     }
-    const int co_tile = bid % a.n_co_tiles;
-    const int px_tile = bid / a.n_co_tiles;
+    const int n_tiles = a.n_px_tiles * a.n_co_tiles;
+    const int co_tile = bid % a.n_co_tiles;        // the same for every tile of this workgroup (nwg % n_co_tiles == 0)
     const int txy = a.tiles_x * a.tiles_y;
-    const int n = px_tile / txy;
-    const int trem = px_tile - n * txy;
-    const int ty = trem / a.tiles_x;
-    const int tx = trem - ty * a.tiles_x;
-    const int y0 = ty * TH, x0 = tx * TW;
 
     const int nc0 = a.C0 >> 5, nchunks = (a.C0 + a.C1) >> 5;
     const int S = nchunks * 9;
     const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
     const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
 
-    // per-lane tables (as in the 4-wave kernel): 5 patch pieces per wave (piece = wave + 8t)
-    int pd_full[5], pd_half[5];
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
+    // tile coordinates
+    auto tile_coords = [&](int t, int &n, int &y0, int &x0) {
+        const int px_tile = t / a.n_co_tiles;
+        n = px_tile / txy;
+        const int trem = px_tile - n * txy;
+        const int ty = trem / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (trem - ty * a.tiles_x) * TW;
+    };
+    // DMA source descriptor of patch piece (wave + 8t) for a tile at (n, y0, x0):
+    // (source pixel index << 5) | (swizzled 16-B slot * 8 elements), -1 = zero page
+    auto desc = [&](int n, int y0, int x0, int t, bool hf) -> int {
         const int L = (wave + 8 * t) * 64 + lane;
         const int pix = L >> 2, phys = L & 3;
-        {
+        if (!hf) {
             const int pr = pix / PW, pc = pix - pr * PW;
             const int y = y0 - 1 + pr, x = x0 - 1 + pc;
             const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            pd_full[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+            return ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
         }
-        {
-            const int Hs = a.H >> 1, Ws = a.W >> 1;
-            const int pr = pix / PW0, pc = pix - pr * PW0;
-            const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
-            const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-            pd_half[t] = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
-        }
-    }
-    int frow[4], ct_full[4][3], ct_half[4][3];
+        const int Hs = a.H >> 1, Ws = a.W >> 1;
+        const int pr = pix / PW0, pc = pix - pr * PW0;
+        const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+        const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        return ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+    };
+
+    // per-lane fragment tables.  ONE column-offset table, valid for the resolution of the chunk being computed (it is
+    // rebuilt at the at most two points of a tile where the source resolution changes): keeping a full- and a
+    // half-resolution copy side by side cost 12 VGPRs this kernel does not have (256-VGPR budget, 128 accumulators).
+    int frow[4], ct[4][3];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) {
-        const int col = (f & 1) * 16 + fj;
-        frow[f] = 8 * grp + 2 * wv + (f >> 1);
+    for (int f = 0; f < 4; ++f) frow[f] = 8 * grp + 2 * wv + (f >> 1);
+    auto build_ct = [&](bool hf) {
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int pcf = col + kx;
-            const int pch = ((col + kx - 1) >> 1) + 1;
-            ct_full[f][kx] = ((pcf << 2) + (fq ^ ((pcf >> 1) & 3))) * 16;
-            ct_half[f][kx] = ((pch << 2) + (fq ^ ((pch >> 1) & 3))) * 16;
+        for (int f = 0; f < 4; ++f) {
+            const int col = (f & 1) * 16 + fj;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int pc = hf ? (((col + kx - 1) >> 1) + 1) : (col + kx);
+                ct[f][kx] = ((pc << 2) + (fq ^ ((pc >> 1) & 3))) * 16;
+            }
         }
-    }
+    };
 
     const bool has_w = wave < W_PIECES;                       // wave-uniform
     const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
     auto issue_dummy = [&]() { glds16s(zero_page, s_dummy); };
-    auto issue_weights = [&](int s) {                         // exactly one DMA
-        if (has_w && s < S) glds16s(wsrc + (size_t)s * (BCO * 32), s_ring + (s & (RING - 1)) * SLICE_BYTES + wave * 1024);
+    auto issue_slice = [&](int slice, int slot, bool real) {  // exactly one DMA
+        if (has_w && real) glds16s(wsrc + (size_t)slice * (BCO * 32), s_ring + slot * SLICE_BYTES + wave * 1024);
         else issue_dummy();
     };
-    auto issue_patch_piece = [&](int kc, int t, int buf) {    // exactly one DMA
+    auto issue_piece = [&](int d, int kc, int t, int buf) {   // exactly one DMA; d = descriptor of this lane
         const bool first = kc < nc0;
-        const bool hf = first && a.up0;
-        int d = hf ? pd_half[0] : pd_full[0];
-#pragma unroll
-        for (int u = 1; u < 5; ++u) d = (t == u) ? (hf ? pd_half[u] : pd_full[u]) : d;
         const uint16_t *src = first ? a.in0 : a.in1;
         const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
         const unsigned off = (unsigned)(d >> 5) * cs + (unsigned)((first ? kc : kc - nc0) * 32 + (d & 31));
         glds16s(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + buf * PATCH8_BYTES + (wave + 8 * t) * 1024);
     };
+    const bool chunk0_half = (nc0 > 0) && a.up0;
 
-    // prologue: patch of chunk 0 (5 pieces per wave), then the 2-DMA groups of steps 0, 1, 2
+    int tile = bid;
+    int n, y0, x0;
+    tile_coords(tile, n, y0, x0);
+    // patch descriptors (5 pieces per wave) of the fill that is in progress / comes next; rebuilt when the fill's tile or
+    // source resolution changes
+    int pd[5];
+    bool pd_half = chunk0_half;
 #pragma unroll
-    for (int t = 0; t < 5; ++t) issue_patch_piece(0, t, 0);
-    issue_weights(0); issue_dummy();
-    issue_weights(1); issue_dummy();
-    issue_weights(2); issue_dummy();
+    for (int t = 0; t < 5; ++t) pd[t] = desc(n, y0, x0, t, pd_half);
+
+    // prologue of the FIRST tile: patch of chunk 0 (5 pieces per wave), then the 2-DMA groups of steps 0, 1, 2
+#pragma unroll
+    for (int t = 0; t < 5; ++t) issue_piece(pd[t], 0, t, 0);
+    issue_slice(0, 0, true); issue_dummy();
+    issue_slice(1, 1, true); issue_dummy();
+    issue_slice(2, 2, true); issue_dummy();
     wait_vmcnt<4>();                       // patch 0 and slice 0 have landed (groups 1 and 2 may be in flight)
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();   // half-step offset
 
-    f32x4_t acc[TCO][4];
-#pragma unroll
-    for (int i = 0; i < TCO; ++i)
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    int g = 0;        // global step counter: ring slot of step s of any tile = g & (RING - 1)
+    int gc = 0;       // global chunk counter: patch buffer = gc & 1
+    int relaxed = 0;  // steps left whose wait must tolerate the previous tile's output stores
+    for (;;) {
+        const int next = tile + nwg;
+        const bool has_next = PERSIST && next < n_tiles;
+        int nn = 0, ny0 = 0, nx0 = 0;
+        if (has_next) tile_coords(next, nn, ny0, nx0);
 
-    int s = 0;
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const char *pb = s_patch + (kc & 1) * PATCH8_BYTES;
-        const bool half = (kc < nc0) && a.up0;
-        const int sh = half ? 1 : 0, row_bytes = (half ? PW0 : PW) * 64;
+        f32x4_t acc[TCO][4];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        int s = 0;
+        for (int kc = 0; kc < nchunks; ++kc, ++gc) {
+            const char *pb = s_patch + (gc & 1) * PATCH8_BYTES;
+            const bool half = (kc < nc0) && a.up0;
+            const int sh = half ? 1 : 0, row_bytes = (half ? PW0 : PW) * 64;
+            const bool last_chunk = kc + 1 == nchunks;
+            // the patch that streams in during this chunk: the tile's next chunk, or chunk 0 of the NEXT tile.  The current
+            // tile's descriptors are dead once its last chunk has started, so the tables switch to the next tile here.
+            const int kcn = last_chunk ? 0 : kc + 1;
+            const bool fill = !last_chunk || has_next;
+            const bool hfn = (kcn < nc0) && a.up0;
+            if ((last_chunk && has_next) || (fill && hfn != pd_half)) {   // next tile / the source resolution changes
+                const int dn = last_chunk ? nn : n, dy = last_chunk ? ny0 : y0, dx = last_chunk ? nx0 : x0;
+#pragma unroll
+                for (int t = 0; t < 5; ++t) {
+                    pd[t] = desc(dn, dy, dx, t, hfn);
+                    __builtin_amdgcn_sched_barrier(0);   // one descriptor at a time: their temporaries sit on top of 176 live registers
+                }
+                pd_half = hfn;
+            }
+            if (kc == 0 || kc == nc0) build_ct(half);  // wave-uniform
 #pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-            int rowoff[4];
+            for (int ky = 0; ky < 3; ++ky) {
+                int rowoff[4];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) rowoff[f] = (((frow[f] + ky - sh) >> sh) + sh) * row_bytes;
+                for (int f = 0; f < 4; ++f) rowoff[f] = (((frow[f] + ky - sh) >> sh) + sh) * row_bytes;
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx, ++s) {
-                const int tap = ky * 3 + kx;
-                // ---- L(s): DMAs of step s+3, fragments of step s
-                issue_weights(s + 3);
-                if (tap < 5 && kc + 1 < nchunks) issue_patch_piece(kc + 1, tap, (kc + 1) & 1);
-                else issue_dummy();
-                const char *ws = s_ring + (s & (RING - 1)) * SLICE_BYTES;
-                bf16x8_t fa[TCO], fb[4];
+                for (int kx = 0; kx < 3; ++kx, ++s, ++g) {
+                    const int tap = ky * 3 + kx;
+                    // ---- L(s): DMAs of step s+3 (wrapping into the next tile), fragments of step s
+                    {
+                        const int s3 = s + 3;
+                        issue_slice(s3 < S ? s3 : s3 - S, (g + 3) & (RING - 1), s3 < S || has_next);
+                    }
+                    if (tap < 5 && fill) {
+                        int d = pd[0];
 #pragma unroll
-                for (int f = 0; f < 4; ++f)
-                    fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + (half ? ct_half[f][kx] : ct_full[f][kx]));
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-                    fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
-                wait_vmcnt<4>();                                   // own pieces of slice s+1 (and older) have landed
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers (R2)
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- M(s)
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
+                        for (int u = 1; u < 5; ++u) d = (tap == u) ? pd[u] : d;
+                        issue_piece(d, kcn, tap, (gc + 1) & 1);
+                    } else {
+                        issue_dummy();
+                    }
+                    const char *ws = s_ring + (g & (RING - 1)) * SLICE_BYTES;
+                    bf16x8_t fa[TCO], fb[4];
 #pragma unroll
                     for (int f = 0; f < 4; ++f)
-                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+                        fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + ct[f][kx]);
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+                        fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+                    // own pieces of slice s+1 (and older) have landed; right after an epilogue its stores are younger
+                    // than that group and may stay in flight
+                    if (relaxed > 0) {
+                        wait_vmcnt<4 + N_ST>();
+                        --relaxed;
+                    } else {
+                        wait_vmcnt<4>();
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers (R2)
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    // ---- M(s)
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
+        stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+        if (!has_next) break;
+        tile = next;
+        n = nn;
+        y0 = ny0;
+        x0 = nx0;
+        relaxed = 2;   // pd[] holds this tile's chunk-0 descriptors (its fill was issued during the previous tile's last chunk)
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the offset barrier of group 1
-    stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+}
+
+static int v2x_num_cus() {
+    // hipDeviceGetAttribute, NOT hipGetDeviceProperties: one call of the latter anywhere in the process made EVERY kernel of
+    // the step 4-8 % slower on the MI355X boxes (interleaved A/B, 4 250 vs 4 440 frames/s; a clock/power-state side effect)
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
 }
 
 template <int BCO, int EPI>
@@ -546,7 +634,17 @@ static int launch_stream8(const StreamArgs &a, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(512), smem, s, a);
+    // persistent grid: one workgroup per CU, rounded down to a multiple of n_co_tiles so that a workgroup's tiles
+    // (bid, bid + grid, ...) all belong to one channel tile; fewer tiles than CUs (or a channel-tile count that does not
+    // divide) -> one tile per workgroup.  V2X_STREAM_PERSIST=0 forces the one-tile form (A/B runs).
+    const int n_tiles = a.n_px_tiles * a.n_co_tiles;
+    int grid = n_tiles;
+    const char *e = getenv("V2X_STREAM_PERSIST");
+    if (!(e && e[0] == '0')) {
+        int g = v2x_num_cus() / a.n_co_tiles * a.n_co_tiles;
+        if (EPI != SEPI_CHAIN && g > 0 && g < n_tiles && ((a.C0 + a.C1) >> 5) >= 2) grid = g;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
     V2X_CHECK_LAUNCH("conv3x3_stream8_kernel");
     return V2X_OK;
 }

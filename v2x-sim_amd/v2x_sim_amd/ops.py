@@ -208,6 +208,29 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0):
 
     split > 0: returns (out[..., :split], out2[..., Cout-split]) as two contiguous tensors."""
     lib = _lib.load()
+    # the gather kernel does its row arithmetic in 24 bits (N*H*W < 2^24): larger batches go through in slices of whole
+    # maps (contiguous NHWC views, same stream) -- the only kernel with that limit, and only 256x256 inputs reach it
+    if not pc.w_layout and in0.dtype != torch.int32:
+        Hx, Wx = (in1.shape[1], in1.shape[2]) if in1 is not None else (in0.shape[1] << pc.up0, in0.shape[2] << pc.up0)
+        N0 = in0.shape[0]
+        if N0 * Hx * Wx >= (1 << 24) and N0 > 1:
+            Ho, Wo = conv_out_hw(pc, Hx, Wx)
+            odt = torch.float32 if pc.epilogue == V2X_EPI_F32 else torch.bfloat16
+            cfin = pc.Cout2 if pc.Cout2 else pc.Cout
+            o1 = o2 = None
+            if split:
+                o1 = torch.empty((N0, Ho, Wo, split), dtype=odt, device=in0.device)
+                o2 = torch.empty((N0, Ho, Wo, cfin - split), dtype=odt, device=in0.device)
+            elif out is None:
+                out = torch.empty((N0, Ho, Wo, cfin), dtype=odt, device=in0.device)
+            step = max(1, ((1 << 24) - 1) // (Hx * Wx))
+            for a0 in range(0, N0, step):
+                sl = slice(a0, min(a0 + step, N0))
+                r = conv2d(pc, in0[sl], None if in1 is None else in1[sl], None if split else out[sl], out_coff, split, zbits)
+                if split:
+                    o1[sl].copy_(r[0])
+                    o2[sl].copy_(r[1])
+            return (o1, o2) if split else out
     d = ConvDesc()
     from_bits = in0.dtype == torch.int32  # the voxelizer's bit grid (N, H, W): first layer, halo kernel only
     if from_bits:
