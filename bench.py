@@ -41,7 +41,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames-per-gpu", type=int, default=64)
+    ap.add_argument("--frames-per-gpu", type=int, default=128,
+                    help="frames per step and GPU (two half-batches of 64 = 320 maps: every conv layer then splits into a "
+                         "whole number of rounds of 256 workgroups; 64 frames/GPU leaves the 32x32 layers at 2.5 rounds, -4 %%)")
     ap.add_argument("--gnn-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -216,9 +218,9 @@ def main():
             roofline = {"bound": "hbm", "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": achieved / PEAK_HBM_GBS, "traffic": None}
         # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
-        # WRITE_SIZE, gfx950-corrected by tools/pmc_traffic.py); valid for the default 32 frames/GPU workload only
+        # WRITE_SIZE, gfx950-corrected by tools/pmc_traffic.py); valid for the default workload (128 frames/GPU) only
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and args.frames_per_gpu == 64 and world == 1:  # 2 half-batches of 32 = the profiled launches
+        if os.path.exists(tfile) and args.frames_per_gpu == 128 and world == 1:  # 2 half-batches of 64 = the profiled launches
             with open(tfile) as fh:
                 tk = json.load(fh)["kernels"].get(dom)
             if tk:

@@ -34,7 +34,7 @@ def main():
         write = 1024.0 * w[k][1] / w[k][0]
         out[short(k)] = {"launches_profiled": f[k][0], "hbm_read_bytes_per_launch": fetch,
                          "hbm_write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --graph 0, default workload (64 frames/step as two 32-frame half-batches: every launch covers 160 (agent,frame) items)",
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --graph 0, default workload (128 frames/step as two 64-frame half-batches: every launch covers 320 (agent,frame) items; the gather kernel's 256x256 layer runs as two launches)",
                "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950 128-B requests tallied at 64 B); WRITE_SIZE x1",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)
     for k, v in sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_launch"]):

@@ -18,6 +18,8 @@ find $OUT -name "*.csv" | head -20
 python3 tools/pmc_traffic.py $(find $OUT/pf -name "*counter_collection.csv") $(find $OUT/pw -name "*counter_collection.csv") $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_sq_summary.py $(find $OUT/sq -name "*counter_collection.csv") $OUT/pmc_sq.csv > /dev/null 2>&1
 cp $(find $OUT/kt -name "*kernel_stats.csv") $OUT/kernel_stats.csv 2>/dev/null
-# keep the pull small: drop the raw traces
-rm -rf $OUT/kt/*/*kernel_trace.csv $OUT/pf $OUT/pw $OUT/sq 2>/dev/null
+# keep the pull small: drop the kernel trace, keep the raw counter csv files next to their summaries
+cp $(find $OUT/pf -name "*counter_collection.csv") $OUT/pmc_fetch_size.csv 2>/dev/null
+cp $(find $OUT/pw -name "*counter_collection.csv") $OUT/pmc_write_size.csv 2>/dev/null
+rm -rf $OUT/kt/*kernel_trace.csv $OUT/kt/*/*kernel_trace.csv $OUT/pf $OUT/pw $OUT/sq 2>/dev/null
 ls -la $OUT
