@@ -157,9 +157,11 @@ int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
  *        the items it owns after the all-gather).
  * coef:  fp32 [n_out][A] weight of source agent j for output m (0 = skip). j == ego is
  *        taken unwarped.
- * mode:  V2X_FUSE_WSUM  out = sum_j coef*warp_j ;  V2X_FUSE_MEAN  out = (sum_{coef!=0} warp_j) / count
+ * mode:  V2X_FUSE_WSUM  out = sum_j coef*warp_j ;  V2X_FUSE_MEAN  out = (sum_{coef!=0} warp_j) / count ;
+ *        V2X_FUSE_MAX   out = max_{coef!=0} warp_j  (elementwise; the zero padding of a warped map takes part, as in
+ *        upstream's torch.max(torch.stack(...)) of MaxFusion)
  * out:   bf16 NHWC [n_out][H][W][C].   C % 8 == 0. */
-enum { V2X_FUSE_WSUM = 0, V2X_FUSE_MEAN = 1 };
+enum { V2X_FUSE_WSUM = 0, V2X_FUSE_MEAN = 1, V2X_FUSE_MAX = 2 };
 int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
                   const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
                   v2x_stream_t stream);

@@ -390,6 +390,72 @@ class V2VNet(IntermediateModelBase):
 
 
 # ----------------------------------------------------------------------------
+# simple fusion baselines  (upstream SumFusion.py / MeanFusion.py / MaxFusion.py / CatFusion.py on FusionBase.py)
+# ----------------------------------------------------------------------------
+class FusionBase(IntermediateModelBase):
+    """Per ego: [ego map, every neighbour's map warped into the ego frame] -> self.fusion(list).  The list starts with
+    the ego (upstream: neighbor_feat_list.append(tg_agent) before the neighbour loop) -- recollected, frozen here."""
+
+    def fusion(self, feats):  # pragma: no cover - abstract
+        raise NotImplementedError
+
+    def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
+        e = self.emulate_bf16
+        bevs = bevs.permute(0, 1, 4, 2, 3)
+        enc = self.u_encoder(bevs, e)
+        lcm = self.local_com_mat(enc[self.layer], batch_size)
+        size = (1,) + tuple(lcm.shape[2:])
+        update = lcm.clone()
+        for b in range(batch_size):
+            n = int(num_agent_tensor[b, 0])
+            for i in range(n):
+                feats = [lcm[b, i]]
+                for j in range(n):
+                    if j != i:
+                        feats.append(feature_transformation(lcm[b, j], trans_matrices[b, i][j], size))
+                update[b, i] = self.fusion(feats)
+        x = self.decode_heads(enc, self.agents_to_batch(update))
+        return self.get_cls_loc_result(x)
+
+
+class SumFusion(FusionBase):
+    def fusion(self, feats):
+        return _q(torch.sum(torch.stack(feats), dim=0), self.emulate_bf16)
+
+
+class MeanFusion(FusionBase):
+    def fusion(self, feats):
+        return _q(torch.mean(torch.stack(feats), dim=0), self.emulate_bf16)
+
+
+class MaxFusion(FusionBase):
+    def fusion(self, feats):
+        return _q(torch.max(torch.stack(feats), dim=0).values, self.emulate_bf16)
+
+
+class ModulationLayer3(nn.Module):
+    def __init__(self, channel=256):
+        super().__init__()
+        self.conv1_1 = nn.Conv2d(2 * channel, channel, kernel_size=1, stride=1, padding=0)
+        self.bn1_1 = nn.BatchNorm2d(channel)
+
+    def forward(self, x, emulate=False):
+        return cbr(x, self.conv1_1, self.bn1_1, emulate)
+
+
+class CatFusion(FusionBase):
+    def __init__(self, layer=3, in_channels=13, num_agent=5):
+        super().__init__(layer, in_channels, num_agent)
+        self.modulation_layer_3 = ModulationLayer3(LAYER_SHAPES[layer][0])
+
+    def fusion(self, feats):
+        e = self.emulate_bf16
+        mean_feat = _q(torch.mean(torch.stack(feats), dim=0), e)
+        cat_feat = torch.cat([feats[0], mean_feat], dim=0).unsqueeze(0)
+        return self.modulation_layer_3(cat_feat, e).squeeze(0)
+
+
+# ----------------------------------------------------------------------------
 # when2com / who2com  (upstream When2com.py)
 # ----------------------------------------------------------------------------
 class Conv2DBatchNormRelu(nn.Module):

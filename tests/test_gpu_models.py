@@ -84,6 +84,24 @@ def test_v2vnet(device, gnn_iter, source):
             check(got["loc"], ref["loc"], tol, "v2vnet loc emu=%s" % emu)
 
 
+@pytest.mark.parametrize("name", ["SumFusion", "MeanFusion", "MaxFusion", "CatFusion"])
+def test_simple_fusion_baselines(device, name):
+    """Row f-4: sum / mean / max / cat intermediate fusion (one warp_fuse launch + CatFusion's two-source 1x1 conv),
+    ragged batch (second frame has 4 real agents)."""
+    from v2x_sim_amd.models import det
+    A, B = 5, 2
+    pm, om = build(getattr(det, name), getattr(R, name), device, seed=4)
+    _, bev, T = make_inputs(A, B, n_pts=8000, seed=9)
+    nat = torch.tensor([[5] * A, [4] * A])
+    with torch.no_grad():
+        got = pm(bev.to(device), T.to(device), nat, batch_size=B)
+        for emu, tol in ((True, TOL_EMU), (False, TOL_FP32)):
+            om.emulate_bf16 = emu
+            ref = om(bev, T, nat, batch_size=B)
+            check(got["cls"], ref["cls"], tol, "%s cls emu=%s" % (name, emu))
+            check(got["loc"], ref["loc"], tol, "%s loc emu=%s" % (name, emu))
+
+
 def test_v2vnet_ragged_agents_and_batch(device):
     """B=2 frames, the second with only 3 real agents: padding agents keep their own features."""
     from v2x_sim_amd.models.det import V2VNet

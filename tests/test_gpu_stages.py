@@ -256,7 +256,10 @@ def _warp_ref(feat, T, items, coef, A, Bt, mode):
                 continue
             cnt += 1
             v = feat[j * Bt + f] if j == ego else R.feature_transformation(feat[j * Bt + f], T[f, ego, j], (1, C, H, W))
-            acc = acc + (v if mode == 1 else c * v)
+            if mode == 2:
+                acc = v if cnt == 1 else torch.maximum(acc, v)
+            else:
+                acc = acc + (v if mode == 1 else c * v)
         out[m] = acc / cnt if (mode == 1 and cnt) else acc
     return out
 
@@ -278,7 +281,7 @@ def test_warp_golden_and_identity(device):
     assert torch.allclose(got[1], feat[0], atol=1e-6)
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 def test_warp_fuse_vs_oracle(device, mode):
     from v2x_sim_amd import ops
     from v2x_sim_amd.utils.synthetic import synthetic_poses
@@ -287,7 +290,10 @@ def test_warp_fuse_vs_oracle(device, mode):
     feat = bf16r(torch.randn(A * Bt, C, H, W, generator=g))
     T = torch.from_numpy(synthetic_poses(Bt, A, seed=4))
     items = [(a, f) for a in range(A) for f in range(Bt)]
-    if mode == 1:
+    if mode == 2:       # MaxFusion: ego (unwarped) and neighbours, the warped maps' zero padding takes part in the max
+        coef = torch.ones(len(items), A)
+        coef[3, 4] = 0
+    elif mode == 1:
         coef = torch.ones(len(items), A)
         for m, (a, f) in enumerate(items):
             coef[m, a] = 0

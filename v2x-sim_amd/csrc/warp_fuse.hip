@@ -136,8 +136,18 @@ __global__ __launch_bounds__(256) void warp_fuse_kernel(const uint16_t *__restri
             const float wj = (mode == V2X_FUSE_MEAN) ? 1.0f : cj;
             if (j == ego) {
 #pragma unroll
-                for (int v = 0; v < CV; ++v)
-                    fma8(acc[v], *reinterpret_cast<const uint4 *>(src + (size_t)pix * C + c0 + v * 8), wj);
+                for (int v = 0; v < CV; ++v) {
+                    if (mode == V2X_FUSE_MAX) {
+                        float ev[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ev[e] = 0.f;
+                        fma8(ev, *reinterpret_cast<const uint4 *>(src + (size_t)pix * C + c0 + v * 8), 1.0f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[v][e] = (count == 1) ? ev[e] : fmaxf(acc[v][e], ev[e]);
+                    } else {
+                        fma8(acc[v], *reinterpret_cast<const uint4 *>(src + (size_t)pix * C + c0 + v * 8), wj);
+                    }
+                }
                 continue;
             }
             const float *T = trans + (((size_t)f * A + ego) * A + j) * 16;
@@ -168,7 +178,10 @@ __global__ __launch_bounds__(256) void warp_fuse_kernel(const uint16_t *__restri
 #pragma unroll
             for (int v = 0; v < CV; ++v)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[v][e] += vv[v][e] * wj;
+                for (int e = 0; e < 8; ++e) {
+                    if (mode == V2X_FUSE_MAX) acc[v][e] = (count == 1) ? vv[v][e] : fmaxf(acc[v][e], vv[v][e]);
+                    else acc[v][e] += vv[v][e] * wj;
+                }
         }
 #pragma unroll
         for (int v = 0; v < CV; ++v) {
@@ -193,7 +206,7 @@ extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, 
     V2X_REQUIRE(feat && trans && items && coef && out, "v2x_warp_fuse: null pointer");
     V2X_REQUIRE(A > 0 && A <= 32 && Bt > 0 && H > 0 && W > 0, "v2x_warp_fuse: bad dims");
     V2X_REQUIRE(C > 0 && C % 8 == 0, "v2x_warp_fuse: C=%d must be a multiple of 8", C);
-    V2X_REQUIRE(mode == V2X_FUSE_WSUM || mode == V2X_FUSE_MEAN, "v2x_warp_fuse: bad mode");
+    V2X_REQUIRE(mode == V2X_FUSE_WSUM || mode == V2X_FUSE_MEAN || mode == V2X_FUSE_MAX, "v2x_warp_fuse: bad mode");
     V2X_REQUIRE(n_out >= 0 && n_out <= 65535, "v2x_warp_fuse: n_out out of range");
     if (n_out == 0) return V2X_OK;
     const int cv = C % 16 == 0 ? 2 : 1;

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU = 0, 1, 2
-V2X_FUSE_WSUM, V2X_FUSE_MEAN = 0, 1
+V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
 ABI_VERSION = 2
 
 

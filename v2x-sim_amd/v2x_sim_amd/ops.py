@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_FUSE_MEAN, V2X_FUSE_WSUM  # noqa: F401
+from ._lib import ConvDesc, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_FUSE_MAX, V2X_FUSE_MEAN, V2X_FUSE_WSUM  # noqa: F401
 
 
 def _stream():
