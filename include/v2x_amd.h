@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 2
+#define V2X_AMD_ABI_VERSION 3
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -184,6 +184,22 @@ int v2x_attn_handshake(const float *keys, const float *querys, const float *w_li
  * conf int64 [n_cls][n_cls] (rows = label, cols = prediction), accumulated (caller zeroes). */
 int v2x_seg_argmax_confusion(const float *logits, const uint8_t *label, int n, int H, int W, int n_cls,
                              uint8_t *pred, long long *conf, v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- f-1: detection post-processing
+ * Replaces coperception/utils/postprocess.py::apply_nms_det per (agent, frame) map: foreground softmax score, score
+ * threshold, 'faf' anchor decode (x, y, w, h, yaw) and greedy NMS on the axis-aligned stand-up boxes, in
+ * (score descending, anchor index ascending) order.
+ *
+ * cls: fp32 [n][M][2] logits;  loc: fp32 [n][M][6] box codes;  anchors: fp32 [M][6] (x, y, w, h, sin, cos), M = X*Y*A.
+ * cap: candidate capacity per map, a power of two in [64, 4096].
+ * out_boxes fp32 [n][cap][5], out_scores fp32 [n][cap], out_index int32 [n][cap] (anchor index of each detection),
+ * out_count int32 [n]: number of detections of map i, or -(number of candidates) when more than `cap` anchors passed the
+ * threshold (nothing else is written for that map: the caller retries with a higher threshold or post-processes on the host).
+ * key_scratch: uint64 [n][cap], count_scratch: int32 [n] (caller-owned workspace). */
+int v2x_det_postprocess(const float *cls, const float *loc, const float *anchors, int n, int M, float score_thr,
+                        float nms_thr, int cap, float *out_boxes, float *out_scores, int32_t *out_index,
+                        int32_t *out_count, unsigned long long *key_scratch, int32_t *count_scratch,
+                        v2x_stream_t stream);
 
 #ifdef __cplusplus
 }

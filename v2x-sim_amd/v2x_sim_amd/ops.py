@@ -340,6 +340,30 @@ def attn_handshake(keys, querys, w_lin, b_lin, A, Bt, mode, thres=0.2):
     return prob, coef
 
 
+# ------------------------------------------------------------------ f-1
+def det_postprocess(cls, loc, anchors, score_thr=0.7, nms_thr=0.01, cap=4096):
+    """cls (n, M, 2) fp32, loc (n, ..., 6) fp32 with M anchors per map, anchors (M, 6) fp32 on the device ->
+    (boxes (n, cap, 5), scores (n, cap), index (n, cap) int32, count (n,) int32); count < 0: more than `cap` candidates."""
+    lib = _lib.load()
+    n, M = cls.shape[0], cls.shape[1]
+    loc = loc.reshape(n, M, 6)
+    anchors = anchors.reshape(M, 6)
+    dev = cls.device
+    boxes = torch.empty((n, cap, 5), dtype=torch.float32, device=dev)
+    scores = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    index = torch.empty((n, cap), dtype=torch.int32, device=dev)
+    count = torch.empty((n,), dtype=torch.int32, device=dev)
+    keys = torch.empty((n, cap), dtype=torch.int64, device=dev)
+    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+    _lib.check(lib.v2x_det_postprocess(_dev(cls, torch.float32, "cls"), _dev(loc, torch.float32, "loc"),
+                                       _dev(anchors, torch.float32, "anchors"), n, M, C.c_float(score_thr),
+                                       C.c_float(nms_thr), cap, _dev(boxes, torch.float32, "boxes"),
+                                       _dev(scores, torch.float32, "scores"), _dev(index, torch.int32, "index"),
+                                       _dev(count, torch.int32, "count"), _dev(keys, torch.int64, "keys"),
+                                       _dev(cnt, torch.int32, "cnt"), _stream()), "v2x_det_postprocess")
+    return boxes, scores, index, count
+
+
 # ------------------------------------------------------------------ a8
 def seg_argmax_confusion(logits, label=None, want_pred=True):
     """logits (n, H, W, n_cls) fp32 NHWC; label (n, H, W) uint8 -> (pred uint8, conf int64 [n_cls, n_cls])."""

@@ -22,6 +22,9 @@ class FaFModule(object):
         self.anchors = postprocess.build_anchor_map(config)
         self.score_thr = 0.7
         self.nms_thr = 0.01
+        self.device_postprocess = True    # False: upstream's host-side numpy path (utils/postprocess.apply_nms_det)
+        self.cap = 4096                   # candidate capacity per map of the device path
+        self._anchors_dev = None
 
     def step(self, data, batch_size, num_agent=5):
         """One optimisation step.  data: 'bev_seq' (A*B, 1, X, Y, Z), 'labels' (A*B, X, Y, A', 2), 'reg_targets'
@@ -41,6 +44,30 @@ class FaFModule(object):
         self.optimizer.step()
         return loss.item(), cls_loss.item(), loc_loss.item()
 
+    def postprocess(self, result):
+        """Device-side score / threshold / decode / NMS (v2x_det_postprocess) for every map of `result` -> list of
+        dict(boxes, corners, scores) like postprocess.apply_nms_det; maps with more than `cap` candidates fall back to the
+        host function (with random weights tens of thousands of anchors can pass the threshold)."""
+        from .. import ops
+        cls, loc = result["cls"], result["loc"]
+        if self._anchors_dev is None or self._anchors_dev.device != cls.device:
+            self._anchors_dev = torch.from_numpy(np.ascontiguousarray(self.anchors.reshape(-1, 6))).to(cls.device)
+        boxes, scores, _, count = ops.det_postprocess(cls.contiguous(), loc.contiguous(), self._anchors_dev, self.score_thr,
+                                                      self.nms_thr, self.cap)
+        count = count.cpu().numpy()
+        kmax = int(max(1, count.max()))
+        boxes, scores = boxes[:, :kmax].cpu().numpy(), scores[:, :kmax].cpu().numpy()
+        out = []
+        for i in range(cls.shape[0]):
+            if count[i] < 0:
+                out.append(postprocess.apply_nms_det(loc[i].float().cpu().numpy(), cls[i].float().cpu().numpy(), self.anchors,
+                                                     self.score_thr, self.nms_thr))
+                continue
+            b = boxes[i, :count[i]]
+            out.append({"boxes": b, "corners": postprocess.box_corners(b) if count[i] else np.zeros((0, 4, 2), np.float32),
+                        "scores": scores[i, :count[i]]})
+        return out
+
     def predict_all(self, data, batch_size, validation=True, num_agent=5):
         """data: dict with 'bev_seq' (A*B, 1, X, Y, Z), 'trans_matrices' (B, A, A, 4, 4),
         'num_agent' (B, A).  -> (loss, cls_loss, loc_loss, seq_results) with the losses None
@@ -51,15 +78,17 @@ class FaFModule(object):
                 result = self.model(bev_seq, data["trans_matrices"], data["num_agent"], batch_size=batch_size)
             else:
                 result = self.model(bev_seq)
-        cls = result["cls"].float().cpu().numpy()
-        loc = result["loc"].float().cpu().numpy()
         occupied = (bev_seq.reshape(bev_seq.shape[0], -1) != 0).any(dim=1).cpu().numpy()
         seq_results = [[] for _ in range(num_agent)]
+        dets = self.postprocess(result) if self.device_postprocess else None
+        if dets is None:
+            cls = result["cls"].float().cpu().numpy()
+            loc = result["loc"].float().cpu().numpy()
         for k in range(num_agent):
             for b in range(batch_size):
                 row = k * batch_size + b
                 if not occupied[row]:
                     continue
-                seq_results[k].append(postprocess.apply_nms_det(loc[row], cls[row], self.anchors, self.score_thr,
-                                                                self.nms_thr))
+                seq_results[k].append(dets[row] if dets is not None else
+                                      postprocess.apply_nms_det(loc[row], cls[row], self.anchors, self.score_thr, self.nms_thr))
         return None, None, None, seq_results
