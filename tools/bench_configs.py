@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Throughput of all five BASELINE.json configs on ONE MI355X (frames/s = 5-agent collaborative frames per second,
+points -> logits, inputs resident in HBM, synthetic data, random-init weights, 64 frames per launch).
+
+    python tools/bench_configs.py [--frames 64] [--reps 5]
+
+bench.py (the driver's contract) measures config 2 only; this tool puts the other configs next to it.  Config 0
+(lowerbound on PyTorch-CPU) is the oracle and appears in bench.py as `cpu_baseline`; here the lowerbound NETWORK is run
+on the HIP path for comparison."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, "v2x-sim_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet, V2VNet, When2com
+    from v2x_sim_amd.models.det.base import LidarEncoder
+    from v2x_sim_amd.models.seg import V2VNetSeg
+    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet, ShardedWhen2com
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
+    dev = torch.device("cuda:0")
+    A, B = 5, args.frames
+    cfg = Config("test")
+    grid = ops.VoxelGrid()
+    Z = grid.dims[2]
+    pts = torch.from_numpy(np.concatenate([synthetic_points(1, 65536, seed=1000 + r) for r in range(A * B)])).to(dev)
+    n_pts = torch.full((A * B,), 65536, dtype=torch.int32, device=dev)
+    T = synthetic_poses(B, A, seed=99)
+    trans = torch.from_numpy(T).to(dev)
+    nat = torch.full((B, A), A)
+    shard = AgentShard(A, B, 0, 1)
+
+    def timed(fn):
+        with torch.no_grad():
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / args.reps
+
+    out = {}
+    # -- config 0 network / config 1: FaFNet (no fusion); upperbound = early-fused clouds (25 scatter jobs per frame)
+    faf = init_synthetic_weights(FaFNet(cfg), seed=0).to(dev)
+
+    def lowerbound():
+        bits = ops.voxelize_bits(pts, n_pts, grid)
+        pk = faf.packed(dev)
+        feats = LidarEncoder.run(pk["enc"], bits, zbits=Z)
+        from v2x_sim_amd.models.det.base import LidarDecoder
+        return faf.get_cls_loc_result(LidarDecoder.run(pk["dec"], *feats), pk["heads"])
+    out["0n lowerbound network (no fusion), HIP path"] = timed(lowerbound)
+
+    xf, src, dst = [], [], []
+    for f in range(B):
+        for i in range(A):
+            for j in range(A):
+                xf.append(T[f, i, j][:3])
+                src.append(j * B + f)
+                dst.append(i * B + f)
+    xf = torch.tensor(np.stack(xf), dtype=torch.float32, device=dev)
+    src = torch.tensor(src, dtype=torch.int32, device=dev)
+    dst = torch.tensor(dst, dtype=torch.int32, device=dev)
+
+    def upperbound():
+        bits = ops.voxelize_fused_bits(pts, n_pts, xf, src, dst, A * B, grid)
+        pk = faf.packed(dev)
+        feats = LidarEncoder.run(pk["enc"], bits, zbits=Z)
+        from v2x_sim_amd.models.det.base import LidarDecoder
+        return faf.get_cls_loc_result(LidarDecoder.run(pk["dec"], *feats), pk["heads"])
+    out["1 upperbound (early fusion: 5x the points per ego grid)"] = timed(upperbound)
+
+    # -- config 2: V2VNet
+    v2v = init_synthetic_weights(V2VNet(cfg), seed=0).to(dev)
+    r2 = ShardedV2VNet(v2v, shard)
+    plan2 = shard.fusion_plan(nat, dev)
+    out["2 V2VNet (warp + ConvGRU, gnn_iter=1)"] = timed(lambda: r2.forward_points(pts, n_pts, trans, plan2))
+
+    # -- config 3: when2com (inference 'activated') and who2com ('argmax_test')
+    w2c = init_synthetic_weights(When2com(cfg), seed=0).to(dev)
+    r3 = ShardedWhen2com(w2c, shard)
+    plan3 = r3.plan(nat, dev)
+    for name, inf in (("3 when2com (attention handshake, 'activated')", "activated"), ("3b who2com ('argmax_test')", "argmax_test")):
+        out[name] = timed(lambda: r3.forward_bits(ops.voxelize_bits(pts, n_pts, grid), Z, trans, plan3, inference=inf))
+
+    # -- config 4: V2VNet segmentation (+ argmax / confusion matrix)
+    seg = init_synthetic_weights(V2VNetSeg(cfg), seed=0).to(dev)
+    label = torch.randint(0, 8, (A * B, 256, 256), dtype=torch.uint8, device=dev)
+    plan4 = seg.make_plan(nat, B, dev)
+
+    def seg_step():
+        bits = ops.voxelize_bits(pts, n_pts, grid)
+        logits = seg.forward_nhwc(ops.bits_to_nhwc(bits, Z, 32), trans, nat, batch_size=B, plan=plan4)
+        return ops.seg_argmax_confusion(logits, label)
+    out["4 V2VNet segmentation (8 classes, argmax + confusion matrix)"] = timed(seg_step)
+
+    rec = {"frames_per_launch": B, "agents": A, "points_per_agent": 65536,
+           "configs": {k: {"ms_per_launch": v, "frames_per_s": B / v * 1e3} for k, v in out.items()}}
+    for k, v in rec["configs"].items():
+        print("%-62s %8.2f ms  %8.0f frames/s" % (k, v["ms_per_launch"], v["frames_per_s"]))
+    print(json.dumps(rec))
+
+
+if __name__ == "__main__":
+    main()
