@@ -184,3 +184,29 @@ def test_stream8_persistent_equals_one_tile_per_workgroup_bitwise(device, cfg, m
     monkeypatch.delenv("V2X_STREAM_PERSIST")
     for _ in range(5):
         assert torch.equal(run(), ref)
+
+
+
+@pytest.mark.parametrize("cfg", [
+    # (C, Cout, N, H, W): H % 8 == 0, W % 64 == 0
+    (32, 64, 3, 16, 64),      # conv1_1 class (one chunk, BCO = 64)
+    (64, 128, 2, 24, 128),    # conv2_1 class (two chunks, BCO = 128)
+    (128, 256, 2, 8, 64),     # conv3_1 class (two channel tiles)
+])
+def test_stride2_stream_conv_vs_torch_and_gather(device, cfg):
+    """Stride-2 streamed kernel (conv_stream_s2.hip: parity-de-interleaved patch) vs torch fp32 on the same bf16 operands
+    (one bf16 ulp) and vs the gather kernel on the same layer."""
+    from v2x_sim_amd import ops, packing
+    C, Cout, N, H, W = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = bf16r(torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    ref = F.relu(F.conv2d(x, bf16r(w), None, 2, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = packing.pack_conv_stream("s2", w, scale, shift, C0=C, stride=2, device=device)
+    got = back(ops.conv2d(pc, nhwc(x, device)))
+    assert got.shape == ref.shape == (N, Cout, H // 2, W // 2)
+    assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
+    pg = packing.pack_conv("g", w, scale, shift, stride=2, pad=1, relu=True, device=device)
+    alt = back(ops.conv2d(pg, nhwc(x, device)))
+    assert torch.allclose(got, alt, atol=2e-3, rtol=2 ** -7)

@@ -328,6 +328,7 @@ static int dispatch_rows(const ConvArgs &a, int rows, hipStream_t s) {
 
 int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s);    // conv_halo.hip
 int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s);  // conv_stream.hip
+int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s);  // conv_stream_s2.hip
 
 extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
     V2X_REQUIRE(d, "v2x_conv2d: null descriptor");
@@ -366,7 +367,7 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
     if (d->w_layout == 2) {
         V2X_REQUIRE(d->in0 && d->weight && d->scale && d->out, "v2x_conv2d(stream): null tensor pointer");
         V2X_REQUIRE(d->epilogue == V2X_EPI_GRU || d->shift, "v2x_conv2d(stream): null shift");
-        V2X_REQUIRE(d->ksize == 3 && d->stride == 1 && d->pad == 1, "v2x_conv2d(stream): 3x3 stride 1 pad 1 only");
+        V2X_REQUIRE(d->ksize == 3 && (d->stride == 1 || d->stride == 2) && d->pad == 1, "v2x_conv2d(stream): 3x3 stride 1/2 pad 1 only");
         V2X_REQUIRE(d->C0 > 0 && d->C0 % 32 == 0 && d->C1 >= 0 && d->C1 % 32 == 0 && (d->C1 == 0 || d->in1),
                     "v2x_conv2d(stream): C0=%d, C1=%d must be multiples of 32", d->C0, d->C1);
         V2X_REQUIRE(d->up0 == 0 || (d->up0 == 1 && d->H % 2 == 0 && d->W % 2 == 0), "v2x_conv2d(stream): bad up0");
@@ -377,6 +378,11 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
         V2X_REQUIRE(rows > 0 && d->w_rows == need && d->w_rows % rows == 0 && d->split == 0 &&
                     d->out_cstride >= d->out_coff + d->Cout && d->out_coff >= 0,
                     "v2x_conv2d(stream): unsupported Cout=%d / w_rows=%d / output window", d->Cout, d->w_rows);
+        if (d->stride == 2) {
+            const int rc2 = v2x_conv_stream_s2_dispatch(d, (hipStream_t)stream);
+            V2X_REQUIRE(rc2 != 1, "v2x_conv2d(stream, stride 2): needs one bf16 source, H %% 8 == 0, W %% 64 == 0 (got %dx%d)", d->H, d->W);
+            return rc2;
+        }
         const int rc = v2x_conv_stream_dispatch(d, (hipStream_t)stream);
         V2X_REQUIRE(rc != 1, "v2x_conv2d(stream): extent %dx%d not tileable (8x32 or 16x16 tiles)", d->H, d->W);
         return rc;

@@ -1,0 +1,246 @@
+// Streamed-weights kernel for the STRIDE-2 3x3 convolutions of the encoder (conv1_1, conv2_1, conv3_1 of upstream
+// Backbone.py::LidarEncoder; code absent from /root/reference, see include/v2x_amd.h).
+//
+// The gather kernel (conv_igemm.hip) re-fetches every input pixel of a stride-2 layer 2.25 times through L2 -> LDS, one
+// im2col slot at a time, and tops out at 290-590 TFLOP/s on these layers (conv1_1 additionally at 2.9 TB/s of a 5+ TB/s
+// HBM-bound layer).  Here, as in conv_stream.hip, a workgroup owns an output tile (4 rows x 32 columns) x BCO output
+// channels and walks K as (32-channel chunk) x (9 taps):
+//   * the (2*4+1) x (2*32+1) input patch of a chunk is brought in ONCE by LDS-DMA and serves all 9 taps;
+//   * the patch columns are DE-INTERLEAVED BY PARITY while they are written (the DMA's per-lane source address is free):
+//     a patch row is [33 even columns][32 odd columns], so tap kx reads 16 CONSECUTIVE entries of one half (kx = 0: even
+//     half, entry c; kx = 1: odd half, entry c; kx = 2: even half, entry c + 1) and the stride-2 fragment reads are as
+//     conflict-free as the stride-1 ones (same 16-B slot XOR ((entry >> 1) & 3));
+//   * weights stream through the same 4-slot ring with counted s_waitcnt vmcnt(N) and raw s_barrier; the weight layout is
+//     the one of conv_stream.hip (packing.pack_conv_stream), so a layer is packed the same way for either stride.
+// One patch buffer (37 KiB) + ring (16 / 32 KiB) = 53 / 69 KiB -> three / two workgroups per CU; the patch refill at a
+// chunk boundary (everything drains there) is what the other workgroups cover.
+#include "common.h"
+
+typedef const __attribute__((address_space(1))) void *gptr_t;
+typedef __attribute__((address_space(3))) void *lptr_t;
+
+__device__ __forceinline__ void glds16q(const void *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+struct S2Args {
+    const uint16_t *in;   // [N][H][W][C] bf16
+    int C, N, H, W;       // input extent (H, W even)
+    const uint16_t *w;    // [n_co_tiles][n_chunks][9][4][BCO][8] bf16 + 64 B zero page
+    const float *scale, *shift;
+    int relu;
+    uint16_t *out;        // [N][H/2][W/2][out_cstride]
+    int out_cstride, out_coff, Cout;
+    int tiles_x, tiles_y, n_px_tiles, n_co_tiles;
+};
+
+constexpr int S2_TH = 4, S2_TW = 32;
+constexpr int S2_PH = 2 * S2_TH + 1;             // 9 patch rows
+constexpr int S2_NE = S2_TW + 1, S2_NO = S2_TW;  // 33 even + 32 odd patch columns
+constexpr int S2_ROW_SLOTS = (S2_NE + S2_NO) * 4;            // 16-B slots per patch row (260)
+constexpr int S2_SLOTS = S2_PH * S2_ROW_SLOTS;               // 2340
+constexpr int S2_PIECES = (S2_SLOTS + 63) / 64;              // 37 wave instructions of 1 KiB
+constexpr int S2_PPW = (S2_PIECES + 3) / 4;                  // pieces per wave (10)
+constexpr int S2_PATCH_BYTES = S2_PIECES * 1024;             // 37 KiB (pieces 37..39 of the per-wave loop are never issued)
+constexpr int S2_RING = 4;
+
+template <int N>
+__device__ __forceinline__ void s2_wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BCO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv3x3_s2_stream_kernel(const S2Args a) {
+    constexpr int TCO = BCO / 16;
+    constexpr int W_PIECES = BCO / 16;           // 1 KiB pieces per weight slice
+    constexpr int NW = W_PIECES / 4;             // weight DMAs per wave and step (1 or 2)
+    constexpr int SLICE_BYTES = BCO * 64;
+    static_assert(BCO == 64 || BCO == 128, "channel tiles of 64 or 128");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_ring = smem;
+    char *s_patch = smem + S2_RING * SLICE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15, fq = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int co_tile = bid % a.n_co_tiles;
+    const int px_tile = bid / a.n_co_tiles;
+    const int txy = a.tiles_x * a.tiles_y;
+    const int n = px_tile / txy;
+    const int trem = px_tile - n * txy;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int y0 = ty * S2_TH, x0 = tx * S2_TW;       // output coordinates
+
+    const int nchunks = a.C >> 5;
+    const int S = nchunks * 9;
+    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+
+    // per-lane DMA descriptors of this wave's patch pieces (piece = wave + 4t): (input pixel index << 5) | (logical 16-B
+    // slot * 8 elements), -1 = zero page (outside the image, or the padding slots behind the patch)
+    int pd[S2_PPW];
+#pragma unroll
+    for (int t = 0; t < S2_PPW; ++t) {
+        const int L = (wave + 4 * t) * 64 + lane;
+        const int r = L / S2_ROW_SLOTS, q = L - r * S2_ROW_SLOTS;
+        const int ent = q >> 2, phys = q & 3;
+        const bool odd = ent >= S2_NE;
+        const int idx = odd ? ent - S2_NE : ent;
+        const int pc = 2 * idx + (odd ? 1 : 0);               // patch column
+        const int y = 2 * y0 - 1 + r, x = 2 * x0 - 1 + pc;   // input pixel
+        const bool ok = L < S2_SLOTS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        pd[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((idx >> 1) & 3)) << 3)) : -1;
+    }
+    // fragment column offsets: fragment f covers output columns f*16 + fj; tap kx reads entry (f*16 + fj + (kx == 2)) of the
+    // even (kx = 0, 2) or odd (kx = 1) half
+    int ct[2][3];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int idx = f * 16 + fj + (kx == 2 ? 1 : 0);
+            ct[f][kx] = (((kx == 1 ? S2_NE : 0) + idx) * 4 + (fq ^ ((idx >> 1) & 3))) * 16;
+        }
+
+    const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
+    auto issue_weights = [&](int s) {   // NW DMAs
+        char *dst = s_ring + (s & (S2_RING - 1)) * SLICE_BYTES;
+        const uint16_t *src = wsrc + (size_t)s * (BCO * 32);
+        glds16q(src, dst + wave * 1024);
+        if (NW == 2) glds16q(src + 4 * 512, dst + (wave + 4) * 1024);
+    };
+    auto issue_patch = [&](int kc) {    // this wave's pieces of chunk kc (pieces >= S2_PIECES do not exist)
+#pragma unroll
+        for (int t = 0; t < S2_PPW; ++t) {
+            if (wave + 4 * t >= S2_PIECES) break;            // wave-uniform
+            const int d = pd[t];
+            const unsigned off = (unsigned)(d >> 5) * (unsigned)a.C + (unsigned)(kc * 32 + (d & 31));
+            glds16q(d >= 0 ? (const void *)(a.in + off) : zero_page, s_patch + (wave + 4 * t) * 1024);
+        }
+    };
+
+    f32x4_t acc[TCO][2];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    // prologue: weight slices of steps 0..2 (S >= 9), then the patch of chunk 0
+    issue_weights(0);
+    issue_weights(1);
+    issue_weights(2);
+
+    int s = 0;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        // ---- chunk boundary: everyone has left the previous chunk's patch (and ring slot s-1) -> refill, drain, meet
+        if (kc > 0) __builtin_amdgcn_s_barrier();
+        issue_patch(kc);
+        s2_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            const int rowoff = (2 * wave + ky) * (S2_ROW_SLOTS * 16);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx, ++s) {
+                const int tap = ky * 3 + kx;
+                if (tap > 0) {
+                    // this step's slice has landed (groups s+1, s+2 may be in flight); everyone is done with slot s-1
+                    if (s + 2 >= S) s2_wait_vmcnt<0>();
+                    else s2_wait_vmcnt<2 * NW>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (s + 3 < S) issue_weights(s + 3);
+                const char *ws = s_ring + (s & (S2_RING - 1)) * SLICE_BYTES;
+                bf16x8_t fa[TCO], fb[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) fb[f] = *reinterpret_cast<const bf16x8_t *>(s_patch + rowoff + ct[f][kx]);
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TCO + 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TCO * 2, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: BN / ReLU, bf16, 8-byte NHWC stores
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+#pragma unroll
+    for (int i = 0; i < TCO; ++i) {
+        const int co = co_tile * BCO + i * 16 + fq * 4;
+        if (co >= a.Cout) continue;
+        const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
+        const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
+            float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
+            if (a.relu) {
+                v0 = fmaxf(v0, 0.f);
+                v1 = fmaxf(v1, 0.f);
+                v2 = fmaxf(v2, 0.f);
+                v3 = fmaxf(v3, 0.f);
+            }
+            uint2 o;
+            o.x = pack_bf16x2(v0, v1);
+            o.y = pack_bf16x2(v2, v3);
+            const size_t pix = (size_t)(n * Ho + y0 + wave) * Wo + x0 + f * 16 + fj;
+            *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
+        }
+    }
+}
+
+template <int BCO>
+static int launch_s2(const S2Args &a, hipStream_t s) {
+    constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES;
+    static bool attr_done = false;
+    auto kern = &conv3x3_s2_stream_kernel<BCO>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_s2_stream_kernel");
+    return V2X_OK;
+}
+
+// Returns V2X_OK if handled, 1 if the shape is not covered (caller reports).
+int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
+    if (d->C1 != 0 || d->up0 != 0 || d->Cout2 != 0 || d->epilogue != V2X_EPI_BF16) return 1;
+    if (d->H % (2 * S2_TH) != 0 || d->W % (2 * S2_TW) != 0) return 1;
+    const int rows = (d->Cout % 128 == 0) ? 128 : ((d->Cout % 64 == 0) ? 64 : 0);
+    if (rows == 0 || d->w_rows != d->Cout) return 1;
+    S2Args a;
+    a.in = d->in0;
+    a.C = d->C0;
+    a.N = d->N;
+    a.H = d->H;
+    a.W = d->W;
+    a.w = d->weight;
+    a.scale = d->scale;
+    a.shift = d->shift;
+    a.relu = d->relu;
+    a.out = reinterpret_cast<uint16_t *>(d->out);
+    a.out_cstride = d->out_cstride;
+    a.out_coff = d->out_coff;
+    a.Cout = d->Cout;
+    a.tiles_x = (d->W / 2) / S2_TW;
+    a.tiles_y = (d->H / 2) / S2_TH;
+    a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
+    a.n_co_tiles = d->Cout / rows;
+    return rows == 128 ? launch_s2<128>(a, s) : launch_s2<64>(a, s);
+}

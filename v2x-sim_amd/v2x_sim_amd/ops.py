@@ -44,6 +44,8 @@ _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 12
 
 def conv_kernel_name(pc, H=0, W=0, bits=False):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
+    if pc.w_layout == 2 and pc.stride == 2:
+        return "conv3x3_s2_stream_kernel<%d>" % (128 if pc.Cout % 128 == 0 else 64)
     if pc.w_layout == 2:
         rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
         th, tw = (8, 32) if W % 32 == 0 else (16, 16)
@@ -410,7 +412,11 @@ def run_layer(layer, in0, in1=None, zbits=0):
     else:
         H, W = in0.shape[1], in0.shape[2]
     h = layer.halo
-    if h is not None and halo_eligible(H, W, h.w_layout):
+    if h is not None and h.stride == 2:
+        # stride-2 streamed kernel: 4x32 output tiles.  16x16 outputs (conv4_1) stay on the gather kernel.
+        if H % 8 == 0 and W % 64 == 0:
+            return conv2d(h, in0, in1, split=layer.split)
+    elif h is not None and halo_eligible(H, W, h.w_layout):
         use = True
         if h.w_layout == 2:
             # streamed kernel = one 256-pixel x <=128-channel tile per workgroup.  The choice looks at the map extent

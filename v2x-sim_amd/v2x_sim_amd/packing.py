@@ -175,13 +175,15 @@ def pack_conv_halo(name, weight, scale, shift, *, C0=None, C1=0, relu=True, cin_
 
 
 def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
-    """conv+BN(+ReLU) as an ops.Layer: gather-kernel packing always, halo packing when the layer is
-    3x3 stride 1 with <= 96 input channels (the kernel instantiations that exist)."""
+    """conv+BN(+ReLU) as an ops.Layer: gather-kernel packing always, plus the packing of the patch-based kernel that
+    covers the layer -- halo (3x3 stride 1, <= 96 input channels), streamed (3x3 stride 1, >= 128 input channels),
+    or stride-2 streamed (3x3 stride 2, one source, Cin % 32 == 0, Cout % 64 == 0)."""
     from .ops import Layer
     fb = pack_conv_bn(name, conv, bn, relu=relu, device=device, **kw)
     h = None
     cin_p = fb.C0 + fb.C1
-    if halo and conv.kernel_size[-1] == 3 and conv.stride[-1] == 1 and conv.out_channels % 32 == 0:
+    k3 = conv.kernel_size[-1] == 3
+    if halo and k3 and conv.stride[-1] == 1 and conv.out_channels % 32 == 0:
         scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
         cin_h = _ceil_to(cin_p, 32)
         key = (fb.C0 if fb.C1 else 0, fb.C1 if fb.C1 else cin_h, conv.out_channels)
@@ -192,12 +194,17 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
               and STREAM_KERNEL):
             h = pack_conv_stream(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, up0=fb.up0, relu=relu,
                                  device=device)
+    elif (halo and STREAM_S2 and STREAM_KERNEL and k3 and conv.stride[-1] == 2 and not fb.C1 and cin_p % 32 == 0
+          and conv.out_channels % 64 == 0):
+        scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
+        h = pack_conv_stream(name, conv.weight, scale, shift, C0=cin_p, relu=relu, stride=2, device=device)
     return Layer([fb], h, name=name)
 
 
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
 CHAIN_STREAM = True   # conv1_2 -> conv3d_1 and conv2_2 -> conv3d_2: 1x1 chained in the streamed kernel's epilogue (False: separate launches for conv3d_2)
 STREAM_64 = False     # 64 -> 64 layers (conv7_2): streamed kernel instead of the resident-weights halo kernel
+STREAM_S2 = True      # stride-2 3x3 layers (conv1_1, conv2_1, conv3_1): patch-based stride-2 kernel instead of the gather kernel
 
 
 # ------------------------------------------------------------------ streamed-weights kernel layout (conv_stream.hip)
@@ -210,8 +217,9 @@ def _stream_layout(wk, rows_tile, cin):
     return torch.cat([flat, torch.zeros(32, dtype=flat.dtype)])   # + 64 B of zeros: the kernel's zero page
 
 
-def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=True, chain=None, device="cuda"):
-    """3x3 stride-1 conv with C0, C1 multiples of 32 and Cout a multiple of 64, for conv_stream.hip.
+def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=True, chain=None, stride=1, device="cuda"):
+    """3x3 conv with C0, C1 multiples of 32 and Cout a multiple of 64, for conv_stream.hip (stride 1) or
+    conv_stream_s2.hip (stride 2: one source, no chain) -- same weight layout for both.
     chain = (weight2 [Cout, Cout, 1, 1], scale2, shift2, relu2): 1x1 conv fused in the epilogue (Cout == 64 or 128: all
     channels in one workgroup); the hidden rows are stored in the chain order of conv_halo.hip."""
     lib = _lib.load()
@@ -230,8 +238,10 @@ def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=T
     pc = PackedConv(name=name, weight=_stream_layout(wk, tile, cin).to(torch.bfloat16).to(device).contiguous(),
                     scale=scale.detach().float().to(device).contiguous(),
                     shift=shift.detach().float().to(device).contiguous(), C0=C0, C1=C1, Cout=cout, ksize=3,
-                    stride=1, pad=1, up0=up0, epilogue=V2X_EPI_BF16, relu=relu, w_rows=cout, w_kpad=9 * cin,
+                    stride=stride, pad=1, up0=up0, epilogue=V2X_EPI_BF16, relu=relu, w_rows=cout, w_kpad=9 * cin,
                     w_layout=2, Cout2=0)
+    if stride == 2 and (C1 or up0 or chain is not None):
+        raise ValueError("%s: the stride-2 streamed kernel takes one plain source" % name)
     if chain is not None:
         w2, s2, t2, relu2 = chain
         pc.Cout2, pc.relu2 = cout, relu2
