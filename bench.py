@@ -199,7 +199,7 @@ def main():
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         groups = {}
-        for name, fl, by, e0, e1 in recs:
+        for name, fl, by, e0, e1, _layer in recs:
             gdict = groups.setdefault(name, {"ms": 0.0, "flops": 0.0, "bytes": 0.0, "launches": 0})
             gdict["ms"] += e0.elapsed_time(e1)
             gdict["flops"] += fl

@@ -210,3 +210,32 @@ def test_stride2_stream_conv_vs_torch_and_gather(device, cfg):
     pg = packing.pack_conv("g", w, scale, shift, stride=2, pad=1, relu=True, device=device)
     alt = back(ops.conv2d(pg, nhwc(x, device)))
     assert torch.allclose(got, alt, atol=2e-3, rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("cfg", [
+    # (C_up, C, N, H, W, chain)
+    (128, 64, 2, 32, 64, False),   # conv7_1 class: half-resolution source + skip
+    (0, 64, 3, 16, 32, False),     # conv7_2 class (one 16x32 tile per map)
+    (0, 64, 2, 32, 32, True),      # conv1_2 -> conv3d_1 chain
+])
+def test_wide_kernel_equals_256_pixel_kernel_bitwise(device, cfg, monkeypatch):
+    """The wide 4-wave form (128 pixels per wave, single-buffered patch) walks K in the same order with the same
+    fragments as the 256-pixel kernel and shares its epilogue: identical bits, also over repeated launches."""
+    from v2x_sim_amd import ops, packing
+    cup, c, N, H, W, chain = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:5]))
+    x = torch.randn(N, H, W, c, generator=g).to(torch.bfloat16).to(device)
+    w = torch.randn(64, cup + c, 3, 3, generator=g) * (2.0 / ((cup + c) * 9)) ** 0.5
+    ch = (torch.randn(64, 64, 1, 1, generator=g) * 0.2, torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2, True) if chain else None
+    pc = packing.pack_conv_stream("t", w, torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2,
+                                  C0=cup if cup else c, C1=c if cup else 0, up0=1 if cup else 0, chain=ch, device=device)
+    if cup:
+        x0 = torch.randn(N, H // 2, W // 2, cup, generator=g).to(torch.bfloat16).to(device)
+        run = lambda: ops.conv2d(pc, x0, x)
+    else:
+        run = lambda: ops.conv2d(pc, x)
+    monkeypatch.setenv("V2X_STREAM_WIDE", "0")
+    ref = run()
+    monkeypatch.delenv("V2X_STREAM_WIDE")
+    for _ in range(5):
+        assert torch.equal(run(), ref)

@@ -54,9 +54,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // ---- epilogue shared by the 4-wave and the 8-wave kernels -------------------------------------------
-template <int BCO, int TW, int EPI>
-__device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&acc)[BCO / 16][4], int co_tile, int n, int y0,
-                                                int x0, const int (&frow)[4], int fj, int fq) {
+template <int BCO, int TW, int EPI, int NF = 4>
+__device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&acc)[BCO / 16][NF], int co_tile, int n, int y0,
+                                                int x0, const int (&frow)[NF], int fj, int fq) {
     constexpr int TCO = BCO / 16;
     if constexpr (EPI == SEPI_GRU) {
         // rows are (r,z,n) triples of 16 hidden channels: tiles 3g, 3g+1, 3g+2  (packing.pack_gru_stream)
@@ -68,7 +68,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
 #pragma unroll
             for (int r = 0; r < 4; ++r) bias[r] = reinterpret_cast<const float4 *>(a.scale)[hc + r];
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < NF; ++f) {
                 float h[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -93,7 +93,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // leave the counted-DMA regime before ordinary loads
         // hidden activations of all 4 pixel fragments as B fragments (bf16): NKS x 4 registers each.  k-step outermost so
         // that only two tiles' scale/shift are live and the accumulator tiles die as they are consumed (register pressure).
-        bf16x8_t hb[4][NKS];
+        bf16x8_t hb[NF][NKS];
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             float4 sc[2], sf[2];
@@ -105,7 +105,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
                 sf[hf] = *reinterpret_cast<const float4 *>(a.shift + kappa);
             }
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < NF; ++f) {
                 float h[8];
 #pragma unroll
                 for (int hf = 0; hf < 2; ++hf) {
@@ -127,9 +127,9 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
                 hb[f][ks] = __builtin_bit_cast(bf16x8_t, p);
             }
         }
-        size_t pix[4];
+        size_t pix[NF];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
+        for (int f = 0; f < NF; ++f)
             pix[f] = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
         // second GEMM: one output-channel tile at a time; its NKS weight fragments (L1/L2-resident, BCO*BCO*2 bytes in
         // all) are loaded once and serve the 4 pixel fragments
@@ -143,7 +143,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
             const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < NF; ++f) {
                 f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int ks = 0; ks < NKS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks], hb[f][ks], d, 0, 0, 0);
@@ -168,7 +168,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
             const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
+            for (int f = 0; f < NF; ++f) {
                 float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
                 float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
                 if (a.relu) {
@@ -649,6 +649,195 @@ static int launch_stream8(const StreamArgs &a, hipStream_t s) {
     return V2X_OK;
 }
 
+// ---- "wide" 4-wave form for the 64-row layers ----------------------------------------------------------
+// conv7_1 (192 -> 64), conv1_2 -> conv3d_1 and conv7_2 (64 -> 64) at 128x128 have only ONE 64-row channel tile: with the
+// 256-pixel tile above a wave does 16 MFMAs per step against 1 weight + 1 patch DMA and a barrier (twice the overhead per
+// MFMA of the 128-row tiles), and every 256 pixels re-stream the layer's whole weight tensor from L2 (4.5 GB per conv7_1
+// launch).  Here a wave owns 128 pixels (4 rows x 32 columns, 8 B fragments): 32 MFMAs per step from 4 + 8 fragment
+// reads, the same ratios as the 128-row kernels, and a weight slice is fetched once per 512 pixels.  The 16x32 tile's
+// patch is 40 KiB, so it is SINGLE-buffered (ring 16 + patch 40 = 56 KiB -> two workgroups per CU, as in
+// conv_stream_s2.hip): at a chunk boundary everything drains, the patch is refilled and the co-resident workgroup's MFMAs
+// cover the refill.  Weight ring, counted waits and K order are those of the 256-pixel kernel.
+constexpr int WPATCH_PIECES = 39;               // 18 x 34 pixels x 64 B = 38.25 KiB
+constexpr int WPATCH_BYTES = WPATCH_PIECES * 1024;
+
+template <int BCO, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wide_kernel(const StreamArgs a) {
+    constexpr int TH = 16, TW = 32, NF = 8;
+    constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
+    constexpr int TCO = BCO / 16;
+    constexpr int SLICE_BYTES = BCO * 64;
+    constexpr int PPW = (WPATCH_PIECES + 3) / 4;   // patch pieces per wave (10)
+    static_assert(BCO == 64, "wide form: one 64-row channel tile (1 weight DMA per wave and step)");
+    static_assert(PH * PW * 4 <= WPATCH_PIECES * 64, "patch must fit its buffer");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_ring = smem;
+    char *s_patch = smem + RING * SLICE_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15, fq = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int co_tile = bid % a.n_co_tiles;
+    const int px_tile = bid / a.n_co_tiles;
+    const int txy = a.tiles_x * a.tiles_y;
+    const int n = px_tile / txy;
+    const int trem = px_tile - n * txy;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    const int nc0 = a.C0 >> 5, nchunks = (a.C0 + a.C1) >> 5;
+    const int S = nchunks * 9;
+    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+
+    // DMA descriptors of this wave's patch pieces (piece = wave + 4t) for the resolution of the chunk being filled;
+    // rebuilt when the resolution changes (at most twice per tile)
+    int pd[PPW];
+    auto build_pd = [&](bool hf) {
+        // opaque copy of the lane id: without it the compiler evaluates BOTH resolutions' descriptors for all ten pieces
+        // ahead of the chunk loop (loop-invariant code motion) and keeps ~40 intermediates alive across it (spills)
+        int lane_o = lane;
+        asm volatile("" : "+v"(lane_o));
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            const int L = (wave + 4 * t) * 64 + lane_o;
+            const int pix = L >> 2, phys = L & 3;
+            int d;
+            if (!hf) {
+                const int pr = pix / PW, pc = pix - pr * PW;
+                const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+                const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                d = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+            } else {
+                const int Hs = a.H >> 1, Ws = a.W >> 1;
+                const int pr = pix / PW0, pc = pix - pr * PW0;
+                const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+                const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+                d = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+            }
+            pd[t] = d;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // column offsets depend on the fragment's column half (f & 1) only: 6 registers instead of 24
+    int frow[NF], ct[2][3];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) frow[f] = 4 * wave + (f >> 1);
+    auto build_ct = [&](bool hf) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = c * 16 + fj;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int pc = hf ? (((col + kx - 1) >> 1) + 1) : (col + kx);
+                ct[c][kx] = ((pc << 2) + (fq ^ ((pc >> 1) & 3))) * 16;
+            }
+        }
+    };
+
+    const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
+    auto issue_weights = [&](int s) {   // one DMA (BCO = 64: 4 pieces, one per wave)
+        glds16s(wsrc + (size_t)s * (BCO * 32), s_ring + (s & (RING - 1)) * SLICE_BYTES + wave * 1024);
+    };
+    auto issue_patch = [&](int kc, bool hf) {
+        const bool first = kc < nc0;
+        const uint16_t *src = first ? a.in0 : a.in1;
+        const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
+        const int npieces = hf ? (PH0 * PW0 * 4 + 63) / 64 : WPATCH_PIECES;   // the half-resolution patch is 3x smaller
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            if (wave + 4 * t >= npieces) break;              // wave-uniform
+            int d = pd[t];
+            asm volatile("" : "+v"(d));   // keep the address arithmetic HERE: hoisted out of the chunk loop it becomes ten
+                                          // live 64-bit addresses on top of 176 busy registers (it spilled)
+            const unsigned off = (unsigned)(d >> 5) * cs + (unsigned)((first ? kc : kc - nc0) * 32 + (d & 31));
+            glds16s(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + (wave + 4 * t) * 1024);
+        }
+    };
+
+    f32x4_t acc[TCO][NF];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue_weights(0);   // S >= 18
+    issue_weights(1);
+    issue_weights(2);
+
+    int s = 0;
+    bool cur_half = false;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const bool half = (kc < nc0) && a.up0;
+        const int sh = half ? 1 : 0, row_bytes = (half ? PW0 : PW) * 64;
+        if (kc == 0 || half != cur_half) {   // wave-uniform
+            build_pd(half);
+            build_ct(half);
+            cur_half = half;
+        }
+        // ---- chunk boundary: everyone has left the previous chunk's patch (and ring slot s-1) -> refill, drain, meet
+        if (kc > 0) __builtin_amdgcn_s_barrier();
+        issue_patch(kc, half);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+            int rowoff[NF / 2];          // fragments 2r, 2r+1 share a row
+#pragma unroll
+            for (int r = 0; r < NF / 2; ++r) rowoff[r] = (((4 * wave + r + ky - sh) >> sh) + sh) * row_bytes;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx, ++s) {
+                const int tap = ky * 3 + kx;
+                if (tap > 0) {
+                    // this step's slice has landed (groups s+1, s+2 may be in flight); everyone is done with ring slot s-1
+                    if (s + 2 >= S) wait_vmcnt<0>();
+                    else wait_vmcnt<2>();
+                    __builtin_amdgcn_s_barrier();
+                }
+                if (s + 3 < S) issue_weights(s + 3);
+                const char *ws = s_ring + (s & (RING - 1)) * SLICE_BYTES;
+                bf16x8_t fa[TCO], fb[NF];
+#pragma unroll
+                for (int f = 0; f < NF; ++f) fb[f] = *reinterpret_cast<const bf16x8_t *>(s_patch + rowoff[f >> 1] + ct[f & 1][kx]);
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < NF; ++f)
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TCO + NF, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, TCO * NF, 0);
+            }
+        }
+    }
+    stream_epilogue<BCO, TW, EPI, NF>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+}
+
+template <int BCO, int EPI>
+static int launch_wide(const StreamArgs &a, hipStream_t s) {
+    constexpr int smem = RING * BCO * 64 + WPATCH_BYTES;   // 55 KiB: two workgroups per CU
+    static bool attr_done = false;
+    auto kern = &conv3x3_wide_kernel<BCO, EPI>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_wide_kernel");
+    return V2X_OK;
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 template <int BCO, int TH, int TW, int EPI>
 static int launch_stream(const StreamArgs &a, hipStream_t s) {
@@ -720,6 +909,15 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
             if (d->epilogue == V2X_EPI_GRU) return launch_stream8<96, SEPI_GRU>(a, s);
             if (chain) return launch_stream8<128, SEPI_CHAIN>(a, s);
             return launch_stream8<128, SEPI_BF16>(a, s);
+        }
+    }
+    // 64-row layers on maps that tile into 16x32: the wide 4-wave form (V2X_STREAM_WIDE=0 keeps the 256-pixel kernel: A/B)
+    if (!t16 && d->H % 16 == 0 && rows == 64 && d->epilogue == V2X_EPI_BF16 && ((d->C0 + d->C1) >> 5) >= 2) {
+        const char *e = getenv("V2X_STREAM_WIDE");
+        if (!(e && e[0] == '0')) {
+            a.tiles_y = d->H / 16;
+            a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
+            return chain ? launch_wide<64, SEPI_CHAIN>(a, s) : launch_wide<64, SEPI_BF16>(a, s);
         }
     }
     if (chain) {

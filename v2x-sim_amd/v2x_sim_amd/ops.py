@@ -18,7 +18,7 @@ def _stream():
 
 
 # Optional per-launch instrumentation used by bench.py's roofline pass: when PROFILE is a list,
-# every wrapper appends (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event)
+# every wrapper appends (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event, layer_name)
 # with HIP events recorded on the stream the kernel is launched on.
 PROFILE = None
 
@@ -26,11 +26,11 @@ PROFILE = None
 class _Prof:
     __slots__ = ("rec",)
 
-    def __init__(self, name, flops, nbytes):
+    def __init__(self, name, flops, nbytes, layer=None):
         self.rec = None
         if PROFILE is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.rec = (name, float(flops), float(nbytes), e0, e1)
+            self.rec = (name, float(flops), float(nbytes), e0, e1, layer or name)
             e0.record(torch.cuda.current_stream())
 
     def done(self):
@@ -50,6 +50,9 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
         th, tw = (8, 32) if W % 32 == 0 else (16, 16)
         epi = 2 if pc.epilogue == V2X_EPI_GRU else (1 if pc.Cout2 else 0)
+        if W % 32 == 0 and H % 16 == 0 and rows == 64 and pc.epilogue == V2X_EPI_BF16 and (pc.C0 + pc.C1) >= 64 \
+                and os.environ.get("V2X_STREAM_WIDE", "1") != "0":
+            return "conv3x3_wide_kernel<64, %d>" % epi   # 128 pixels per wave (conv_stream.hip)
         if W % 32 == 0 and H % 16 == 0 and rows in (96, 128) \
                 and not os.environ.get("V2X_STREAM_WAVES", "").startswith("4"):
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
@@ -294,7 +297,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0):
         nbytes = in0.numel() * (4 if from_bits else 2) + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
-        prof = _Prof(conv_kernel_name(pc, H, W, from_bits), flops, nbytes)
+        prof = _Prof(conv_kernel_name(pc, H, W, from_bits), flops, nbytes, pc.name)
     rc = lib.v2x_conv2d(C.byref(d), _stream())
     if prof is not None:
         prof.done()

@@ -203,7 +203,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
 
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
 CHAIN_STREAM = True   # conv1_2 -> conv3d_1 and conv2_2 -> conv3d_2: 1x1 chained in the streamed kernel's epilogue (False: separate launches for conv3d_2)
-STREAM_64 = False     # 64 -> 64 layers (conv7_2): streamed kernel instead of the resident-weights halo kernel
+STREAM_64 = True      # 64 -> 64 layers (conv7_2): streamed (wide 4-wave) kernel instead of the resident-weights halo kernel (471 vs 495 us)
 STREAM_S2 = True      # stride-2 3x3 layers (conv1_1, conv2_1, conv3_1): patch-based stride-2 kernel instead of the gather kernel
 
 
