@@ -77,6 +77,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own HIP runtime; it must be the one already resident when libv2x_amd.so resolves
+    # libamdhip64, otherwise the process holds two runtimes and every pointer torch allocated is foreign to ours
+    # (observed: hipMemsetAsync fails with "invalid value" when this library was loaded before `import torch`).
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise V2XLibraryError(
             "libv2x_amd.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
