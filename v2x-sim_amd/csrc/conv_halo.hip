@@ -23,6 +23,7 @@
 //     the second MFMA (hidden channel kappa = 32*(i>>1) + 8*q + 4*(i&1) + r for tile i, lane group q,
 //     register r) -- no cross-lane traffic, the hidden map never exists in memory.
 #include "common.h"
+#include <cstdlib>
 
 // 64 B of zeros for out-of-image patch pixels (own copy: no relocatable device code needed)
 static __device__ __attribute__((aligned(64))) unsigned int g_zero_page_h[16];
@@ -464,9 +465,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---- host side ---------------------------------------------------------------------------------
 template <int C0, int C1, int COUT, int COUT2, int EPI2, bool BITS>
 static int launch_halo_sb(const HaloArgs &a, hipStream_t s) {
-    constexpr int NS1 = round64(PH * PW * (C1 / 8));
-    constexpr int NS0 = C0 ? round64(PH0 * PW0 * (C0 / 8)) : 0;
-    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + (NS0 + NS1) * 16;
+    static_assert(C0 == 0, "single-buffer form: one source");
+    // bit-grid input: the patch is written with ds_write for exactly PH*PW pixels, so it is allocated WITHOUT the 768-B
+    // wave padding the LDS-DMA fill needs -- 39.25 KiB, which lets a 4th workgroup fit beside the slack rule below
+    // (measured per launch at 320 maps: 2 / 3 / 4 workgroups per CU = 684 / 568 / 520 us).  The bf16-input layers get
+    // SLOWER with a 4th workgroup (628 / 577 / 649 us) and keep the padded 40-KiB allocation = 3 per CU.
+    constexpr int smem = 9 * C1 / 8 * COUT * 16 + (BITS ? PH * PW * (C1 / 8) : round64(PH * PW * (C1 / 8))) * 16;
     static bool attr_done = false;
     auto kern = &conv3x3_halo_sb_kernel<C0, C1, COUT, COUT2, EPI2, BITS>;
     if (!attr_done) {
