@@ -126,8 +126,39 @@ def g_v2vnet_small():
                         T=T, weight_abs_sum=wsum, **out)
 
 
+def g_postprocess():
+    """Detection post-processing (build-owned spec): logits of a 32x32x6 anchor map with a few confident
+    blobs -> boxes / scores of the host function.  Pins the host spec against drift and is the known-answer test of
+    v2x_det_postprocess (tests/test_gpu_postprocess.py)."""
+    from v2x_sim_amd.utils import postprocess as P
+    rng = np.random.default_rng(31)
+    X = Y = 32
+    A = 6
+    anc = np.zeros((X, Y, A, 6), np.float32)
+    anc[..., 0] = (-4.0 + (np.arange(X) + 0.5) * 0.25)[:, None, None]
+    anc[..., 1] = (-4.0 + (np.arange(Y) + 0.5) * 0.25)[None, :, None]
+    for a, (w, h, yaw) in enumerate(R.ANCHOR_SIZE):
+        anc[:, :, a, 2], anc[:, :, a, 3] = w * 0.25, h * 0.25
+        anc[:, :, a, 4], anc[:, :, a, 5] = np.sin(yaw), np.cos(yaw)
+    cls = np.zeros((X, Y, A, 2), np.float32)
+    cls[..., 0] = 2.0 + rng.normal(0, 0.3, (X, Y, A))
+    cls[..., 1] = -2.0 + rng.normal(0, 0.3, (X, Y, A))
+    loc = rng.normal(0, 0.05, (X, Y, A, 1, 6)).astype(np.float32)
+    loc[..., 5] += 1.0
+    for _ in range(12):
+        x, y, a = rng.integers(3, X - 3), rng.integers(3, Y - 3), rng.integers(0, A)
+        for dx in range(-1, 2):
+            for dy in range(-1, 2):
+                s = 4.0 - 1.2 * (abs(dx) + abs(dy)) + rng.normal(0, 0.05)
+                cls[x + dx, y + dy, a] = (-s, s)
+    cls = cls.astype(np.float32).reshape(-1, 2)
+    det = P.apply_nms_det(loc, cls, anc, 0.7, 0.01)
+    np.savez_compressed(os.path.join(HERE, "postprocess_small.npz"), cls=cls, loc=loc, anchors=anc, boxes=det["boxes"],
+                        scores=det["scores"], corners=det["corners"])
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
-    for fn in (g_voxel, g_conv, g_warp, g_gru, g_attn, g_v2vnet_small):
+    for fn in (g_voxel, g_conv, g_warp, g_gru, g_attn, g_v2vnet_small, g_postprocess):
         fn()
         print("wrote", fn.__name__)

@@ -114,3 +114,18 @@ def test_predict_all_device_equals_host_path(device):
     _, _, _, seq_host = module.predict_all(data, B, validation=False, num_agent=A)
     _compare([seq_dev[k][0] for k in range(A)], [seq_host[k][0] for k in range(A)])
     assert sum(s[0]["scores"].shape[0] for s in seq_host) > 30
+
+
+def test_device_postprocess_golden(device):
+    """Known-answer test: tests/golden/postprocess_small.npz (generated from the host spec by make_golden.py)."""
+    import os
+    from v2x_sim_amd import ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "postprocess_small.npz"))
+    cls = torch.from_numpy(g["cls"])[None].to(device)
+    loc = torch.from_numpy(g["loc"])[None].to(device)
+    boxes, scores, index, count = ops.det_postprocess(cls, loc, torch.from_numpy(g["anchors"].reshape(-1, 6)).to(device),
+                                                      0.7, 0.01, 256)
+    n = int(count[0])
+    assert n == g["boxes"].shape[0]
+    assert np.allclose(boxes[0, :n].cpu().numpy(), g["boxes"], atol=1e-4)
+    assert np.allclose(scores[0, :n].cpu().numpy(), g["scores"], atol=1e-6)

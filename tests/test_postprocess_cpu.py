@@ -84,3 +84,13 @@ def test_eval_map_hand_cases():
     shifted = _det([[0.3, 0, 2, 4, 0.0]], [0.9])
     assert P.eval_map([shifted], [gt[:1]], 0.5)[0] == 1.0 and P.eval_map([shifted], [gt[:1]], 0.8)[0] == 0.0
     assert P.eval_map([_det(np.zeros((0, 5)), [])], [gt], 0.5)[0] == 0.0
+
+
+def test_postprocess_golden_known_answer():
+    """tests/golden/postprocess_small.npz pins the host spec (softmax score, 0.7 threshold, 'faf' decode, stand-up NMS)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "postprocess_small.npz"))
+    det = P.apply_nms_det(g["loc"], g["cls"], g["anchors"], 0.7, 0.01)
+    assert det["boxes"].shape == g["boxes"].shape == (7, 5)
+    assert np.allclose(det["boxes"], g["boxes"], atol=1e-6) and np.allclose(det["scores"], g["scores"], atol=1e-7)
+    assert np.allclose(det["corners"], g["corners"], atol=1e-6)
