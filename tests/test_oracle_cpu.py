@@ -217,3 +217,38 @@ def test_early_fusion_transform_spec():
     for j in range(3):
         union = np.maximum(union, VR.voxelize_occupy(VR.transform_points_f32(clouds[j], T[0, j])))
     assert np.array_equal(merged, union)
+
+
+def test_warp_pose_convention_of_synthetic_scenes():
+    """The synthetic scenes' `trans` (utils/synthetic_scene.make_scene) is in the axis convention the upstream warp formula
+    presumes: a feature blob at a world point in agent j's map lands on that world point's cell in agent i's map."""
+    import math
+    from v2x_sim_amd.utils import synthetic_scene as S
+    sc = S.make_scene(agents=4, n_cars=6, seed=5)
+    rng = np.random.default_rng(1)
+    hits = plain = n = 0
+    for i in range(4):
+        for j in range(4):
+            if i == j:
+                continue
+            G = sc["trans_geo"][i, j].astype(np.float64)          # p_i = G p_j
+            for _ in range(5):
+                pj = np.array([*rng.uniform(-20, 20, 2), 0.0, 1.0])
+                pi = G @ pj
+                ci = (int(math.floor(pi[0] / 2)) + 16, int(math.floor(pi[1] / 2)) + 16)   # layer-3 cell (2 m), dim0 = x
+                cj = (int(math.floor(pj[0] / 2)) + 16, int(math.floor(pj[1] / 2)) + 16)
+                if not all(2 <= c < 30 for c in ci + cj):
+                    continue
+                n += 1
+                F = torch.zeros(1, 32, 32)
+                F[0, cj[0], cj[1]] = 1.0
+                for T, which in ((sc["trans"][i, j], "conv"), (sc["trans_geo"][i, j], "plain")):
+                    out = R.feature_transformation(F, torch.from_numpy(T), (1, 1, 32, 32))[0]
+                    pk = np.unravel_index(int(out.argmax()), out.shape)
+                    ok = float(out.max()) > 0 and max(abs(pk[0] - ci[0]), abs(pk[1] - ci[1])) <= 1
+                    if which == "conv":
+                        hits += ok
+                    else:
+                        plain += ok
+    assert n >= 20 and hits == n, (n, hits)
+    assert plain < n // 2          # the geometric matrix itself is NOT what the formula expects

@@ -32,11 +32,12 @@ def init_for_training(model, fg_prior=0.01, seed=0):
     return model
 
 
-def synthetic_batch_on_device(config, frames, agents, seed, device, grid=None, anchors=None, with_targets=True):
+def synthetic_batch_on_device(config, frames, agents, seed, device, grid=None, anchors=None, with_targets=True, **scene_kw):
     """-> data dict in FaFModule.step / predict_all's format (+ 'gt_boxes'[agent][frame] host arrays)."""
     anchors = postprocess.build_anchor_map(config) if anchors is None else anchors
     grid = grid or ops.VoxelGrid(config.voxel_size, config.area_extents)
-    b = synthetic_scene.make_batch(frames, agents, seed=seed, anchors=anchors if with_targets else None, targets="sparse")
+    b = synthetic_scene.make_batch(frames, agents, seed=seed, anchors=anchors if with_targets else None, targets="sparse",
+                                   **scene_kw)
     pts = torch.from_numpy(b["points"]).to(device)
     bits = ops.voxelize_bits(pts, torch.from_numpy(b["n_pts"]).to(device), grid)
     data = {"bev_seq": ops.bits_to_dense(bits, grid.dims[2])[:, None],
@@ -48,7 +49,8 @@ def synthetic_batch_on_device(config, frames, agents, seed, device, grid=None, a
     return data
 
 
-def train_synthetic(model, config, steps, frames_per_step=2, lr=1e-3, seed=0, device="cuda:0", log=None, agents=None):
+def train_synthetic(model, config, steps, frames_per_step=2, lr=1e-3, seed=0, device="cuda:0", log=None, agents=None,
+                    **scene_kw):
     """Adam on freshly generated synthetic scenes (never the same scene twice).  -> list of (loss, cls, loc)."""
     agents = agents or model.agent_num
     device = torch.device(device)
@@ -59,7 +61,8 @@ def train_synthetic(model, config, steps, frames_per_step=2, lr=1e-3, seed=0, de
     grid = ops.VoxelGrid(config.voxel_size, config.area_extents)
     hist = []
     for it in range(steps):
-        data = synthetic_batch_on_device(config, frames_per_step, agents, seed * 1000003 + it, device, grid, module.anchors)
+        data = synthetic_batch_on_device(config, frames_per_step, agents, seed * 1000003 + it, device, grid, module.anchors,
+                                         **scene_kw)
         hist.append(module.step(data, frames_per_step, agents))
         sched.step()
         if log and (it % log == 0 or it == steps - 1):

@@ -28,9 +28,14 @@ def _pose(yaw, x, y):
     return M
 
 
-def make_scene(agents=5, n_cars=24, seed=0, ground_pts=6000, clutter_pts=1200, pts_per_car=400, max_pts=16384):
-    """-> dict(points (A, max_pts, 4) f32 zero-padded, n_pts (A,) i32, trans (A, A, 4, 4) f32 with
-    trans[i, j] = inv(P_i) @ P_j, gt_boxes list of (G_a, 5) f32 per agent)."""
+def make_scene(agents=5, n_cars=24, seed=0, ground_pts=6000, clutter_pts=1200, pts_per_car=400, max_pts=16384,
+               sensor_range=SENSOR_RANGE, gt="own"):
+    """-> dict(points (A, max_pts, 4) f32 zero-padded, n_pts (A,) i32, trans (A, A, 4, 4) f32 = the pose of agent j w.r.t.
+    agent i in the warp's axis convention (see the end of this function), trans_geo = inv(P_i) @ P_j, gt_boxes list of
+    (G_a, 5) f32 per agent).
+    gt='own': an agent's ground truth = the cars inside its BEV extents AND its own sensor range;
+    gt='any': ... inside its BEV extents and in range of ANY agent -- cars the ego cannot see itself but a neighbour can
+    (with a short sensor_range this is the setting in which collaboration must help, tests/test_gpu_train.py)."""
     rng = np.random.default_rng(seed)
     P = [_pose(rng.uniform(-math.pi, math.pi), *rng.uniform(-12, 12, 2)) for _ in range(agents)]
     cars = []
@@ -50,7 +55,7 @@ def make_scene(agents=5, n_cars=24, seed=0, ground_pts=6000, clutter_pts=1200, p
         ax, ay = P[a][0, 3], P[a][1, 3]
         chunks = []
         for cx, cy, w, h, yaw in cars:
-            if math.hypot(cx - ax, cy - ay) > SENSOR_RANGE:
+            if math.hypot(cx - ax, cy - ay) > sensor_range:
                 continue
             n = pts_per_car
             lx = rng.uniform(-w / 2, w / 2, n)
@@ -63,7 +68,7 @@ def make_scene(agents=5, n_cars=24, seed=0, ground_pts=6000, clutter_pts=1200, p
             lz = np.where(side, rng.uniform(-1.6, -0.3, n), lz)
             c, s = math.cos(yaw), math.sin(yaw)
             chunks.append(np.stack([cx + lx * c - ly * s, cy + lx * s + ly * c, lz], 1))
-        r = SENSOR_RANGE * np.sqrt(rng.random(ground_pts))
+        r = sensor_range * np.sqrt(rng.random(ground_pts))
         t = rng.uniform(0, 2 * math.pi, ground_pts)
         chunks.append(np.stack([ax + r * np.cos(t), ay + r * np.sin(t), -1.8 + rng.normal(0, 0.03, ground_pts)], 1))
         chunks.append(np.stack([ax + rng.uniform(-32, 32, clutter_pts), ay + rng.uniform(-32, 32, clutter_pts),
@@ -76,15 +81,29 @@ def make_scene(agents=5, n_cars=24, seed=0, ground_pts=6000, clutter_pts=1200, p
         n_pts[a] = local.shape[0]
         yaw_a = math.atan2(P[a][1, 0], P[a][0, 0])
         ctr = cars[:, :2] @ inv[:2, :2].T + inv[:2, 3]
-        inside = (np.abs(ctr[:, 0]) < 29.0) & (np.abs(ctr[:, 1]) < 29.0) & \
-                 (np.hypot(cars[:, 0] - ax, cars[:, 1] - ay) <= SENSOR_RANGE)
+        if gt == "any":
+            seen = np.zeros(cars.shape[0], bool)
+            for b in range(agents):
+                seen |= np.hypot(cars[:, 0] - P[b][0, 3], cars[:, 1] - P[b][1, 3]) <= sensor_range
+        else:
+            seen = np.hypot(cars[:, 0] - ax, cars[:, 1] - ay) <= sensor_range
+        inside = (np.abs(ctr[:, 0]) < 29.0) & (np.abs(ctr[:, 1]) < 29.0) & seen
         g = np.concatenate([ctr, cars[:, 2:4], (cars[:, 4:5] - yaw_a)], 1)[inside]
         gts.append(g.astype(np.float32))
+    # trans_geo[i, j] = inv(P_i) @ P_j: the geometric transform, agent j's BEV frame -> agent i's (p_i = R p_j + t).
+    # trans[i, j] = the same pose in the axis convention upstream's warp PRESUMES of the dataset's trans_matrices: the
+    # formula shifts the WIDTH axis (BEV y) by 4*T03/128 and the HEIGHT axis (BEV x) by -4*T13/128, which aligns features
+    # iff T03 = -t_y and T13 = t_x (sensor axes rotated 90 degrees against the BEV array axes; the rotation block commutes
+    # and is unchanged).  Verified numerically against the oracle's feature_transformation (tests/test_oracle_cpu.py):
+    # with the plain (t_x, t_y) a warped blob never lands on its cell, with (-t_y, t_x) it always does.
+    T_geo = np.zeros((agents, agents, 4, 4), np.float32)
     T = np.zeros((agents, agents, 4, 4), np.float32)
     for i in range(agents):
         for j in range(agents):
-            T[i, j] = (np.linalg.inv(P[i]) @ P[j]).astype(np.float32)
-    return {"points": points, "n_pts": n_pts, "trans": T, "gt_boxes": gts}
+            T_geo[i, j] = (np.linalg.inv(P[i]) @ P[j]).astype(np.float32)
+            T[i, j] = T_geo[i, j]
+            T[i, j, 0, 3], T[i, j, 1, 3] = -T_geo[i, j, 1, 3], T_geo[i, j, 0, 3]
+    return {"points": points, "n_pts": n_pts, "trans": T, "trans_geo": T_geo, "gt_boxes": gts}
 
 
 def anchor_targets_sparse(gt_boxes, anchors):
@@ -138,6 +157,7 @@ def make_batch(frames, agents=5, seed=0, anchors=None, targets="dense", **kw):
     out = {"points": np.stack([scenes[b]["points"][a] for a in range(agents) for b in range(frames)]),
            "n_pts": np.asarray([scenes[b]["n_pts"][a] for a in range(agents) for b in range(frames)], np.int32),
            "trans": np.stack([s["trans"] for s in scenes]),
+           "trans_geo": np.stack([s["trans_geo"] for s in scenes]),
            "num_agent": np.full((frames, agents), agents, np.int64),
            "gt_boxes": [[scenes[b]["gt_boxes"][a] for b in range(frames)] for a in range(agents)]}
     if anchors is not None and targets == "dense":
