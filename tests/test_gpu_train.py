@@ -169,3 +169,21 @@ def test_collaboration_helps(device):
         res[name] = 100 * ap
         print("%-10s final loss %.3f  mAP@0.5 %.2f  (%d detections, %d gt)" % (name, hist[-1][0], 100 * ap, info["num_det"], info["num_gt"]))
     assert res["v2v"] > res["lowerbound"] + 15.0, res
+
+
+def test_when2com_trains_and_serves(device):
+    """when2com: 40 optimisation steps through FaFModule.step (soft attention scores in training) reduce the loss, and the
+    trained parameters then serve on the HIP path with the hard 'activated' selection (communication graph reported)."""
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import When2com
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device, train_synthetic
+    cfg = Config("train")
+    model = init_for_training(When2com(cfg), seed=0)
+    hist = train_synthetic(model, cfg, 40, frames_per_step=1, lr=1e-3, seed=3, device=device)
+    first, last = np.mean([h[0] for h in hist[:5]]), np.mean([h[0] for h in hist[-5:]])
+    print("when2com loss %.3f -> %.3f" % (first, last))
+    assert last < 0.7 * first
+    data = synthetic_batch_on_device(cfg, 1, 5, seed=99, device=device, with_targets=False)
+    with torch.no_grad():
+        res = model(data["bev_seq"], data["trans_matrices"], data["num_agent"], training=False, inference="activated", batch_size=1)
+    assert res["cls"].shape[0] == 5 and torch.isfinite(res["cls"]).all() and 0.0 <= res["num_connect"] <= 4.0

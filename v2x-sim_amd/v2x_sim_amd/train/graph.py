@@ -6,7 +6,7 @@ the same graph written with torch ops on the MI355X (MIOpen convolutions, autogr
 the nn.Conv2d / nn.BatchNorm2d containers that models/det/base.py holds under the upstream names -- so an optimizer
 steps the very tensors the HIP engine packs (DetModelBase.packed() notices the version bump and re-packs).
 
-Graph = upstream Backbone.py / DetModelBase.py / V2VNet.py semantics (PyTorch 1.8 per README.md:88-95): nearest x2
+Graph = upstream Backbone.py / DetModelBase.py / V2VNet.py / When2com.py semantics (PyTorch 1.8 per README.md:88-95): nearest x2
 upsample, concat (up, skip), two-step affine_grid/grid_sample warp with align_corners=False, ConvGRU step with h0 = 0.
 It is NOT a fallback for inference: models refuse to run forward() off the GPU library, and this graph is only
 reached through FaFModule.step() / train_forward().
@@ -102,7 +102,45 @@ def v2v_fuse(model, feat, trans, num_agent_tensor, B):
     return cur
 
 
-def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1):
+def when2com_fuse(model, x, feat, trans, num_agent_tensor, B, training=True, inference="softmax"):
+    """when2com / who2com fusion (upstream When2com.py): policy tower -> key / query MLPs -> scores = key . Linear(query),
+    softmax over the keys; training uses the soft scores, inference 'activated' / 'argmax_test' as the HIP path.
+    x (A*B, Z, X, Y) input, feat (A*B, C, H, W) fusion-layer maps -> fused maps (zeros for padding agents)."""
+    A = model.agent_num
+    qk = model.query_key_net
+    y = encoder(qk.lidar_encoder, x)[4]
+    for i in range(1, 6):
+        u = getattr(qk, "conv%d" % i).cbr_unit
+        y = _cbr(y, u[0], u[1])
+    flat = y.reshape(y.shape[0], -1)                       # NCHW flatten, as upstream
+    keys, querys = model.key_net.fc(flat), model.query_net.fc(flat)
+    key_mat = torch.stack([keys[B * i:B * (i + 1)] for i in range(A)], 1)       # (B, A, K)
+    query_mat = torch.stack([querys[B * i:B * (i + 1)] for i in range(A)], 1)   # (B, A, Q)
+    prob = torch.softmax(torch.bmm(key_mat, model.attention_net.linear(query_mat).transpose(2, 1)), dim=1)  # (B, k, q)
+    if training or inference == "softmax":
+        coef = prob
+    elif inference == "activated":
+        coef = prob * (prob > 0.2).to(prob.dtype)
+    elif inference == "argmax_test":
+        coef = F.one_hot(prob.max(dim=1)[1], num_classes=A).to(prob.dtype).transpose(1, 2)
+    else:
+        raise ValueError("Incorrect inference mode")
+    counts, items, rows = model.frame_plan(num_agent_tensor, B, A)
+    dev = feat.device
+    pairs = [(m, k * B + f, f, q, k) for m, (q, f) in enumerate(items) for k in range(counts[f])]
+    src = torch.tensor([p[1] for p in pairs], device=dev)
+    dst = torch.tensor([p[0] for p in pairs], device=dev)
+    Tp = torch.stack([trans[f, q, k] for (_, _, f, q, k) in pairs]).to(feat.dtype)
+    own = torch.tensor([1.0 if q == k else 0.0 for (_, _, _, q, k) in pairs], device=dev, dtype=feat.dtype).view(-1, 1, 1, 1)
+    maps = feat.index_select(0, src)
+    val = own * maps + (1.0 - own) * warp_batch(maps, Tp)                       # the ego map is taken unwarped
+    w = torch.stack([coef[f, k, q] for (_, _, f, q, k) in pairs]).view(-1, 1, 1, 1)
+    fused_items = torch.zeros((len(items),) + tuple(feat.shape[1:]), device=dev, dtype=feat.dtype).index_add_(0, dst, w * val)
+    fused = torch.zeros_like(feat).index_copy(0, torch.tensor(rows, device=dev), fused_items)
+    return fused, prob, coef
+
+
+def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
     """bevs (A*B, 1, X, Y, Z) dense occupancy (the Dataset format) -> {'loc', 'cls'} with the shapes of the HIP path.
     Uses batch-statistics BN when model.training, running statistics otherwise."""
     x = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)
@@ -113,4 +151,11 @@ def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch
         feats = encoder(model.u_encoder, x)
         feats[model.layer] = v2v_fuse(model, feats[model.layer], trans_matrices.to(x.device), num_agent_tensor, batch_size)
         return heads(model, decoder(model.decoder, *feats))
-    raise NotImplementedError("training graph exists for FaFNet and V2VNet (when2com training: DESIGN.md section 9)")
+    if hasattr(model, "query_key_net"):             # when2com / who2com
+        feats = encoder(model.u_encoder, x)
+        feats[model.layer], prob, coef = when2com_fuse(model, x, feats[model.layer], trans_matrices.to(x.device),
+                                                       num_agent_tensor, batch_size, model.training, inference)
+        res = heads(model, decoder(model.decoder, *feats))
+        res["prob_action"], res["coef"] = prob, coef
+        return res
+    raise NotImplementedError("training graph exists for FaFNet, V2VNet and When2com")
