@@ -128,7 +128,8 @@ typedef struct v2x_conv_desc {
     int32_t w_layout;    /* 0: row-major [w_rows][w_kpad] (gather kernel)                          */
                          /* 1: k-slot-major [9*Cin/8][Cout][8] (halo kernel; H%8==0, W%32==0)      */
                          /* 2: streamed slices [co_tile][Cin/32][9][4][rows][8] (conv_stream.hip:    */
-                         /*    3x3 stride 1, C0,C1 % 32 == 0, tiles 8x32 or 16x16)                  */
+                         /*    3x3 stride 1, C0,C1 % 32 == 0, tiles 8x32 / 16x32 / 16x16;           */
+                         /*    conv_stream_s2.hip: 3x3 stride 2, one source, H % 8 == 0, W % 64 == 0) */
     int32_t Cout2;       /* > 0: chain a 1x1 conv on the (never stored) Cout-channel result:       */
     const uint16_t *weight2; /* bf16 [ceil16(Cout2)][Cout] row-major; `epilogue`/`split`/out* then  */
     const float *scale2; /*   describe the FINAL output, scale/shift/relu the hidden layer and     */
