@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Segmentation evaluation driver -- the flag surface of upstream coperception/tools/seg/test_seg.py
+(/root/reference/README.md:101): model on the HIP path -> argmax + confusion matrix on the device -> per-class IoU / mIoU.
+
+    python tools/seg/test_seg.py --data synthetic --com v2v --resume out/epoch_1.pth --frames 8"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for _p in (ROOT, os.path.join(ROOT, "v2x-sim_amd"), os.path.dirname(os.path.abspath(__file__))):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch  # noqa: E402
+
+
+def build_parser():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-d", "--data", default="synthetic", type=str)
+    ap.add_argument("--com", default="v2v", choices=["lowerbound", "upperbound", "v2v"])
+    ap.add_argument("--resume", default="", type=str)
+    ap.add_argument("--num_agent", default=5, type=int)
+    ap.add_argument("--frames", default=8, type=int)
+    ap.add_argument("--batch", default=2, type=int)
+    ap.add_argument("--seed", default=4242, type=int)
+    return ap
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    from train_seg import seg_batch
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.seg import FaFNetSeg, V2VNetSeg
+    from v2x_sim_amd.utils.SegModule import SegModule, iou_from_confusion
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    if not torch.cuda.is_available():
+        raise SystemExit("test_seg.py needs the MI355X: the hot path has no CPU fallback")
+    device = torch.device("cuda:0")
+    config = Config("test", binary=True, only_det=True)
+    A = args.num_agent
+    model = V2VNetSeg(config, num_agent=A) if args.com == "v2v" else FaFNetSeg(config, num_agent=A)
+    if args.resume:
+        ckpt = torch.load(args.resume, map_location="cpu")
+        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=False)
+    else:
+        print("no --resume given: evaluating seeded synthetic weights")
+        init_synthetic_weights(model, seed=0)
+    model = model.to(device).eval()
+    module = SegModule(model, None, config, None, 0)
+    grid = ops.VoxelGrid(config.voxel_size, config.area_extents)
+    conf = torch.zeros((model.n_classes, model.n_classes), dtype=torch.int64, device=device)
+    for start in range(0, args.frames, args.batch):
+        B = min(args.batch, args.frames - start)
+        data = seg_batch(config, B, A, args.seed + start, device, grid)
+        _, c = module.predict(data, batch_size=B, label=data["labels"].to(torch.uint8))
+        conf += c
+    iou = iou_from_confusion(conf.cpu())
+    present = ~torch.isnan(iou)
+    for k in range(model.n_classes):
+        if present[k]:
+            print("class %d IoU %.4f" % (k, float(iou[k])))
+    miou = float(iou[present].mean())
+    print("mIoU %.4f over %d present classes" % (miou, int(present.sum())))
+    return {"iou": iou, "miou": miou, "confusion": conf.cpu()}
+
+
+if __name__ == "__main__":
+    main()

@@ -144,6 +144,14 @@ def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch
     """bevs (A*B, 1, X, Y, Z) dense occupancy (the Dataset format) -> {'loc', 'cls'} with the shapes of the HIP path.
     Uses batch-statistics BN when model.training, running statistics otherwise."""
     x = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)
+    if hasattr(model, "outc"):                      # segmentation variants: det backbone + 1x1 head, NHWC fp32 logits
+        if hasattr(model, "stpn"):
+            y = decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x))
+        else:
+            feats = encoder(model.u_encoder, x)
+            feats[model.layer] = v2v_fuse(model, feats[model.layer], trans_matrices.to(x.device), num_agent_tensor, batch_size)
+            y = decoder(model.decoder, *feats)
+        return model.outc.conv(y).permute(0, 2, 3, 1).contiguous()
     if hasattr(model, "stpn"):                      # FaFNet: lowerbound / upperbound
         feats = encoder(model.stpn.encoder, x)
         return heads(model, decoder(model.stpn.decoder, *feats))

@@ -190,3 +190,25 @@ def dense_targets_on_device(pos, pos_reg, n_items, anchors_shape, device):
         reg[m, i, j, k, 0] = torch.as_tensor(pos_reg, device=device)
         mask[m, i, j, k, 0] = True
     return labels, reg, mask
+
+
+def seg_labels(gt_boxes, config, n_classes=8):
+    """(G, 5) boxes -> (X, Y) uint8 BEV label map: class 1 = vehicle footprint (cell centre inside the rotated box),
+    class 0 = everything else.  (V2X-Sim's seg set has 8 classes, README.md:36; the synthetic scenes only contain cars.)"""
+    X, Y = config.map_dims[0], config.map_dims[1]
+    vx, vy = config.voxel_size[0], config.voxel_size[1]
+    x0, y0 = config.area_extents[0][0], config.area_extents[1][0]
+    lab = np.zeros((X, Y), np.uint8)
+    for gx, gy, gw, gh, gyaw in np.asarray(gt_boxes, np.float64).reshape(-1, 5):
+        r = 0.5 * math.hypot(gw, gh)
+        i0, i1 = max(0, int((gx - r - x0) / vx)), min(X, int((gx + r - x0) / vx) + 2)
+        j0, j1 = max(0, int((gy - r - y0) / vy)), min(Y, int((gy + r - y0) / vy) + 2)
+        if i0 >= i1 or j0 >= j1:
+            continue
+        cx = x0 + (np.arange(i0, i1) + 0.5) * vx - gx
+        cy = y0 + (np.arange(j0, j1) + 0.5) * vy - gy
+        c, s_ = math.cos(gyaw), math.sin(gyaw)
+        lx = cx[:, None] * c + cy[None, :] * s_          # cell centre in the box frame
+        ly = -cx[:, None] * s_ + cy[None, :] * c
+        lab[i0:i1, j0:j1][(np.abs(lx) <= gw / 2) & (np.abs(ly) <= gh / 2)] = 1
+    return lab
