@@ -15,6 +15,7 @@
 // One patch buffer (37 KiB) + ring (16 / 32 KiB) = 53 / 69 KiB -> three / two workgroups per CU; the patch refill at a
 // chunk boundary (everything drains there) is what the other workgroups cover.
 #include "common.h"
+#include <cstdlib>
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -204,6 +205,141 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
 }
 
+// ---- resident-weights form for ONE-chunk layers (conv1_1: 32 -> 64) ------------------------------------
+// With 32 input channels the whole K walk is 9 steps of 8 MFMAs: in the streamed form above every one of them sits behind
+// its own barrier + counted wait, and the three weight slices of the prologue are re-fetched for every 128-pixel tile.
+// Here the 9 slices (36 KiB) are loaded ONCE per workgroup and stay in LDS; the workgroup is persistent over tiles and a
+// tile is: refill the patch (37 KiB, single buffer), one wait + barrier, 72 MFMAs without any synchronisation, 8 stores.
+// 73 KiB -> two workgroups per CU cover each other's refill; the layer is HBM-bound (6.3 MB per map).
+template <int BCO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s2_resident_kernel(const S2Args a) {
+    constexpr int TCO = BCO / 16;
+    constexpr int SLICE_BYTES = BCO * 64;
+    constexpr int W_BYTES = 9 * SLICE_BYTES;
+    static_assert(BCO == 64, "one 64-row channel tile");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_w = smem;
+    char *s_patch = smem + W_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15, fq = lane >> 4;
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * 9 * (BCO * 32);
+
+    // weights of the (single) channel tile: one linear LDS-DMA copy
+    for (int off = wave * 1024; off < W_BYTES; off += 4096)
+        glds16q(reinterpret_cast<const char *>(a.w) + off + lane * 16, s_w + off);
+
+    int ct[2][3];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int idx = f * 16 + fj + (kx == 2 ? 1 : 0);
+            ct[f][kx] = (((kx == 1 ? S2_NE : 0) + idx) * 4 + (fq ^ ((idx >> 1) & 3))) * 16;
+        }
+    // tile-independent part of the patch descriptors: (patch row << 20) | (patch column << 8) | (swizzled slot << 3), -1 = padding
+    int pdt[S2_PPW];
+#pragma unroll
+    for (int t = 0; t < S2_PPW; ++t) {
+        const int L = (wave + 4 * t) * 64 + lane;
+        const int r = L / S2_ROW_SLOTS, q = L - r * S2_ROW_SLOTS;
+        const int ent = q >> 2, phys = q & 3;
+        const bool odd = ent >= S2_NE;
+        const int idx = odd ? ent - S2_NE : ent;
+        const int pc = 2 * idx + (odd ? 1 : 0);
+        pdt[t] = L < S2_SLOTS ? ((r << 20) | (pc << 8) | ((phys ^ ((idx >> 1) & 3)) << 3)) : -1;
+    }
+    const int txy = a.tiles_x * a.tiles_y;
+    const int Ho = a.H >> 1, Wo = a.W >> 1;
+    const float4 *scv = reinterpret_cast<const float4 *>(a.scale), *sfv = reinterpret_cast<const float4 *>(a.shift);
+
+    bool first = true;
+    for (int tile = blockIdx.x; tile < a.n_px_tiles; tile += gridDim.x) {
+        const int n = tile / txy;
+        const int trem = tile - n * txy;
+        const int ty = trem / a.tiles_x;
+        const int y0 = ty * S2_TH, x0 = (trem - ty * a.tiles_x) * S2_TW;
+        // everyone has left the patch of the previous tile (its MFMAs consumed their fragments)
+        if (!first) __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int t = 0; t < S2_PPW; ++t) {
+            if (wave + 4 * t >= S2_PIECES) break;            // wave-uniform
+            const int d = pdt[t];
+            const int y = 2 * y0 - 1 + (d >> 20), x = 2 * x0 - 1 + ((d >> 8) & 0xfff);
+            const bool ok = d >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const unsigned off = ((unsigned)(n * a.H + y) * (unsigned)a.W + (unsigned)x) * (unsigned)a.C + (unsigned)(d & 0xff);
+            glds16q(ok ? (const void *)(a.in + off) : zero_page, s_patch + (wave + 4 * t) * 1024);
+        }
+        s2_wait_vmcnt<0>();     // the patch (and, the first time, the weights; later also the previous tile's stores)
+        __builtin_amdgcn_s_barrier();
+        first = false;
+
+        f32x4_t acc[TCO][2];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int rowoff = (2 * wave + ky) * (S2_ROW_SLOTS * 16);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const char *ws = s_w + (ky * 3 + kx) * SLICE_BYTES;
+                bf16x8_t fa[TCO], fb[2];
+#pragma unroll
+                for (int f = 0; f < 2; ++f) fb[f] = *reinterpret_cast<const bf16x8_t *>(s_patch + rowoff + ct[f][kx]);
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < 2; ++f)
+                        acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int co = i * 16 + fq * 4;
+            const float4 sc = scv[co >> 2], sf = sfv[co >> 2];
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
+                float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
+                if (a.relu) {
+                    v0 = fmaxf(v0, 0.f);
+                    v1 = fmaxf(v1, 0.f);
+                    v2 = fmaxf(v2, 0.f);
+                    v3 = fmaxf(v3, 0.f);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                const size_t pix = (size_t)(n * Ho + y0 + wave) * Wo + x0 + f * 16 + fj;
+                *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
+            }
+        }
+    }
+}
+
+static int launch_s2_resident(const S2Args &a, hipStream_t s) {
+    constexpr int smem = 9 * 64 * 64 + S2_PATCH_BYTES;   // 36 + 37 KiB
+    static bool attr_done = false;
+    auto kern = &conv3x3_s2_resident_kernel<64>;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr_done = true;
+    }
+    int grid = 512;                                       // two workgroups per CU
+    if (grid > a.n_px_tiles) grid = a.n_px_tiles;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_s2_resident_kernel");
+    return V2X_OK;
+}
+
 template <int BCO>
 static int launch_s2(const S2Args &a, hipStream_t s) {
     constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES;
@@ -242,5 +378,9 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.tiles_y = (d->H / 2) / S2_TH;
     a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
     a.n_co_tiles = d->Cout / rows;
+    if (rows == 64 && a.n_co_tiles == 1 && d->C0 == 32) {   // one chunk, one channel tile: resident weights (conv1_1)
+        const char *e = getenv("V2X_S2_RESIDENT");
+        if (!(e && e[0] == '0')) return launch_s2_resident(a, s);
+    }
     return rows == 128 ? launch_s2<128>(a, s) : launch_s2<64>(a, s);
 }

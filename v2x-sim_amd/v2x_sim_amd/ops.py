@@ -45,6 +45,8 @@ _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 12
 def conv_kernel_name(pc, H=0, W=0, bits=False):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
     if pc.w_layout == 2 and pc.stride == 2:
+        if pc.Cout == 64 and pc.C0 == 32 and os.environ.get("V2X_S2_RESIDENT", "1") != "0":
+            return "conv3x3_s2_resident_kernel<64>"
         return "conv3x3_s2_stream_kernel<%d>" % (128 if pc.Cout % 128 == 0 else 64)
     if pc.w_layout == 2:
         rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
