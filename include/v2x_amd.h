@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 3
+#define V2X_AMD_ABI_VERSION 4
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -185,6 +185,14 @@ int v2x_attn_handshake(const float *keys, const float *querys, const float *w_li
  * conf int64 [n_cls][n_cls] (rows = label, cols = prediction), accumulated (caller zeroes). */
 int v2x_seg_argmax_confusion(const float *logits, const uint8_t *label, int n, int H, int W, int n_cls,
                              uint8_t *pred, long long *conf, v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- f-4 (DiscoNet): per-pixel softmax-weighted fusion
+ * Replaces the tail of coperception/models/det/DiscoNet.py::fusion.  scores fp32 [n_items][A][H][W][score_stride] (channel 0
+ * = the ReLU'd 1-channel output of PixelWeightedFusionSoftmax for source k), valid fp32 [n_items][A] (0 = source absent),
+ * maps bf16 [n_items][A][H][W][C] (source k warped into the ego frame) -> out bf16 [n_items][H][W][C]:
+ * w_k = exp(s_k) / sum_j exp(s_j) per pixel, out = sum_k w_k * map_k. */
+int v2x_pixel_weighted_fuse(const float *scores, int score_stride, const float *valid, const uint16_t *maps, int n_items,
+                            int A, int H, int W, int C, uint16_t *out, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-1: detection post-processing
  * Replaces coperception/utils/postprocess.py::apply_nms_det per (agent, frame) map: foreground softmax score, score

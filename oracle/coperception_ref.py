@@ -455,6 +455,43 @@ class CatFusion(FusionBase):
         return self.modulation_layer_3(cat_feat, e).squeeze(0)
 
 
+class PixelWeightedFusionSoftmax(nn.Module):
+    """upstream DiscoNet.py: 1x1 convs 2C -> 128 -> 32 -> 8 (+BN+ReLU) -> 1 (+ReLU) on cat(ego, neighbour)."""
+
+    def __init__(self, channel=256):
+        super().__init__()
+        self.conv1_1 = nn.Conv2d(channel * 2, 128, 1)
+        self.bn1_1 = nn.BatchNorm2d(128)
+        self.conv1_2 = nn.Conv2d(128, 32, 1)
+        self.bn1_2 = nn.BatchNorm2d(32)
+        self.conv1_3 = nn.Conv2d(32, 8, 1)
+        self.bn1_3 = nn.BatchNorm2d(8)
+        self.conv1_4 = nn.Conv2d(8, 1, 1)
+
+    def forward(self, x, emulate=False):
+        x = cbr(x, self.conv1_1, self.bn1_1, emulate)
+        x = cbr(x, self.conv1_2, self.bn1_2, emulate)
+        x = cbr(x, self.conv1_3, self.bn1_3, emulate)
+        return F.relu(conv_linear(x, self.conv1_4, emulate))
+
+
+class DiscoNet(FusionBase):
+    """DiscoNet's pixel-wise weighted fusion WITHOUT the knowledge-distillation teacher (kd_flag = 0): every source map
+    (ego first, then the warped neighbours) gets a per-pixel scalar from PixelWeightedFusionSoftmax(cat(ego, source));
+    the fused map is the softmax-over-sources weighted sum.  exp() without max-subtraction, as upstream."""
+
+    def __init__(self, layer=3, in_channels=13, num_agent=5):
+        super().__init__(layer, in_channels, num_agent)
+        self.pixel_weighted_fusion = PixelWeightedFusionSoftmax(LAYER_SHAPES[layer][0])
+
+    def fusion(self, feats):
+        e = self.emulate_bf16
+        feats = [feats[0]] + [_q(f, e) for f in feats[1:]]          # the HIP path stores the warped maps in bf16
+        ws = [torch.exp(self.pixel_weighted_fusion(torch.cat([feats[0], f], 0).unsqueeze(0), e)[0, 0]) for f in feats]
+        total = sum(ws)
+        return _q(sum((w / total).unsqueeze(0) * f for w, f in zip(ws, feats)), e)
+
+
 # ----------------------------------------------------------------------------
 # when2com / who2com  (upstream When2com.py)
 # ----------------------------------------------------------------------------

@@ -84,9 +84,9 @@ def test_v2vnet(device, gnn_iter, source):
             check(got["loc"], ref["loc"], tol, "v2vnet loc emu=%s" % emu)
 
 
-@pytest.mark.parametrize("name", ["SumFusion", "MeanFusion", "MaxFusion", "CatFusion"])
+@pytest.mark.parametrize("name", ["SumFusion", "MeanFusion", "MaxFusion", "CatFusion", "DiscoNet"])
 def test_simple_fusion_baselines(device, name):
-    """Row f-4: sum / mean / max / cat intermediate fusion (one warp_fuse launch + CatFusion's two-source 1x1 conv),
+    """Row f-4: sum / mean / max / cat / DiscoNet (pixel-weighted) intermediate fusion (one warp_fuse launch + 1x1 convs),
     ragged batch (second frame has 4 real agents)."""
     from v2x_sim_amd.models import det
     A, B = 5, 2

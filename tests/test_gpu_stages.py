@@ -435,3 +435,20 @@ def test_voxelize_early_fusion_bit_exact(device):
     one = ops.voxelize_fused_bits(pts, cnt, eye, torch.tensor([2], dtype=torch.int32, device=device),
                                   torch.tensor([0], dtype=torch.int32, device=device), 1, grid)
     assert torch.equal(one[0], ops.voxelize_bits(pts, cnt, grid)[2])
+
+
+def test_pixel_weighted_fuse_vs_torch(device):
+    """f-4 / DiscoNet tail: per-pixel exp / normalise over the valid sources + weighted sum, vs torch fp32 (one bf16 ulp)."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(77)
+    n, A, H, W, C = 3, 5, 8, 16, 64
+    maps = bf16r(torch.randn(n, A, H, W, C, generator=g))
+    scores = torch.rand(n, A, H, W, 4, generator=g) * 3.0
+    valid = torch.ones(n, A)
+    valid[1, 4] = 0
+    valid[2, 2:] = 0
+    e = torch.exp(scores[..., 0]) * valid.view(n, A, 1, 1)
+    w = e / e.sum(1, keepdim=True)
+    ref = (w.unsqueeze(-1) * maps).sum(1)
+    out = ops.pixel_weighted_fuse(scores.to(device), valid.to(device), maps.to(torch.bfloat16).to(device))
+    assert torch.allclose(out.float().cpu(), bf16r(ref), atol=2e-3, rtol=2 ** -7)

@@ -24,7 +24,7 @@ import torch  # noqa: E402
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("-d", "--data", required=True, type=str, help="the {split} directory holding agent{k}/")
-    ap.add_argument("--com", default="v2v", choices=["lowerbound", "upperbound", "v2v", "when2com", "who2com", "sum", "mean", "max", "cat"])
+    ap.add_argument("--com", default="v2v", choices=["lowerbound", "upperbound", "v2v", "when2com", "who2com", "sum", "mean", "max", "cat", "disco"])
     ap.add_argument("--resume", default="", type=str, help="checkpoint with 'model_state_dict' (or a bare state_dict)")
     ap.add_argument("--num_agent", default=5, type=int)
     ap.add_argument("--rsu", default=1, type=int, help="1: agent0 (the RSU) takes part, 0: vehicles only")
@@ -43,7 +43,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     from v2x_sim_amd.configs import Config, ConfigGlobal
     from v2x_sim_amd.datasets import V2XSimDet, collate_dense
-    from v2x_sim_amd.models.det import CatFusion, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
+    from v2x_sim_amd.models.det import CatFusion, DiscoNet, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
     from v2x_sim_amd.utils import postprocess as P
     from v2x_sim_amd.utils.CoDetModule import FaFModule
     from v2x_sim_amd.utils.synthetic import init_synthetic_weights
@@ -60,8 +60,8 @@ def main(argv=None):
         model = FaFNet(config, layer=args.layer, kd_flag=0, num_agent=A)
     elif args.com == "v2v":
         model = V2VNet(config, gnn_iter_times=args.gnn_iter_times, layer=args.layer, layer_channel=256, num_agent=A)
-    elif args.com in ("sum", "mean", "max", "cat"):
-        model = {"sum": SumFusion, "mean": MeanFusion, "max": MaxFusion, "cat": CatFusion}[args.com](
+    elif args.com in ("sum", "mean", "max", "cat", "disco"):
+        model = {"sum": SumFusion, "mean": MeanFusion, "max": MaxFusion, "cat": CatFusion, "disco": DiscoNet}[args.com](
             config, layer=args.layer, kd_flag=0, num_agent=A)
     else:
         model = When2com(config, layer=args.layer, warp_flag=args.warp_flag, num_agent=A)

@@ -136,3 +136,64 @@ extern "C" int v2x_seg_argmax_confusion(const float *logits, const uint8_t *labe
     V2X_CHECK_LAUNCH("seg_argmax_confusion_kernel");
     return V2X_OK;
 }
+
+
+// ---- f-4 (DiscoNet): per-pixel softmax over the source agents + weighted sum of their warped maps -------
+// Replaces the tail of upstream coperception/models/det/DiscoNet.py::fusion: w_k = exp(s_k) / sum_j exp(s_j) per pixel
+// (s_k = the 1-channel output of PixelWeightedFusionSoftmax for source k, already ReLU'd), out = sum_k w_k * map_k.
+// scores fp32 [n_items][A][HW][score_stride] (channel 0 is read), valid fp32 [n_items][A] (0 = source absent),
+// maps bf16 [n_items][A][HW][C] -> out bf16 [n_items][HW][C].  One thread per (pixel, 8 channels); fp32 accumulation in
+// source-index order; exp without max-subtraction, exactly as upstream (scores are small non-negative numbers).
+__global__ __launch_bounds__(256) void pixel_weighted_fuse_kernel(const float *__restrict__ scores, int score_stride,
+                                                                  const float *__restrict__ valid,
+                                                                  const uint16_t *__restrict__ maps, int A, int HW, int C,
+                                                                  uint16_t *__restrict__ out) {
+    const int m = blockIdx.y;
+    const int cvecs = C >> 3;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < HW * cvecs; idx += gridDim.x * blockDim.x) {
+        const int pix = idx / cvecs, cv = idx - pix * cvecs;
+        float e[32];
+        float sum = 0.f;
+        for (int k = 0; k < A; ++k) {
+            const bool ok = valid[m * A + k] != 0.f;
+            e[k] = ok ? expf(scores[(((size_t)m * A + k) * HW + pix) * score_stride]) : 0.f;
+            sum += e[k];
+        }
+        float acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+        for (int k = 0; k < A; ++k) {
+            if (e[k] == 0.f) continue;
+            const float w = e[k] / sum;
+            const uint4 v = *reinterpret_cast<const uint4 *>(maps + (((size_t)m * A + k) * HW + pix) * C + cv * 8);
+            acc[0] += __uint_as_float(v.x << 16) * w;
+            acc[1] += __uint_as_float(v.x & 0xffff0000u) * w;
+            acc[2] += __uint_as_float(v.y << 16) * w;
+            acc[3] += __uint_as_float(v.y & 0xffff0000u) * w;
+            acc[4] += __uint_as_float(v.z << 16) * w;
+            acc[5] += __uint_as_float(v.z & 0xffff0000u) * w;
+            acc[6] += __uint_as_float(v.w << 16) * w;
+            acc[7] += __uint_as_float(v.w & 0xffff0000u) * w;
+        }
+        uint4 o;
+        o.x = pack_bf16x2(acc[0], acc[1]);
+        o.y = pack_bf16x2(acc[2], acc[3]);
+        o.z = pack_bf16x2(acc[4], acc[5]);
+        o.w = pack_bf16x2(acc[6], acc[7]);
+        *reinterpret_cast<uint4 *>(out + ((size_t)m * HW + pix) * C + cv * 8) = o;
+    }
+}
+
+extern "C" int v2x_pixel_weighted_fuse(const float *scores, int score_stride, const float *valid, const uint16_t *maps,
+                                       int n_items, int A, int H, int W, int C, uint16_t *out, v2x_stream_t stream) {
+    V2X_REQUIRE(scores && valid && maps && out, "v2x_pixel_weighted_fuse: null pointer");
+    V2X_REQUIRE(n_items >= 0 && n_items <= 65535 && A > 0 && A <= 32 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && score_stride > 0,
+                "v2x_pixel_weighted_fuse: bad dims (A <= 32, C %% 8 == 0)");
+    if (n_items == 0) return V2X_OK;
+    int gx = (H * W * (C / 8) + 255) / 256;
+    if (gx > 256) gx = 256;
+    hipLaunchKernelGGL(pixel_weighted_fuse_kernel, dim3(gx, n_items), dim3(256), 0, (hipStream_t)stream, scores, score_stride,
+                       valid, maps, A, H * W, C, out);
+    V2X_CHECK_LAUNCH("pixel_weighted_fuse_kernel");
+    return V2X_OK;
+}

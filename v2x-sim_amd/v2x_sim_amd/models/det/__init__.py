@@ -4,7 +4,7 @@ from .base import (ClassificationHead, DetModelBase, IntermediateModelBase, Lida
 from .FaFNet import FaFNet  # noqa: F401
 from .V2VNet import V2VNet  # noqa: F401
 from .When2com import When2com  # noqa: F401
-from .fusion import CatFusion, MaxFusion, MeanFusion, SumFusion  # noqa: F401
+from .fusion import CatFusion, DiscoNet, MaxFusion, MeanFusion, SumFusion  # noqa: F401
 
-__all__ = ["FaFNet", "V2VNet", "When2com", "SumFusion", "MeanFusion", "MaxFusion", "CatFusion", "LidarEncoder",
+__all__ = ["FaFNet", "V2VNet", "When2com", "SumFusion", "MeanFusion", "MaxFusion", "CatFusion", "DiscoNet", "LidarEncoder",
            "LidarDecoder", "DetModelBase"]

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from ... import ops, packing
 from ..._lib import V2X_FUSE_MAX, V2X_FUSE_MEAN, V2X_FUSE_WSUM
-from .base import IntermediateModelBase, LidarDecoder, LidarEncoder, _ParamsOnly
+from .base import IntermediateModelBase, LidarDecoder, LidarEncoder, _ParamsOnly  # noqa: F401
 
 
 class FusionBase(IntermediateModelBase):
@@ -98,3 +98,73 @@ class CatFusion(FusionBase):
 
     def post_fusion(self, ego, fused, pk):
         return ops.conv2d(pk["mod"], ego, fused)     # cat(ego, mean) never exists: two-source 1x1 conv
+
+
+class PixelWeightedFusionSoftmax(_ParamsOnly):
+    def __init__(self, channel=256):
+        super().__init__()
+        self.conv1_1 = nn.Conv2d(channel * 2, 128, 1)
+        self.bn1_1 = nn.BatchNorm2d(128)
+        self.conv1_2 = nn.Conv2d(128, 32, 1)
+        self.bn1_2 = nn.BatchNorm2d(32)
+        self.conv1_3 = nn.Conv2d(32, 8, 1)
+        self.bn1_3 = nn.BatchNorm2d(8)
+        self.conv1_4 = nn.Conv2d(8, 1, 1)
+
+
+class DiscoNet(FusionBase):
+    """DiscoNet's pixel-wise weighted fusion (upstream coperception/models/det/DiscoNet.py) without the distillation teacher
+    (kd_flag must be 0: the teacher / KD loss is out of scope).
+
+    MI355X mapping: one warp_fuse launch materialises every (ego, source) map (one-hot coefficients; the ego's own map is
+    copied unwarped), the four 1x1 convs run as implicit-GEMM layers over the (item x source) batch with the concat as the
+    two-source loader, and v2x_pixel_weighted_fuse does exp / normalise / weighted sum per pixel."""
+    FUSE_MODE = V2X_FUSE_WSUM
+
+    def __init__(self, config, layer=3, in_channels=13, kd_flag=0, num_agent=5, compress_level=0, only_v2i=False):
+        super().__init__(config, layer, in_channels, kd_flag, num_agent, compress_level, only_v2i)
+        self.pixel_weighted_fusion = PixelWeightedFusionSoftmax(self.fusion_shape()[0])
+
+    def _pack(self, device):
+        pk = super()._pack(device)
+        c = self.fusion_shape()[0]
+        m = self.pixel_weighted_fusion
+        w4 = torch.zeros((4, 8, 1, 1))                       # the 1-channel score padded to the kernel's 4-channel store quantum
+        w4[0] = m.conv1_4.weight.detach().float().cpu()[0]
+        b4 = torch.zeros(4)
+        b4[0] = float(m.conv1_4.bias.detach()[0])
+        pk["pw"] = [packing.pack_conv_bn("pixel_weighted_fusion.conv1_1", m.conv1_1, m.bn1_1, C0=c, C1=c, device=device),
+                    packing.pack_conv_bn("pixel_weighted_fusion.conv1_2", m.conv1_2, m.bn1_2, device=device),
+                    packing.pack_conv_bn("pixel_weighted_fusion.conv1_3", m.conv1_3, m.bn1_3, device=device),
+                    packing.pack_conv("pixel_weighted_fusion.conv1_4", w4, torch.ones(4), b4, stride=1, pad=0, relu=True,
+                                      epilogue=packing.V2X_EPI_F32, device=device)]
+        return pk
+
+    def make_plan(self, num_agent_tensor, batch_size, device):
+        plan = super().make_plan(num_agent_tensor, batch_size, device)
+        A = self.agent_num
+        n = plan["items"].shape[0]
+        # virtual items (m, k): the map of source k in the frame of ego item m  ->  one-hot coefficient rows
+        plan["items2"] = plan["items"].repeat_interleave(A, 0).contiguous()
+        valid = plan["coef"]                                               # (n, A): 1 for real agents
+        plan["coef2"] = (torch.eye(A, device=device).repeat(n, 1) * valid.repeat_interleave(A, 0)).contiguous()
+        plan["valid"] = valid.contiguous()
+        return plan
+
+    def fuse(self, feat, trans_matrices, plan, batch_size, pk):
+        A = self.agent_num
+        maps = ops.warp_fuse(feat, A, batch_size, trans_matrices.to(torch.float32).contiguous(), plan["items2"], plan["coef2"],
+                             V2X_FUSE_WSUM)                                 # (n*A, H, W, C): source k in ego m's frame
+        rows = plan["rows"]
+        ego = feat if rows is None else feat.index_select(0, rows)
+        x = ops.conv2d(pk["pw"][0], ego.repeat_interleave(A, 0).contiguous(), maps)
+        x = ops.conv2d(pk["pw"][1], x)
+        x = ops.conv2d(pk["pw"][2], x)
+        scores = ops.conv2d(pk["pw"][3], x)                                # (n*A, H, W, 4) fp32, channel 0 = the score
+        n, H, W, C = ego.shape
+        out = ops.pixel_weighted_fuse(scores.view(n, A, H, W, 4), plan["valid"], maps.view(n, A, H, W, C))
+        if rows is None:
+            return out
+        cur = feat.clone()
+        cur.index_copy_(0, rows, out)
+        return cur

@@ -347,6 +347,18 @@ def attn_handshake(keys, querys, w_lin, b_lin, A, Bt, mode, thres=0.2):
     return prob, coef
 
 
+# ------------------------------------------------------------------ f-4 (DiscoNet)
+def pixel_weighted_fuse(scores, valid, maps):
+    """scores (n, A, H, W, S) fp32 (channel 0 used), valid (n, A) fp32, maps (n, A, H, W, C) bf16 -> (n, H, W, C) bf16."""
+    lib = _lib.load()
+    n, A, H, W, Cc = maps.shape
+    out = torch.empty((n, H, W, Cc), dtype=torch.bfloat16, device=maps.device)
+    _lib.check(lib.v2x_pixel_weighted_fuse(_dev(scores, torch.float32, "scores"), scores.shape[-1],
+                                           _dev(valid, torch.float32, "valid"), _dev(maps, torch.bfloat16, "maps"), n, A, H, W,
+                                           Cc, _dev(out, torch.bfloat16, "out"), _stream()), "v2x_pixel_weighted_fuse")
+    return out
+
+
 # ------------------------------------------------------------------ f-1
 def det_postprocess(cls, loc, anchors, score_thr=0.7, nms_thr=0.01, cap=4096):
     """cls (n, M, 2) fp32, loc (n, ..., 6) fp32 with M anchors per map, anchors (M, 6) fp32 on the device ->
