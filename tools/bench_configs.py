@@ -94,6 +94,16 @@ def main():
     r2 = ShardedV2VNet(v2v, shard)
     plan2 = shard.fusion_plan(nat, dev)
     out["2 V2VNet (warp + ConvGRU, gnn_iter=1)"] = timed(lambda: r2.forward_points(pts, n_pts, trans, plan2))
+    # ... followed by the device-side post-processing (row f-1).  Random weights give no meaningful 0.7 threshold: the score
+    # threshold is set at the 99.9 % quantile (~390 candidates per map, a trained detector's order of magnitude)
+    from v2x_sim_amd.utils import postprocess as P
+    with torch.no_grad():
+        res = r2.forward_points(pts, n_pts, trans, plan2)
+    fg = torch.softmax(res["cls"][:8].float(), -1)[..., 1]
+    thr = float(torch.quantile(fg.flatten()[:4000000], 0.999))
+    anchors = torch.from_numpy(P.build_anchor_map(cfg).reshape(-1, 6)).to(dev)
+    out["2+ device post-processing alone (score, threshold, decode, NMS; %d maps)" % (A * B)] = timed(
+        lambda: ops.det_postprocess(res["cls"], res["loc"], anchors, thr, 0.01, 4096))
 
     # -- config 3: when2com (inference 'activated') and who2com ('argmax_test')
     w2c = init_synthetic_weights(When2com(cfg), seed=0).to(dev)
