@@ -95,6 +95,53 @@ def test_voxelize_edges_and_cross_road_extents(device):
     assert np.array_equal(ops.bits_to_dense(bits, 13)[0].cpu().numpy(), ref)
 
 
+def test_voxelize_lds_form_equals_atomic_form(device, monkeypatch):
+    """The LDS-binned kernel (default) and the global-atomic scatter kernel are bit-identical, for the packed float4
+    cloud, a stride-5 cloud (scalar loads), ragged counts incl. 0 and a grid that is too big for the LDS (fallback)."""
+    from v2x_sim_amd import ops
+    rng = np.random.default_rng(5)
+    sizes = (65536, 0, 1, 4097, 30000)
+    clouds = [VR.synthetic_points(n, seed=200 + i, n_edge=min(64, n // 4)) if n else np.zeros((0, 4), np.float32)
+              for i, n in enumerate(sizes)]
+    # adversarial cloud: every voxel boundary of every axis, and its two fp32 neighbours (strict bounds, floor of the
+    # fp64 quotient: where any arithmetic shortcut would show)
+    kx = np.arange(-130, 131)
+    bx = (kx * 0.25).astype(np.float32)
+    bz = (np.arange(-9, 7) * 0.4).astype(np.float32)
+    edge = []
+    for b, axis in ((bx, 0), (bx, 1), (bz, 2)):
+        for v in (b, np.nextafter(b, np.float32(np.inf)), np.nextafter(b, np.float32(-np.inf))):
+            e = np.zeros((v.size, 4), np.float32)
+            e[:, 0], e[:, 1], e[:, 2] = 0.1, -0.1, 0.1
+            e[:, axis] = v
+            edge.append(e)
+    clouds[2] = np.concatenate(edge)
+    sizes = tuple(c.shape[0] for c in clouds)
+    mp = max(sizes)
+    cnt = torch.tensor(sizes, dtype=torch.int32, device=device)
+    for stride in (4, 5):
+        buf = rng.uniform(-40, 40, (len(sizes), mp, stride)).astype(np.float32)   # garbage past n_pts must be ignored
+        for i, c in enumerate(clouds):
+            buf[i, :c.shape[0], :4] = c
+        pts = torch.from_numpy(buf).to(device)
+        grid = ops.VoxelGrid()
+        monkeypatch.setenv("V2X_VOXELIZE_LDS", "1")
+        lds = ops.voxelize_bits(pts, cnt, grid).clone()
+        monkeypatch.setenv("V2X_VOXELIZE_LDS", "0")
+        atm = ops.voxelize_bits(pts, cnt, grid).clone()
+        monkeypatch.delenv("V2X_VOXELIZE_LDS")
+        assert torch.equal(lds, atm)
+        dense = ops.bits_to_dense(lds, 13).cpu().numpy()
+        for i, c in enumerate(clouds):
+            assert np.array_equal(dense[i], VR.voxelize_occupy(c))
+    # 0.125 m voxels: 512 x 512 grid = 512 KiB of 16-bit words, does not fit the LDS -> atomic form, same spec
+    big = ops.VoxelGrid(voxel_size=(0.125, 0.125, 0.4))
+    pts = torch.from_numpy(np.stack([clouds[0]])).to(device)
+    b = ops.voxelize_bits(pts, cnt[:1], big)
+    ref = VR.voxelize_occupy(clouds[0], np.array([0.125, 0.125, 0.4]))
+    assert np.array_equal(ops.bits_to_dense(b, 13)[0].cpu().numpy(), ref)
+
+
 def test_dense_to_nhwc(device):
     from v2x_sim_amd import ops
     bev = (torch.rand(3, 32, 48, 13) < 0.1).float()

@@ -4,11 +4,11 @@
 // scatter of coperception/datasets/V2XSimDet.py::__getitem__ (code absent from
 // /root/reference; see include/v2x_amd.h).  The numpy lexsort+unique formulation is
 // replaced by an idempotent bit scatter: one uint32 word per BEV pixel, bit z = occupied.
-// 13 z-bins fit one word, so the whole 256x256x13 grid of one agent is 256 KiB and stays
-// L2-resident while 64k points scatter into it with atomicOr; duplicates collapse for
-// free and the result is order-independent (bit-exact, deterministic).  The dense
-// layouts the network / the reference API want are then produced by fully coalesced
-// expansion kernels (HBM-bound streaming writes).
+// 13 z-bins fit one word (16 bits in LDS), so the whole 256x256x13 grid of one agent is 128 KiB and is binned inside
+// ONE CU's LDS while its 64k points stream through (voxelize_lds_kernel); duplicates collapse for free and the result is
+// order-independent (bit-exact, deterministic).  Grids too large for the LDS scatter with device-scope atomicOr into
+// the L2-resident global grid instead (voxelize_scatter_kernel, same arithmetic).  The dense layouts the network / the
+// reference API want are then produced by fully coalesced expansion kernels (HBM-bound streaming writes).
 //
 // Numerics: strict  lo < p < hi  in fp64 on the promoted fp32
 // coordinate; idx = floor(fp64(p) / fp64(voxel)) - floor(lo / voxel).  IEEE fp64
@@ -43,6 +43,88 @@ __global__ __launch_bounds__(256) void voxelize_scatter_kernel(const float *__re
         if ((unsigned)ix >= (unsigned)vp.X || (unsigned)iy >= (unsigned)vp.Y || (unsigned)iz >= (unsigned)vp.Z)
             continue;
         atomicOr(&grid[(size_t)ix * vp.Y + iy], 1u << iz);
+    }
+}
+
+// LDS-binned form of the scatter (the default when the grid of one cloud fits the LDS): ONE workgroup per cloud keeps
+// the whole occupancy grid in LDS as 16-bit words (Z <= 16; 256 x 256 x 2 B = 128 KiB of the CU's 160 KiB), so every
+// atomic is a ds_or_b32 instead of a device-scope L2 atomic, and the grid leaves the CU exactly once, as linear 16-B
+// stores of the expanded 32-bit words -- no memset pass, no HBM read-modify-write.  Arithmetic per point is the scatter
+// kernel's, so the two forms are bit-identical (tests/test_gpu_stages.py runs both).  The loads are issued UNR deep
+// per thread before the fp64 work so that a single CU keeps ~64 KiB of the cloud in flight.
+constexpr int VOX_LDS_THREADS = 1024;
+constexpr int VOX_LDS_UNR = 4;
+
+__device__ __forceinline__ void vox_lds_point(bool valid, double x, double y, double z, const VoxParams &vp,
+                                              uint32_t *sgrid) {
+    const bool keep = valid && (vp.lo[0] < x) && (x < vp.hi[0]) && (vp.lo[1] < y) && (y < vp.hi[1]) &&
+                      (vp.lo[2] < z) && (z < vp.hi[2]);
+    if (!keep) return;
+    const int ix = (int)(floor(x / vp.vs[0]) - vp.mn[0]);
+    const int iy = (int)(floor(y / vp.vs[1]) - vp.mn[1]);
+    const int iz = (int)(floor(z / vp.vs[2]) - vp.mn[2]);
+    if ((unsigned)ix >= (unsigned)vp.X || (unsigned)iy >= (unsigned)vp.Y || (unsigned)iz >= (unsigned)vp.Z) return;
+    const int pix = ix * vp.Y + iy;
+    atomicOr(&sgrid[pix >> 1], (1u << iz) << ((pix & 1) * 16));
+}
+
+template <bool VEC4>
+__global__ __launch_bounds__(VOX_LDS_THREADS) void voxelize_lds_kernel(const float *__restrict__ pts,
+                                                                       const int32_t *__restrict__ n_pts, int max_pts,
+                                                                       int pt_stride, VoxParams vp,
+                                                                       uint32_t *__restrict__ bits) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sgrid[];   // [X*Y/2]: two 16-bit pixels per word
+    const int cloud = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n_words = (vp.X * vp.Y) >> 1;
+    for (int i = tid * 4; i < n_words; i += VOX_LDS_THREADS * 4) *reinterpret_cast<uint4 *>(&sgrid[i]) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int n = min(n_pts[cloud], max_pts);
+    const float *base = pts + (size_t)cloud * max_pts * pt_stride;
+    // software pipeline: the loads of batch k+1 are in flight while batch k goes through the index math.  Loads
+    // are unconditional (index clamped to the last point) so that the compiler keeps all UNR of them in flight; the
+    // validity predicate is applied to the scatter only.
+    float px[VOX_LDS_UNR], py[VOX_LDS_UNR], pz[VOX_LDS_UNR];
+    auto load_batch = [&](int i0, float *ox, float *oy, float *oz) {
+#pragma unroll
+        for (int u = 0; u < VOX_LDS_UNR; ++u) {
+            const int i = min(i0 + u * VOX_LDS_THREADS + tid, n - 1);
+            if (VEC4) {
+                const float4 p = reinterpret_cast<const float4 *>(base)[i];
+                ox[u] = p.x;
+                oy[u] = p.y;
+                oz[u] = p.z;
+            } else {
+                ox[u] = base[(size_t)i * pt_stride + 0];
+                oy[u] = base[(size_t)i * pt_stride + 1];
+                oz[u] = base[(size_t)i * pt_stride + 2];
+            }
+        }
+    };
+    constexpr int BATCH = VOX_LDS_THREADS * VOX_LDS_UNR;
+    if (n > 0) load_batch(0, px, py, pz);
+    for (int i0 = 0; i0 < n; i0 += BATCH) {
+        float nx[VOX_LDS_UNR], ny[VOX_LDS_UNR], nz[VOX_LDS_UNR];
+        const bool more = i0 + BATCH < n;   // workgroup-uniform
+        if (more) load_batch(i0 + BATCH, nx, ny, nz);
+#pragma unroll
+        for (int u = 0; u < VOX_LDS_UNR; ++u)
+            vox_lds_point(i0 + u * VOX_LDS_THREADS + tid < n, (double)px[u], (double)py[u], (double)pz[u], vp, sgrid);
+        if (more) {
+#pragma unroll
+            for (int u = 0; u < VOX_LDS_UNR; ++u) {
+                px[u] = nx[u];
+                py[u] = ny[u];
+                pz[u] = nz[u];
+            }
+        }
+    }
+    __syncthreads();
+    // expand 16 -> 32 bits on the way out: LDS words 2k, 2k+1 -> pixels 4k .. 4k+3 (one 16-B store)
+    uint32_t *grid = bits + (size_t)cloud * vp.X * vp.Y;
+    for (int k = tid; k < (n_words >> 1); k += VOX_LDS_THREADS) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(&sgrid[2 * k]);
+        *reinterpret_cast<uint4 *>(&grid[4 * k]) = make_uint4(w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16);
     }
 }
 
@@ -251,6 +333,26 @@ extern "C" int v2x_voxelize_bits(const float *pts, const int32_t *n_pts, int n_c
     vp.X = dims_xyz[0];
     vp.Y = dims_xyz[1];
     vp.Z = dims_xyz[2];
+    // LDS-binned form: the cloud's grid as 16-bit words must fit one CU's LDS (and split into 16-B pieces)
+    const size_t lds_bytes = (size_t)vp.X * vp.Y * 2;
+    const char *lds_env = getenv("V2X_VOXELIZE_LDS");   // read per call: tests toggle it to compare the two forms
+    const bool lds_off = lds_env && lds_env[0] == '0';
+    if (!lds_off && vp.Z <= 16 && lds_bytes <= 128 * 1024 && ((size_t)vp.X * vp.Y) % 8 == 0 && max_pts > 0 &&
+        (reinterpret_cast<uintptr_t>(bits) & 15) == 0) {
+        const bool vec4 = pt_stride == 4 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0;
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(voxelize_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(voxelize_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            attr_done = true;
+        }
+        if (vec4)
+            hipLaunchKernelGGL(voxelize_lds_kernel<true>, dim3(n_clouds), dim3(VOX_LDS_THREADS), lds_bytes, s, pts, n_pts, max_pts, pt_stride, vp, bits);
+        else
+            hipLaunchKernelGGL(voxelize_lds_kernel<false>, dim3(n_clouds), dim3(VOX_LDS_THREADS), lds_bytes, s, pts, n_pts, max_pts, pt_stride, vp, bits);
+        V2X_CHECK_LAUNCH("voxelize_lds_kernel");
+        return V2X_OK;
+    }
     if (hipMemsetAsync(bits, 0, (size_t)n_clouds * vp.X * vp.Y * sizeof(uint32_t), s) != hipSuccess) {
         v2x_set_error("v2x_voxelize_bits: memset failed");
         return V2X_EIO;

@@ -105,7 +105,9 @@ def voxelize_bits(points, n_pts, grid, out=None):
     X, Y, Z = grid.dims
     if out is None:
         out = torch.empty((n, X, Y), dtype=torch.int32, device=points.device)
-    prof = _Prof("voxelize_scatter_kernel", 0, points.numel() * 4 + 2 * out.numel() * 4)
+    lds = Z <= 16 and X * Y * 2 <= 128 * 1024 and (X * Y) % 8 == 0 and mp > 0 and os.environ.get("V2X_VOXELIZE_LDS", "1")[:1] != "0"
+    prof = (_Prof("voxelize_lds_kernel", 0, points.numel() * 4 + out.numel() * 4) if lds else
+            _Prof("voxelize_scatter_kernel", 0, points.numel() * 4 + 2 * out.numel() * 4))
     rc = lib.v2x_voxelize_bits(_dev(points, torch.float32, "points"), _dev(n_pts, torch.int32, "n_pts"), n, mp, st,
                                grid._ext, grid._vox, grid._dims, _dev(out, torch.int32, "bits"), _stream())
     prof.done()
