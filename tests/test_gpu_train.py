@@ -189,6 +189,33 @@ def test_when2com_trains_and_serves(device):
     assert res["cls"].shape[0] == 5 and torch.isfinite(res["cls"]).all() and 0.0 <= res["num_connect"] <= 4.0
 
 
+@pytest.mark.parametrize("com", ["max", "cat", "disco"])
+def test_fusion_baselines_train_and_serve(device, com):
+    """f-3 x f-4: the simple fusion baselines train through the same FaFModule.step (PyTorch-ROCm graph of
+    train/graph.py::simple_fuse / disco_fuse) and the trained parameters serve on the HIP path: the loss falls, and the
+    eval-mode logits of the training graph agree with the HIP forward on a fresh scene (same network, bf16 vs fp32)."""
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import CatFusion, DiscoNet, MaxFusion
+    from v2x_sim_amd.train import train_forward
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device, train_synthetic
+    cfg = Config("train")
+    model = init_for_training({"max": MaxFusion, "cat": CatFusion, "disco": DiscoNet}[com](cfg), seed=0)
+    hist = train_synthetic(model, cfg, 40, frames_per_step=1, lr=1e-3, seed=5, device=device)
+    first, last = np.mean([h[0] for h in hist[:5]]), np.mean([h[0] for h in hist[-5:]])
+    print("%s loss %.3f -> %.3f" % (com, first, last))
+    assert last < 0.7 * first
+    data = synthetic_batch_on_device(cfg, 1, 5, seed=77, device=device, with_targets=False)
+    model.eval()
+    with torch.no_grad():
+        hip = model(data["bev_seq"], data["trans_matrices"], data["num_agent"], batch_size=1)
+        ref = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], batch_size=1)
+    for k in ("cls", "loc"):
+        scale = float(ref[k].abs().max())
+        err = float((hip[k].float() - ref[k]).abs().max())
+        print("%s %s: max |hip - fp32 graph| = %.4f (scale %.2f)" % (com, k, err, scale))
+        assert err <= 0.02 * scale
+
+
 def test_seg_train_then_test_drivers(device, tmp_path, capsys):
     """BASELINE.json config 4 with the tools/seg driver pair: train V2VNetSeg on synthetic vehicle-footprint labels, save
     upstream's checkpoint format, evaluate on the HIP path (argmax + confusion matrix on the device): the vehicle class is

@@ -21,7 +21,7 @@ def _targets(n, X, Y, A, seed):
 
 def test_train_graph_equals_oracle_cpu():
     from v2x_sim_amd.configs import Config
-    from v2x_sim_amd.models.det import FaFNet, V2VNet, When2com
+    from v2x_sim_amd.models.det import CatFusion, DiscoNet, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
     from v2x_sim_amd.train import detection_loss, train_forward
     from v2x_sim_amd.utils.synthetic import init_synthetic_weights
     from v2x_sim_amd.utils.synthetic import synthetic_poses
@@ -36,7 +36,12 @@ def test_train_graph_equals_oracle_cpu():
     for name, pm, om, extra in (
             ("v2v", V2VNet(cfg, num_agent=A), R.V2VNet(num_agent=A), (T, nat)),
             ("lowerbound", FaFNet(cfg, num_agent=A), R.FaFNet(num_agent=A), ()),
-            ("when2com", When2com(cfg, num_agent=A, image_size=128), R.When2com(num_agent=A, image_size=128), (T, nat))):
+            ("when2com", When2com(cfg, num_agent=A, image_size=128), R.When2com(num_agent=A, image_size=128), (T, nat)),
+            ("sum", SumFusion(cfg, num_agent=A), R.SumFusion(num_agent=A), (T, nat)),
+            ("mean", MeanFusion(cfg, num_agent=A), R.MeanFusion(num_agent=A), (T, nat)),
+            ("max", MaxFusion(cfg, num_agent=A), R.MaxFusion(num_agent=A), (T, nat)),
+            ("cat", CatFusion(cfg, num_agent=A), R.CatFusion(num_agent=A), (T, nat)),
+            ("disco", DiscoNet(cfg, num_agent=A), R.DiscoNet(num_agent=A), (T, nat))):
         init_synthetic_weights(pm, seed=2)   # non-zero biases: keeps empty regions off the ReLU kink
         om.load_state_dict(pm.state_dict())
         for mode in ("train", "eval"):

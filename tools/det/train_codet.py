@@ -23,7 +23,7 @@ import torch  # noqa: E402
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("-d", "--data", default="synthetic", type=str)
-    ap.add_argument("--com", default="v2v", choices=["lowerbound", "upperbound", "v2v", "when2com"])
+    ap.add_argument("--com", default="v2v", choices=["lowerbound", "upperbound", "v2v", "when2com", "sum", "mean", "max", "cat", "disco"])
     ap.add_argument("--batch", default=2, type=int, help="frames per step")
     ap.add_argument("--nepoch", default=1, type=int)
     ap.add_argument("--steps", default=400, type=int, help="steps per epoch (synthetic data has no natural epoch)")
@@ -41,7 +41,7 @@ def build_parser():
 def main(argv=None):
     args = build_parser().parse_args(argv)
     from v2x_sim_amd.configs import Config
-    from v2x_sim_amd.models.det import FaFNet, V2VNet, When2com
+    from v2x_sim_amd.models.det import CatFusion, DiscoNet, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
     from v2x_sim_amd.train.loop import init_for_training, train_synthetic
     if not torch.cuda.is_available():
         raise SystemExit("train_codet.py needs the MI355X")
@@ -53,6 +53,9 @@ def main(argv=None):
         model = V2VNet(config, gnn_iter_times=args.gnn_iter_times, layer=args.layer, num_agent=A)
     elif args.com == "when2com":
         model = When2com(config, layer=args.layer, num_agent=A)
+    elif args.com in ("sum", "mean", "max", "cat", "disco"):
+        cls = {"sum": SumFusion, "mean": MeanFusion, "max": MaxFusion, "cat": CatFusion, "disco": DiscoNet}[args.com]
+        model = cls(config, layer=args.layer, kd_flag=0, num_agent=A)      # DiscoNet without the distillation teacher
     else:
         model = FaFNet(config, layer=args.layer, kd_flag=0, num_agent=A)
     if args.resume:

@@ -6,7 +6,7 @@ the same graph written with torch ops on the MI355X (MIOpen convolutions, autogr
 the nn.Conv2d / nn.BatchNorm2d containers that models/det/base.py holds under the upstream names -- so an optimizer
 steps the very tensors the HIP engine packs (DetModelBase.packed() notices the version bump and re-packs).
 
-Graph = upstream Backbone.py / DetModelBase.py / V2VNet.py / When2com.py semantics (PyTorch 1.8 per README.md:88-95): nearest x2
+Graph = upstream Backbone.py / DetModelBase.py / V2VNet.py / When2com.py / {Sum,Mean,Max,Cat}Fusion.py / DiscoNet.py semantics (PyTorch 1.8 per README.md:88-95): nearest x2
 upsample, concat (up, skip), two-step affine_grid/grid_sample warp with align_corners=False, ConvGRU step with h0 = 0.
 It is NOT a fallback for inference: models refuse to run forward() off the GPU library, and this graph is only
 reached through FaFModule.step() / train_forward().
@@ -17,6 +17,18 @@ import torch.nn.functional as F
 
 def _cbr(x, conv, bn):
     return F.relu(bn(conv(x)))
+
+
+def _cbr_each(x, conv, bn, order=None):
+    """conv + BN + ReLU where upstream calls the layer once per map (batch of 1) inside its per-ego loop: with batch
+    statistics on, each map is normalised by ITS OWN statistics and the running averages take one update per map, in order."""
+    y = conv(x)
+    if not bn.training:
+        return F.relu(bn(y))
+    out = [None] * y.shape[0]
+    for i in (order if order is not None else range(y.shape[0])):   # upstream's call order: the running averages depend on it
+        out[i] = bn(y[i:i + 1])
+    return F.relu(torch.cat(out, 0))
 
 
 def _conv3d_1x1(x, m):
@@ -140,6 +152,71 @@ def when2com_fuse(model, x, feat, trans, num_agent_tensor, B, training=True, inf
     return fused, prob, coef
 
 
+def _ego_views(model, feat, trans, num_agent_tensor, B):
+    """For the simple fusion baselines: every (ego item m, source k) map in the ego's frame (the ego's own map unwarped).
+    -> val (n_pairs, C, H, W), dst (n_pairs,) item index, own (n_pairs,) bool 'k is the ego', items, rows, counts,
+    pairs [(item, source row, frame, ego agent, source agent)]."""
+    A = model.agent_num
+    counts, items, rows = model.frame_plan(num_agent_tensor, B, A)
+    dev = feat.device
+    pairs = [(m, k * B + f, f, q, k) for m, (q, f) in enumerate(items) for k in range(counts[f])]
+    src = torch.tensor([p[1] for p in pairs], device=dev)
+    dst = torch.tensor([p[0] for p in pairs], device=dev)
+    Tp = torch.stack([trans[f, q, k] for (_, _, f, q, k) in pairs]).to(feat.dtype)
+    own = torch.tensor([q == k for (_, _, _, q, k) in pairs], device=dev)
+    maps = feat.index_select(0, src)
+    o = own.to(feat.dtype).view(-1, 1, 1, 1)
+    val = o * maps + (1.0 - o) * warp_batch(maps, Tp)
+    return val, dst, own, items, rows, counts, pairs
+
+
+def simple_fuse(model, feat, trans, num_agent_tensor, B):
+    """Sum / Mean / Max / Cat fusion (upstream {Sum,Mean,Max,Cat}Fusion.py on FusionBase.py): reduce [ego map, warped
+    neighbour maps] per ego; CatFusion = ModulationLayer3(cat(ego, mean))."""
+    from .._lib import V2X_FUSE_MAX, V2X_FUSE_MEAN, V2X_FUSE_WSUM
+    val, dst, own, items, rows, counts, _ = _ego_views(model, feat, trans, num_agent_tensor, B)
+    n = len(items)
+    shape = (n,) + tuple(feat.shape[1:])
+    mode = model.FUSE_MODE
+    if mode == V2X_FUSE_MAX:
+        fused = torch.full(shape, float("-inf"), device=feat.device, dtype=feat.dtype).index_reduce(
+            0, dst, val, "amax", include_self=True)
+    else:
+        fused = torch.zeros(shape, device=feat.device, dtype=feat.dtype).index_add(0, dst, val)
+        if mode == V2X_FUSE_MEAN:
+            cnt = torch.tensor([counts[f] for (_, f) in items], device=feat.device, dtype=feat.dtype).view(-1, 1, 1, 1)
+            fused = fused / cnt
+        elif mode != V2X_FUSE_WSUM:
+            raise ValueError("unknown fusion mode")
+    rows_t = torch.tensor(rows, device=feat.device)
+    if hasattr(model, "modulation_layer_3"):
+        m = model.modulation_layer_3
+        order = sorted(range(n), key=lambda i: (items[i][1], items[i][0]))          # upstream loops frames, then egos
+        fused = _cbr_each(torch.cat([feat.index_select(0, rows_t), fused], 1), m.conv1_1, m.bn1_1, order)
+    return feat.index_copy(0, rows_t, fused)
+
+
+def disco_fuse(model, feat, trans, num_agent_tensor, B):
+    """DiscoNet's pixel-wise weighted fusion (upstream DiscoNet.py, no teacher): score = PixelWeightedFusionSoftmax(
+    cat(ego, source)) per source, weights = exp(score) normalised over the ego's sources (no max-subtraction, as
+    upstream), fused = sum of weight * source map."""
+    val, dst, own, items, rows, counts, pairs = _ego_views(model, feat, trans, num_agent_tensor, B)
+    # upstream: frames, then egos, then [ego itself, neighbours in agent order]
+    order = sorted(range(len(pairs)), key=lambda i: (pairs[i][2], pairs[i][3], pairs[i][3] != pairs[i][4], pairs[i][4]))
+    rows_t = torch.tensor(rows, device=feat.device)
+    ego = feat.index_select(0, rows_t).index_select(0, dst)
+    m = model.pixel_weighted_fusion
+    x = _cbr_each(torch.cat([ego, val], 1), m.conv1_1, m.bn1_1, order)   # upstream scores one (ego, source) pair per call
+    x = _cbr_each(x, m.conv1_2, m.bn1_2, order)
+    x = _cbr_each(x, m.conv1_3, m.bn1_3, order)
+    w = torch.exp(F.relu(m.conv1_4(x)))                                      # (n_pairs, 1, H, W)
+    n = len(items)
+    total = torch.zeros((n, 1) + tuple(w.shape[2:]), device=feat.device, dtype=feat.dtype).index_add(0, dst, w)
+    fused = torch.zeros((n,) + tuple(feat.shape[1:]), device=feat.device, dtype=feat.dtype).index_add(
+        0, dst, (w / total.index_select(0, dst)) * val)
+    return feat.index_copy(0, rows_t, fused)
+
+
 def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
     """bevs (A*B, 1, X, Y, Z) dense occupancy (the Dataset format) -> {'loc', 'cls'} with the shapes of the HIP path.
     Uses batch-statistics BN when model.training, running statistics otherwise."""
@@ -166,4 +243,9 @@ def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch
         res = heads(model, decoder(model.decoder, *feats))
         res["prob_action"], res["coef"] = prob, coef
         return res
-    raise NotImplementedError("training graph exists for FaFNet, V2VNet and When2com")
+    if hasattr(model, "FUSE_MODE"):                 # Sum / Mean / Max / Cat fusion, DiscoNet (no teacher)
+        feats = encoder(model.u_encoder, x)
+        fuse = disco_fuse if hasattr(model, "pixel_weighted_fusion") else simple_fuse
+        feats[model.layer] = fuse(model, feats[model.layer], trans_matrices.to(x.device), num_agent_tensor, batch_size)
+        return heads(model, decoder(model.decoder, *feats))
+    raise NotImplementedError("training graph exists for FaFNet, V2VNet, When2com and the FusionBase family")
