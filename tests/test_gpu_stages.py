@@ -355,6 +355,58 @@ def test_warp_fuse_vs_oracle(device, mode):
     assert torch.allclose(got, bf16r(ref), atol=4e-3, rtol=2 ** -7), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_warp_fuse_lds_form_bitwise_and_oracle(device, mode, monkeypatch):
+    """C = 256 (the fusion layer of the benchmark config) takes the LDS-staged kernel: bit-identical to the direct kernel
+    and within the usual tolerance of the oracle -- incl. poses that leave the map, sub-pixel and exactly-integer-pixel
+    translations (the window-origin rounding corner) and pure rotations."""
+    import math
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.utils.synthetic import synthetic_poses
+    A, Bt, C, H, W = 5, 3, 256, 32, 32
+    g = torch.Generator().manual_seed(31 + mode)
+    feat = bf16r(torch.randn(A * Bt, C, H, W, generator=g))
+    T = torch.from_numpy(synthetic_poses(Bt, A, seed=6))
+    # frame 1: hand-made poses.  translation of k pixels = k * 2 (the warp shifts by 4*T/128 in normalised units = T/2 px)
+    eye = torch.eye(4)
+    def pose(yaw, tx, ty):
+        M = eye.clone()
+        M[0, 0], M[0, 1], M[1, 0], M[1, 1] = math.cos(yaw), -math.sin(yaw), math.sin(yaw), math.cos(yaw)
+        M[0, 3], M[1, 3] = tx, ty
+        return M
+    special = [pose(0.0, 2.0, -4.0), pose(0.0, 1e-3, -1e-3), pose(0.7, 0.0, 0.0), pose(0.0, 80.0, 3.0), pose(3.1, -31.0, 62.0),
+               pose(0.0, 6.0, 6.0), pose(-1.2, 15.9999, -16.0001)]
+    k = 0
+    for i in range(A):
+        for j in range(A):
+            if i != j:
+                T[1, i, j] = special[k % len(special)]
+                k += 1
+    items = [(a, f) for a in range(A) for f in range(Bt)]
+    if mode == 2:
+        coef = torch.ones(len(items), A)
+        coef[3, 4] = 0
+    elif mode == 1:
+        coef = torch.ones(len(items), A)
+        for m, (a, f) in enumerate(items):
+            coef[m, a] = 0
+        coef[3, 4] = 0
+    else:
+        coef = torch.rand(len(items), A, generator=g)
+        coef[coef < 0.3] = 0
+    x = to_nhwc_bf16(feat, device)
+    it = torch.tensor(items, dtype=torch.int32, device=device)
+    monkeypatch.setenv("V2X_WARP_LDS", "1")
+    lds = ops.warp_fuse(x, A, Bt, T.to(device), it, coef.to(device), mode).clone()
+    monkeypatch.setenv("V2X_WARP_LDS", "0")
+    direct = ops.warp_fuse(x, A, Bt, T.to(device), it, coef.to(device), mode).clone()
+    monkeypatch.delenv("V2X_WARP_LDS")
+    assert torch.equal(lds.view(torch.int16), direct.view(torch.int16))
+    ref = _warp_ref(feat, T, items, coef, A, Bt, mode)
+    got = from_nhwc(lds)
+    assert torch.allclose(got, bf16r(ref), atol=4e-3, rtol=2 ** -7), float((got - ref).abs().max())
+
+
 # ------------------------------------------------------------------------------------- a5
 def test_attention_golden(device):
     from v2x_sim_amd import ops

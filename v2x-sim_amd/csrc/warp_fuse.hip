@@ -43,31 +43,15 @@ __device__ __forceinline__ Bilin bilin_setup(float gx, float gy, int W, int H) {
 }
 
 __device__ __forceinline__ void fma8(float (&acc)[8], const uint4 v, float w) {
-    acc[0] += __uint_as_float(v.x << 16) * w;
-    acc[1] += __uint_as_float(v.x & 0xffff0000u) * w;
-    acc[2] += __uint_as_float(v.y << 16) * w;
-    acc[3] += __uint_as_float(v.y & 0xffff0000u) * w;
-    acc[4] += __uint_as_float(v.z << 16) * w;
-    acc[5] += __uint_as_float(v.z & 0xffff0000u) * w;
-    acc[6] += __uint_as_float(v.w << 16) * w;
-    acc[7] += __uint_as_float(v.w & 0xffff0000u) * w;
-}
-
-// value of the ROTATED image of `src` at integer pixel (qx, qy), 8 channels
-__device__ __forceinline__ void rot_sample(const uint16_t *__restrict__ src, int H, int W, int C, int cvec, int qx,
-                                           int qy, float r00, float r01, float r10, float r11, float (&out)[8]) {
-    const float xq = (float)(2 * qx + 1) / (float)W - 1.0f;
-    const float yq = (float)(2 * qy + 1) / (float)H - 1.0f;
-    const Bilin b = bilin_setup(__fmaf_rn(r00, xq, __fmul_rn(r01, yq)), __fmaf_rn(r10, xq, __fmul_rn(r11, yq)), W, H);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) out[e] = 0.f;
-    const bool xl = (unsigned)b.x0 < (unsigned)W, xr = (unsigned)(b.x0 + 1) < (unsigned)W;
-    const bool yt = (unsigned)b.y0 < (unsigned)H, yb = (unsigned)(b.y0 + 1) < (unsigned)H;
-    const uint16_t *base = src + (((long long)b.y0 * W + b.x0) * C + cvec * 8);  // only dereferenced in-bounds
-    if (yt && xl) fma8(out, *reinterpret_cast<const uint4 *>(base), b.nw);
-    if (yt && xr) fma8(out, *reinterpret_cast<const uint4 *>(base + C), b.ne);
-    if (yb && xl) fma8(out, *reinterpret_cast<const uint4 *>(base + (long long)W * C), b.sw);
-    if (yb && xr) fma8(out, *reinterpret_cast<const uint4 *>(base + (long long)W * C + C), b.se);
+    // explicit fma: every kernel form must round identically (see bilin_setup)
+    acc[0] = __fmaf_rn(__uint_as_float(v.x << 16), w, acc[0]);
+    acc[1] = __fmaf_rn(__uint_as_float(v.x & 0xffff0000u), w, acc[1]);
+    acc[2] = __fmaf_rn(__uint_as_float(v.y << 16), w, acc[2]);
+    acc[3] = __fmaf_rn(__uint_as_float(v.y & 0xffff0000u), w, acc[3]);
+    acc[4] = __fmaf_rn(__uint_as_float(v.z << 16), w, acc[4]);
+    acc[5] = __fmaf_rn(__uint_as_float(v.z & 0xffff0000u), w, acc[5]);
+    acc[6] = __fmaf_rn(__uint_as_float(v.w << 16), w, acc[6]);
+    acc[7] = __fmaf_rn(__uint_as_float(v.w & 0xffff0000u), w, acc[7]);
 }
 
 // The coordinate work of a tap (rotation, two bilinear set-ups, clamps, address) is the same for every channel of a pixel;
@@ -77,7 +61,8 @@ __device__ __forceinline__ void rot_sample(const uint16_t *__restrict__ src, int
 // contiguous C*2-byte run.  Measured at 160 output maps: CV=1 336 us, CV=2 257 us, CV=4 290 us (166 VGPRs) per launch.
 template <int CV>
 __device__ __forceinline__ void rot_sample_cv(const uint16_t *__restrict__ src, int H, int W, int C, int c0, int qx, int qy,
-                                              float r00, float r01, float r10, float r11, float (&out)[CV][8]) {
+                                              float r00, float r01, float r10, float r11, float (&out)[CV][8],
+                                              int vstride = 8) {
     const float xq = (float)(2 * qx + 1) / (float)W - 1.0f;
     const float yq = (float)(2 * qy + 1) / (float)H - 1.0f;
     const Bilin b = bilin_setup(__fmaf_rn(r00, xq, __fmul_rn(r01, yq)), __fmaf_rn(r10, xq, __fmul_rn(r11, yq)), W, H);
@@ -87,23 +72,27 @@ __device__ __forceinline__ void rot_sample_cv(const uint16_t *__restrict__ src, 
         for (int e = 0; e < 8; ++e) out[v][e] = 0.f;
     const bool xl = (unsigned)b.x0 < (unsigned)W, xr = (unsigned)(b.x0 + 1) < (unsigned)W;
     const bool yt = (unsigned)b.y0 < (unsigned)H, yb = (unsigned)(b.y0 + 1) < (unsigned)H;
-    const uint16_t *base = src + (((long long)b.y0 * W + b.x0) * C + c0);  // only dereferenced in-bounds
-    if (yt && xl) {
+    if (!((xl || xr) && (yt || yb))) return;   // the whole footprint is zero padding
+    // All four taps are loaded unconditionally from CLAMPED coordinates and a tap that is zero padding gets weight 0: a
+    // load under its own branch is followed by a full s_waitcnt (16 serialised L2 round trips per output and neighbour --
+    // the kernel sat at 54 % wave-wait), here the 4*CV loads of a sample are in flight together.  fma(x, 0, acc) == acc
+    // exactly for the finite x of a real map (acc is never -0), so the result is unchanged.
+    const int cx0 = min(max(b.x0, 0), W - 1), cx1 = min(max(b.x0 + 1, 0), W - 1);
+    const int cy0 = min(max(b.y0, 0), H - 1), cy1 = min(max(b.y0 + 1, 0), H - 1);
+    const uint16_t *row0 = src + ((size_t)cy0 * W) * C + c0, *row1 = src + ((size_t)cy1 * W) * C + c0;
+    uint4 t[4][CV];
 #pragma unroll
-        for (int v = 0; v < CV; ++v) fma8(out[v], *reinterpret_cast<const uint4 *>(base + v * 8), b.nw);
+    for (int v = 0; v < CV; ++v) {
+        t[0][v] = *reinterpret_cast<const uint4 *>(row0 + (size_t)cx0 * C + v * vstride);
+        t[1][v] = *reinterpret_cast<const uint4 *>(row0 + (size_t)cx1 * C + v * vstride);
+        t[2][v] = *reinterpret_cast<const uint4 *>(row1 + (size_t)cx0 * C + v * vstride);
+        t[3][v] = *reinterpret_cast<const uint4 *>(row1 + (size_t)cx1 * C + v * vstride);
     }
-    if (yt && xr) {
+    const float wt[4] = {(yt && xl) ? b.nw : 0.f, (yt && xr) ? b.ne : 0.f, (yb && xl) ? b.sw : 0.f, (yb && xr) ? b.se : 0.f};
 #pragma unroll
-        for (int v = 0; v < CV; ++v) fma8(out[v], *reinterpret_cast<const uint4 *>(base + C + v * 8), b.ne);
-    }
-    if (yb && xl) {
+    for (int k = 0; k < 4; ++k)
 #pragma unroll
-        for (int v = 0; v < CV; ++v) fma8(out[v], *reinterpret_cast<const uint4 *>(base + (long long)W * C + v * 8), b.sw);
-    }
-    if (yb && xr) {
-#pragma unroll
-        for (int v = 0; v < CV; ++v) fma8(out[v], *reinterpret_cast<const uint4 *>(base + (long long)W * C + C + v * 8), b.se);
-    }
+        for (int v = 0; v < CV; ++v) fma8(out[v], t[k][v], wt[k]);
 }
 
 template <int CV>
@@ -168,7 +157,7 @@ __global__ __launch_bounds__(256) void warp_fuse_kernel(const uint16_t *__restri
     if (COND) {                                                                     \
         rot_sample_cv<CV>(src, H, W, C, c0, QX, QY, r00, r01, r10, r11, r);         \
         _Pragma("unroll") for (int v = 0; v < CV; ++v)                              \
-            _Pragma("unroll") for (int e = 0; e < 8; ++e) vv[v][e] += r[v][e] * WT; \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) vv[v][e] = __fmaf_rn(r[v][e], WT, vv[v][e]); \
     }
             V2X_TAP(yt && xl, b.x0, b.y0, b.nw)
             V2X_TAP(yt && xr, b.x0 + 1, b.y0, b.ne)
@@ -180,7 +169,7 @@ __global__ __launch_bounds__(256) void warp_fuse_kernel(const uint16_t *__restri
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (mode == V2X_FUSE_MAX) acc[v][e] = (count == 1) ? vv[v][e] : fmaxf(acc[v][e], vv[v][e]);
-                    else acc[v][e] += vv[v][e] * wj;
+                    else acc[v][e] = __fmaf_rn(vv[v][e], wj, acc[v][e]);
                 }
         }
 #pragma unroll
@@ -200,6 +189,164 @@ __global__ __launch_bounds__(256) void warp_fuse_kernel(const uint16_t *__restri
     }
 }
 
+// ---- LDS-staged form -----------------------------------------------------------------------------------------------
+// The translate step's 4 taps of neighbouring output pixels overlap: an 8x8 output tile touches only a ~9x9 window of
+// the ROTATED image (the translation is a constant shift), so the direct form above evaluates every rotated sample ~3x.
+// Here a workgroup owns one 8x8 tile x 128 channels of one output map and, per neighbour,
+//   phase 1: evaluates the rotated image on the 9x9 window anchored at the tap origin of the tile's first pixel (same
+//            rot_sample_cv arithmetic, fp32) and parks it in LDS (81 positions x 128 ch x 4 B, padded: 51 KiB, 3 WG/CU);
+//   phase 2: every output pixel combines its 4 window entries with the translate weights, in the reference tap order.
+// A tap that falls outside the window (possible only through float rounding of the tap origin) is evaluated directly,
+// so the result is BIT-IDENTICAL to the direct form (tests/test_gpu_stages.py compares them); 324 instead of 1024
+// gathered rotated taps per tile and channel vector.
+constexpr int WL_T = 8;            // tile edge
+constexpr int WL_R = WL_T + 1;     // window edge
+constexpr int WL_CW = 128;         // channels per workgroup
+constexpr int WL_G = WL_CW / 16;   // items per position (an item = 2 channel vectors: g and g + WL_G)
+constexpr int WL_POS4 = 4 * WL_G + 8;   // float4 stride of a window position (+8: adjacent positions land on the other 32 banks)
+
+__global__ __launch_bounds__(256) void warp_fuse_lds_kernel(const uint16_t *__restrict__ feat, int A, int Bt, int H, int W,
+                                                            int C, const float *__restrict__ trans,
+                                                            const int32_t *__restrict__ items,
+                                                            const float *__restrict__ coef, int mode,
+                                                            uint16_t *__restrict__ out) {
+    __shared__ float4 win[WL_R * WL_R * WL_POS4];
+    const int m = blockIdx.y;
+    const int ego = items[2 * m + 0];
+    const int f = items[2 * m + 1];
+    const int tiles_x = W / WL_T;
+    const int tile = blockIdx.x;
+    const int h0 = (tile / tiles_x) * WL_T, w0 = (tile % tiles_x) * WL_T;
+    const int cb = blockIdx.z * WL_CW;
+    const int tid = threadIdx.x;
+    const size_t map_elems = (size_t)H * W * C;
+    // phase-2 items of this thread: i = tid + 256 * s, pixel = i / WL_G, g = i % WL_G
+    constexpr int NI = WL_T * WL_T * WL_G / 256;
+    float acc[NI][2][8];
+#pragma unroll
+    for (int s = 0; s < NI; ++s)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[s][v][e] = 0.f;
+    int count = 0;
+    for (int j = 0; j < A; ++j) {
+        const float cj = coef[m * A + j];
+        if (cj == 0.0f) continue;  // block-uniform
+        const uint16_t *src = feat + ((size_t)j * Bt + f) * map_elems;
+        ++count;
+        const float wj = (mode == V2X_FUSE_MEAN) ? 1.0f : cj;
+        if (j == ego) {
+#pragma unroll
+            for (int s = 0; s < NI; ++s) {
+                const int i = tid + 256 * s;
+                const int pixel = i / WL_G, g = i % WL_G;
+                const int pix = (h0 + pixel / WL_T) * W + w0 + pixel % WL_T;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(src + (size_t)pix * C + cb + (g + v * WL_G) * 8);
+                    if (mode == V2X_FUSE_MAX) {
+                        float ev[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ev[e] = 0.f;
+                        fma8(ev, raw, 1.0f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[s][v][e] = (count == 1) ? ev[e] : fmaxf(acc[s][v][e], ev[e]);
+                    } else {
+                        fma8(acc[s][v], raw, wj);
+                    }
+                }
+            }
+            continue;
+        }
+        const float *T = trans + (((size_t)f * A + ego) * A + j) * 16;
+        const float r00 = T[0], r01 = T[1], r10 = T[4], r11 = T[5];
+        const float tx = (4.0f * T[3]) / 128.0f;
+        const float ty = -((4.0f * T[7]) / 128.0f);
+        // window origin = tap origin of the tile's first pixel (workgroup-uniform)
+        const Bilin b0 = bilin_setup(((float)(2 * w0 + 1) / (float)W - 1.0f) + tx, ((float)(2 * h0 + 1) / (float)H - 1.0f) + ty, W, H);
+        const int qx_lo = b0.x0, qy_lo = b0.y0;
+        __syncthreads();   // the previous neighbour's phase 2 is done with the window
+        for (int i = tid; i < WL_R * WL_R * WL_G; i += 256) {
+            const int pos = i / WL_G, g = i % WL_G;
+            const int qx = qx_lo + pos % WL_R, qy = qy_lo + pos / WL_R;
+            if ((unsigned)qx >= (unsigned)W || (unsigned)qy >= (unsigned)H) continue;   // never read: the tap is zero padding
+            float r[2][8];
+            rot_sample_cv<2>(src, H, W, C, cb + g * 8, qx, qy, r00, r01, r10, r11, r, WL_G * 8);
+            float4 *dst = win + pos * WL_POS4 + g;
+            dst[0 * WL_G] = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
+            dst[1 * WL_G] = make_float4(r[0][4], r[0][5], r[0][6], r[0][7]);
+            dst[2 * WL_G] = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+            dst[3 * WL_G] = make_float4(r[1][4], r[1][5], r[1][6], r[1][7]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NI; ++s) {
+            const int i = tid + 256 * s;
+            const int pixel = i / WL_G, g = i % WL_G;
+            const int h = h0 + pixel / WL_T, w = w0 + pixel % WL_T;
+            const float x = (float)(2 * w + 1) / (float)W - 1.0f;
+            const float y = (float)(2 * h + 1) / (float)H - 1.0f;
+            const Bilin b = bilin_setup(x + tx, y + ty, W, H);
+            float vv[2][8], r[2][8];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[v][e] = 0.f;
+            const bool xl = (unsigned)b.x0 < (unsigned)W, xr = (unsigned)(b.x0 + 1) < (unsigned)W;
+            const bool yt = (unsigned)b.y0 < (unsigned)H, yb = (unsigned)(b.y0 + 1) < (unsigned)H;
+#define V2X_TAP(COND, QX, QY, WT)                                                                                 \
+    if (COND) {                                                                                                   \
+        const int dx = (QX)-qx_lo, dy = (QY)-qy_lo;                                                               \
+        if ((unsigned)dx < (unsigned)WL_R && (unsigned)dy < (unsigned)WL_R) {                                     \
+            const float4 *p = win + (dy * WL_R + dx) * WL_POS4 + g;                                               \
+            const float4 a0 = p[0], a1 = p[WL_G], a2 = p[2 * WL_G], a3 = p[3 * WL_G];                             \
+            r[0][0] = a0.x; r[0][1] = a0.y; r[0][2] = a0.z; r[0][3] = a0.w;                                       \
+            r[0][4] = a1.x; r[0][5] = a1.y; r[0][6] = a1.z; r[0][7] = a1.w;                                       \
+            r[1][0] = a2.x; r[1][1] = a2.y; r[1][2] = a2.z; r[1][3] = a2.w;                                       \
+            r[1][4] = a3.x; r[1][5] = a3.y; r[1][6] = a3.z; r[1][7] = a3.w;                                       \
+        } else {                                                                                                  \
+            rot_sample_cv<2>(src, H, W, C, cb + g * 8, QX, QY, r00, r01, r10, r11, r, WL_G * 8);                  \
+        }                                                                                                         \
+        _Pragma("unroll") for (int v = 0; v < 2; ++v)                                                             \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) vv[v][e] = __fmaf_rn(r[v][e], WT, vv[v][e]);                               \
+    }
+            V2X_TAP(yt && xl, b.x0, b.y0, b.nw)
+            V2X_TAP(yt && xr, b.x0 + 1, b.y0, b.ne)
+            V2X_TAP(yb && xl, b.x0, b.y0 + 1, b.sw)
+            V2X_TAP(yb && xr, b.x0 + 1, b.y0 + 1, b.se)
+#undef V2X_TAP
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (mode == V2X_FUSE_MAX) acc[s][v][e] = (count == 1) ? vv[v][e] : fmaxf(acc[s][v][e], vv[v][e]);
+                    else acc[s][v][e] = __fmaf_rn(vv[v][e], wj, acc[s][v][e]);
+                }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+        const int i = tid + 256 * s;
+        const int pixel = i / WL_G, g = i % WL_G;
+        const int pix = (h0 + pixel / WL_T) * W + w0 + pixel % WL_T;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            if (mode == V2X_FUSE_MEAN && count > 0) {
+                const float d = (float)count;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[s][v][e] = acc[s][v][e] / d;
+            }
+            uint4 o;
+            o.x = pack_bf16x2(acc[s][v][0], acc[s][v][1]);
+            o.y = pack_bf16x2(acc[s][v][2], acc[s][v][3]);
+            o.z = pack_bf16x2(acc[s][v][4], acc[s][v][5]);
+            o.w = pack_bf16x2(acc[s][v][6], acc[s][v][7]);
+            *reinterpret_cast<uint4 *>(out + (size_t)m * map_elems + (size_t)pix * C + cb + (g + v * WL_G) * 8) = o;
+        }
+    }
+}
+
 extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
                              const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
                              v2x_stream_t stream) {
@@ -209,6 +356,13 @@ extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, 
     V2X_REQUIRE(mode == V2X_FUSE_WSUM || mode == V2X_FUSE_MEAN || mode == V2X_FUSE_MAX, "v2x_warp_fuse: bad mode");
     V2X_REQUIRE(n_out >= 0 && n_out <= 65535, "v2x_warp_fuse: n_out out of range");
     if (n_out == 0) return V2X_OK;
+    const char *lds_env = getenv("V2X_WARP_LDS");   // read per call: tests toggle it to compare the two forms
+    if (!(lds_env && lds_env[0] == '0') && H % WL_T == 0 && W % WL_T == 0 && C % WL_CW == 0) {
+        hipLaunchKernelGGL(warp_fuse_lds_kernel, dim3((H / WL_T) * (W / WL_T), n_out, C / WL_CW), dim3(256), 0,
+                           (hipStream_t)stream, feat, A, Bt, H, W, C, trans, items, coef, mode, out);
+        V2X_CHECK_LAUNCH("warp_fuse_lds_kernel");
+        return V2X_OK;
+    }
     const int cv = C % 16 == 0 ? 2 : 1;
     const int total = H * W * (C / (8 * cv));
     int gx = (total + 255) / 256;

@@ -323,7 +323,8 @@ def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
         raise ValueError("coef must be (n_out, A)")
     if out is None:
         out = torch.empty((n_out, H, W, Cc), dtype=torch.bfloat16, device=feat.device)
-    prof = _Prof("warp_fuse_kernel", 0, (n_out * (A - 1) + n_out) * H * W * Cc * 2)
+    lds = H % 8 == 0 and W % 8 == 0 and Cc % 128 == 0 and os.environ.get("V2X_WARP_LDS", "1")[:1] != "0"
+    prof = _Prof("warp_fuse_lds_kernel" if lds else "warp_fuse_kernel", 0, (n_out * (A - 1) + n_out) * H * W * Cc * 2)
     rc = lib.v2x_warp_fuse(_dev(feat, torch.bfloat16, "feat"), A, Bt, H, W, Cc, _dev(trans, torch.float32, "trans"),
                            _dev(items, torch.int32, "items"), n_out, _dev(coef, torch.float32, "coef"), mode,
                            _dev(out, torch.bfloat16, "out"), _stream())
