@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 4
+#define V2X_AMD_ABI_VERSION 5
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -144,6 +144,12 @@ int v2x_conv_tile_rows(int Cout, int epilogue);
 /* Same for the streamed-weights kernel (w_layout 2); 0 = that kernel does not cover (Cout, epilogue). */
 int v2x_conv_stream_tile_rows(int Cout, int epilogue);
 int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
+/* second(first(x)) for two consecutive HBM-bound layers with the intermediate map kept on chip (conv_halo_pair.hip):
+ * replaces Backbone.py::LidarEncoder's conv_pre_1 + bn + relu + conv_pre_2 + bn + relu.  Both descriptors: 3x3, stride 1,
+ * pad 1, w_layout 1, C0 = 32 (13 real + zero-weight padding for the first), C1 = 0, Cout = 32, bf16 epilogue;
+ * first->in_format = 1 (bit grid, in_zbits <= 16); H % 8 == 0, W % 32 == 0.  first->out is ignored; the result is
+ * bit-identical to v2x_conv2d(first) followed by v2x_conv2d(second). */
+int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- a3 (+ the sum of a4/a5): warp + fuse
  * Replaces DetModelBase.py::feature_transformation (affine_grid + grid_sample twice,

@@ -42,6 +42,7 @@ def _kernels(asm):
     ("conv_stream_s2.hip", "_Z26conv3x3_s2_resident_kernel", 1),
     ("conv_halo.hip", "_Z19conv3x3_halo_kernel", 3),
     ("conv_halo.hip", "_Z22conv3x3_halo_sb_kernel", 2),
+    ("conv_halo_pair.hip", "_Z24conv3x3_pair_bits_kernel", 1),
     ("conv_igemm.hip", "_Z17conv_igemm_kernel", 9),
 ])
 def test_conv_kernels_are_spill_free_and_use_lds_dma(tmp_path, src, kernel_prefix, min_kernels):
@@ -77,3 +78,21 @@ def test_stream_kernel_waits_are_counted(tmp_path):
     assert len(idx) >= 1
     for i in idx:
         assert "vmcnt(0)" not in lines[i - 1], lines[i - 3:i + 1]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_pair_kernel_never_drains_its_stores_inside_the_tile_loop(tmp_path):
+    """conv_halo_pair.hip: vmcnt is in-order, so a vmcnt(0) inside the tile loop would wait for the previous tile's output
+    stores (that was 6 us per tile before the loop was restructured).  Past the prologue barrier the only vector-memory
+    waits are vmcnt(9) / vmcnt(8): the next tile's two occupancy words, requested before this tile's 8 stores."""
+    asm = _asm("conv_halo_pair.hip", tmp_path)
+    bodies, _ = _kernels(asm)
+    body = bodies[[n for n in bodies if n.startswith("_Z24conv3x3_pair_bits_kernel")][0]]
+    lines = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(";")]
+    end = next(i for i, ln in enumerate(lines) if ln.startswith("s_endpgm"))
+    bars = [i for i, ln in enumerate(lines[:end]) if ln.startswith("s_barrier")]
+    assert len(bars) == 4, bars                       # LUT, prologue, and the two per-tile barriers
+    loop = lines[bars[1]:end]
+    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(loop))
+    assert waits and set(waits) <= {"8", "9"}, waits    # word 0: one younger load + 8 stores; word 1: the 8 stores
+    assert sum(ln.startswith("v_mfma_f32_16x16x32_bf16") for ln in loop) == 132   # 5 x 6 x 2 (layer A) + 3 x 24 (layer B)

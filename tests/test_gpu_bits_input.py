@@ -55,3 +55,30 @@ def test_points_path_equals_dense_bev_path(device):
             torch.from_numpy(pts).to(device), torch.full((A * B,), 20000, dtype=torch.int32, device=device), T,
             shard.fusion_plan(nat, device))                                      # points -> bits -> conv_pre_1
     assert torch.equal(dense["cls"], pts_out["cls"]) and torch.equal(dense["loc"], pts_out["loc"])
+
+
+@pytest.mark.parametrize("shape", [(3, 256, 256), (2, 8, 32), (5, 40, 96), (1, 64, 32)])
+def test_conv_pair_equals_two_layers_bitwise(device, shape, monkeypatch):
+    """conv_halo_pair.hip (conv_pre_1 -> conv_pre_2 in one launch, intermediate in LDS) against the two stand-alone
+    bit-grid / bf16 halo launches: bit-identical, incl. single-tile maps (every halo pixel is zero padding), extents with
+    many border tiles and dense / empty occupancy."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    pm = init_synthetic_weights(FaFNet(Config("test")), seed=3).to(device)
+    stage = pm.packed(device)["enc"][0]
+    g = torch.Generator().manual_seed(sum(shape))
+    N, H, W = shape
+    dens = torch.rand((N, 1, 1), generator=g) * 0.6                    # per-map occupancy density (first map may be ~empty)
+    dens[0] = 0.0
+    bits = torch.zeros(shape, dtype=torch.int32)
+    for z in range(13):
+        bits |= ((torch.rand(shape, generator=g) < dens).to(torch.int32) << z)
+    bits = (bits | (1 << 17)).to(device)                               # garbage above the height bins must be masked
+    assert ops.pair_eligible(stage[0].halo, stage[1].halo, bits, 13)
+    fused = ops.conv2d_pair(stage[0].halo, stage[1].halo, bits, 13)
+    ref = ops.conv2d(stage[1].halo, ops.conv2d(stage[0].halo, bits, zbits=13))
+    assert torch.equal(fused, ref)
+    monkeypatch.setenv("V2X_CONV_PAIR", "0")
+    assert not ops.pair_eligible(stage[0].halo, stage[1].halo, bits, 13)

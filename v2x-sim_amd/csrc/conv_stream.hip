@@ -612,7 +612,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the offset barrier of group 1
 }
 
-static int v2x_num_cus() {
+int v2x_num_cus() {   // also used by conv_halo_pair.hip
     // hipDeviceGetAttribute, NOT hipGetDeviceProperties: one call of the latter anywhere in the process made EVERY kernel of
     // the step 4-8 % slower on the MI355X boxes (interleaved A/B, 4 250 vs 4 440 frames/s; a clock/power-state side effect)
     static int n = 0;

@@ -103,7 +103,12 @@ class LidarEncoder(_ParamsOnly):
         (conv_pre_1 then expands the bits while filling its LDS patch) -> [x, x_1, x_2, x_3, x_4]."""
         feats = []
         for stage in levels:
-            for layer in stage:
+            k = 0
+            if stage is levels[0] and len(stage) == 2 and ops.pair_eligible(stage[0].halo, stage[1].halo, x, zbits):
+                # conv_pre_1 -> conv_pre_2 in one launch, the 32-channel intermediate stays in LDS (conv_halo_pair.hip)
+                x = ops.conv2d_pair(stage[0].halo, stage[1].halo, x, zbits)
+                k = 2
+            for layer in stage[k:]:
                 x = ops.run_layer(layer, x, zbits=zbits if x.dtype == torch.int32 else 0)
             feats.append(x)
         return feats

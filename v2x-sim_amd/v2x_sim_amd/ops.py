@@ -309,6 +309,49 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0):
     return (out, out2) if split else out
 
 
+def _pair_desc(pc, N, H, W):
+    d = ConvDesc()
+    d.C0, d.C1, d.up0 = pc.C0, pc.C1, pc.up0
+    d.N, d.H, d.W = N, H, W
+    d.ksize, d.stride, d.pad = pc.ksize, pc.stride, pc.pad
+    d.Cout, d.w_rows, d.w_kpad = pc.Cout, pc.w_rows, pc.w_kpad
+    d.weight, d.scale, d.shift = pc.weight.data_ptr(), pc.scale.data_ptr(), pc.shift.data_ptr()
+    d.epilogue, d.relu = pc.epilogue, int(bool(pc.relu))
+    d.w_layout = pc.w_layout or 0
+    return d
+
+
+def pair_eligible(pa, pb, in0, zbits):
+    """conv_halo_pair.hip covers: bit-grid input, two halo-packed 3x3 s1 32 -> 32 bf16 layers, H % 8 == 0, W % 32 == 0."""
+    ok = lambda pc: (pc is not None and pc.w_layout == 1 and pc.ksize == 3 and pc.stride == 1 and pc.C0 == 32 and not pc.C1  # noqa: E731
+                     and pc.Cout == 32 and not pc.Cout2 and pc.epilogue == V2X_EPI_BF16)
+    return (ok(pa) and ok(pb) and in0.dtype == torch.int32 and in0.dim() == 3 and 1 <= zbits <= 16
+            and in0.shape[1] % 8 == 0 and in0.shape[2] % 32 == 0 and os.environ.get("V2X_CONV_PAIR", "1")[:1] != "0")
+
+
+def conv2d_pair(pa, pb, bits, zbits, out=None):
+    """pb(pa(bits)) in one launch, the intermediate map never stored (conv_pre_1 -> conv_pre_2).  bits (N, H, W) int32."""
+    lib = _lib.load()
+    N, H, W = bits.shape
+    if out is None:
+        out = torch.empty((N, H, W, pb.Cout), dtype=torch.bfloat16, device=bits.device)
+    da, db = _pair_desc(pa, N, H, W), _pair_desc(pb, N, H, W)
+    da.in0 = _dev(bits, torch.int32, "bits").value
+    da.in_format, da.in_zbits = 1, zbits
+    db.out = _dev(out, torch.bfloat16, "out").value
+    db.out_cstride, db.out_coff = out.shape[3], 0
+    prof = None
+    if PROFILE is not None:
+        M = N * H * W
+        prof = _Prof("conv3x3_pair_bits_kernel", 2.0 * M * 9 * (pa.Cout * pa.C0 + pb.Cout * pb.C0),
+                     bits.numel() * 4 + out.numel() * 2 + (pa.weight.numel() + pb.weight.numel()) * 2, pa.name + "+" + pb.name)
+    rc = lib.v2x_conv2d_pair(C.byref(da), C.byref(db), _stream())
+    if prof is not None:
+        prof.done()
+    _lib.check(rc, "v2x_conv2d_pair(%s, %s)" % (pa.name, pb.name))
+    return out
+
+
 # ------------------------------------------------------------------ a3
 def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
     """feat (A*Bt, H, W, C) bf16; trans (Bt, A, A, 4, 4) fp32; items (n_out, 2) int32; coef (n_out, A) fp32."""
