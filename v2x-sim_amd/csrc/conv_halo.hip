@@ -93,6 +93,19 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_w = smem;
     char *s_patch = smem + W_BYTES;  // DB: two buffers of PATCH_BYTES, else one
+    // Plain epilogue: scale/shift live in LDS.  vmcnt is in-order, so a GLOBAL load in the epilogue can only be waited for
+    // together with every store issued before it -- reading them per channel tile right before use drained the first
+    // channel tile's output stores (~1-2 us of HBM write latency) before the second could be written (same-box A/B at 320
+    // maps: conv8_1 1.33 -> 1.28 ms, conv8_2 0.54 -> 0.53).  The chained (heads) epilogue keeps its global loads: there
+    // the same change measured 5 % SLOWER (1.29 -> 1.36 ms; the waits pace its 4 GB of fp32 stores).
+    constexpr int PATCH_ALLOC = DB ? 2 * PATCH_BYTES : (BITS ? PH * PW * SPP1 * 16 : PATCH_BYTES);
+    float *s_ss = reinterpret_cast<float *>(smem + W_BYTES + PATCH_ALLOC);   // [scale | shift]
+    if constexpr (COUT2 == 0) {
+        for (int i = threadIdx.x; i < COUT; i += 256) {
+            s_ss[i] = a.scale[i];
+            s_ss[COUT + i] = a.shift[i];
+        }
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -351,8 +364,8 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
 #pragma unroll
             for (int i = 0; i < TCO; ++i) {
                 const int co = i * 16 + fq * 4;
-                const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
-                const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+                const float4 sc = *reinterpret_cast<const float4 *>(s_ss + co);
+                const float4 sf = *reinterpret_cast<const float4 *>(s_ss + COUT + co);
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
@@ -470,7 +483,8 @@ static int launch_halo_sb(const HaloArgs &a, hipStream_t s) {
     // wave padding the LDS-DMA fill needs -- 39.25 KiB, which lets a 4th workgroup fit beside the slack rule below
     // (measured per launch at 320 maps: 2 / 3 / 4 workgroups per CU = 684 / 568 / 520 us).  The bf16-input layers get
     // SLOWER with a 4th workgroup (628 / 577 / 649 us) and keep the padded 40-KiB allocation = 3 per CU.
-    constexpr int smem = 9 * C1 / 8 * COUT * 16 + (BITS ? PH * PW * (C1 / 8) : round64(PH * PW * (C1 / 8))) * 16;
+    constexpr int smem = 9 * C1 / 8 * COUT * 16 + (BITS ? PH * PW * (C1 / 8) : round64(PH * PW * (C1 / 8))) * 16 +
+                         (COUT2 == 0 ? 2 * COUT * 4 : 0);   // + scale/shift
     static bool attr_done = false;
     auto kern = &conv3x3_halo_sb_kernel<C0, C1, COUT, COUT2, EPI2, BITS>;
     if (!attr_done) {
@@ -491,7 +505,7 @@ template <int C0, int C1, int COUT, int COUT2, int EPI2>
 static int launch_halo(const HaloArgs &a, hipStream_t s) {
     constexpr int NS1 = round64(PH * PW * (C1 / 8));
     constexpr int NS0 = C0 ? round64(PH0 * PW0 * (C0 / 8)) : 0;
-    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16;
+    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16 + (COUT2 == 0 ? 2 * COUT * 4 : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
     static bool attr_done = false;
     auto kern = &conv3x3_halo_kernel<C0, C1, COUT, COUT2, EPI2>;
