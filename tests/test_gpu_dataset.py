@@ -122,3 +122,42 @@ def test_train_then_test_drivers_end_to_end(device, tmp_path, capsys):
     print(out[-400:])
     assert "average local mAP@0.5" in out
     assert res[0.5] > 0.3, res
+
+
+def test_train_on_a_parsed_dataset_then_test(device, tmp_path, capsys):
+    """f-3 on the dataset path: tools/det/train_codet.py --data <parsed train split> (sparse sweeps densified and anchor
+    targets built from the stored boxes on the GPU) -> checkpoint -> tools/det/test_codet.py on a parsed test split."""
+    import importlib.util
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.datasets import write_sample
+    from v2x_sim_amd.utils import synthetic_scene
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "det")
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    A = 5
+    grid = ops.VoxelGrid()
+    root = os.path.join(str(tmp_path), "V2X-Sim-det")
+    for split, frames, seed0 in (("train", 48, 20000), ("test", 4, 30000)):
+        for f in range(frames):
+            sc = synthetic_scene.make_scene(A, seed=seed0 + f)
+            bits = ops.voxelize_bits(torch.from_numpy(sc["points"]).to(device), torch.from_numpy(sc["n_pts"]).to(device), grid)
+            idx, cnt = ops.bits_to_indices(bits, grid.dims[2], 32768)
+            idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+            for a in range(A):
+                write_sample(root, split, a, 3, f, idx[a, :cnt[a]], sc["trans"][a], A, gt_boxes=sc["gt_boxes"][a])
+    logdir = os.path.join(str(tmp_path), "log")
+    load("train_codet").main(["--data", os.path.join(root, "train"), "--com", "v2v", "--nepoch", "10", "--batch", "2",
+                              "--logpath", logdir, "--log"])
+    out = capsys.readouterr().out
+    losses = [float(ln.split("steps")[1]) for ln in out.splitlines() if ln.startswith("epoch") and "mean loss" in ln]
+    print("epoch losses", losses)
+    assert len(losses) == 10 and losses[-1] < 0.5 * losses[0]
+    ckpt = os.path.join(logdir, "epoch_10.pth")
+    res = load("test_codet").main(["--data", os.path.join(root, "test"), "--com", "v2v", "--resume", ckpt, "--batch", "2"])
+    out = capsys.readouterr().out
+    print(out[-300:])
+    assert res[0.5] > 0.3, res

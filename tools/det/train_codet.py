@@ -3,10 +3,12 @@
 (/root/reference/README.md:101 points at it; the script itself is not in the reference tree).
 
     python tools/det/train_codet.py --data synthetic --com v2v --nepoch 1 --steps 400 --batch 2 --logpath out/
+    python tools/det/train_codet.py --data /path/V2X-Sim-det/train --com v2v --nepoch 10 --batch 2 --logpath out/
 
 Training = PyTorch-ROCm autograd graph over the parameter tree of the HIP engine (v2x_sim_amd/train/); the sweeps are
 voxelised by the HIP voxeliser.  `--data synthetic` draws fresh synthetic scenes (the V2X-Sim download is not
-available offline, README.md:42-48).  Writes epoch_{n}.pth with 'model_state_dict' (upstream's checkpoint key), which
+available offline, README.md:42-48); a directory trains on a parsed dataset in the README.md:66-79 layout (sparse sweeps
+densified and anchor targets scattered on the GPU, train/loop.py::dataset_batch_on_device).  Writes epoch_{n}.pth with 'model_state_dict' (upstream's checkpoint key), which
 tools/det/test_codet.py --resume loads into the HIP inference path."""
 import argparse
 import os
@@ -35,6 +37,8 @@ def build_parser():
     ap.add_argument("--logpath", default="", type=str)
     ap.add_argument("--seed", default=0, type=int)
     ap.add_argument("--log", action="store_true")
+    ap.add_argument("--nworker", default=0, type=int, help="DataLoader workers (parsed dataset)")
+    ap.add_argument("--rsu", default=1, type=int, help="parsed dataset: 1 = agent0 (the RSU) takes part, 0 = vehicles only")
     return ap
 
 
@@ -42,11 +46,9 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import CatFusion, DiscoNet, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
-    from v2x_sim_amd.train.loop import init_for_training, train_synthetic
+    from v2x_sim_amd.train.loop import init_for_training, train_dataset, train_synthetic
     if not torch.cuda.is_available():
         raise SystemExit("train_codet.py needs the MI355X")
-    if args.data != "synthetic":
-        raise SystemExit("only --data synthetic is wired up (parsed V2X-Sim-det training targets: DESIGN.md section 9)")
     config = Config("train", binary=True, only_det=True)
     A = args.num_agent
     if args.com == "v2v":
@@ -63,8 +65,20 @@ def main(argv=None):
         model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=False)
     else:
         init_for_training(model, seed=args.seed)
+    dataset = None
+    if args.data != "synthetic":
+        # parsed dataset in the README.md:66-79 layout: <data>/agent{k}/{scene}_{frame}/0.npy (agent0 = RSU)
+        from v2x_sim_amd.datasets import V2XSimDet
+        first = 0 if args.rsu else 1
+        roots = [os.path.join(args.data, "agent%d" % k) for k in range(first, first + A)]
+        dataset = V2XSimDet(dataset_roots=roots, config=config, split="train", densify="none")
+        print("training on %d frames x %d agents from %s" % (len(dataset), A, args.data))
     for epoch in range(1, args.nepoch + 1):
-        hist = train_synthetic(model, config, args.steps, args.batch, args.lr, seed=args.seed + epoch, log=20 if args.log else None)
+        if dataset is not None:
+            hist = train_dataset(model, config, dataset, 1, args.batch, args.lr, seed=args.seed + epoch,
+                                 log=20 if args.log else None, num_workers=args.nworker)
+        else:
+            hist = train_synthetic(model, config, args.steps, args.batch, args.lr, seed=args.seed + epoch, log=20 if args.log else None)
         tail = hist[-20:]
         print("epoch %d: mean loss of the last %d steps %.4f" % (epoch, len(tail), sum(h[0] for h in tail) / len(tail)))
         if args.logpath:

@@ -69,3 +69,59 @@ def train_synthetic(model, config, steps, frames_per_step=2, lr=1e-3, seed=0, de
             print("step %4d  loss %.4f  cls %.4f  loc %.4f" % ((it,) + hist[-1]), flush=True)
     model.eval()
     return hist
+
+
+def dataset_batch_on_device(samples, grid, anchors, device):
+    """Parsed-dataset samples (datasets.V2XSimDet with densify='none': sparse voxel indices + poses + gt boxes) -> the
+    data dict of FaFModule.step.  The sweep is densified on the GPU (v2x_indices_to_bits -> v2x_bits_to_dense_f32); the
+    anchor targets upstream's Dataset would return (label_one_hot, reg_target, reg_loss_mask) are built from the stored
+    ground-truth boxes (synthetic_scene.anchor_targets_sparse, the assignment rule of DESIGN.md section 3.7) and scattered
+    on the device."""
+    import numpy as np
+    B, A = len(samples), len(samples[0])
+    items = [(a, b) for a in range(A) for b in range(B)]                       # agent-major, as the models batch
+    cap = max(1, max(samples[b][a][0].shape[0] for a, b in items))
+    idx = np.zeros((len(items), cap, 3), np.int32)
+    cnt = np.zeros((len(items),), np.int32)
+    pos, reg = [], []
+    for m, (a, b) in enumerate(items):
+        it = samples[b][a][0]
+        idx[m, :it.shape[0]] = it
+        cnt[m] = it.shape[0]
+        p, r = synthetic_scene.anchor_targets_sparse(samples[b][a][12], anchors)
+        pos.append(np.concatenate([np.full((p.shape[0], 1), m, np.int64), p], 1))
+        reg.append(r)
+    bits = ops.indices_to_bits(torch.from_numpy(idx).to(device), torch.from_numpy(cnt).to(device), grid)
+    data = {"bev_seq": ops.bits_to_dense(bits, grid.dims[2])[:, None],
+            "trans_matrices": torch.from_numpy(np.stack([np.stack([samples[b][a][11] for a in range(A)])
+                                                         for b in range(B)])).to(device),
+            "num_agent": torch.tensor([[samples[b][a][10] for a in range(A)] for b in range(B)]),
+            "gt_boxes": [[samples[b][a][12] for b in range(B)] for a in range(A)]}
+    data["labels"], data["reg_targets"], data["reg_loss_mask"] = synthetic_scene.dense_targets_on_device(
+        np.concatenate(pos), np.concatenate(reg), len(items), anchors.shape, device)
+    return data
+
+
+def train_dataset(model, config, dataset, epochs=1, batch=2, lr=1e-3, seed=0, device="cuda:0", log=None, num_workers=0):
+    """Adam over a parsed dataset (datasets.V2XSimDet, densify='none'), shuffled per epoch; upstream's
+    train_codet.py loop with the densify and the target scatter moved to the GPU.  -> list of (loss, cls, loc) per step."""
+    from torch.utils.data import DataLoader
+    device = torch.device(device)
+    model.to(device)
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    module = FaFModule(model, None, config, opt, 0)
+    grid = ops.VoxelGrid(config.voxel_size, config.area_extents)
+    loader = DataLoader(dataset, batch_size=batch, shuffle=True, drop_last=False, num_workers=num_workers,
+                        collate_fn=lambda x: x, generator=torch.Generator().manual_seed(seed))
+    steps = epochs * len(loader)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(steps * 0.6), int(steps * 0.85)], gamma=0.3)
+    hist = []
+    for ep in range(epochs):
+        for samples in loader:
+            data = dataset_batch_on_device(samples, grid, module.anchors, device)
+            hist.append(module.step(data, len(samples), len(samples[0])))
+            sched.step()
+            if log and (len(hist) % log == 1 or len(hist) == steps):
+                print("epoch %d step %4d  loss %.4f  cls %.4f  loc %.4f" % ((ep + 1, len(hist)) + hist[-1]), flush=True)
+    model.eval()
+    return hist
