@@ -14,15 +14,19 @@
 //     layout of conv_halo.hip;
 //   * layer B then runs on that patch like the stand-alone kernel (group walk over kx, B fragments shared by the three
 //     ky taps) and stores bf16 NHWC.
-// Both weight tensors stay resident in LDS (2 x 18 KiB).  77.4 KiB of LDS per workgroup -> 2 workgroups per CU; the next
+// Both weight tensors stay resident in LDS (2 x 18 KiB).  76.4 KiB of LDS per workgroup -> 2 workgroups per CU; the next
 // tile's occupancy words are prefetched into registers under the current tile's MFMAs, barriers are raw s_barrier with
 // lgkmcnt waits only, so the output stores of a tile drain under the next tile.
 // Traffic per tile: 1.7 KB read + 16 KB written (the stand-alone pair: 1.7 + 16 | 22 + 16).  The recompute of layer A
 // on the halo ring costs 22/16 of its MFMAs.  Results are bit-identical to running the two layers separately
-// (tests/test_gpu_stages.py::test_conv_pair_equals_two_layers_bitwise).
+// (tests/test_gpu_bits_input.py::test_conv_pair_equals_two_layers_bitwise).
+// Measured and dropped (same-box A/B, 0.69 ms for this form): scale/shift read from LDS instead of held in registers,
+// operand double-buffering in registers, an interior-tile path without the image-border predicate, 8 waves per workgroup
+// -- together 0.79 ms.  Switching phases off one at a time showed the phases of a tile adding up almost linearly (no
+// stores -0.09, no layer-A MFMAs -0.07, no layer-B MFMAs -0.13, no barriers -0.08, no window fetch/expansion -0.06, no
+// layer-A epilogue -0.15 ms): the two waves a SIMD holds overlap little; the MFMA work alone would be 0.31 ms.
 #include "common.h"
 #include <cstdlib>
-#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void *gptr_p_t;
 typedef __attribute__((address_space(3))) void *lptr_p_t;
@@ -45,14 +49,13 @@ constexpr int MH = TH + 2, MW = TW + 2; // layer-A region (= layer B's input pat
 constexpr int IH = TH + 4, IW = TW + 4; // input window
 constexpr int NMID = MH * MW;           // 340 pixels
 constexpr int NFRAG = (NMID + 15) / 16; // 22 linear fragments
+constexpr int FPW = (NFRAG + 3) / 4;    // fragments per wave (6; waves 2,3 use 5)
 constexpr int W_BYTES = 36 * 32 * 16;   // 18 432
 constexpr int IN_PLANE = IH * IW * 16;  // one 8-channel plane of the input window: [pixel][8] bf16
 constexpr int IN_BYTES = 2 * IN_PLANE; // 13 824: channels 0..7 | 8..15, planar so that 16 consecutive pixels are 256 contiguous bytes
 constexpr int MID_BYTES = NMID * 64;    // 21 760
 constexpr int LUT_BYTES = 256 * 16;     // byte of occupancy bits -> 8 bf16 {0,1}: the expansion is one ds_read_b128 instead of ~60 VALU ops
-constexpr int SS_BYTES = 4 * 32 * 4;      // scale/shift of both layers ([scA | shA | scB | shB] x 32 fp32): read per use, not held in 16 VGPRs
-constexpr int ZERO_BYTES = 512;         // zeros: the weights of the non-existent 10th tap
-constexpr int SMEM = 2 * W_BYTES + IN_BYTES + MID_BYTES + LUT_BYTES + SS_BYTES + ZERO_BYTES;
+constexpr int SMEM = 2 * W_BYTES + IN_BYTES + MID_BYTES + LUT_BYTES;
 __device__ __forceinline__ int swz4(int slot, int x) { return slot ^ ((x >> 1) & 3); }
 // ReLU on two packed bf16: as 16-bit integers a negative bf16 (sign bit) is a negative short, so max(x, 0) per half is
 // ONE v_pk_max_i16 for two values (fmaxf on the fp32 values costs two instructions EACH: it canonicalises first).
@@ -69,25 +72,11 @@ __device__ __forceinline__ void lds_barrier() {
 }
 }  // namespace pair
 
-// NW waves per workgroup.  Only NW = 4 is instantiated: the 8-wave form (4 waves per SIMD, half the fragments each) measured
-// the same 0.79 ms -- the per-tile costs that do not shrink with NW (two barriers, tile decode, window expansion) eat the gain.
-// Measured by switching parts off (same box, 0.84 ms with the switches compiled in): no output stores -0.09, no layer-A
-// MFMAs -0.07, no layer-B MFMAs -0.13, no barriers -0.08, no window fetch/expansion -0.06, no layer-A epilogue -0.15 ms,
-// all of them 0.25 ms: the phases of a tile add up almost linearly, i.e. the two waves a SIMD holds overlap little.
-// RELU: both layers end in ReLU (the only use today) -- known at compile time, no per-value selects; false = run-time flags.
-template <int NW, bool RELU>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2, NW / 2))) void conv3x3_pair_bits_kernel(const PairArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_pair_bits_kernel(const PairArgs a) {
     using namespace pair;
-    constexpr int NT = NW * 64;                 // threads
-    constexpr int FPW = (NFRAG + NW - 1) / NW;  // layer-A fragments per wave (the last round is partly behind the region)
-    constexpr int WPT = (IH * IW + NT - 1) / NT; // occupancy words per thread
-    constexpr int RPW = TH / NW;                // layer-B output rows per wave
-    constexpr int NFB = RPW * 2;                // layer-B fragments per wave (row, column half)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_wA = smem, *s_wB = smem + W_BYTES, *s_in = smem + 2 * W_BYTES, *s_mid = smem + 2 * W_BYTES + IN_BYTES;
     char *s_lut = s_mid + MID_BYTES;
-    float *s_ss = reinterpret_cast<float *>(s_lut + LUT_BYTES);
-    char *s_zero = s_lut + LUT_BYTES + SS_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,7 +84,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     const int fj = lane & 15, fq = lane >> 4;
 
     // weights: linear LDS-DMA copies, resident for the whole kernel
-    for (int off = wave * 1024; off < W_BYTES; off += NW * 1024) {
+    for (int off = wave * 1024; off < W_BYTES; off += 4096) {
         __builtin_amdgcn_global_load_lds((gptr_p_t)(reinterpret_cast<const char *>(a.wA) + off + lane * 16), (lptr_p_t)(s_wA + off), 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gptr_p_t)(reinterpret_cast<const char *>(a.wB) + off + lane * 16), (lptr_p_t)(s_wB + off), 16, 0, 0);
     }
@@ -106,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     int rc[FPW];          // region row | column << 8 | valid << 16
 #pragma unroll
     for (int t = 0; t < FPW; ++t) {
-        const int p = (wave + NW * t) * 16 + fj;
+        const int p = (wave + 4 * t) * 16 + fj;
         const int pc = p < NMID ? p : NMID - 1;
         const int r = pc / MW, c = pc - r * MW;
         in_off[t] = (fq & 1) * IN_PLANE + (r * IW + c) * 16;
@@ -116,18 +105,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     }
     // layer A walks K in 5 steps of TWO taps: k-groups 0,1 = the 16 channels of tap 2s, k-groups 2,3 = those of tap 2s+1
     // (channels 16..31 of the padded layer never enter an MFMA).  Per lane: window shift and weight slot of its tap.
-    // Per lane: tap = 2 st + (fq >> 1).  Weight fragment = lane base + st * 4096 + i * 256 (immediates); the lanes of the
-    // non-existent 10th tap (st = 4, fq >= 2) read zeros instead.
-    const int wA_lane = (((fq >> 1) * 4 + (fq & 1)) * 32 + fj) * 16;
-    const int wA_last = fq < 2 ? wA_lane + 4 * 4096 : 2 * W_BYTES + IN_BYTES + MID_BYTES + LUT_BYTES + SS_BYTES;
-    int tap_off[5];
+    int tap_off[5], wA_off[5][2];
 #pragma unroll
     for (int st = 0; st < 5; ++st) {
         const int tap = 2 * st + (fq >> 1);
         const int tc = tap < 9 ? tap : 8;
         tap_off[st] = ((tc / 3) * IW + (tc % 3)) * 16;
+        // the 10th tap does not exist: its lanes read entry 0 of the expansion table (16 zero bytes) as their weights
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            wA_off[st][i] = tap < 9 ? ((tap * 4 + (fq & 1)) * 32 + i * 16 + fj) * 16 : 2 * W_BYTES + IN_BYTES + MID_BYTES - 0;
     }
-    const unsigned out_lane = (unsigned)(fj * a.out_cstride + fq * 4) * 2u;   // byte offset of the lane inside a 16-pixel fragment
     const uint32_t zmask = (a.zbits >= 16) ? 0xffffu : ((1u << a.zbits) - 1u);   // 16 channels exist in LDS (zbits <= 16)
     const int txy = a.tiles_x * a.tiles_y;
 
@@ -135,14 +123,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     // `w = ok ? load : 0` makes the compiler zero the register first, and a VALU write to a register with a possibly
     // pending load costs an s_waitcnt vmcnt(0) at the top of every tile -- which, vmcnt being in-order, waits for the
     // previous tile's output stores.
-    auto fetch_words = [&](int tile, uint32_t (&w)[WPT], uint32_t &okmask) {
+    auto fetch_words = [&](int tile, uint32_t (&w)[2], uint32_t &okmask) {
         const int n = tile / txy;
         const int r = tile - n * txy;
         const int ty = r / a.tiles_x, tx = r - ty * a.tiles_x;
         uint32_t m = 0;
 #pragma unroll
-        for (int s = 0; s < WPT; ++s) {
-            const int p = min(tid + NT * s, IH * IW - 1);
+        for (int s = 0; s < 2; ++s) {
+            const int p = min(tid + 256 * s, IH * IW - 1);
             const int pr = p / IW, pcx = p - pr * IW;
             const int y = ty * TH - 2 + pr, x = tx * TW - 2 + pcx;
             const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
@@ -153,22 +141,29 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
         okmask = m;
     };
 
-    if (tid < 128) s_ss[tid] = (tid < 32 ? a.scA : tid < 64 ? a.shA : tid < 96 ? a.scB : a.shB)[tid & 31];
-    if (tid < ZERO_BYTES / 4) reinterpret_cast<uint32_t *>(s_zero)[tid] = 0u;
+    float4 scA[2], shA[2], scB[2], shB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        scA[i] = *reinterpret_cast<const float4 *>(a.scA + i * 16 + fq * 4);
+        shA[i] = *reinterpret_cast<const float4 *>(a.shA + i * 16 + fq * 4);
+        scB[i] = *reinterpret_cast<const float4 *>(a.scB + i * 16 + fq * 4);
+        shB[i] = *reinterpret_cast<const float4 *>(a.shB + i * 16 + fq * 4);
+    }
+
     {   // expansion table: entry b = the 8 channels of occupancy byte b as bf16 {0, 1}
-        const uint32_t b = tid & 255, one = 0x3f80u;
+        const uint32_t b = tid, one = 0x3f80u;
         uint4 v;
         v.x = ((b & 1u) ? one : 0u) | ((b & 2u) ? (one << 16) : 0u);
         v.y = ((b & 4u) ? one : 0u) | ((b & 8u) ? (one << 16) : 0u);
         v.z = ((b & 16u) ? one : 0u) | ((b & 32u) ? (one << 16) : 0u);
         v.w = ((b & 64u) ? one : 0u) | ((b & 128u) ? (one << 16) : 0u);
-        if (tid < 256) *reinterpret_cast<uint4 *>(s_lut + tid * 16) = v;
+        *reinterpret_cast<uint4 *>(s_lut + tid * 16) = v;
     }
     __syncthreads();
-    auto expand_words = [&](const uint32_t (&w)[WPT], uint32_t okmask) {
+    auto expand_words = [&](const uint32_t (&w)[2], uint32_t okmask) {
 #pragma unroll
-        for (int s = 0; s < WPT; ++s) {
-            const int p = tid + NT * s;
+        for (int s = 0; s < 2; ++s) {
+            const int p = tid + 256 * s;
             if (p < IH * IW) {
                 const uint32_t word = ((okmask >> s) & 1u) ? (w[s] & zmask) : 0u;
 #pragma unroll
@@ -184,11 +179,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
     // the compiler re-waits for it with vmcnt(0) in every iteration -- and (2) the occupancy words of the next tile are
     // requested BEFORE this tile's stores and expanded AFTER them, which the compiler resolves to vmcnt(8), not 0.
     int tile = blockIdx.x;
-    uint32_t words[WPT] = {}, okmask = 0;
+    uint32_t words[2] = {0u, 0u}, okmask = 0;
     if (tile < a.n_tiles) {
         fetch_words(tile, words, okmask);
         expand_words(words, okmask);
     }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        asm volatile("" ::"v"(scA[i].x), "v"(scA[i].w), "v"(shA[i].x), "v"(shA[i].w), "v"(scB[i].x), "v"(scB[i].w), "v"(shB[i].x), "v"(shB[i].w));
     __syncthreads();   // input window of the first tile written; the weight DMA has landed
 
     for (; tile < a.n_tiles; tile += gridDim.x) {
@@ -208,127 +206,98 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW / 2,
                 for (int i = 0; i < 2; ++i) acc[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
             // waves 2 and 3 own 5 fragments: their 6th (k = 22, 23) lies behind the region, every lane is clamped to the last
             // pixel and its result dropped (rc valid bit) -- cheaper than a conditionally defined operand array
-            // operands of step st+1 are read into a second register set before the MFMAs of step st are issued
-            struct FragsA {
-                bf16x8_t A[2], B[FPW];
-            };
-            FragsA fa[2];
-            auto load_a = [&](int st, FragsA &F) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) F.A[i] = *reinterpret_cast<const bf16x8_t *>(smem + (st < 4 ? wA_lane + st * 4096 : wA_last) + i * 256);
-#pragma unroll
-                for (int t = 0; t < FPW; ++t) F.B[t] = *reinterpret_cast<const bf16x8_t *>(s_in + in_off[t] + tap_off[st]);
-            };
-            load_a(0, fa[0]);
 #pragma unroll
             for (int st = 0; st < 5; ++st) {
-                if (st + 1 < 5) load_a(st + 1, fa[(st + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
+                bf16x8_t A[2], B[FPW];
 #pragma unroll
-                for (int t = 0; t < FPW; ++t)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[st & 1].A[i], fa[st & 1].B[t], acc[t][i], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            // epilogue A: bf16 as the stand-alone layer stores it; zero outside the image (layer B's padding).  A tile that
-            // does not touch the image border (wave-uniform test) has no such pixel and skips the per-lane predicate.
-            const bool border = ty == 0 || tx == 0 || ty == a.tiles_y - 1 || tx == a.tiles_x - 1;
-            const bool reluA = RELU || a.reluA;
-            auto finish_a = [&](auto border_tag) {
-                constexpr bool BORDER = decltype(border_tag)::value;
+                for (int i = 0; i < 2; ++i) A[i] = *reinterpret_cast<const bf16x8_t *>(smem + wA_off[st][i]);
 #pragma unroll
                 for (int t = 0; t < FPW; ++t) {
-                    if (!(rc[t] >> 16)) continue;
-                    bool inside = true;
-                    if constexpr (BORDER) {
-                        const int r = rc[t] & 0xff, c = (rc[t] >> 8) & 0xff;
-                        const int y = ty * TH - 1 + r, x = tx * TW - 1 + c;
-                        inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float4 sc = *reinterpret_cast<const float4 *>(s_ss + i * 16 + fq * 4), sf = *reinterpret_cast<const float4 *>(s_ss + 32 + i * 16 + fq * 4);
-                        float v0 = acc[t][i][0] * sc.x + sf.x, v1 = acc[t][i][1] * sc.y + sf.y;
-                        float v2 = acc[t][i][2] * sc.z + sf.z, v3 = acc[t][i][3] * sc.w + sf.w;
-                        uint2 o;
-                        o.x = pack_bf16x2(v0, v1);
-                        o.y = pack_bf16x2(v2, v3);
-                        if (reluA) {
-                            o.x = relu_bf16x2(o.x);
-                            o.y = relu_bf16x2(o.y);
-                        }
-                        if constexpr (BORDER) {
-                            o.x = inside ? o.x : 0u;
-                            o.y = inside ? o.y : 0u;
-                        }
-                        *reinterpret_cast<uint2 *>(s_mid + mid_off[t][i]) = o;
-                    }
+                    B[t] = *reinterpret_cast<const bf16x8_t *>(s_in + in_off[t] + tap_off[st]);
                 }
-            };
-            if (border) finish_a(std::true_type{});
-            else finish_a(std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < FPW; ++t) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], B[t], acc[t][i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // epilogue A: bf16 as the stand-alone layer stores it; zero outside the image (layer B's padding)
+#pragma unroll
+            for (int t = 0; t < FPW; ++t) {
+                const int r = rc[t] & 0xff, c = (rc[t] >> 8) & 0xff;
+                const int y = ty * TH - 1 + r, x = tx * TW - 1 + c;
+                const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                if (!(rc[t] >> 16)) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    float v0 = acc[t][i][0] * scA[i].x + shA[i].x, v1 = acc[t][i][1] * scA[i].y + shA[i].y;
+                    float v2 = acc[t][i][2] * scA[i].z + shA[i].z, v3 = acc[t][i][3] * scA[i].w + shA[i].w;
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
+                    if (a.reluA) {
+                        o.x = relu_bf16x2(o.x);
+                        o.y = relu_bf16x2(o.y);
+                    }
+                    o.x = inside ? o.x : 0u;
+                    o.y = inside ? o.y : 0u;
+                    *reinterpret_cast<uint2 *>(s_mid + mid_off[t][i]) = o;
+                }
+            }
         }
         lds_barrier();
 
         // ---- (e) layer B on the region, as conv_halo.hip's 32 -> 32 form ----------------------------------------
         {
-            f32x4_t acc[2][NFB];
+            f32x4_t acc[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int f = 0; f < NFB; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            struct FragsB {
-                bf16x8_t A[3][2], B[(RPW + 2) * 2];
-            };
-            FragsB fb[2];
-            auto load_b = [&](int kx, FragsB &F) {
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        F.A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_wB + (((ky * 3 + kx) * 4 + fq) * 32 + i * 16 + fj) * 16);
-#pragma unroll
-                for (int q = 0; q < RPW + 2; ++q)
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) {
-                        const int pr = RPW * wave + q, pc = ch * 16 + fj + kx;
-                        F.B[q * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(s_mid + ((pr * MW + pc) * 4 + swz4(fq, pc)) * 16);
-                    }
-            };
-            load_b(0, fb[0]);
+                for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                if (kx + 1 < 3) load_b(kx + 1, fb[(kx + 1) & 1]);
+                bf16x8_t A[3][2], B[8];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_wB + (((ky * 3 + kx) * 4 + fq) * 32 + i * 16 + fj) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int pr = 2 * wave + q, pc = ch * 16 + fj + kx;
+                        B[q * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(s_mid + ((pr * MW + pc) * 4 + swz4(fq, pc)) * 16);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int f = 0; f < NFB; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[kx & 1].A[ky][i], fb[kx & 1].B[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
+                        for (int f = 0; f < 4; ++f)
+                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // stores: wave-uniform 64-bit base per (row, column half) + one hoisted 32-bit lane offset + an immediate
-            const bool reluB = RELU || a.reluB;
-            char *tile_out = reinterpret_cast<char *>(a.out) +
-                             (((size_t)(n * a.H + ty * TH + RPW * wave) * a.W + tx * TW) * a.out_cstride + a.out_coff) * 2;
 #pragma unroll
-            for (int f = 0; f < NFB; ++f) {
-                char *frag_out = tile_out + ((size_t)(f >> 1) * a.W + (f & 1) * 16) * a.out_cstride * 2;
+            for (int i = 0; i < 2; ++i) {
+                const int co = i * 16 + fq * 4;
+                const float4 sc = scB[i], sf = shB[i];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const float4 sc = *reinterpret_cast<const float4 *>(s_ss + 64 + i * 16 + fq * 4), sf = *reinterpret_cast<const float4 *>(s_ss + 96 + i * 16 + fq * 4);
+                for (int f = 0; f < 4; ++f) {
+                    const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
                     float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
                     float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
                     uint2 o;
                     o.x = pack_bf16x2(v0, v1);
                     o.y = pack_bf16x2(v2, v3);
-                    if (reluB) {
+                    if (a.reluB) {
                         o.x = relu_bf16x2(o.x);
                         o.y = relu_bf16x2(o.y);
                     }
-                    *reinterpret_cast<uint2 *>(frag_out + out_lane + i * 32) = o;
+                    *reinterpret_cast<uint2 *>(a.out + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co) = o;
                 }
             }
         }
@@ -383,16 +352,12 @@ extern "C" int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *
     a.n_tiles = a.N * a.tiles_x * a.tiles_y;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_pair_bits_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, pair::SMEM);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_pair_bits_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, pair::SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_pair_bits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pair::SMEM);
         attr_done = true;
     }
     int grid = v2x_num_cus() * 2;
     if (grid > a.n_tiles) grid = a.n_tiles;
-    if (a.reluA && a.reluB)
-        hipLaunchKernelGGL((conv3x3_pair_bits_kernel<4, true>), dim3(grid), dim3(256), pair::SMEM, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((conv3x3_pair_bits_kernel<4, false>), dim3(grid), dim3(256), pair::SMEM, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(conv3x3_pair_bits_kernel, dim3(grid), dim3(256), pair::SMEM, (hipStream_t)stream, a);
     V2X_CHECK_LAUNCH("conv3x3_pair_bits_kernel");
     return V2X_OK;
 }
