@@ -85,6 +85,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int S = nchunks * 9;
     const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
     const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+    // scale/shift rows of this channel tile in LDS (read in the epilogue, many barriers later): a global load between the
+    // stores of two channel tiles can only be waited for together with those stores (in-order vmcnt)
+    float *s_ss = reinterpret_cast<float *>(smem + S2_RING * SLICE_BYTES + S2_PATCH_BYTES);   // [BCO scale | BCO shift]
+    for (int i = tid; i < BCO; i += 256) {
+        s_ss[i] = a.scale[co_tile * BCO + i];       // both arrays hold n_co_tiles * BCO entries
+        s_ss[BCO + i] = a.shift[co_tile * BCO + i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // before the counted-DMA regime starts
 
     // per-lane DMA descriptors of this wave's patch pieces (piece = wave + 4t): (input pixel index << 5) | (logical 16-B
     // slot * 8 elements), -1 = zero page (outside the image, or the padding slots behind the patch)
@@ -184,8 +192,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     for (int i = 0; i < TCO; ++i) {
         const int co = co_tile * BCO + i * 16 + fq * 4;
         if (co >= a.Cout) continue;
-        const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
-        const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+        const float4 sc = *reinterpret_cast<const float4 *>(s_ss + i * 16 + fq * 4);
+        const float4 sf = *reinterpret_cast<const float4 *>(s_ss + BCO + i * 16 + fq * 4);
 #pragma unroll
         for (int f = 0; f < 2; ++f) {
             float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
@@ -221,6 +229,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_w = smem;
     char *s_patch = smem + W_BYTES;
+    // scale/shift in LDS: a global load between the stores of two channel tiles can only be waited for (in-order vmcnt)
+    // together with the stores before it -- four store drains per tile
+    float *s_ss = reinterpret_cast<float *>(smem + W_BYTES + S2_PATCH_BYTES);   // [64 scale | 64 shift]
+    if (threadIdx.x < 64) {
+        s_ss[threadIdx.x] = a.scale[threadIdx.x];
+        s_ss[64 + threadIdx.x] = a.shift[threadIdx.x];
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -254,7 +269,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     const int txy = a.tiles_x * a.tiles_y;
     const int Ho = a.H >> 1, Wo = a.W >> 1;
-    const float4 *scv = reinterpret_cast<const float4 *>(a.scale), *sfv = reinterpret_cast<const float4 *>(a.shift);
 
     bool first = true;
     for (int tile = blockIdx.x; tile < a.n_px_tiles; tile += gridDim.x) {
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
             const int co = i * 16 + fq * 4;
-            const float4 sc = scv[co >> 2], sf = sfv[co >> 2];
+            const float4 sc = *reinterpret_cast<const float4 *>(s_ss + co), sf = *reinterpret_cast<const float4 *>(s_ss + 64 + co);
 #pragma unroll
             for (int f = 0; f < 2; ++f) {
                 float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
@@ -326,7 +340,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 static int launch_s2_resident(const S2Args &a, hipStream_t s) {
-    constexpr int smem = 9 * 64 * 64 + S2_PATCH_BYTES;   // 36 + 37 KiB
+    constexpr int smem = 9 * 64 * 64 + S2_PATCH_BYTES + 512;   // 36 + 37 KiB + scale/shift
     static bool attr_done = false;
     auto kern = &conv3x3_s2_resident_kernel<64>;
     if (!attr_done) {
@@ -342,7 +356,7 @@ static int launch_s2_resident(const S2Args &a, hipStream_t s) {
 
 template <int BCO>
 static int launch_s2(const S2Args &a, hipStream_t s) {
-    constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES;
+    constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES + 2 * BCO * 4;
     static bool attr_done = false;
     auto kern = &conv3x3_s2_stream_kernel<BCO>;
     if (!attr_done) {
