@@ -96,8 +96,8 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     // Plain epilogue: scale/shift live in LDS.  vmcnt is in-order, so a GLOBAL load in the epilogue can only be waited for
     // together with every store issued before it -- reading them per channel tile right before use drained the first
     // channel tile's output stores (~1-2 us of HBM write latency) before the second could be written (same-box A/B at 320
-    // maps: conv8_1 1.33 -> 1.28 ms, conv8_2 0.54 -> 0.53).  The chained (heads) epilogue keeps its global loads: there
-    // the same change measured 5 % SLOWER (1.29 -> 1.36 ms; the waits pace its 4 GB of fp32 stores).
+    // maps: conv8_1 1.33 -> 1.28 ms, conv8_2 0.54 -> 0.53).  The chained (heads) epilogue reads its vectors from global memory
+    // ONCE per tile, before its first store (registers): 1.29 -> 1.09 ms same-box, whereas the LDS form measured 1.36.
     constexpr int PATCH_ALLOC = DB ? 2 * PATCH_BYTES : (BITS ? PH * PW * SPP1 * 16 : PATCH_BYTES);
     float *s_ss = reinterpret_cast<float *>(smem + W_BYTES + PATCH_ALLOC);   // [scale | shift]
     if constexpr (COUT2 == 0) {
@@ -395,6 +395,14 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 sc[i] = *reinterpret_cast<const float4 *>(a.scale + kappa);
                 sf[i] = *reinterpret_cast<const float4 *>(a.shift + kappa);
             }
+            // the chained layer's scale/shift for all its channel tiles, loaded ONCE per tile before the first store (a load
+            // issued between stores can only be waited for together with them: in-order vmcnt)
+            float4 s2v[TCO2 > 0 ? TCO2 : 1], t2v[TCO2 > 0 ? TCO2 : 1];
+#pragma unroll
+            for (int i2 = 0; i2 < TCO2; ++i2) {
+                s2v[i2] = *reinterpret_cast<const float4 *>(a.scale2 + i2 * 16 + fq * 4);
+                t2v[i2] = *reinterpret_cast<const float4 *>(a.shift2 + i2 * 16 + fq * 4);
+            }
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 bf16x8_t hb[COUT / 32];
@@ -430,8 +438,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][s], hb[s], d, 0, 0, 0);
                     const int co = i2 * 16 + fq * 4;
                     if (co >= a.cout2_real) continue;
-                    const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
-                    const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
+                    const float4 s2 = s2v[i2], t2 = t2v[i2];
                     float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
                     if (a.relu2) {
                         v0 = fmaxf(v0, 0.f);
