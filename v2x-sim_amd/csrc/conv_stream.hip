@@ -54,9 +54,32 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // ---- epilogue shared by the 4-wave and the 8-wave kernels -------------------------------------------
-template <int BCO, int TW, int EPI, int NF = 4>
+// Chained epilogue with its second-GEMM operands staged in LDS (stage_chain): [w2 in fragment order (i2, ks, fq, fj) x 16 B |
+// scale2 | shift2].  vmcnt is in-order: a global load issued between the stores of two output-channel tiles can only be
+// waited for together with those stores, and the chain needs NKS weight fragments + two vectors per channel tile.
+template <int BCO>
+constexpr int chain_lds_bytes() { return BCO * BCO * 2 + 2 * BCO * 4; }
+
+template <int BCO, int NT>
+__device__ __forceinline__ void stage_chain(const StreamArgs &a, char *cl) {
+    constexpr int NKS = BCO / 32;
+    for (int p = threadIdx.x; p < BCO * BCO / 8; p += NT) {
+        const int row = p / (BCO / 8), c8 = p - row * (BCO / 8);
+        const int i2 = row >> 4, fj = row & 15, ks = c8 >> 2, fq = c8 & 3;
+        *reinterpret_cast<uint4 *>(cl + (((i2 * NKS + ks) * 4 + fq) * 16 + fj) * 16) =
+            *reinterpret_cast<const uint4 *>(a.w2 + (size_t)row * BCO + c8 * 8);
+    }
+    float *ss = reinterpret_cast<float *>(cl + BCO * BCO * 2);
+    for (int i = threadIdx.x; i < BCO; i += NT) {
+        ss[i] = a.scale2[i];
+        ss[BCO + i] = a.shift2[i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // before the counted-DMA regime starts; read after many barriers
+}
+
+template <int BCO, int TW, int EPI, int NF = 4, bool CL = false>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&acc)[BCO / 16][NF], int co_tile, int n, int y0,
-                                                int x0, const int (&frow)[NF], int fj, int fq) {
+                                                int x0, const int (&frow)[NF], int fj, int fq, const char *cl = nullptr) {
     constexpr int TCO = BCO / 16;
     if constexpr (EPI == SEPI_GRU) {
         // rows are (r,z,n) triples of 16 hidden channels: tiles 3g, 3g+1, 3g+2  (packing.pack_gru_stream)
@@ -138,10 +161,11 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             bf16x8_t w2f[NKS];
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
-                w2f[ks] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * BCO + ks * 32 + fq * 8);
+                w2f[ks] = CL ? *reinterpret_cast<const bf16x8_t *>(cl + (((i2 * NKS + ks) * 4 + fq) * 16 + fj) * 16)
+                             : *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * BCO + ks * 32 + fq * 8);
             const int co = i2 * 16 + fq * 4;
-            const float4 s2 = *reinterpret_cast<const float4 *>(a.scale2 + co);
-            const float4 t2 = *reinterpret_cast<const float4 *>(a.shift2 + co);
+            const float4 s2 = *reinterpret_cast<const float4 *>(CL ? reinterpret_cast<const float *>(cl + BCO * BCO * 2) + co : a.scale2 + co);
+            const float4 t2 = *reinterpret_cast<const float4 *>(CL ? reinterpret_cast<const float *>(cl + BCO * BCO * 2) + BCO + co : a.shift2 + co);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -430,6 +454,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int S = nchunks * 9;
     const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
     const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+    char *s_chain = smem + RING * SLICE_BYTES + 2 * PATCH8_BYTES;
+    if constexpr (EPI == SEPI_CHAIN) stage_chain<BCO, 512>(a, s_chain);
 
     // tile coordinates
     auto tile_coords = [&](int t, int &n, int &y0, int &x0) {
@@ -601,7 +627,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+        stream_epilogue<BCO, TW, EPI, 4, EPI == SEPI_CHAIN>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain);
         if (!has_next) break;
         tile = next;
         n = nn;
@@ -627,7 +653,7 @@ int v2x_num_cus() {   // also used by conv_halo_pair.hip
 
 template <int BCO, int EPI>
 static int launch_stream8(const StreamArgs &a, hipStream_t s) {
-    constexpr int smem = RING * BCO * 64 + 2 * PATCH8_BYTES;  // 112 KiB at BCO=128: one 8-wave workgroup per CU
+    constexpr int smem = RING * BCO * 64 + 2 * PATCH8_BYTES + (EPI == SEPI_CHAIN ? chain_lds_bytes<BCO>() : 0);  // 112 KiB at BCO=128 (+33 chained): one 8-wave workgroup per CU
     static bool attr_done = false;
     auto kern = &conv3x3_stream8_kernel<BCO, EPI>;
     if (!attr_done) {
@@ -698,6 +724,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int S = nchunks * 9;
     const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
     const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+    char *s_chain = smem + RING * SLICE_BYTES + WPATCH_BYTES;
+    if constexpr (EPI == SEPI_CHAIN) stage_chain<BCO, 256>(a, s_chain);
 
     // DMA descriptors of this wave's patch pieces (piece = wave + 4t) for the resolution of the chunk being filled;
     // rebuilt when the resolution changes (at most twice per tile)
@@ -821,12 +849,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
-    stream_epilogue<BCO, TW, EPI, NF>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+    stream_epilogue<BCO, TW, EPI, NF, EPI == SEPI_CHAIN>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain);
 }
 
 template <int BCO, int EPI>
 static int launch_wide(const StreamArgs &a, hipStream_t s) {
-    constexpr int smem = RING * BCO * 64 + WPATCH_BYTES;   // 55 KiB: two workgroups per CU
+    constexpr int smem = RING * BCO * 64 + WPATCH_BYTES + (EPI == SEPI_CHAIN ? chain_lds_bytes<BCO>() : 0);   // 55 KiB (+8.5 chained): two workgroups per CU
     static bool attr_done = false;
     auto kern = &conv3x3_wide_kernel<BCO, EPI>;
     if (!attr_done) {
