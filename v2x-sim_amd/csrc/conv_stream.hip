@@ -53,10 +53,6 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ float gru_sigmoid(float x) {
-    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.44269504088896341f));
-}
-
 // ---- epilogue shared by the 4-wave and the 8-wave kernels -------------------------------------------
 // Chained epilogue with its second-GEMM operands staged in LDS (stage_chain): [w2 in fragment order (i2, ks, fq, fj) x 16 B |
 // scale2 | shift2].  vmcnt is in-order: a global load issued between the stores of two output-channel tiles can only be
@@ -99,12 +95,9 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
                 float h[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    // gates through the hardware exp2 / rcp (1 ulp each): sigmoid(x) = rcp(1 + 2^(-x log2 e)),
-                    // tanh(y) = 2 sigmoid(2y) - 1.  The IEEE division and libm tanhf were ~70 % of this epilogue's
-                    // instructions; the result is rounded to bf16.
-                    const float rg = gru_sigmoid(acc[3 * g][f][r] + bias[r].x);
-                    const float zg = gru_sigmoid(acc[3 * g + 1][f][r] + bias[r].y);
-                    const float ng = 2.0f * gru_sigmoid(2.0f * (acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w)) - 1.0f;
+                    const float rg = 1.0f / (1.0f + __expf(-(acc[3 * g][f][r] + bias[r].x)));
+                    const float zg = 1.0f / (1.0f + __expf(-(acc[3 * g + 1][f][r] + bias[r].y)));
+                    const float ng = tanhf(acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w);
                     h[r] = ng + zg * (0.0f - ng);
                 }
                 uint2 o;
