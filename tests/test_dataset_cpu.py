@@ -55,3 +55,20 @@ def test_errors(tmp_path):
     os.makedirs(tmp_path / "empty")
     with pytest.raises(RuntimeError):
         V2XSimDet(dataset_roots=[str(tmp_path / "empty")], config=Config("test"), split="test")
+
+
+def test_prefetcher_host_logic():
+    """DevicePrefetcher (row f-2) host side: structure mapping, argument checks; the copies themselves need the GPU
+    (tests/test_gpu_prefetch.py)."""
+    import pytest
+    import torch
+    from v2x_sim_amd.datasets import DevicePrefetcher
+    from v2x_sim_amd.datasets.prefetch import _map
+    seen = []
+    out = _map({"a": [1, (2, 3)], "b": "x"}, lambda v: seen.append(v) or (v, type(v).__name__))
+    assert out == {"a": [(1, "int"), ((2, "int"), (3, "int"))], "b": ("x", "str")} and seen == [1, 2, 3, "x"]
+    with pytest.raises(RuntimeError):
+        DevicePrefetcher(iter([]), "cpu")
+    if not torch.cuda.is_available():
+        with pytest.raises(Exception):
+            DevicePrefetcher(iter([]), "cuda:0", depth=0)
