@@ -68,6 +68,10 @@ def test_tile_rows_and_validation_without_gpu():
     d = _lib.ConvDesc()
     assert lib.v2x_conv2d(ctypes.byref(d), None) == -22
     assert lib.v2x_warp_fuse(None, 5, 1, 32, 32, 256, None, None, 1, None, 0, None, None) == -22
+    assert lib.v2x_conv2d_pair(None, None, None) == -22 and b"null descriptor" in lib.v2x_last_error()
+    d2 = _lib.ConvDesc()
+    assert lib.v2x_conv2d_pair(ctypes.byref(d), ctypes.byref(d2), None) == -22     # not halo-packed 3x3 32 -> 32 layers
+    assert b"v2x_conv2d_pair" in lib.v2x_last_error()
     assert lib.v2x_voxelize_bits(None, None, 1, 1, 4, None, None, None, None, None) == -22
     assert lib.v2x_attn_handshake(None, None, None, None, 5, 1, 1024, 32, 0, 0.2, None, None, None) == -22
     with pytest.raises(_lib.V2XLibraryError):
