@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Headline benchmark: BEV frames/sec of V2VNet 5-agent detection on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1 without a launcher environment: this process starts `python -m torch.distributed.run --nproc-per-node N`
+      on itself BEFORE any GPU call and relays rank 0's JSON line and the exit code; under torchrun (WORLD_SIZE set)
+      it is a rank.  `--dry-run` walks launcher + rendezvous + shard plan + collective on gloo without a GPU.
 
 One step = one pass of the whole hot path over one batch of synthetic frames, inputs already
 resident in HBM:  LiDAR points -> voxel scatter (a1) -> encoder (a2) -> [RCCL all-gather of the
@@ -10,6 +13,10 @@ Work items are (agent, frame) maps sharded agent-major over the ranks (v2x_sim_a
 per-GPU work is fixed as N grows (weak scaling): frames = frames_per_gpu * N, run as two half-batches whose
 all-gathers are asynchronous and hidden under the other half's compute.
 
+Execution mode is the SAME for every N (`exec_mode` in the record): the step's four collective-free segments
+(encoder A, encoder B, fusion+decoder+heads A, ... B) are replayed from hipGraphs and the exchange runs between them
+(at N = 1 there is nothing to exchange), so the 1 -> 8 curve compares equals.
+
 Prints ONE JSON line (rank 0).  `roofline` is computed from HIP events recorded live around every
 kernel launch of an instrumented pass on the launch stream; `cpu_baseline` times the CPU oracle
 (oracle/, PyTorch-CPU fp32) on a bounded sample of the same workload.
@@ -17,6 +24,8 @@ kernel launch of an instrumented pass on the launch stream; `cpu_baseline` times
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,9 +43,11 @@ PEAK_HBM_GBS = 8000.0
 PEAK_MFMA_TFLOPS = 2500.0
 AGENTS = 5
 POINTS_PER_SWEEP = 65536
+# committed PMC traffic summaries, newest first (tools/profile_round.sh -> tools/pmc_traffic.py)
+TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -47,8 +58,14 @@ def parse():
     ap.add_argument("--gnn-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--graph", type=int, default=1, help="replay the step from a captured hipGraph (N=1 only)")
-    return ap.parse_args()
+    ap.add_argument("--graph", type=int, default=1,
+                    help="1: four hipGraph segments with the exchange between them (every N); 0: eager launches; "
+                         "2: the whole step as ONE hipGraph (N = 1 only, for comparison)")
+    ap.add_argument("--transport", choices=("allgather", "needed"), default="allgather",
+                    help="fusion-map exchange: RCCL all-gather (default) or grouped point-to-point of the needed rows only")
+    ap.add_argument("--no-extras", action="store_true", help="skip the latency and other-config sub-records")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: launcher, rendezvous (gloo), shard plan, collective, JSON relay")
+    return ap.parse_args(argv)
 
 
 def cpu_baseline(model_state, gnn_iters, budget_s=20.0):
@@ -85,18 +102,136 @@ def cpu_baseline(model_state, gnn_iters, budget_s=20.0):
                       "%d threads, after 1 warm-up frame" % (n, torch.get_num_threads())}
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, argv):
+    """Parent of an N > 1 run started as plain `python bench.py --gpus N`: starts the ranks as CHILD processes through
+    torch.distributed.run (one per GPU, RCCL over xGMI; 127.0.0.1 rendezvous) and relays their output.  Nothing here
+    touches the GPU -- a process that has initialised HIP must never be re-exec'd or forked into ranks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    record = None
+    for line in proc.stdout:
+        if line.startswith('{"metric"'):
+            record = line.rstrip("\n")          # printed last, after everything else the ranks wrote
+        else:
+            sys.stdout.write(line)
+    rc = proc.wait()
+    sys.stdout.flush()
+    if record is not None:
+        print(record, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the ranks exited 0 without a JSON record", file=sys.stderr)
+    return rc
+
+
+def dry_run(args, world, rank):
+    """CPU walk through everything around the kernels: rendezvous, agent-major partition, fusion plan, the exchange
+    calls (gloo instead of RCCL), barrier + max-over-ranks timing, one JSON line from rank 0."""
+    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    Bh = args.frames_per_gpu * world // 2
+    shard = AgentShard(AGENTS, Bh, rank, world)
+
+    class _NoModel:
+        gnn_iter_num, neighbor_source, layer = 1, "initial", 3
+    runner = ShardedV2VNet(_NoModel(), shard, transport=args.transport)
+    plan = shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), "cpu")
+    local = torch.stack([torch.full((2, 2, 8), float(r)) for r in shard.rows])  # fp32: row ids beyond 256 stay exact
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gathered, work = runner.start_exchange(local)
+        runner.wait(work)
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    # every map an owned ego reads (all agents of its frame) must sit at its agent-major row
+    ok = torch.tensor([int(all(float(gathered[j * Bh + f, 0, 0, 0]) == j * Bh + f
+                               for _, f in plan["items"].tolist() for j in range(AGENTS)))])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "BEV frames/sec, V2VNet 5-agent detection (256x256 BEV)", "value": None, "unit": "frames/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": world,
+                          "exchange_ok": bool(int(ok)), "transport": args.transport,
+                          "items_per_rank": shard.per_rank, "elapsed_s": float(t)}), flush=True)
+    return 0 if int(ok) else 1
+
+
+def measure_latency(model, dev, frames_list=(1, 8, 32), reps=30):
+    """Latency mode (SURVEY.md 8d batch sizes): ONE hipGraph replay of points -> logits for `frames` collaborative frames,
+    host-synchronised per replay, median over `reps`."""
+    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+    from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
+    out = {}
+    for frames in frames_list:
+        sh = AgentShard(AGENTS, frames, 0, 1)
+        rn = ShardedV2VNet(model, sh)
+        pts = torch.from_numpy(np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=5000 + r) for r in sh.rows])).to(dev)
+        n_pts = torch.full((sh.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=dev)
+        trans = torch.from_numpy(synthetic_poses(frames, AGENTS, seed=7)).to(dev)
+        plan = sh.fusion_plan(torch.full((frames, AGENTS), AGENTS), dev)
+        with torch.no_grad():
+            for _ in range(2):
+                rn.forward_points(pts, n_pts, trans, plan)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                res = rn.forward_points(pts, n_pts, trans, plan)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            g.replay()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        ts.sort()
+        out["b%d_ms" % frames] = ts[len(ts) // 2]
+        out["b%d_frames_per_s" % frames] = frames / ts[len(ts) // 2] * 1e3
+        del g, res
+    out["mode"] = "one hipGraph replay of points->logits per batch, host-synchronised, median of %d" % reps
+    return out
+
+
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        sys.exit(launch_ranks(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
-                             % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    if args.frames_per_gpu % 2:
+        raise SystemExit("--frames-per-gpu must be even (the step runs as two half-batches)")
+    if args.dry_run:
+        sys.exit(dry_run(args, world, rank))
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs the MI355X: the product path has no CPU fallback")
+        print("bench.py needs the MI355X: the product path has no CPU fallback (use --dry-run for the launcher walk)",
+              file=sys.stderr)
+        sys.exit(3)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # V2X_FORCE_DIST=1: exercise the RCCL code path (process group, bf16 all-gather, barrier, all-reduce) even with
@@ -114,26 +249,23 @@ def main():
     from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
     from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
 
-    if args.frames_per_gpu % 2:
-        raise SystemExit("--frames-per-gpu must be even (the step runs as two half-batches)")
     Bt = args.frames_per_gpu * world            # frames per step, whole job
     Bh = Bt // 2                                # frames per half-batch
     model = init_synthetic_weights(V2VNet(Config("test"), gnn_iter_times=args.gnn_iters, num_agent=AGENTS), seed=0)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    # The step is two independent half-batches of Bh frames, each agent-sharded over all ranks.  Half A's all-gather
+    L = model.layer
+    # The step is two independent half-batches of Bh frames, each agent-sharded over all ranks.  Half A's exchange
     # is started asynchronously and flies under half B's encoder; half B's flies under half A's fusion/decoder/heads.
     # The decomposition is the same for every N (at N = 1 there is simply nothing to gather): weak scaling.
     shard = AgentShard(AGENTS, Bh, rank, world)
-    runner = ShardedV2VNet(model, shard)
+    runner = ShardedV2VNet(model, shard, transport=args.transport)
     if force_dist and world == 1:
         class _ForcedWorld1(ShardedV2VNet):     # take the world > 1 code path (async RCCL all-gather) on one rank
-            def begin(self, points, n_pts):
-                pk = self.model.packed(points.device)
-                feats = self.encode_points(points, n_pts, pk)
-                local = feats[self.model.layer].contiguous()
-                out = torch.empty_like(local)
-                return feats, out, dist.all_gather_into_tensor(out, local, async_op=True)
+            def start_exchange(self, local, out=None, counts=None):
+                local = local.contiguous()
+                out = torch.empty_like(local) if out is None else out
+                return out, dist.all_gather_into_tensor(out, local, async_op=True)
         runner = _ForcedWorld1(model, shard)
     halves = []
     for h in range(2):
@@ -144,35 +276,82 @@ def main():
                        "trans": torch.from_numpy(synthetic_poses(Bh, AGENTS, seed=99 + h)).to(dev),
                        "plan": shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), dev)})
     model.packed(dev)
+    wait_events = []    # (start, end) HIP events around the stream-level wait for an exchange: the EXPOSED part of it
+
+    def timed_wait(work):
+        if work is None:
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        runner.wait(work)
+        e1.record()
+        wait_events.append((e0, e1))
 
     def step():
         with torch.no_grad():
             a, b = halves
-            fa = runner.begin(a["points"], a["n_pts"])
-            fb = runner.begin(b["points"], b["n_pts"])
-            out_a = runner.finish(*fa, a["trans"], a["plan"])
-            out_b = runner.finish(*fb, b["trans"], b["plan"])
+            fa, ga, wa = runner.begin(a["points"], a["n_pts"])
+            fb, gb, wb = runner.begin(b["points"], b["n_pts"])
+            timed_wait(wa)
+            out_a = runner.decode(fa, ga, a["trans"], a["plan"])
+            timed_wait(wb)
+            out_b = runner.decode(fb, gb, b["trans"], b["plan"])
             return out_a, out_b
 
     def barrier():
         if use_dist:
             dist.barrier()
 
-    for _ in range(max(args.warmup, 1) if args.graph and not use_dist else args.warmup):
+    for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
         out = step()
     torch.cuda.synchronize()
 
-    use_graph = bool(args.graph) and not use_dist
-    if use_graph:
+    mode = args.graph
+    if mode == 2 and use_dist:
+        raise SystemExit("--graph 2 (whole step in one hipGraph) is for N = 1 without V2X_FORCE_DIST")
+    if mode == 2:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             out = step()
         run = g.replay
-        for _ in range(2):
-            run()
+        exec_mode = "one hipGraph per step"
+    elif mode == 1:
+        # four collective-free segments, each a hipGraph on a shared pool (replayed in capture order); the exchange
+        # (RCCL, eager) runs between them on static buffers
+        pool = torch.cuda.graph_pool_handle()
+        with torch.no_grad():
+            for h in halves:
+                h["xbuf"] = None
+                if use_dist:
+                    h["xbuf"] = torch.empty((world * shard.per_rank, 32, 32, 256), dtype=torch.bfloat16, device=dev)
+            for h in halves:
+                h["g_enc"] = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(h["g_enc"], pool=pool):
+                    h["feats"] = runner.encode(h["points"], h["n_pts"])
+            for h in halves:
+                h["g_dec"] = torch.cuda.CUDAGraph()
+                gathered = h["xbuf"] if use_dist else h["feats"][L]
+                with torch.cuda.graph(h["g_dec"], pool=pool):
+                    h["out"] = runner.decode(h["feats"], gathered, h["trans"], h["plan"])
+
+        def run():
+            a, b = halves
+            a["g_enc"].replay()
+            _, wa = runner.start_exchange(a["feats"][L], out=a["xbuf"]) if use_dist else (None, None)
+            b["g_enc"].replay()
+            _, wb = runner.start_exchange(b["feats"][L], out=b["xbuf"]) if use_dist else (None, None)
+            timed_wait(wa)
+            a["g_dec"].replay()
+            timed_wait(wb)
+            b["g_dec"].replay()
+        exec_mode = "4 hipGraph segments per step (encoder A, encoder B, fusion+decoder+heads A, B); exchange between them"
     else:
         run = step
+        exec_mode = "eager launches"
+    for _ in range(2):
+        run()
     torch.cuda.synchronize()
+    wait_events.clear()
 
     barrier()
     torch.cuda.synchronize()
@@ -188,6 +367,16 @@ def main():
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     fps = Bt * args.steps / elapsed
+    # exposed exchange time per step on every rank (0 when the collective finished under the other half's compute)
+    exposed = sum(e0.elapsed_time(e1) for e0, e1 in wait_events) / max(args.steps, 1)
+    wait_events.clear()
+    exposed_all = [exposed]
+    if use_dist:
+        ex = torch.tensor([exposed], dtype=torch.float64, device=dev)
+        gl = [torch.zeros_like(ex) for _ in range(world)]
+        dist.all_gather(gl, ex)
+        exposed_all = [float(x) for x in gl]
+    ranks_seen = dist.get_world_size() if use_dist else 1
 
     roofline = None
     if not args.no_roofline:
@@ -219,22 +408,46 @@ def main():
                         "frac": achieved / PEAK_HBM_GBS, "traffic": None}
         # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE /
         # WRITE_SIZE, gfx950-corrected by tools/pmc_traffic.py); valid for the default workload (128 frames/GPU) only
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and args.frames_per_gpu == 128 and world == 1:  # 2 half-batches of 64 = the profiled launches
-            with open(tfile) as fh:
-                tk = json.load(fh)["kernels"].get(dom)
-            if tk:
-                roofline["traffic"] = tk["hbm_bytes_per_launch"]
+        roofline["traffic_source"] = None
+        for tname in TRAFFIC_FILES:
+            tfile = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tfile) and args.frames_per_gpu == 128:  # 2 half-batches of 64 = the profiled launches
+                with open(tfile) as fh:
+                    tk = json.load(fh)["kernels"].get(dom)
+                if tk:
+                    roofline["traffic"] = tk["hbm_bytes_per_launch"]
+                    roofline["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc passes of this workload; not re-measured in this run)" % tname
+                    break
         roofline.update({"kernel": dom, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                          "launches_per_step": d["launches"] // n_inst,
                          "share_of_kernel_time": d["ms"] / total_ms,
                          "alg_flops_per_launch": d["flops"] / d["launches"],
-                         "alg_bytes_per_launch": d["bytes"] / d["launches"]})
+                         "alg_bytes_per_launch": d["bytes"] / d["launches"],
+                         "timing": "HIP events around every launch of a separate EAGER pass of the same step (not the timed "
+                                   "graph replay; the per-kernel sum therefore exceeds ms_per_step by the event overhead)"})
         kernels = {k: {"us_per_step": v["ms"] * 1e3 / n_inst, "launches_per_step": v["launches"] // n_inst,
                        "tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "gbs": v["bytes"] / max(v["ms"], 1e-9) / 1e6}
                    for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
     else:
         kernels = None
+
+    latency = configs = None
+    if rank == 0 and world == 1 and not args.no_extras and not force_dist:
+        # free the step's graphs and buffers first: the extras build their own
+        for h in halves:
+            for k in ("g_enc", "g_dec", "feats", "out", "xbuf"):
+                h.pop(k, None)
+        out = run = None
+        torch.cuda.empty_cache()
+        latency = measure_latency(model, dev)
+        try:
+            import importlib.util
+            spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))
+            bc = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(bc)
+            configs = bc.run_configs(64, 5, dev)
+        except Exception as e:  # the headline record must not die with a side table
+            configs = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -250,11 +463,13 @@ def main():
                        "agents": AGENTS, "frames_per_step": Bt, "frames_per_gpu": args.frames_per_gpu,
                        "half_batches": 2,
                        "points_per_agent": POINTS_PER_SWEEP, "bev": [256, 256, 13],
-                       "sharding": "agent-major (agent,frame) items, contiguous slices; async RCCL all-gather of the fusion "
-                                   "maps of one half-batch overlapped with the other half's compute"
+                       "sharding": ("agent-major (agent,frame) items, contiguous slices; async RCCL %s of the fusion "
+                                    "maps of one half-batch overlapped with the other half's compute"
+                                    % ("all-gather" if args.transport == "allgather" else "grouped send/recv of the needed rows"))
                                    if world > 1 else "single GPU, no collective",
-                       "hip_graph": use_graph},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+                       "exec_mode": exec_mode, "hip_graph": bool(mode)},
+            "ranks_seen": ranks_seen, "exposed_exchange_ms_per_step": exposed_all,
+            "roofline": roofline, "cpu_baseline": cpu, "latency": latency, "configs": configs, "kernels": kernels,
         }
     if use_dist:
         dist.destroy_process_group()

@@ -1,0 +1,53 @@
+"""bench.py --gpus N must start its own ranks: run as plain `python bench.py --gpus 2 ...`, i.e.
+without a launcher environment, it spawns torch.distributed.run on itself before any GPU call, the ranks rendezvous on
+127.0.0.1, and the parent relays exactly one JSON line (last on stdout) plus the exit code.  `--dry-run` swaps RCCL for
+gloo and the kernels for a row-id exchange so the whole control path runs here."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(flags), cwd=ROOT, env=env,
+                          capture_output=True, text=True, timeout=600)
+
+
+@pytest.mark.parametrize("transport", ["allgather", "needed"])
+def test_self_launch_two_ranks_gloo_dry_run(transport):
+    p = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--transport", transport)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    rec = json.loads(lines[-1])                      # the record is the LAST stdout line
+    assert sum(ln.startswith('{"metric"') for ln in lines) == 1
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["dry_run"] and rec["exchange_ok"]
+    assert rec["items_per_rank"] == 5 * 64 and rec["transport"] == transport
+
+
+def test_n1_dry_run_needs_no_launcher():
+    p = _run("--gpus", "1", "--dry-run", "--steps", "2")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert json.loads(p.stdout.splitlines()[-1])["ranks_seen"] == 1
+
+
+def test_ranks_fail_loudly_without_a_gpu():
+    """Without --dry-run on a box without GPUs every rank stops at the 'needs the MI355X' check; the parent relays
+    a non-zero exit code and no record (never a CPU fallback number)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU box: the real run is the driver's")
+    p = _run("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert p.returncode != 0
+    assert "needs the MI355X" in p.stderr
+    assert not any(ln.startswith('{"metric"') for ln in p.stdout.splitlines())
+
+
+def test_world_size_mismatch_is_refused():
+    p = _run("--gpus", "2", "--dry-run", env_extra={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in p.stderr

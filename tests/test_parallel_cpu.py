@@ -97,3 +97,131 @@ def test_all_gather_exchange_gloo_world2():
 def test_exchange_world1_is_identity():
     t = torch.randn(3, 2, 2, 8)
     assert exchange_features(t, 1) is t
+
+
+# ------------------------------------------------------------------ point-to-point transports (SURVEY.md 8e "comm-sparsity path")
+def _check_plans(plans, needs, per_rank):
+    world = len(plans)
+    for r in range(world):
+        got = []
+        for src, lo, hi in plans[r]["recv"]:
+            assert lo // per_rank == (hi - 1) // per_rank == src != r, "a range crosses an owner boundary"
+            got += list(range(lo, hi))
+        own = set(range(r * per_rank, (r + 1) * per_rank))
+        assert sorted(got) == sorted(set(needs[r]) - own), "rank %d does not receive exactly what it needs" % r
+        assert plans[r]["rows"] == len(got)
+        for dst in range(world):  # pairwise: src's send list == dst's recv list, same order
+            s = [(lo, hi) for d, lo, hi in plans[r]["send"] if d == dst]
+            q = [(lo, hi) for sr, lo, hi in plans[dst]["recv"] if sr == r]
+            assert s == q and s == sorted(s)
+
+
+def test_row_exchange_plan_v2vnet_needed_rows():
+    from v2x_sim_amd.parallel import ShardedV2VNet
+    A = 5
+    for world, Bt in ((2, 2), (4, 4), (8, 8), (8, 64)):
+        class _M:
+            gnn_iter_num, neighbor_source = 1, "initial"
+        rn = ShardedV2VNet(_M(), AgentShard(A, Bt, 0, world), transport="needed")
+        plans = rn.needed_plan()
+        sh = rn.shard
+        needs = []
+        for r in range(world):
+            fr = {row % Bt for row in range(r * sh.per_rank, (r + 1) * sh.per_rank)}
+            needs.append([j * Bt + f for f in fr for j in range(A)])
+        _check_plans(plans, needs, sh.per_rank)
+        dense = (world - 1) * sh.per_rank
+        assert all(p["rows"] <= dense for p in plans)
+        if world == 8 and Bt == 64:  # 40 rows per rank cover 40 frames of one agent: 4 x 40 foreign maps instead of 7 x 40
+            assert max(p["rows"] for p in plans) == 160 < dense == 280
+    # ragged frame: agents beyond the count are neither egos nor sources
+    rn = ShardedV2VNet(_M(), AgentShard(A, 2, 0, 2), transport="needed")
+    plans = rn.needed_plan(counts=[5, 3])
+    assert not any(lo <= 3 * 2 + 1 < hi or lo <= 4 * 2 + 1 < hi for p in plans for _, lo, hi in p["recv"])
+
+
+def test_row_exchange_plan_when2com_sparsity():
+    from v2x_sim_amd.parallel import plan_row_exchange, when2com_needs
+    A, Bt, world = 5, 8, 4
+    g = torch.Generator().manual_seed(3)
+    coef = (torch.rand(Bt, A, A, generator=g) > 0.7).float() * torch.rand(Bt, A, A, generator=g)
+    counts = [5, 5, 4, 5, 2, 5, 5, 3]
+    sh = AgentShard(A, Bt, 0, world)
+    needs = when2com_needs(sh, coef, counts)
+    plans = plan_row_exchange(needs, sh.per_rank)
+    _check_plans(plans, needs, sh.per_rank)
+    # every needed row is justified by a non-zero coefficient of an ego the rank owns; nothing else travels
+    for r in range(world):
+        for row in needs[r]:
+            k, f = divmod(row, Bt)
+            egos = [q for q in range(counts[f]) if (q * Bt + f) // sh.per_rank == r and q != k]
+            assert k < counts[f] and any(float(coef[f, k, q]) != 0 for q in egos)
+    who2com = torch.zeros(Bt, A, A)
+    who2com[:, 0, :] = 1.0                     # everybody listens to agent 0 only
+    plans = plan_row_exchange(when2com_needs(sh, who2com, [A] * Bt), sh.per_rank)
+    assert sum(p["rows"] for p in plans) == sum(len({0 * Bt + (row % Bt) for row in range(r * 10, r * 10 + 10)} - set(range(r * 10, r * 10 + 10)))
+                                                for r in range(world))
+    assert plans[0]["rows"] == 0 and not plans[0]["recv"]  # rank 0 owns agent 0's maps itself
+
+
+def _sparse_worker(rank, world, port, A, Bt, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from v2x_sim_amd.parallel import ShardedV2VNet, ShardedWhen2com, plan_row_exchange, sparse_exchange, when2com_needs
+        shard = AgentShard(A, Bt, rank, world)
+        H, W, C = 4, 4, 8
+        mk = lambda rows: torch.stack([torch.full((H, W, C), float(r)) + torch.arange(C) / 16.0 for r in rows]).to(torch.bfloat16)  # noqa: E731
+        local = mk(shard.rows)
+        dense = exchange_features(local, world)                                   # the all-gather path = reference
+        # --- V2VNet "needed" transport
+        class _M:
+            gnn_iter_num, neighbor_source = 1, "initial"
+        rn = ShardedV2VNet(_M(), shard, transport="needed")
+        full, work = rn.start_exchange(local, out=torch.full((A * Bt, H, W, C), -1.0).to(torch.bfloat16))
+        rn.wait(work)
+        need = set(r for p in [rn.needed_plan()[rank]] for _, lo, hi in p["recv"] for r in range(lo, hi)) | set(shard.rows)
+        for r in range(A * Bt):
+            if r in need:
+                assert torch.equal(full[r].view(torch.int16), dense[r].view(torch.int16)), "row %d differs from the all-gather" % r
+            else:
+                assert float(full[r, 0, 0, 0]) == -1.0, "row %d travelled although nobody reads it" % r
+        # --- when2com sparse transport, byte-counted
+        g = torch.Generator().manual_seed(11)
+        coef = (torch.rand(Bt, A, A, generator=g) > 0.6).float()
+        counts = [A] * (Bt - 1) + [3]
+        rw = ShardedWhen2com(None, shard)
+        full = rw.fetch_maps(local, coef, counts, "activated")
+        needs = when2com_needs(shard, coef, counts)[rank]
+        for r in needs | set(shard.rows):
+            assert torch.equal(full[r].view(torch.int16), dense[r].view(torch.int16))
+        st = rw.last_comm
+        foreign = len(needs - set(shard.rows))
+        assert st["transport"] == "sparse" and st["rows_received"] == foreign
+        assert st["bytes_received"] == foreign * H * W * C * 2 < st["rows_allgather"] * H * W * C * 2
+        dense2 = rw.fetch_maps(local, coef, counts, "softmax")                    # dense weights: falls back to the all-gather
+        assert rw.last_comm["transport"] == "allgather" and torch.equal(dense2.view(torch.int16), dense.view(torch.int16))
+        sent = torch.tensor([st["bytes_sent"], st["bytes_received"]], dtype=torch.int64)
+        dist.all_reduce(sent)
+        assert int(sent[0]) == int(sent[1]), "bytes sent != bytes received over the job"
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sparse_transports_gloo_world2():
+    world, A, Bt = 2, 5, 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, A, Bt, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

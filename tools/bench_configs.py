@@ -21,11 +21,11 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--frames", type=int, default=64)
-    ap.add_argument("--reps", type=int, default=5)
-    args = ap.parse_args()
+def run_configs(frames=64, reps=5, dev=None):
+    """-> {"frames_per_launch", "agents", "points_per_agent", "configs": {name: {"ms_per_launch", "frames_per_s"}}}.
+    Called by bench.py (rank 0, N = 1) for the `configs` sub-record of the driver-visible line."""
+    import types
+    args = types.SimpleNamespace(frames=frames, reps=reps)
     from v2x_sim_amd import ops
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import FaFNet, V2VNet, When2com
@@ -33,7 +33,7 @@ def main():
     from v2x_sim_amd.models.seg import V2VNetSeg
     from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet, ShardedWhen2com
     from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
-    dev = torch.device("cuda:0")
+    dev = dev or torch.device("cuda:0")
     A, B = 5, args.frames
     cfg = Config("test")
     grid = ops.VoxelGrid()
@@ -123,8 +123,16 @@ def main():
         return ops.seg_argmax_confusion(logits, label)
     out["4 V2VNet segmentation (8 classes, argmax + confusion matrix)"] = timed(seg_step)
 
-    rec = {"frames_per_launch": B, "agents": A, "points_per_agent": 65536,
-           "configs": {k: {"ms_per_launch": v, "frames_per_s": B / v * 1e3} for k, v in out.items()}}
+    return {"frames_per_launch": B, "agents": A, "points_per_agent": 65536, "mode": "eager launches, points -> logits",
+            "configs": {k: {"ms_per_launch": v, "frames_per_s": B / v * 1e3} for k, v in out.items()}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    rec = run_configs(args.frames, args.reps)
     for k, v in rec["configs"].items():
         print("%-62s %8.2f ms  %8.0f frames/s" % (k, v["ms_per_launch"], v["frames_per_s"]))
     print(json.dumps(rec))
