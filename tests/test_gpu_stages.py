@@ -551,3 +551,26 @@ def test_pixel_weighted_fuse_vs_torch(device):
     ref = (w.unsqueeze(-1) * maps).sum(1)
     out = ops.pixel_weighted_fuse(scores.to(device), valid.to(device), maps.to(torch.bfloat16).to(device))
     assert torch.allclose(out.float().cpu(), bf16r(ref), atol=2e-3, rtol=2 ** -7)
+
+
+def test_voxelize_counts_beyond_capacity_and_bad_jobs(device, monkeypatch):
+    """n_pts[i] > max_pts must be clamped in EVERY form (the scatter kernels used to run into the next cloud),
+    and an early-fusion job naming a cloud / grid that does not exist is skipped, not executed out of bounds."""
+    from v2x_sim_amd import ops
+    grid = ops.VoxelGrid()
+    clouds = [VR.synthetic_points(4096, seed=300 + i, n_edge=16) for i in range(3)]
+    pts = torch.from_numpy(np.stack(clouds)).to(device)
+    over = torch.tensor([4096 + 5000, 4096, 1 << 30], dtype=torch.int32, device=device)   # counts beyond the capacity
+    exact = torch.full((3,), 4096, dtype=torch.int32, device=device)
+    ref = ops.voxelize_bits(pts, exact, grid).clone()
+    for form in ("1", "0"):
+        monkeypatch.setenv("V2X_VOXELIZE_LDS", form)
+        assert torch.equal(ops.voxelize_bits(pts, over, grid), ref), "form %s read past the cloud" % form
+    monkeypatch.delenv("V2X_VOXELIZE_LDS")
+    eye = torch.eye(4)[:3].unsqueeze(0).repeat(4, 1, 1).contiguous().to(device)
+    src = torch.tensor([0, 7, 1, -1], dtype=torch.int32, device=device)       # jobs 1 and 3 name clouds that do not exist
+    dst = torch.tensor([0, 0, 9, 1], dtype=torch.int32, device=device)        # job 2 names a grid that does not exist
+    got = ops.voxelize_fused_bits(pts, over, eye, src, dst, 2, grid)
+    assert torch.equal(got[0], ref[0]) and int(got[1].abs().sum()) == 0
+    with pytest.raises(ValueError, match="one count per cloud"):
+        ops.voxelize_bits(pts, exact[:2], grid)

@@ -123,3 +123,17 @@ def test_synthetic_poses_are_consistent():
 def test_seg_model_has_head():
     m = V2VNetSeg(Config("train"), n_classes=8)
     assert m.outc.conv.weight.shape == (8, 32, 1, 1)
+
+
+def test_voxelize_wrapper_validates_the_count_vector():
+    """ops.voxelize_bits / voxelize_fused_bits check n_pts against the number of clouds before any launch."""
+    import pytest
+    import torch
+    from v2x_sim_amd import ops
+    grid = ops.VoxelGrid()
+    pts = torch.zeros((3, 16, 4))
+    with pytest.raises(ValueError, match="one count per cloud"):
+        ops.voxelize_bits(pts, torch.zeros(2, dtype=torch.int32), grid)
+    with pytest.raises(ValueError, match="one count per cloud"):
+        ops.voxelize_fused_bits(pts, torch.zeros(4, dtype=torch.int32), torch.zeros((1, 3, 4)), torch.zeros(1, dtype=torch.int32),
+                                torch.zeros(1, dtype=torch.int32), 1, grid)

@@ -67,7 +67,8 @@ def main(argv=None):
         model = When2com(config, layer=args.layer, warp_flag=args.warp_flag, num_agent=A)
     if args.resume:
         ckpt = torch.load(args.resume, map_location="cpu")
-        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=False)
+        # strict: a checkpoint whose keys do not match must not be scored as if it had been loaded
+        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=True)
         model.eval()
     else:
         print("no --resume given: evaluating seeded synthetic weights (there is no released checkpoint in this tree)")
@@ -84,18 +85,11 @@ def main(argv=None):
         B = len(samples)
         bevs, trans, nat = collate_dense(samples)
         data = {"bev_seq": bevs.to(device), "trans_matrices": trans.to(device), "num_agent": nat}
-        if args.com in ("when2com", "who2com"):
-            with torch.no_grad():
-                result = model(data["bev_seq"], data["trans_matrices"], nat, training=False, inference=inference,
-                               batch_size=B)
-            cls, loc = result["cls"].float().cpu().numpy(), result["loc"].float().cpu().numpy()
-            seq = [[P.apply_nms_det(loc[k * B + b], cls[k * B + b], module.anchors, module.score_thr, module.nms_thr)
-                    for b in range(B)] for k in range(A)]
-        else:
-            _, _, _, seq = module.predict_all(data, B, validation=False, num_agent=A)
+        # one rule for every --com: predict_all returns a slot per (agent, frame), None where the agent's sweep is empty
+        _, _, _, seq = module.predict_all(data, B, validation=False, num_agent=A, inference=inference)
         for k in range(A):
             for b in range(B):
-                if b < len(seq[k]):
+                if seq[k][b] is not None:   # paired BY FRAME: frame b's detections meet frame b's ground truth
                     det_results[k].append(seq[k][b])
                     annotations[k].append(P.box_corners(samples[b][k][12].astype(np.float64)))
         if args.log:

@@ -46,7 +46,7 @@ def main(argv=None):
     args = build_parser().parse_args(argv)
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import CatFusion, DiscoNet, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
-    from v2x_sim_amd.train.loop import init_for_training, train_dataset, train_synthetic
+    from v2x_sim_amd.train.loop import init_for_training, make_optimizer, train_dataset, train_synthetic
     if not torch.cuda.is_available():
         raise SystemExit("train_codet.py needs the MI355X")
     config = Config("train", binary=True, only_det=True)
@@ -60,9 +60,10 @@ def main(argv=None):
         model = cls(config, layer=args.layer, kd_flag=0, num_agent=A)      # DiscoNet without the distillation teacher
     else:
         model = FaFNet(config, layer=args.layer, kd_flag=0, num_agent=A)
+    ckpt = None
     if args.resume:
         ckpt = torch.load(args.resume, map_location="cpu")
-        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=False)
+        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=True)  # a key mismatch must not train from init silently
     else:
         init_for_training(model, seed=args.seed)
     dataset = None
@@ -73,17 +74,34 @@ def main(argv=None):
         roots = [os.path.join(args.data, "agent%d" % k) for k in range(first, first + A)]
         dataset = V2XSimDet(dataset_roots=roots, config=config, split="train", densify="none")
         print("training on %d frames x %d agents from %s" % (len(dataset), A, args.data))
-    for epoch in range(1, args.nepoch + 1):
+    # ONE optimizer and ONE scheduler for the whole run (upstream keeps both across epochs): Adam's moments and the
+    # decay survive epoch boundaries, and both travel in the checkpoint.  --nepoch is the run's LAST epoch number, so a
+    # resumed run continues the numbering (and the schedule) where the checkpoint stopped.
+    model.to("cuda:0")
+    per_epoch = args.steps if dataset is None else (len(dataset) + args.batch - 1) // args.batch
+    opt, sched = make_optimizer(model, args.lr, args.nepoch * per_epoch)
+    start = 1
+    if ckpt is not None and "optimizer_state_dict" in ckpt:
+        opt.load_state_dict(ckpt["optimizer_state_dict"])
+        sched.load_state_dict(ckpt["scheduler_state_dict"])
+    if ckpt is not None and "epoch" in ckpt:
+        start = int(ckpt["epoch"]) + 1
+    if start > args.nepoch:
+        print("checkpoint is at epoch %d: nothing left to train up to --nepoch %d" % (start - 1, args.nepoch))
+    for epoch in range(start, args.nepoch + 1):
         if dataset is not None:
             hist = train_dataset(model, config, dataset, 1, args.batch, args.lr, seed=args.seed + epoch,
-                                 log=20 if args.log else None, num_workers=args.nworker)
+                                 log=20 if args.log else None, num_workers=args.nworker, opt=opt, sched=sched)
         else:
-            hist = train_synthetic(model, config, args.steps, args.batch, args.lr, seed=args.seed + epoch, log=20 if args.log else None)
+            hist = train_synthetic(model, config, args.steps, args.batch, args.lr, seed=args.seed + epoch,
+                                   log=20 if args.log else None, opt=opt, sched=sched)
         tail = hist[-20:]
-        print("epoch %d: mean loss of the last %d steps %.4f" % (epoch, len(tail), sum(h[0] for h in tail) / len(tail)))
+        print("epoch %d: mean loss of the last %d steps %.4f  lr %.2e" % (epoch, len(tail), sum(h[0] for h in tail) / len(tail),
+                                                                           opt.param_groups[0]["lr"]))
         if args.logpath:
             os.makedirs(args.logpath, exist_ok=True)
-            torch.save({"epoch": epoch, "model_state_dict": model.state_dict()}, os.path.join(args.logpath, "epoch_%d.pth" % epoch))
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": opt.state_dict(),
+                        "scheduler_state_dict": sched.state_dict()}, os.path.join(args.logpath, "epoch_%d.pth" % epoch))
     return model
 
 

@@ -30,6 +30,18 @@ void v2x_set_error(const char *fmt, ...);
         }                                                                        \
     } while (0)
 
+// One-time per-DEVICE setup (hipFuncSetAttribute is a per-device property: a process-global flag would leave the second
+// GPU of a process without its > 64 KiB dynamic-LDS opt-in).  hipGetDevice is a thread-local lookup, no driver call.
+#define V2X_MAX_DEVICES 32
+struct v2x_once_per_device { bool done[V2X_MAX_DEVICES]; };
+static inline bool v2x_first_use_on_device(v2x_once_per_device &o) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= V2X_MAX_DEVICES) return true;  // unknown device: just set it again
+    if (o.done[dev]) return false;
+    o.done[dev] = true;   // benign race: the attribute call is idempotent
+    return true;
+}
+
 // fp32 -> bf16, round-to-nearest-even (matches torch .to(torch.bfloat16) for finite values)
 __device__ __forceinline__ uint16_t f32_to_bf16_rne(float f) {
     uint32_t u = __float_as_uint(f);

@@ -492,11 +492,10 @@ static int launch_halo_sb(const HaloArgs &a, hipStream_t s) {
     // SLOWER with a 4th workgroup (628 / 577 / 649 us) and keep the padded 40-KiB allocation = 3 per CU.
     constexpr int smem = 9 * C1 / 8 * COUT * 16 + (BITS ? PH * PW * (C1 / 8) : round64(PH * PW * (C1 / 8))) * 16 +
                          (COUT2 == 0 ? 2 * COUT * 4 : 0);   // + scale/shift
-    static bool attr_done = false;
+    static v2x_once_per_device attr_once;
     auto kern = &conv3x3_halo_sb_kernel<C0, C1, COUT, COUT2, EPI2, BITS>;
-    if (!attr_done) {
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     int per_cu = (160 * 1024 - 2048) / smem;  // leave a little LDS slack: exactly-full allocations may not co-reside
     if (per_cu > 4) per_cu = 4;
@@ -514,11 +513,10 @@ static int launch_halo(const HaloArgs &a, hipStream_t s) {
     constexpr int NS0 = C0 ? round64(PH0 * PW0 * (C0 / 8)) : 0;
     constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16 + (COUT2 == 0 ? 2 * COUT * 4 : 0);
     static_assert(smem <= 160 * 1024, "LDS budget");
-    static bool attr_done = false;
+    static v2x_once_per_device attr_once;
     auto kern = &conv3x3_halo_kernel<C0, C1, COUT, COUT2, EPI2>;
-    if (!attr_done) {
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     const int per_cu = (160 * 1024) / smem >= 2 ? 2 : 1;
     int grid = 256 * per_cu;

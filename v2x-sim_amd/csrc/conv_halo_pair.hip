@@ -350,10 +350,9 @@ extern "C" int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *
     a.tiles_x = a.W / pair::TW;
     a.tiles_y = a.H / pair::TH;
     a.n_tiles = a.N * a.tiles_x * a.tiles_y;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static v2x_once_per_device attr_once;
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_pair_bits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pair::SMEM);
-        attr_done = true;
     }
     int grid = v2x_num_cus() * 2;
     if (grid > a.n_tiles) grid = a.n_tiles;

@@ -303,11 +303,10 @@ extern "C" int v2x_conv_tile_rows(int Cout, int epilogue) {
 template <int BCO, int BPX, int WCO, int WPX, int EPI>
 static int launch_cfg(const ConvArgs &a, hipStream_t s) {
     constexpr int smem = (BCO + BPX) * 128 * 2;
-    static bool attr_done = false;  // benign race: idempotent attribute
-    if (!attr_done) {
+    static v2x_once_per_device attr_once;
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv_igemm_kernel<BCO, BPX, WCO, WPX, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     const int n_co = a.w_rows / BCO;
     const int n_px = (a.M + BPX - 1) / BPX;

@@ -641,24 +641,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 int v2x_num_cus() {   // also used by conv_halo_pair.hip
     // hipDeviceGetAttribute, NOT hipGetDeviceProperties: one call of the latter anywhere in the process made EVERY kernel of
     // the step 4-8 % slower on the MI355X boxes (interleaved A/B, 4 250 vs 4 440 frames/s; a clock/power-state side effect)
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
-    }
-    return n;
+    static int n[V2X_MAX_DEVICES] = {0};   // per device, like the attribute caches
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= V2X_MAX_DEVICES) return 256;
+    if (n[dev] == 0)
+        n[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    return n[dev];
 }
 
 template <int BCO, int EPI>
 static int launch_stream8(const StreamArgs &a, hipStream_t s) {
     constexpr int smem = RING * BCO * 64 + 2 * PATCH8_BYTES + (EPI == SEPI_CHAIN ? chain_lds_bytes<BCO>() : 0);  // 112 KiB at BCO=128 (+33 chained): one 8-wave workgroup per CU
-    static bool attr_done = false;
+    static v2x_once_per_device attr_once;
     auto kern = &conv3x3_stream8_kernel<BCO, EPI>;
-    if (!attr_done) {
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     // persistent grid: one workgroup per CU, rounded down to a multiple of n_co_tiles so that a workgroup's tiles
     // (bid, bid + grid, ...) all belong to one channel tile; fewer tiles than CUs (or a channel-tile count that does not
@@ -855,11 +852,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int BCO, int EPI>
 static int launch_wide(const StreamArgs &a, hipStream_t s) {
     constexpr int smem = RING * BCO * 64 + WPATCH_BYTES + (EPI == SEPI_CHAIN ? chain_lds_bytes<BCO>() : 0);   // 55 KiB (+8.5 chained): two workgroups per CU
-    static bool attr_done = false;
+    static v2x_once_per_device attr_once;
     auto kern = &conv3x3_wide_kernel<BCO, EPI>;
-    if (!attr_done) {
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(256), smem, s, a);
     V2X_CHECK_LAUNCH("conv3x3_wide_kernel");
@@ -870,11 +866,10 @@ static int launch_wide(const StreamArgs &a, hipStream_t s) {
 template <int BCO, int TH, int TW, int EPI>
 static int launch_stream(const StreamArgs &a, hipStream_t s) {
     constexpr int smem = RING * BCO * 64 + 2 * PATCH_BYTES;  // 80 KiB at BCO=128: two workgroups per CU
-    static bool attr_done = false;
+    static v2x_once_per_device attr_once;
     auto kern = &conv3x3_stream_kernel<BCO, TH, TW, EPI>;
-    if (!attr_done) {
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(256), smem, s, a);
     V2X_CHECK_LAUNCH("conv3x3_stream_kernel");

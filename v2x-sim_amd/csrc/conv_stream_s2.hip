@@ -341,11 +341,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 static int launch_s2_resident(const S2Args &a, hipStream_t s) {
     constexpr int smem = 9 * 64 * 64 + S2_PATCH_BYTES + 512;   // 36 + 37 KiB + scale/shift
-    static bool attr_done = false;
+    static v2x_once_per_device attr_once;
     auto kern = &conv3x3_s2_resident_kernel<64>;
-    if (!attr_done) {
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     int grid = 512;                                       // two workgroups per CU
     if (grid > a.n_px_tiles) grid = a.n_px_tiles;
@@ -357,11 +356,10 @@ static int launch_s2_resident(const S2Args &a, hipStream_t s) {
 template <int BCO>
 static int launch_s2(const S2Args &a, hipStream_t s) {
     constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES + 2 * BCO * 4;
-    static bool attr_done = false;
+    static v2x_once_per_device attr_once;
     auto kern = &conv3x3_s2_stream_kernel<BCO>;
-    if (!attr_done) {
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(256), smem, s, a);
     V2X_CHECK_LAUNCH("conv3x3_s2_stream_kernel");

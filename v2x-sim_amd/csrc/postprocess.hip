@@ -177,10 +177,9 @@ extern "C" int v2x_det_postprocess(const float *cls, const float *loc, const flo
     hipLaunchKernelGGL(det_candidates_kernel, dim3(gx, n), dim3(256), 0, s, cls, n, M, score_thr, cap, key_scratch, count_scratch);
     V2X_CHECK_LAUNCH("det_candidates_kernel");
     const int smem = cap * 28;   // keys 8 B + stand-up boxes 16 B + kept list 4 B per candidate
-    static bool attr_done = false;
-    if (!attr_done) {
+    static v2x_once_per_device attr_once;
+    if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX_CAP * 28);
-        attr_done = true;
     }
     hipLaunchKernelGGL(det_nms_kernel, dim3(n), dim3(256), smem, s, loc, anchors, M, cap, nms_thr, key_scratch, count_scratch,
                        out_boxes, out_scores, out_index, out_count);

@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void voxelize_scatter_kernel(const float *__re
                                                                int pt_stride, VoxParams vp,
                                                                uint32_t *__restrict__ bits) {
     const int cloud = blockIdx.y;
-    const int n = n_pts[cloud];
+    const int n = min(n_pts[cloud], max_pts);   // a count beyond the cloud's capacity must not read the next cloud (same clamp as the LDS form)
     const float *base = pts + (size_t)cloud * max_pts * pt_stride;
     uint32_t *grid = bits + (size_t)cloud * vp.X * vp.Y;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -137,10 +137,14 @@ __global__ __launch_bounds__(256) void voxelize_fused_scatter_kernel(const float
                                                                      int pt_stride, const float *__restrict__ xform,
                                                                      const int32_t *__restrict__ src,
                                                                      const int32_t *__restrict__ dst, VoxParams vp,
-                                                                     uint32_t *__restrict__ bits) {
+                                                                     uint32_t *__restrict__ bits, int n_clouds,
+                                                                     int n_grids) {
     const int job = blockIdx.y;
     const int cloud = src[job];
-    const int n = n_pts[cloud];
+    // src / dst arrive as device data the host wrapper cannot inspect: a job naming a cloud or grid that does not
+    // exist is skipped instead of reading / writing out of bounds
+    if ((unsigned)cloud >= (unsigned)n_clouds || (unsigned)dst[job] >= (unsigned)n_grids) return;
+    const int n = min(n_pts[cloud], max_pts);
     const float *base = pts + (size_t)cloud * max_pts * pt_stride;
     const float *m = xform + (size_t)job * 12;
     uint32_t *grid = bits + (size_t)dst[job] * vp.X * vp.Y;
@@ -340,11 +344,10 @@ extern "C" int v2x_voxelize_bits(const float *pts, const int32_t *n_pts, int n_c
     if (!lds_off && vp.Z <= 16 && lds_bytes <= 128 * 1024 && ((size_t)vp.X * vp.Y) % 8 == 0 && max_pts > 0 &&
         (reinterpret_cast<uintptr_t>(bits) & 15) == 0) {
         const bool vec4 = pt_stride == 4 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0;
-        static bool attr_done = false;
-        if (!attr_done) {
+        static v2x_once_per_device attr_once;
+        if (v2x_first_use_on_device(attr_once)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(voxelize_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(voxelize_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-            attr_done = true;
         }
         if (vec4)
             hipLaunchKernelGGL(voxelize_lds_kernel<true>, dim3(n_clouds), dim3(VOX_LDS_THREADS), lds_bytes, s, pts, n_pts, max_pts, pt_stride, vp, bits);
@@ -466,7 +469,7 @@ extern "C" int v2x_voxelize_fused_bits(const float *pts, const int32_t *n_pts, i
     dim3 grid((max_pts + 255) / 256, n_jobs);
     if (grid.x > 256) grid.x = 256;
     hipLaunchKernelGGL(voxelize_fused_scatter_kernel, grid, dim3(256), 0, s, pts, n_pts, max_pts, pt_stride, xform,
-                       src_cloud, dst_grid, vp, bits);
+                       src_cloud, dst_grid, vp, bits, n_clouds, n_grids);
     V2X_CHECK_LAUNCH("voxelize_fused_scatter_kernel");
     return V2X_OK;
 }

@@ -102,6 +102,8 @@ def voxelize_bits(points, n_pts, grid, out=None):
     if points.dim() != 3:
         raise ValueError("points must be (n_clouds, max_pts, stride)")
     n, mp, st = points.shape
+    if tuple(n_pts.shape) != (n,):
+        raise ValueError("n_pts must hold one count per cloud: expected shape (%d,), got %s" % (n, tuple(n_pts.shape)))
     X, Y, Z = grid.dims
     if out is None:
         out = torch.empty((n, X, Y), dtype=torch.int32, device=points.device)
@@ -121,6 +123,8 @@ def voxelize_fused_bits(points, n_pts, xform, src_cloud, dst_grid, n_grids, grid
     lib = _lib.load()
     n, mp, st = points.shape
     n_jobs = xform.shape[0]
+    if tuple(n_pts.shape) != (n,):
+        raise ValueError("n_pts must hold one count per cloud: expected shape (%d,), got %s" % (n, tuple(n_pts.shape)))
     if tuple(xform.shape) != (n_jobs, 3, 4) or src_cloud.shape[0] != n_jobs or dst_grid.shape[0] != n_jobs:
         raise ValueError("xform (n_jobs, 3, 4), src_cloud (n_jobs,), dst_grid (n_jobs,) expected")
     X, Y, Z = grid.dims

@@ -49,14 +49,24 @@ def synthetic_batch_on_device(config, frames, agents, seed, device, grid=None, a
     return data
 
 
+def make_optimizer(model, lr, total_steps):
+    """Adam + the step-wise MultiStepLR (x0.3 at 60 % and 85 % of `total_steps`) every loop here uses.  Drivers that
+    train for several epochs create the pair ONCE over the whole run and hand it to the loops, so that Adam's moments and
+    the decay schedule survive epoch boundaries (and checkpoints)."""
+    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(total_steps * 0.6), int(total_steps * 0.85)], gamma=0.3)
+    return opt, sched
+
+
 def train_synthetic(model, config, steps, frames_per_step=2, lr=1e-3, seed=0, device="cuda:0", log=None, agents=None,
-                    **scene_kw):
-    """Adam on freshly generated synthetic scenes (never the same scene twice).  -> list of (loss, cls, loc)."""
+                    opt=None, sched=None, **scene_kw):
+    """Adam on freshly generated synthetic scenes (never the same scene twice).  -> list of (loss, cls, loc).
+    opt / sched: the run's optimizer and scheduler (make_optimizer); created here for a single self-contained run."""
     agents = agents or model.agent_num
     device = torch.device(device)
     model.to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
-    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(steps * 0.6), int(steps * 0.85)], gamma=0.3)
+    if opt is None:
+        opt, sched = make_optimizer(model, lr, steps)
     module = FaFModule(model, None, config, opt, 0)
     grid = ops.VoxelGrid(config.voxel_size, config.area_extents)
     hist = []
@@ -64,7 +74,8 @@ def train_synthetic(model, config, steps, frames_per_step=2, lr=1e-3, seed=0, de
         data = synthetic_batch_on_device(config, frames_per_step, agents, seed * 1000003 + it, device, grid, module.anchors,
                                          **scene_kw)
         hist.append(module.step(data, frames_per_step, agents))
-        sched.step()
+        if sched is not None:
+            sched.step()
         if log and (it % log == 0 or it == steps - 1):
             print("step %4d  loss %.4f  cls %.4f  loc %.4f" % ((it,) + hist[-1]), flush=True)
     model.eval()
@@ -102,25 +113,31 @@ def dataset_batch_on_device(samples, grid, anchors, device):
     return data
 
 
-def train_dataset(model, config, dataset, epochs=1, batch=2, lr=1e-3, seed=0, device="cuda:0", log=None, num_workers=0):
+def train_dataset(model, config, dataset, epochs=1, batch=2, lr=1e-3, seed=0, device="cuda:0", log=None, num_workers=0,
+                  opt=None, sched=None):
     """Adam over a parsed dataset (datasets.V2XSimDet, densify='none'), shuffled per epoch; upstream's
-    train_codet.py loop with the densify and the target scatter moved to the GPU.  -> list of (loss, cls, loc) per step."""
+    train_codet.py loop with the densify and the target scatter moved to the GPU.  -> list of (loss, cls, loc) per step.
+    opt / sched as in train_synthetic."""
     from torch.utils.data import DataLoader
     device = torch.device(device)
     model.to(device)
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    own = opt is None
+    if own:
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
     module = FaFModule(model, None, config, opt, 0)
     grid = ops.VoxelGrid(config.voxel_size, config.area_extents)
     loader = DataLoader(dataset, batch_size=batch, shuffle=True, drop_last=False, num_workers=num_workers,
                         collate_fn=lambda x: x, generator=torch.Generator().manual_seed(seed))
     steps = epochs * len(loader)
-    sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(steps * 0.6), int(steps * 0.85)], gamma=0.3)
+    if own:
+        sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(steps * 0.6), int(steps * 0.85)], gamma=0.3)
     hist = []
     for ep in range(epochs):
         for samples in loader:
             data = dataset_batch_on_device(samples, grid, module.anchors, device)
             hist.append(module.step(data, len(samples), len(samples[0])))
-            sched.step()
+            if sched is not None:
+                sched.step()
             if log and (len(hist) % log == 1 or len(hist) == steps):
                 print("epoch %d step %4d  loss %.4f  cls %.4f  loc %.4f" % ((ep + 1, len(hist)) + hist[-1]), flush=True)
     model.eval()

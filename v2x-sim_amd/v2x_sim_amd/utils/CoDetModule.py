@@ -68,13 +68,18 @@ class FaFModule(object):
                         "scores": scores[i, :count[i]]})
         return out
 
-    def predict_all(self, data, batch_size, validation=True, num_agent=5):
+    def predict_all(self, data, batch_size, validation=True, num_agent=5, inference="activated"):
         """data: dict with 'bev_seq' (A*B, 1, X, Y, Z), 'trans_matrices' (B, A, A, 4, 4),
         'num_agent' (B, A).  -> (loss, cls_loss, loc_loss, seq_results) with the losses None
-        (no labels are consumed at inference) and seq_results[k] = list of detections of agent k."""
+        (no labels are consumed at inference) and seq_results[k][b] = detections of agent k in frame b, or None when
+        that agent's BEV is empty (upstream skips such agents; the slot is kept so that callers pair detections with
+        ground truth BY FRAME, never by list position).  when2com / who2com models run in `inference` mode."""
         bev_seq = data["bev_seq"]
         with torch.no_grad():
-            if hasattr(self.model, "fuse") or hasattr(self.model, "handshake"):
+            if hasattr(self.model, "handshake"):
+                result = self.model(bev_seq, data["trans_matrices"], data["num_agent"], training=False, inference=inference,
+                                    batch_size=batch_size)
+            elif hasattr(self.model, "fuse"):
                 result = self.model(bev_seq, data["trans_matrices"], data["num_agent"], batch_size=batch_size)
             else:
                 result = self.model(bev_seq)
@@ -88,7 +93,9 @@ class FaFModule(object):
             for b in range(batch_size):
                 row = k * batch_size + b
                 if not occupied[row]:
+                    seq_results[k].append(None)
                     continue
                 seq_results[k].append(dets[row] if dets is not None else
                                       postprocess.apply_nms_det(loc[row], cls[row], self.anchors, self.score_thr, self.nms_thr))
+        self.last_result = result
         return None, None, None, seq_results
