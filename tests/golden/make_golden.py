@@ -128,9 +128,9 @@ def g_v2vnet_small():
 
 def g_postprocess():
     """Detection post-processing (build-owned spec): logits of a 32x32x6 anchor map with a few confident
-    blobs -> boxes / scores of the host function.  Pins the host spec against drift and is the known-answer test of
-    v2x_det_postprocess (tests/test_gpu_postprocess.py)."""
-    from v2x_sim_amd.utils import postprocess as P
+    blobs -> boxes / scores / kept anchor indices of the ORACLE (oracle/postprocess_ref.py, scalar float64 -- not the
+    product's utils/postprocess.py, which is checked against this fixture like the HIP kernel is)."""
+    from oracle import postprocess_ref as PR
     rng = np.random.default_rng(31)
     X = Y = 32
     A = 6
@@ -152,13 +152,17 @@ def g_postprocess():
                 s = 4.0 - 1.2 * (abs(dx) + abs(dy)) + rng.normal(0, 0.05)
                 cls[x + dx, y + dy, a] = (-s, s)
     cls = cls.astype(np.float32).reshape(-1, 2)
-    det = P.apply_nms_det(loc, cls, anc, 0.7, 0.01)
-    np.savez_compressed(os.path.join(HERE, "postprocess_small.npz"), cls=cls, loc=loc, anchors=anc, boxes=det["boxes"],
-                        scores=det["scores"], corners=det["corners"])
+    det = PR.detect(cls, loc.reshape(-1, 6), anc.reshape(-1, 6), 0.7, 0.01)
+    np.savez_compressed(os.path.join(HERE, "postprocess_small.npz"), cls=cls, loc=loc, anchors=anc,
+                        boxes=np.asarray([d["box"] for d in det], np.float64), scores=np.asarray([d["score"] for d in det], np.float64),
+                        corners=np.asarray([d["corners"] for d in det], np.float64), index=np.asarray([d["index"] for d in det], np.int32))
 
 
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    only = sys.argv[1:]
     for fn in (g_voxel, g_conv, g_warp, g_gru, g_attn, g_v2vnet_small, g_postprocess):
+        if only and fn.__name__ not in only:
+            continue
         fn()
         print("wrote", fn.__name__)

@@ -3,9 +3,9 @@ when2com/who2com, V2VNet-seg) running on the HIP kernels vs the build-owned CPU 
 same seeded synthetic inputs and weights.  PARITY UNPINNED w.r.t. the reference itself.
 
 Tolerances (bf16 storage / fp32 accumulate through ~25 layers), relative to max|ref|:
-    max|diff| <= 4e-2 * max|ref|   and   mean|diff| <= 5e-3 * max|ref|
+    max|diff| <= 2.5e-2 * max|ref|   and   mean|diff| <= 3e-3 * max|ref|
 against BOTH the fp32 oracle (the spec) and the bf16-emulating oracle.  Measured on MI355X
-(round 1): max 1.3-1.8e-2, mean 1.2-2.5e-3 for every model.  Per stage the emulating oracle is
+(round 1): max 1.3-1.8e-2, mean 1.2-2.5e-3 for every model; the bar is that + ~40 % (round 1 allowed 4e-2 / 5e-3).  Per stage the emulating oracle is
 matched to <= 1 bf16 ulp (tests/test_gpu_stages.py; the MFMA accumulation is as accurate as
 torch-CPU fp32 vs fp64, 0.005-0.025 % of outputs round differently per layer), but end to end each
 differently-rounded activation perturbs 9*Cout downstream sums and flips further roundings, so
@@ -23,8 +23,8 @@ from oracle import voxelize_ref as VR
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
-TOL_EMU = (4e-2, 5e-3)
-TOL_FP32 = (4e-2, 5e-3)
+TOL_EMU = (2.5e-2, 3e-3)
+TOL_FP32 = (2.5e-2, 3e-3)
 
 
 def check(got, ref, tol, what):
@@ -125,8 +125,10 @@ def test_v2vnet_golden_small(device):
     A = 3
     pm, _ = build(V2VNet, R.V2VNet, device, seed=3, pkw=dict(num_agent=A), okw=dict(num_agent=A))
     wsum = float(sum(p.double().abs().sum() for p in pm.state_dict().values()))
-    if not math.isclose(wsum, float(g["weight_abs_sum"]), rel_tol=1e-9):
-        pytest.skip("torch RNG stream differs from the one the fixture was generated with")
+    assert math.isclose(wsum, float(g["weight_abs_sum"]), rel_tol=1e-9), (
+        "the seeded synthetic weights differ from the ones tests/golden/v2vnet_small.npz was generated with (torch RNG "
+        "stream or init_synthetic_weights changed): regenerate with `python tests/golden/make_golden.py g_v2vnet_small` "
+        "and commit the fixture -- a silent skip would un-pin the end-to-end known-answer test")
     shape = tuple(int(v) for v in g["bev_shape"])
     bev = torch.from_numpy(np.unpackbits(g["bev"])[: int(np.prod(shape))].reshape(shape).astype(np.float32))
     with torch.no_grad():
@@ -138,32 +140,54 @@ def test_v2vnet_golden_small(device):
     check(cls, torch.from_numpy(g["cls_fp32"]), TOL_FP32, "golden cls (fp32)")
 
 
+def _separate_attention_scores(pm, om, bev, B):
+    """With random weights the 5-way softmax is ~0.2 everywhere = the 'activated' threshold, so which links are selected
+    is decided by bf16 noise and a comparison of the fused logits would be vacuous (VERDICT r1 'weak' #3).  Here the
+    attention layer (W, b of MIMOGeneralDotProductAttention.linear -- the same parameters on both sides) is SOLVED so
+    that, on this input, key . (W query + b) equals a designed logit matrix: per query the scores are a rotation of
+    (0.45, 0.33, 0.073, 0.073, 0.073) -- 0.12 away from the 0.2 threshold and from the runner-up, five times the
+    measured bf16 noise of the scores (<= 2e-2).  Keys / queries come from the fp32 oracle tower; frame 0 only."""
+    A = om.agent_num
+    with torch.no_grad():
+        qk = om.query_key_net(bev.permute(0, 1, 4, 2, 3), False)
+        K = torch.stack([om.key_net(qk, False)[B * i] for i in range(A)]).double()       # (A, 1024)
+        Q = torch.stack([om.query_net(qk, False)[B * i] for i in range(A)]).double()     # (A, 32)
+        base = torch.tensor([0.45, 0.33, 0.22 / 3, 0.22 / 3, 0.22 / 3], dtype=torch.float64)
+        target = torch.stack([torch.roll(base, q) for q in range(A)], 1).log()            # [key k][query q]
+        W = torch.linalg.pinv(K) @ target @ torch.linalg.pinv(Q.T)                         # K W Q^T == target exactly
+        for m in (pm, om):
+            lin = m.attention_net.linear
+            lin.weight.copy_(W.float().to(lin.weight.device))
+            lin.bias.zero_()
+    return target.softmax(0)
+
+
 @pytest.mark.parametrize("inference", ["softmax", "activated", "argmax_test"])
 def test_when2com(device, inference):
+    """BASELINE.json config 3 end to end: tower -> keys/queries -> handshake -> selection -> weighted warp -> decoder ->
+    heads.  The scores are separated by construction, so the selection is identical on both sides and the logits are
+    ALWAYS compared."""
     from v2x_sim_amd.models.det import When2com
     A, B = 5, 1
     pm, om = build(When2com, R.When2com, device)
     _, bev, T = make_inputs(A, B)
     nat = torch.full((B, A), A)
+    want = _separate_attention_scores(pm, om, bev, B)
     om.emulate_bf16 = True
     with torch.no_grad():
         got = pm(bev.to(device), T.to(device), nat, training=False, inference=inference, batch_size=B)
         ref = om(bev, T, nat, training=False, inference=inference, batch_size=B)
-    # attention scores: softmax of 1024-long key.query dot products fed by a 17-layer bf16 tower and a
-    # 4096-wide MLP -- the bf16 noise floor of the logits is amplified by the softmax; measured 8.9e-2
-    # of max|prob| (0.036 abs).  The handshake kernel itself is pinned to 1e-5 in test_gpu_stages.
-    check(got["prob_action"], ref["prob_action"], (2e-1, 6e-2), "when2com prob (%s)" % inference)
-    # the selection is discrete; compare the fused result only when both sides selected the same links
-    same = torch.equal(got["coef"].cpu() != 0, ref["coef"] != 0)
-    if same:
-        check(got["cls"], ref["cls"], TOL_EMU, "when2com cls (%s)" % inference)
-        check(got["loc"], ref["loc"], TOL_EMU, "when2com loc (%s)" % inference)
-        assert abs(got["num_connect"] - ref["num_connect"]) < 1e-9
-    else:
-        # a score within rounding distance of the 0.2 threshold / of the runner-up: legitimate
-        margin = (ref["prob_action"] - 0.2).abs().min() if inference == "activated" else \
-            (ref["prob_action"].topk(2, dim=1).values[:, 0] - ref["prob_action"].topk(2, dim=1).values[:, 1]).min()
-        assert float(margin) < 8e-2, "selection differs although no score is near the decision boundary"
+    dp = (got["prob_action"].cpu() - ref["prob_action"]).abs().max()
+    print("when2com prob (%s): max |HIP - oracle| %.3e, max |oracle - designed| %.3e"
+          % (inference, float(dp), float((ref["prob_action"][0].double() - want).abs().max())))
+    assert float(dp) <= 2e-2, "attention scores differ by %.3e" % float(dp)
+    assert torch.equal(got["coef"].cpu() != 0, ref["coef"] != 0), "HIP and oracle selected different links"
+    n_links = int((ref["coef"][0] != 0).sum())
+    assert n_links == {"softmax": 25, "activated": 10, "argmax_test": 5}[inference], ref["coef"]
+    check(got["coef"], ref["coef"], (5e-2, 1e-2), "when2com coef (%s)" % inference)
+    check(got["cls"], ref["cls"], TOL_EMU, "when2com cls (%s)" % inference)
+    check(got["loc"], ref["loc"], TOL_EMU, "when2com loc (%s)" % inference)
+    assert abs(got["num_connect"] - ref["num_connect"]) < 1e-9
 
 
 def test_v2vnet_seg(device):
