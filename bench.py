@@ -305,6 +305,8 @@ def main():
     for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
         out = step()
     torch.cuda.synchronize()
+    barrier()               # every rank's warm-up collectives are finished before anybody starts capturing
+    wait_events.clear()
 
     mode = args.graph
     if mode == 2 and use_dist:
@@ -318,7 +320,11 @@ def main():
     elif mode == 1:
         # four collective-free segments, each a hipGraph on a shared pool (replayed in capture order); the exchange
         # (RCCL, eager) runs between them on static buffers
+        # capture_error_mode="thread_local": RCCL's watchdog thread polls the events of earlier collectives while this
+        # thread captures -- under the default global mode that query is "operation not permitted when stream is
+        # capturing" and takes the process down (seen with V2X_FORCE_DIST=1 on one GPU)
         pool = torch.cuda.graph_pool_handle()
+        cap = dict(pool=pool, capture_error_mode="thread_local")
         with torch.no_grad():
             for h in halves:
                 h["xbuf"] = None
@@ -326,12 +332,12 @@ def main():
                     h["xbuf"] = torch.empty((world * shard.per_rank, 32, 32, 256), dtype=torch.bfloat16, device=dev)
             for h in halves:
                 h["g_enc"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(h["g_enc"], pool=pool):
+                with torch.cuda.graph(h["g_enc"], **cap):
                     h["feats"] = runner.encode(h["points"], h["n_pts"])
             for h in halves:
                 h["g_dec"] = torch.cuda.CUDAGraph()
                 gathered = h["xbuf"] if use_dist else h["feats"][L]
-                with torch.cuda.graph(h["g_dec"], pool=pool):
+                with torch.cuda.graph(h["g_dec"], **cap):
                     h["out"] = runner.decode(h["feats"], gathered, h["trans"], h["plan"])
 
         def run():

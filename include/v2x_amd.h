@@ -23,13 +23,14 @@
 #ifndef V2X_AMD_H
 #define V2X_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 5
+#define V2X_AMD_ABI_VERSION 6
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -134,10 +135,58 @@ typedef struct v2x_conv_desc {
     const uint16_t *weight2; /* bf16 [ceil16(Cout2)][Cout] row-major; `epilogue`/`split`/out* then  */
     const float *scale2; /*   describe the FINAL output, scale/shift/relu the hidden layer and     */
     const float *shift2; /*   scale2/shift2/relu2 (fp32 [ceil16(Cout2)]) the chained one.          */
-    int32_t relu2;       /*   weight rows must be in the chain order documented in conv_halo.hip.  */
+    int32_t relu2;       /*   weight rows must be in the chain order ("weight layouts" below).     */
     int32_t in_format;   /* 0: in0 is bf16 NHWC.  1 (w_layout 1, C0 == 32, C1 == 0 only): in0 is the voxelizer's  */
     int32_t in_zbits;    /*    uint32 bit grid [N][H][W]; bit z < in_zbits = channel z, expanded on the fly.      */
 } v2x_conv_desc;
+
+/* ---------------------------------------------------------------- weight layouts and their packers (HOST side)
+ * A checkpoint holds conv weights as fp32 OIHW [Cout][Cin][k][k] (the ConvGRU: weight_ih [3*hidden][Cin][3][3], gates in
+ * (r, z, n) order).  Every kernel reads bf16 (round-to-nearest-even) in one of three layouts, selected by
+ * v2x_conv_desc.w_layout.  With Cin' = Cin zero-padded to `cin_pad`, K = k*k*Cin' and the reduction index
+ * kk = (ky*k + kx)*Cin' + c  (tap-major, channels fastest, matching NHWC activations):
+ *
+ *   w_layout 0 (gather kernel, any shape):  [w_rows][w_kpad] row-major; w_rows = Cout rounded up to
+ *       v2x_conv_tile_rows(Cout, epilogue), w_kpad = K rounded up to 64, padding = zeros.  scale / shift hold w_rows floats.
+ *       GRU: w_rows = hidden/16*48; packed row g*48 + gate*16 + e holds source row gate*hidden + g*16 + e, i.e. the
+ *       (r, z, n) rows of 16 hidden channels are adjacent so that one wave owns all three gates of its channels; `scale`
+ *       is then float4 [hidden] = (b_ir + b_hr, b_iz + b_hz, b_in, b_hn)  (v2x_pack_gru_bias), `shift` unused.
+ *   w_layout 1 (halo kernel, 3x3 stride 1, Cin' % 32 == 0, Cout % 32 == 0):  k-slot-major [K/8][Cout][8]: element
+ *       (s, co, j) = W[co][kk = 8*s + j].  w_rows = Cout, w_kpad = K; scale / shift hold Cout floats in natural order.
+ *   w_layout 2 (streamed kernels, 3x3, Cin' % 32 == 0, Cout % 64 == 0 or GRU hidden % 32 == 0):  slices
+ *       [co_tile][Cin'/32][9 taps][4 slots][rows][8] with rows = v2x_conv_stream_tile_rows(Cout, epilogue): element
+ *       (t, ch, tap, slot, r, j) = W[t*rows + r][kk = tap*Cin' + 32*ch + 8*slot + j], followed by 64 B of zeros (the
+ *       kernel's zero page).  GRU rows in the (r, z, n)-triple order above (w_rows = 3*hidden); w_kpad = K.
+ *   chained layers (Cout2 > 0; layouts 1 and 2): the rows of the FIRST layer are stored in "chain order": packed row
+ *       rho = 16*i + 4*q + r holds output channel kappa = 32*(i>>1) + 8*q + 4*(i&1) + r (a lane's accumulators of the first
+ *       GEMM are then exactly its B fragment of the second); its scale / shift stay in natural channel order.  The chained
+ *       1x1 weights are bf16 [ceil16(Cout2)][Cout] row-major, scale2 / shift2 fp32 [ceil16(Cout2)]  (v2x_pack_chain_1x1).
+ *
+ * The packers below run on the HOST (no GPU call): query the size, allocate, pack, upload, fill the descriptor. */
+typedef struct v2x_pack_spec {
+    int32_t Cout;     /* output channels (GRU: hidden channels; the source tensor then has 3*Cout rows) */
+    int32_t Cin;      /* input channels of the source tensor                                             */
+    int32_t ksize;    /* 1 or 3                                                                          */
+    int32_t cin_pad;  /* 0 = Cin, else Cin zero-padded to this many channels (13 -> 32 for the first layer); % 8 == 0 */
+    int32_t w_layout; /* 0, 1 or 2 (above)                                                               */
+    int32_t epilogue; /* V2X_EPI_*: selects the row tile; V2X_EPI_GRU = (r, z, n) row regrouping           */
+    int32_t chain;    /* 1: the layer is followed by a chained 1x1 (Cout2 > 0): rows in chain order       */
+} v2x_pack_spec;
+
+/* Bytes of the packed bf16 buffer (0 = unsupported spec, see v2x_last_error) and the w_rows / w_kpad to put in the descriptor. */
+size_t v2x_pack_conv_size(const v2x_pack_spec *spec, int32_t *w_rows, int32_t *w_kpad);
+/* w_oihw: HOST fp32 [rows][Cin][k][k]; dst: HOST buffer of v2x_pack_conv_size bytes. */
+int v2x_pack_conv(const v2x_pack_spec *spec, const float *w_oihw, uint16_t *dst);
+/* Chained 1x1: w2 HOST fp32 [Cout2][Cout] -> dst_w bf16 [ceil16(Cout2)][Cout]; scale2 / shift2 (NULL = ones / zeros)
+ * -> fp32 [ceil16(Cout2)], zero beyond Cout2. */
+int v2x_pack_chain_1x1(int Cout2, int Cout, const float *w2, const float *scale2, const float *shift2, uint16_t *dst_w,
+                       float *dst_scale, float *dst_shift);
+/* ConvGRU biases (h0 = 0): bias_ih, bias_hh HOST fp32 [3*hidden] -> dst float4 [hidden] = (b_ir+b_hr, b_iz+b_hz, b_in, b_hn). */
+int v2x_pack_gru_bias(int hidden, const float *bias_ih, const float *bias_hh, float *dst);
+/* Eval-mode BatchNorm folded behind the fp32 accumulation: scale = gamma / sqrt(var + eps), shift = beta + scale*(conv_bias
+ * - mean); gamma == NULL: no BN (scale 1, shift = conv_bias).  Writes n_out >= C floats each, zeros beyond C. */
+int v2x_fold_bn(int C, int n_out, const float *conv_bias, const float *gamma, const float *beta, const float *mean,
+                const float *var, float eps, float *scale, float *shift);
 
 /* Rows-per-tile the kernel will use for (Cout, epilogue); the weight packer pads w_rows to a multiple. */
 int v2x_conv_tile_rows(int Cout, int epilogue);

@@ -1,0 +1,173 @@
+/* A non-Python caller of the C ABI: plain C99, no torch, no ctypes.
+ *
+ *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/c_abi_smoke.c \
+ *       -Lv2x-sim_amd/v2x_sim_amd/lib -lv2x_amd -L/opt/rocm/lib -lamdhip64 -lm -o c_abi_smoke
+ *   ./c_abi_smoke --pack-only      host part only (no GPU): packs one layer into w_layout 0 / 1 / 2 and checks every element
+ *                                  against the index formulas documented in include/v2x_amd.h ("weight layouts")
+ *   ./c_abi_smoke                  + uploads them, runs v2x_conv2d through the gather, halo and streamed kernels and
+ *                                  compares the three results with each other and with a float loop on the host
+ *
+ * The layer: 3x3 stride-1 conv 64 -> 64 + folded BN + ReLU on 2 x 32 x 64 NHWC bf16 maps (all three kernels cover it).
+ * Driven by tests/test_c_abi.py (build + --pack-only on the CPU box, full run under -m gpu). */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "v2x_amd.h"
+
+#define NB 2 /* maps */
+#define HH 32
+#define WW 64
+#define CIN 64
+#define COUT 64
+#define K (9 * CIN)
+
+static uint32_t rng_state = 12345u;
+static float frand(void) { /* xorshift in [-1, 1) */
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 17;
+    rng_state ^= rng_state << 5;
+    return (float)(rng_state & 0xffffff) / 8388608.0f - 1.0f;
+}
+static uint16_t to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float from_bf16(uint16_t h) {
+    uint32_t u = (uint32_t)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+#define CHECK(cond, ...)                  \
+    do {                                  \
+        if (!(cond)) {                    \
+            fprintf(stderr, __VA_ARGS__); \
+            fprintf(stderr, "\n");        \
+            return 1;                     \
+        }                                 \
+    } while (0)
+#define HIPOK(call) CHECK((call) == hipSuccess, "HIP call failed: %s", #call)
+
+int main(int argc, char **argv) {
+    const int pack_only = argc > 1 && strcmp(argv[1], "--pack-only") == 0;
+    CHECK(v2x_abi_version() == V2X_AMD_ABI_VERSION, "ABI version: library %d, header %d", v2x_abi_version(), V2X_AMD_ABI_VERSION);
+
+    /* ---- parameters as a checkpoint holds them: OIHW fp32 weight, conv bias, BN gamma/beta/mean/var */
+    float *w = (float *)malloc(sizeof(float) * COUT * CIN * 9);
+    float bias[COUT], gamma[COUT], beta[COUT], mean[COUT], var[COUT], scale[COUT], shift[COUT];
+    for (int i = 0; i < COUT * CIN * 9; ++i) w[i] = 0.06f * frand();
+    for (int c = 0; c < COUT; ++c) {
+        bias[c] = 0.1f * frand();
+        gamma[c] = 1.0f + 0.3f * frand();
+        beta[c] = 0.2f * frand();
+        mean[c] = 0.1f * frand();
+        var[c] = 0.5f + 0.4f * (frand() + 1.0f);
+    }
+    CHECK(v2x_fold_bn(COUT, COUT, bias, gamma, beta, mean, var, 1e-5f, scale, shift) == V2X_OK, "fold_bn: %s", v2x_last_error());
+
+    /* ---- pack into the three layouts */
+    uint16_t *packed[3];
+    size_t bytes[3];
+    int32_t rows[3], kpad[3];
+    for (int layout = 0; layout < 3; ++layout) {
+        v2x_pack_spec spec = {COUT, CIN, 3, 0, layout, V2X_EPI_BF16, 0};
+        bytes[layout] = v2x_pack_conv_size(&spec, &rows[layout], &kpad[layout]);
+        CHECK(bytes[layout] > 0, "pack_conv_size(layout %d): %s", layout, v2x_last_error());
+        packed[layout] = (uint16_t *)malloc(bytes[layout]);
+        CHECK(v2x_pack_conv(&spec, w, packed[layout]) == V2X_OK, "pack_conv(layout %d): %s", layout, v2x_last_error());
+    }
+    CHECK(rows[0] == 64 && kpad[0] == 576 && rows[1] == 64 && kpad[1] == K && rows[2] == 64 && kpad[2] == K, "unexpected w_rows / w_kpad");
+    CHECK(bytes[2] == (size_t)COUT * K * 2 + 64, "layout 2 must end with a 64-byte zero page");
+    /* every element, through the formulas of the header:  kk = (ky*3 + kx)*Cin + c */
+    const int tile = v2x_conv_stream_tile_rows(COUT, V2X_EPI_BF16);
+    CHECK(tile == 64, "stream tile rows %d", tile);
+    for (int co = 0; co < COUT; ++co)
+        for (int t = 0; t < 9; ++t)
+            for (int c = 0; c < CIN; ++c) {
+                const int kk = t * CIN + c;
+                const uint16_t want = to_bf16(w[(co * CIN + c) * 9 + t]);
+                const uint16_t l0 = packed[0][(size_t)co * kpad[0] + kk];
+                const uint16_t l1 = packed[1][((size_t)(kk / 8) * COUT + co) * 8 + kk % 8];
+                const int ch = c / 32, slot = (c % 32) / 8, j = c % 8, tl = co / tile, r = co % tile;
+                const uint16_t l2 = packed[2][(((((size_t)tl * (CIN / 32) + ch) * 9 + t) * 4 + slot) * tile + r) * 8 + j];
+                CHECK(l0 == want && l1 == want && l2 == want, "layout mismatch at co=%d tap=%d c=%d: %04x %04x %04x want %04x", co, t, c, l0, l1, l2, want);
+            }
+    for (int i = 0; i < 32; ++i) CHECK(packed[2][(size_t)COUT * K + i] == 0, "zero page not zero");
+    printf("pack OK: layouts 0 / 1 / 2 agree with the header's index formulas (%zu / %zu / %zu bytes)\n", bytes[0], bytes[1], bytes[2]);
+    if (pack_only) return 0;
+
+    /* ---- device run */
+    const size_t n_in = (size_t)NB * HH * WW * CIN, n_out = (size_t)NB * HH * WW * COUT;
+    uint16_t *x = (uint16_t *)malloc(n_in * 2);
+    for (size_t i = 0; i < n_in; ++i) x[i] = to_bf16(frand());
+    void *d_x, *d_scale, *d_shift, *d_w[3], *d_y[3];
+    HIPOK(hipMalloc(&d_x, n_in * 2));
+    HIPOK(hipMalloc(&d_scale, sizeof(scale)));
+    HIPOK(hipMalloc(&d_shift, sizeof(shift)));
+    HIPOK(hipMemcpy(d_x, x, n_in * 2, hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(d_scale, scale, sizeof(scale), hipMemcpyHostToDevice));
+    HIPOK(hipMemcpy(d_shift, shift, sizeof(shift), hipMemcpyHostToDevice));
+    hipStream_t stream;
+    HIPOK(hipStreamCreate(&stream));
+    uint16_t *y[3];
+    for (int layout = 0; layout < 3; ++layout) {
+        HIPOK(hipMalloc(&d_w[layout], bytes[layout]));
+        HIPOK(hipMalloc(&d_y[layout], n_out * 2));
+        HIPOK(hipMemcpy(d_w[layout], packed[layout], bytes[layout], hipMemcpyHostToDevice));
+        HIPOK(hipMemset(d_y[layout], 0xff, n_out * 2));
+        v2x_conv_desc d;
+        memset(&d, 0, sizeof(d));
+        d.in0 = (const uint16_t *)d_x;
+        d.C0 = CIN;
+        d.N = NB, d.H = HH, d.W = WW;
+        d.ksize = 3, d.stride = 1, d.pad = 1;
+        d.Cout = COUT, d.w_rows = rows[layout], d.w_kpad = kpad[layout];
+        d.weight = (const uint16_t *)d_w[layout];
+        d.scale = (const float *)d_scale, d.shift = (const float *)d_shift;
+        d.epilogue = V2X_EPI_BF16, d.relu = 1;
+        d.out = d_y[layout], d.out_cstride = COUT;
+        d.w_layout = layout;
+        CHECK(v2x_conv2d(&d, stream) == V2X_OK, "v2x_conv2d(layout %d): %s", layout, v2x_last_error());
+        HIPOK(hipStreamSynchronize(stream));
+        y[layout] = (uint16_t *)malloc(n_out * 2);
+        HIPOK(hipMemcpy(y[layout], d_y[layout], n_out * 2, hipMemcpyDeviceToHost));
+    }
+    /* host reference: fp32 accumulation over the same bf16 operands, then scale/shift, ReLU */
+    double worst[3] = {0, 0, 0};
+    size_t ulp_diff_12 = 0, diff_01 = 0;
+    for (int n = 0; n < NB; ++n)
+        for (int yy = 0; yy < HH; ++yy)
+            for (int xx = 0; xx < WW; ++xx)
+                for (int co = 0; co < COUT; ++co) {
+                    float acc = 0.0f;
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = yy + t / 3 - 1, ix = xx + t % 3 - 1;
+                        if (iy < 0 || iy >= HH || ix < 0 || ix >= WW) continue;
+                        const uint16_t *px = x + (((size_t)n * HH + iy) * WW + ix) * CIN;
+                        const uint16_t *wr = packed[0] + (size_t)co * kpad[0] + t * CIN;
+                        for (int c = 0; c < CIN; ++c) acc += from_bf16(px[c]) * from_bf16(wr[c]);
+                    }
+                    float ref = acc * scale[co] + shift[co];
+                    if (ref < 0.0f) ref = 0.0f;
+                    const size_t o = (((size_t)n * HH + yy) * WW + xx) * COUT + co;
+                    for (int l = 0; l < 3; ++l) {
+                        const double e = fabs((double)from_bf16(y[l][o]) - ref) / (fabs(ref) + 1e-2);
+                        if (e > worst[l]) worst[l] = e;
+                    }
+                    diff_01 += y[0][o] != y[1][o];
+                    const int du = (int)y[1][o] - (int)y[2][o];
+                    ulp_diff_12 += (du > 1 || du < -1);
+                }
+    printf("gather / halo / streamed kernel vs host float loop: worst relative error %.2e / %.2e / %.2e (bf16 ulp = 7.8e-3)\n", worst[0], worst[1], worst[2]);
+    printf("gather vs halo: %zu of %zu outputs differ;  halo vs streamed: %zu differ by more than one bf16 ulp\n", diff_01, n_out, ulp_diff_12);
+    CHECK(worst[0] < 1.2e-2 && worst[1] < 1.2e-2 && worst[2] < 1.2e-2, "a kernel is further than one bf16 rounding from the host reference");
+    CHECK(diff_01 == 0, "halo kernel is documented bit-identical to the gather kernel");
+    CHECK(ulp_diff_12 == 0, "streamed kernel differs from the halo kernel by more than one bf16 ulp");
+    printf("C ABI smoke OK\n");
+    return 0;
+}

@@ -161,3 +161,34 @@ def test_train_on_a_parsed_dataset_then_test(device, tmp_path, capsys):
     out = capsys.readouterr().out
     print(out[-300:])
     assert res[0.5] > 0.3, res
+
+
+def test_train_driver_keeps_optimizer_and_schedule_across_epochs_and_resume(device, tmp_path, capsys):
+    """one Adam + one MultiStepLR for the whole run (not per epoch), both in the checkpoint, --resume restores
+    them and continues the epoch numbering.  3 epochs x 10 steps: milestones at steps 18 and 25 -> lr 1e-3, 3e-4, 9e-5 at
+    the ends of epochs 1, 2, 3; a run resumed from epoch_1.pth ends with the same schedule state and never rewrites epoch_1."""
+    import importlib.util
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "det")
+    spec = importlib.util.spec_from_file_location("train_codet", os.path.join(tools, "train_codet.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    full, part = os.path.join(str(tmp_path), "full"), os.path.join(str(tmp_path), "part")
+    common = ["--data", "synthetic", "--com", "lowerbound", "--steps", "10", "--batch", "1", "--num_agent", "2"]
+    mod.main(common + ["--nepoch", "3", "--logpath", full])
+    lrs = []
+    for ep in (1, 2, 3):
+        ck = torch.load(os.path.join(full, "epoch_%d.pth" % ep), map_location="cpu")
+        assert ck["epoch"] == ep and {"model_state_dict", "optimizer_state_dict", "scheduler_state_dict"} <= set(ck)
+        assert ck["scheduler_state_dict"]["last_epoch"] == 10 * ep                      # the schedule never restarts
+        assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 10 * ep               # neither do Adam's moments
+        lrs.append(ck["optimizer_state_dict"]["param_groups"][0]["lr"])
+    assert lrs[0] == pytest.approx(1e-3) and lrs[1] == pytest.approx(3e-4) and lrs[2] == pytest.approx(9e-5)
+    capsys.readouterr()
+    mod.main(common + ["--nepoch", "3", "--logpath", part, "--resume", os.path.join(full, "epoch_1.pth")])
+    out = capsys.readouterr().out
+    assert "epoch 2 " in out and "epoch 3 " in out and "epoch 1 " not in out
+    assert not os.path.exists(os.path.join(part, "epoch_1.pth"))
+    ck = torch.load(os.path.join(part, "epoch_3.pth"), map_location="cpu")
+    assert ck["scheduler_state_dict"]["last_epoch"] == 30 and ck["optimizer_state_dict"]["param_groups"][0]["lr"] == pytest.approx(9e-5)
+    with pytest.raises(RuntimeError, match="Missing key|Unexpected key|size mismatch"):   # strict loading: a foreign checkpoint is refused
+        mod.main(["--data", "synthetic", "--com", "v2v", "--steps", "1", "--nepoch", "1", "--resume", os.path.join(full, "epoch_1.pth")])

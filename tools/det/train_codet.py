@@ -96,8 +96,8 @@ def main(argv=None):
             hist = train_synthetic(model, config, args.steps, args.batch, args.lr, seed=args.seed + epoch,
                                    log=20 if args.log else None, opt=opt, sched=sched)
         tail = hist[-20:]
-        print("epoch %d: mean loss of the last %d steps %.4f  lr %.2e" % (epoch, len(tail), sum(h[0] for h in tail) / len(tail),
-                                                                           opt.param_groups[0]["lr"]))
+        print("epoch %d (lr %.2e): mean loss of the last %d steps %.4f" % (epoch, opt.param_groups[0]["lr"], len(tail),
+                                                                           sum(h[0] for h in tail) / len(tail)))
         if args.logpath:
             os.makedirs(args.logpath, exist_ok=True)
             torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": opt.state_dict(),

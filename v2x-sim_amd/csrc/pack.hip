@@ -1,0 +1,179 @@
+// Host-side weight packing of libv2x_amd.so: OIHW fp32 parameters (what a PyTorch checkpoint holds) -> the bf16 device
+// layouts v2x_conv2d's kernels consume (include/v2x_amd.h, "weight layouts").  Pure host code, no HIP call: a C, C++ or
+// ctypes caller builds every `w_layout` buffer with these entry points, uploads it, and fills v2x_conv_desc from the
+// sizes v2x_pack_conv_size reports.  v2x_sim_amd/packing.py produces the same bytes with torch ops;
+// tests/test_pack_cpu.py holds the two to bit equality for every layout the models use.
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static inline uint16_t host_bf16_rne(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+static inline int ceil_to(int x, int m) { return (x + m - 1) / m * m; }
+
+// packed row rho = 16*i + 4*q + r of a layer with a chained 1x1 computes hidden channel kappa (conv_halo.hip: the lane's
+// accumulators of the first GEMM are then exactly its B fragment of the second)
+static inline int chain_kappa(int rho) {
+    const int i = rho >> 4, q = (rho >> 2) & 3, r = rho & 3;
+    return 32 * (i >> 1) + 8 * q + 4 * (i & 1) + r;
+}
+
+struct PackGeom {
+    int rows_src;   // rows of the source weight tensor (Cout, or 3*hidden for the GRU)
+    int cin_p;      // input channels after zero padding
+    int K;          // ksize*ksize*cin_p
+    int w_rows, w_kpad;
+    size_t elems;   // bf16 elements of the packed buffer
+    int tile;       // layout 2: rows per channel tile
+};
+
+static int pack_geometry(const v2x_pack_spec *p, PackGeom *g) {
+    V2X_REQUIRE(p, "v2x_pack_conv: null spec");
+    V2X_REQUIRE(p->Cout > 0 && p->Cin > 0 && (p->ksize == 1 || p->ksize == 3), "v2x_pack_conv: Cout, Cin > 0 and ksize in {1, 3}");
+    const bool gru = p->epilogue == V2X_EPI_GRU;
+    g->cin_p = p->cin_pad > 0 ? p->cin_pad : p->Cin;
+    V2X_REQUIRE(g->cin_p >= p->Cin && g->cin_p % 8 == 0, "v2x_pack_conv: cin_pad=%d must be >= Cin=%d and a multiple of 8", g->cin_p, p->Cin);
+    V2X_REQUIRE(!gru || p->Cout % 32 == 0, "v2x_pack_conv: GRU hidden size must be a multiple of 32");
+    V2X_REQUIRE(!(gru && p->chain), "v2x_pack_conv: the GRU epilogue has no chained layer");
+    g->rows_src = gru ? 3 * p->Cout : p->Cout;
+    g->K = p->ksize * p->ksize * g->cin_p;
+    g->tile = 0;
+    switch (p->w_layout) {
+    case 0: {
+        const int tile = v2x_conv_tile_rows(p->Cout, p->epilogue);
+        V2X_REQUIRE(!p->chain, "v2x_pack_conv: layout 0 (gather kernel) has no chained epilogue");
+        g->w_rows = gru ? p->Cout / 16 * 48 : ceil_to(p->Cout, tile);
+        g->w_kpad = ceil_to(g->K, 64);
+        g->elems = (size_t)g->w_rows * g->w_kpad;
+        return V2X_OK;
+    }
+    case 1:
+        V2X_REQUIRE(p->ksize == 3 && !gru && g->cin_p % 32 == 0 && p->Cout % 32 == 0,
+                    "v2x_pack_conv: layout 1 (halo kernel) needs 3x3, Cin (padded) %% 32 == 0, Cout %% 32 == 0, no GRU");
+        g->w_rows = p->Cout;
+        g->w_kpad = g->K;
+        g->elems = (size_t)g->K * p->Cout;
+        return V2X_OK;
+    case 2: {
+        g->tile = v2x_conv_stream_tile_rows(p->Cout, p->epilogue);
+        V2X_REQUIRE(p->ksize == 3 && g->tile > 0 && g->cin_p % 32 == 0,
+                    "v2x_pack_conv: layout 2 (streamed kernel) needs 3x3, Cin %% 32 == 0 and Cout %% 64 == 0 (GRU: hidden %% 32 == 0)");
+        V2X_REQUIRE(!p->chain || p->Cout == 64 || p->Cout == 128, "v2x_pack_conv: the streamed kernel chains only at Cout 64 / 128");
+        g->w_rows = g->rows_src;
+        g->w_kpad = g->K;
+        g->elems = (size_t)g->rows_src * g->K + 32;   // + 64 B of zeros: the kernel's zero page
+        return V2X_OK;
+    }
+    default:
+        v2x_set_error("v2x_pack_conv: w_layout=%d unknown", p->w_layout);
+        return V2X_EINVAL;
+    }
+}
+
+extern "C" size_t v2x_pack_conv_size(const v2x_pack_spec *spec, int32_t *w_rows, int32_t *w_kpad) {
+    PackGeom g;
+    if (pack_geometry(spec, &g) != V2X_OK) return 0;
+    if (w_rows) *w_rows = g.w_rows;
+    if (w_kpad) *w_kpad = g.w_kpad;
+    return g.elems * sizeof(uint16_t);
+}
+
+extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16_t *dst) {
+    PackGeom g;
+    const int rc = pack_geometry(p, &g);
+    if (rc != V2X_OK) return rc;
+    V2X_REQUIRE(w_oihw && dst, "v2x_pack_conv: null pointer");
+    const int ks = p->ksize, taps = ks * ks, cin = p->Cin, cin_p = g.cin_p, K = g.K;
+    const bool gru = p->epilogue == V2X_EPI_GRU;
+    const int hid = p->Cout;
+    // wk[row][k], k = (ky*ks + kx)*cin_p + c, rows in the order the kernel wants them
+    std::vector<uint16_t> wk((size_t)g.rows_src * K, 0);
+    for (int row = 0; row < g.rows_src; ++row) {
+        int src = row;
+        if (gru) {  // packed row grp*48 + gate*16 + e  <-  gate row gate*hid + grp*16 + e  ((r, z, n) triples per 16 channels)
+            const int grp = row / 48, gate = (row % 48) / 16, e = row % 16;
+            src = gate * hid + grp * 16 + e;
+        } else if (p->chain) {
+            src = chain_kappa(row);
+        }
+        const float *ws = w_oihw + (size_t)src * cin * taps;
+        uint16_t *wd = wk.data() + (size_t)row * K;
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < taps; ++t) wd[t * cin_p + c] = host_bf16_rne(ws[c * taps + t]);
+    }
+    memset(dst, 0, g.elems * sizeof(uint16_t));
+    if (p->w_layout == 0) {   // [w_rows][w_kpad] row-major, zero padded
+        for (int row = 0; row < g.rows_src; ++row) memcpy(dst + (size_t)row * g.w_kpad, wk.data() + (size_t)row * K, (size_t)K * 2);
+    } else if (p->w_layout == 1) {   // k-slot-major [K/8][Cout][8]
+        for (int s = 0; s < K / 8; ++s)
+            for (int co = 0; co < p->Cout; ++co) memcpy(dst + ((size_t)s * p->Cout + co) * 8, wk.data() + (size_t)co * K + s * 8, 16);
+    } else {   // streamed slices [co_tile][chunk][tap][slot][row][8], k = tap*cin + chunk*32 + slot*8 + j
+        const int n_tiles = g.rows_src / g.tile, n_chunks = cin_p / 32;
+        size_t o = 0;
+        for (int t = 0; t < n_tiles; ++t)
+            for (int ch = 0; ch < n_chunks; ++ch)
+                for (int tap = 0; tap < 9; ++tap)
+                    for (int slot = 0; slot < 4; ++slot)
+                        for (int r = 0; r < g.tile; ++r, o += 8)
+                            memcpy(dst + o, wk.data() + (size_t)(t * g.tile + r) * K + tap * cin_p + ch * 32 + slot * 8, 16);
+    }
+    return V2X_OK;
+}
+
+extern "C" int v2x_pack_chain_1x1(int Cout2, int Cout, const float *w2, const float *scale2, const float *shift2,
+                                  uint16_t *dst_w, float *dst_scale, float *dst_shift) {
+    V2X_REQUIRE(Cout2 > 0 && Cout > 0 && w2 && dst_w, "v2x_pack_chain_1x1: bad arguments");
+    const int rows = ceil_to(Cout2, 16);
+    memset(dst_w, 0, (size_t)rows * Cout * 2);
+    for (int r = 0; r < Cout2; ++r)
+        for (int c = 0; c < Cout; ++c) dst_w[(size_t)r * Cout + c] = host_bf16_rne(w2[(size_t)r * Cout + c]);
+    for (int r = 0; r < rows; ++r) {
+        if (dst_scale) dst_scale[r] = (r < Cout2 && scale2) ? scale2[r] : (r < Cout2 ? 1.0f : 0.0f);
+        if (dst_shift) dst_shift[r] = (r < Cout2 && shift2) ? shift2[r] : 0.0f;
+    }
+    return V2X_OK;
+}
+
+extern "C" int v2x_pack_gru_bias(int hidden, const float *bias_ih, const float *bias_hh, float *dst) {
+#pragma clang fp contract(off)
+    V2X_REQUIRE(hidden > 0 && bias_ih && bias_hh && dst, "v2x_pack_gru_bias: bad arguments");
+    for (int c = 0; c < hidden; ++c) {
+        dst[4 * c + 0] = bias_ih[c] + bias_hh[c];
+        dst[4 * c + 1] = bias_ih[hidden + c] + bias_hh[hidden + c];
+        dst[4 * c + 2] = bias_ih[2 * hidden + c];
+        dst[4 * c + 3] = bias_hh[2 * hidden + c];
+    }
+    return V2X_OK;
+}
+
+extern "C" int v2x_fold_bn(int C, int n_out, const float *conv_bias, const float *gamma, const float *beta, const float *mean,
+                           const float *var, float eps, float *scale, float *shift) {
+#pragma clang fp contract(off)   // torch rounds the product and the sum separately: no FMA here, or the last bit differs
+    V2X_REQUIRE(C > 0 && n_out >= C && scale && shift, "v2x_fold_bn: bad arguments");
+    const bool bn = gamma && beta && mean && var;
+    for (int c = 0; c < n_out; ++c) {
+        if (c >= C) {
+            scale[c] = shift[c] = 0.0f;
+            continue;
+        }
+        const float cb = conv_bias ? conv_bias[c] : 0.0f;
+        if (!bn) {
+            scale[c] = 1.0f;
+            shift[c] = cb;
+        } else {   // the order of torch's fp32 ops in packing.fold_bn: g / sqrt(var + eps);  b + s * (cb - mu)
+            const float s = gamma[c] / sqrtf(var[c] + eps);
+            scale[c] = s;
+            shift[c] = beta[c] + s * (cb - mean[c]);
+        }
+    }
+    return V2X_OK;
+}

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU = 0, 1, 2
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class ConvDesc(C.Structure):
@@ -31,6 +31,12 @@ class ConvDesc(C.Structure):
         ("weight2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("relu2", C.c_int32),
         ("in_format", C.c_int32), ("in_zbits", C.c_int32),
     ]
+
+
+class PackSpec(C.Structure):
+    """Mirror of `struct v2x_pack_spec` (include/v2x_amd.h)."""
+    _fields_ = [("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("cin_pad", C.c_int32),
+                ("w_layout", C.c_int32), ("epilogue", C.c_int32), ("chain", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/v2x_amd.h declares
@@ -52,6 +58,12 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_indices_to_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p]),
+    "v2x_pack_conv_size": (C.c_size_t, [C.POINTER(PackSpec), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "v2x_pack_conv": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_void_p]),
+    "v2x_pack_chain_1x1": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_pack_gru_bias": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_fold_bn": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                              C.c_void_p, C.c_void_p]),
     "v2x_conv_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "v2x_conv_stream_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "v2x_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
