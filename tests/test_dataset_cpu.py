@@ -72,3 +72,37 @@ def test_prefetcher_host_logic():
     if not torch.cuda.is_available():
         with pytest.raises(Exception):
             DevicePrefetcher(iter([]), "cuda:0", depth=0)
+
+
+def test_seg_dataset_layout_and_roundtrip(tmp_path):
+    """V2X-Sim-seg (README.md:66-79 lists it next to V2X-Sim-det): same tree, 0.npy additionally holds the class map."""
+    from v2x_sim_amd.datasets import V2XSimSeg, write_seg_sample
+    A, frames = 3, 2
+    pts = synthetic_points(A * frames, 2000, seed=5)
+    T = synthetic_poses(frames, A, seed=6)
+    rng = np.random.default_rng(0)
+    segs, grids = {}, {}
+    for f in range(frames):
+        for a in range(A):
+            grid, idx = VR.voxelize_occupy(pts[a * frames + f], return_indices=True)
+            seg = rng.integers(0, 8, (256, 256))
+            segs[(a, f)], grids[(a, f)] = seg, grid
+            write_seg_sample(str(tmp_path), "train", a, 11, f, idx, T[f, a], A, seg)
+    roots = [os.path.join(str(tmp_path), "train", "agent%d" % a) for a in range(A)]
+    assert os.path.isfile(os.path.join(roots[0], "11_1", "0.npy"))
+    ds = V2XSimSeg(dataset_roots=roots, config=Config("train"), split="train")
+    assert len(ds) == 2 and ds.seq_names == ["11_0", "11_1"]
+    s = ds[1]
+    for a in range(A):
+        pvp, seg, name, tid, ns, trans = s[a]
+        assert pvp.shape == (1, 256, 256, 13) and np.array_equal(pvp[0], grids[(a, 1)])
+        assert seg.dtype == np.uint8 and np.array_equal(seg, segs[(a, 1)])
+        assert name.endswith("11_1") and tid == a and ns == A and np.allclose(trans, T[1, a])
+    sparse = V2XSimSeg(dataset_roots=roots, config=Config("train"), split="train", densify="none")[0][2][0]
+    assert sparse.shape[1] == 3 and sparse.dtype == np.int32
+    # a det sample is not a seg sample; an out-of-range or mis-shaped class map is refused at write time
+    write_sample(str(tmp_path), "val", 0, 1, 0, np.zeros((1, 3), np.int32), T[0, 0], 1)
+    with pytest.raises(KeyError, match="bev_seg"):
+        V2XSimSeg(dataset_roots=[os.path.join(str(tmp_path), "val", "agent0")], config=Config("train"), split="val")[0]
+    with pytest.raises(ValueError):
+        write_seg_sample(str(tmp_path), "val", 0, 1, 1, np.zeros((1, 3), np.int32), T[0, 0], 1, np.full((256, 256), 300))

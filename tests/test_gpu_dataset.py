@@ -55,7 +55,7 @@ def test_dataset_dense_and_sparse_paths_agree(device, tmp_path):
     assert torch.equal(a["cls"], b["cls"]) and torch.equal(a["loc"], b["loc"])
 
 
-@pytest.mark.parametrize("com", ["v2v", "lowerbound", "who2com"])
+@pytest.mark.parametrize("com", ["v2v", "lowerbound", "upperbound", "who2com"])
 def test_test_codet_driver_runs_on_a_parsed_tree(device, tmp_path, com, capsys):
     """tools/det/test_codet.py (upstream flag surface) end to end on a synthetic parsed dataset + a saved checkpoint."""
     import importlib.util
@@ -69,11 +69,25 @@ def test_test_codet_driver_runs_on_a_parsed_tree(device, tmp_path, com, capsys):
     rng = np.random.default_rng(1)
     for f in range(frames):
         for a in range(A):
-            _, idx = VR.voxelize_occupy(pts[a * frames + f], return_indices=True)
+            if com == "upperbound":
+                # upstream's upperbound set stores the MERGED sweep of every agent (early fusion at data-creation time):
+                # here the HIP early-fusion voxeliser writes it (3 jobs into one grid), read back as the sparse index list
+                from v2x_sim_amd import ops
+                grid = ops.VoxelGrid()
+                cl = torch.from_numpy(np.stack([pts[j * frames + f] for j in range(A)])).to(device)
+                bits = ops.voxelize_fused_bits(cl, torch.full((A,), cl.shape[1], dtype=torch.int32, device=device),
+                                               torch.tensor(np.stack([T[f, a, j][:3] for j in range(A)]), dtype=torch.float32, device=device),
+                                               torch.arange(A, dtype=torch.int32, device=device),
+                                               torch.zeros(A, dtype=torch.int32, device=device), 1, grid)
+                ix, ct = ops.bits_to_indices(bits, grid.dims[2], 65536)
+                idx = ix[0, :int(ct[0])].cpu().numpy()
+                assert idx.shape[0] > VR.voxelize_occupy(pts[a * frames + f]).sum()
+            else:
+                _, idx = VR.voxelize_occupy(pts[a * frames + f], return_indices=True)
             gt = np.concatenate([rng.uniform(-25, 25, (6, 2)), np.tile([2.0, 4.0], (6, 1)), rng.uniform(-1, 1, (6, 1))], 1)
             write_sample(str(tmp_path), "test", a, 3, f, idx, T[f, a], A, gt_boxes=gt)
-    cls = {"v2v": V2VNet, "lowerbound": FaFNet, "who2com": When2com}[com]
-    kw = {"kd_flag": 0} if com == "lowerbound" else {}
+    cls = {"v2v": V2VNet, "lowerbound": FaFNet, "upperbound": FaFNet, "who2com": When2com}[com]
+    kw = {"kd_flag": 0} if com in ("lowerbound", "upperbound") else {}
     ckpt = os.path.join(str(tmp_path), "ckpt.pth")
     torch.save({"epoch": 1, "model_state_dict": init_synthetic_weights(cls(Config("test"), num_agent=A, **kw), seed=4).state_dict()}, ckpt)
     spec = importlib.util.spec_from_file_location("test_codet", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "det", "test_codet.py"))
@@ -192,3 +206,43 @@ def test_train_driver_keeps_optimizer_and_schedule_across_epochs_and_resume(devi
     assert ck["scheduler_state_dict"]["last_epoch"] == 30 and ck["optimizer_state_dict"]["param_groups"][0]["lr"] == pytest.approx(9e-5)
     with pytest.raises(RuntimeError, match="Missing key|Unexpected key|size mismatch"):   # strict loading: a foreign checkpoint is refused
         mod.main(["--data", "synthetic", "--com", "v2v", "--steps", "1", "--nepoch", "1", "--resume", os.path.join(full, "epoch_1.pth")])
+
+
+def test_seg_drivers_on_a_parsed_dataset(device, tmp_path, capsys):
+    """Row f-2 for segmentation: a V2X-Sim-seg tree (README.md:66-79 layout, 0.npy with 'bev_seg') written from synthetic scenes ->
+    tools/seg/train_seg.py --data <dir> (GPU densify shared with the det reader) -> tools/seg/test_seg.py --data <dir> --resume.
+    12 frames x 8 epochs learn the vehicle class well above chance; the confusion matrix counts every labelled cell once."""
+    import importlib.util
+    import sys
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.datasets import write_seg_sample
+    from v2x_sim_amd.utils import synthetic_scene
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "seg")
+    sys.path.insert(0, tools)
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(tools, name + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    A = 5
+    cfg = Config("train")
+    grid = ops.VoxelGrid()
+    root = os.path.join(str(tmp_path), "V2X-Sim-seg")
+    for split, frames, seed0 in (("train", 12, 41000), ("test", 3, 42000)):
+        for f in range(frames):
+            sc = synthetic_scene.make_scene(A, seed=seed0 + f)
+            bits = ops.voxelize_bits(torch.from_numpy(sc["points"]).to(device), torch.from_numpy(sc["n_pts"]).to(device), grid)
+            idx, cnt = ops.bits_to_indices(bits, grid.dims[2], 32768)
+            idx, cnt = idx.cpu().numpy(), cnt.cpu().numpy()
+            for a in range(A):
+                write_seg_sample(root, split, a, 5, f, idx[a, :cnt[a]], sc["trans"][a], A, synthetic_scene.seg_labels(sc["gt_boxes"][a], cfg))
+    logdir = os.path.join(str(tmp_path), "log")
+    load("train_seg").main(["--data", os.path.join(root, "train"), "--com", "v2v", "--nepoch", "8", "--batch", "2", "--logpath", logdir])
+    ck = torch.load(os.path.join(logdir, "epoch_8.pth"), map_location="cpu")
+    assert ck["epoch"] == 8 and "optimizer_state_dict" in ck
+    res = load("test_seg").main(["--data", os.path.join(root, "test"), "--com", "v2v", "--resume", os.path.join(logdir, "epoch_8.pth")])
+    print(capsys.readouterr().out[-400:])
+    assert int(res["confusion"].sum()) == 3 * A * 256 * 256
+    assert float(res["iou"][0]) > 0.95 and float(res["iou"][1]) > 0.25, res["iou"]

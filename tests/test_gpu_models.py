@@ -67,6 +67,43 @@ def test_fafnet_lowerbound(device):
     assert got["cls"].shape == (2, 256 * 256 * 6, 2) and got["loc"].shape == (2, 256, 256, 6, 1, 6)
 
 
+def test_upperbound_full_size_points_to_logits(device):
+    """BASELINE.json config 1 at its full size, end to end: 5 agents x 65 536 points, every ego grid = the union of all five
+    sweeps moved into the ego frame (25 transform + scatter jobs, ONE launch) -> FaFNet on the HIP path.  The occupancy
+    is bit-exact against the oracle's early fusion and the logits are inside the end-to-end tolerance of both oracles."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.models.det.base import LidarDecoder, LidarEncoder
+    from v2x_sim_amd.utils.synthetic import synthetic_poses
+    A, n = 5, 65536
+    clouds = [VR.synthetic_points(n, seed=500 + a, n_edge=64) for a in range(A)]
+    Tgeo = synthetic_poses(1, A, seed=17)[0]                                   # T[i, j]: agent j's frame -> agent i's frame
+    pm, om = build(FaFNet, R.FaFNet, device, seed=2)
+    pts = torch.from_numpy(np.stack(clouds)).to(device)
+    cnt = torch.full((A,), n, dtype=torch.int32, device=device)
+    xf = torch.tensor(np.stack([Tgeo[i, j][:3] for i in range(A) for j in range(A)]), dtype=torch.float32, device=device)
+    src = torch.tensor([j for i in range(A) for j in range(A)], dtype=torch.int32, device=device)
+    dst = torch.tensor([i for i in range(A) for j in range(A)], dtype=torch.int32, device=device)
+    grid = ops.VoxelGrid()
+    with torch.no_grad():
+        bits = ops.voxelize_fused_bits(pts, cnt, xf, src, dst, A, grid)
+        pk = pm.packed(device)
+        feats = LidarEncoder.run(pk["enc"], bits, zbits=grid.dims[2])            # conv_pre_1 reads the bit grid directly
+        got = pm.get_cls_loc_result(LidarDecoder.run(pk["dec"], *feats), pk["heads"])
+    ref_bev = np.stack([VR.voxelize_early_fusion(clouds, [Tgeo[i, j] for j in range(A)]) for i in range(A)])
+    assert np.array_equal(ops.bits_to_dense(bits, grid.dims[2]).cpu().numpy(), ref_bev), "merged occupancy is not bit-exact"
+    merged_occ = ref_bev.reshape(A, -1).sum(1)
+    single_occ = np.array([VR.voxelize_occupy(c).sum() for c in clouds])
+    assert (merged_occ > 2.5 * single_occ).all()                                 # the union really holds several sweeps
+    bev = torch.from_numpy(ref_bev)[:, None]
+    with torch.no_grad():
+        for emu, tol in ((True, TOL_EMU), (False, TOL_FP32)):
+            om.emulate_bf16 = emu
+            ref = om(bev)
+            check(got["cls"], ref["cls"], tol, "upperbound cls emu=%s" % emu)
+            check(got["loc"], ref["loc"], tol, "upperbound loc emu=%s" % emu)
+
+
 @pytest.mark.parametrize("gnn_iter,source", [(1, "initial"), (2, "updated")])
 def test_v2vnet(device, gnn_iter, source):
     from v2x_sim_amd.models.det import V2VNet

@@ -2,7 +2,8 @@
 """Segmentation evaluation driver -- the flag surface of upstream coperception/tools/seg/test_seg.py
 (/root/reference/README.md:101): model on the HIP path -> argmax + confusion matrix on the device -> per-class IoU / mIoU.
 
-    python tools/seg/test_seg.py --data synthetic --com v2v --resume out/epoch_1.pth --frames 8"""
+    python tools/seg/test_seg.py --data synthetic --com v2v --resume out/epoch_1.pth --frames 8
+    python tools/seg/test_seg.py --data /path/V2X-Sim-seg/test --com v2v --resume out/epoch_5.pth"""
 import argparse
 import os
 import sys
@@ -24,6 +25,7 @@ def build_parser():
     ap.add_argument("--frames", default=8, type=int)
     ap.add_argument("--batch", default=2, type=int)
     ap.add_argument("--seed", default=4242, type=int)
+    ap.add_argument("--rsu", default=1, type=int, help="parsed dataset: 1 = agent0 (the RSU) takes part, 0 = vehicles only")
     return ap
 
 
@@ -43,7 +45,7 @@ def main(argv=None):
     model = V2VNetSeg(config, num_agent=A) if args.com == "v2v" else FaFNetSeg(config, num_agent=A)
     if args.resume:
         ckpt = torch.load(args.resume, map_location="cpu")
-        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=False)
+        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=True)   # a key mismatch must not score init weights
     else:
         print("no --resume given: evaluating seeded synthetic weights")
         init_synthetic_weights(model, seed=0)
@@ -51,9 +53,18 @@ def main(argv=None):
     module = SegModule(model, None, config, None, 0)
     grid = ops.VoxelGrid(config.voxel_size, config.area_extents)
     conf = torch.zeros((model.n_classes, model.n_classes), dtype=torch.int64, device=device)
-    for start in range(0, args.frames, args.batch):
-        B = min(args.batch, args.frames - start)
-        data = seg_batch(config, B, A, args.seed + start, device, grid)
+    if args.data != "synthetic":
+        # parsed dataset (README.md:66-79): <data>/agent{k}/{scene}_{frame}/0.npy with 'bev_seg'
+        from v2x_sim_amd.datasets import V2XSimSeg, seg_batch_on_device
+        first = 0 if args.rsu else 1
+        roots = [os.path.join(args.data, "agent%d" % k) for k in range(first, first + A)]
+        dataset = V2XSimSeg(dataset_roots=roots, config=config, split="test", val=True, densify="none")
+        batches = ([dataset[i] for i in range(s0, min(s0 + args.batch, len(dataset)))] for s0 in range(0, len(dataset), args.batch))
+        batches = ((seg_batch_on_device(smp, grid, device), len(smp)) for smp in batches)
+    else:
+        batches = ((seg_batch(config, min(args.batch, args.frames - s0), A, args.seed + s0, device, grid),
+                    min(args.batch, args.frames - s0)) for s0 in range(0, args.frames, args.batch))
+    for data, B in batches:
         _, c = module.predict(data, batch_size=B, label=data["labels"].to(torch.uint8))
         conf += c
     iou = iou_from_confusion(conf.cpu())

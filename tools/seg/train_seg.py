@@ -3,6 +3,7 @@
 (/root/reference/README.md:101 points at it; the script itself is not in the reference tree).
 
     python tools/seg/train_seg.py --data synthetic --com v2v --steps 300 --batch 2 --logpath out/
+    python tools/seg/train_seg.py --data /path/V2X-Sim-seg/train --com v2v --nepoch 5 --batch 2 --logpath out/
 
 Synthetic scenes (utils/synthetic_scene.py: vehicle footprints as class 1), PyTorch-ROCm autograd over the HIP engine's
 parameter tree, checkpoint with upstream's 'model_state_dict' key for tools/seg/test_seg.py --resume."""
@@ -41,6 +42,8 @@ def build_parser():
     ap.add_argument("--logpath", default="", type=str)
     ap.add_argument("--seed", default=0, type=int)
     ap.add_argument("--log", action="store_true")
+    ap.add_argument("--rsu", default=1, type=int, help="parsed dataset: 1 = agent0 (the RSU) takes part, 0 = vehicles only")
+    ap.add_argument("--resume", default="", type=str)
     return ap
 
 
@@ -53,27 +56,52 @@ def main(argv=None):
     from v2x_sim_amd.utils.SegModule import SegModule
     if not torch.cuda.is_available():
         raise SystemExit("train_seg.py needs the MI355X")
-    if args.data != "synthetic":
-        raise SystemExit("only --data synthetic is wired up")
     device = torch.device("cuda:0")
     config = Config("train", binary=True, only_det=True)
     A = args.num_agent
     model = V2VNetSeg(config, num_agent=A) if args.com == "v2v" else FaFNetSeg(config, num_agent=A)
-    init_for_training(model, seed=args.seed)
+    ckpt = None
+    if args.resume:
+        ckpt = torch.load(args.resume, map_location="cpu")
+        model.load_state_dict(ckpt.get("model_state_dict", ckpt), strict=True)
+    else:
+        init_for_training(model, seed=args.seed)
     model.to(device)
+    loader = None
+    if args.data != "synthetic":
+        # parsed dataset in the README.md:66-79 layout: <data>/agent{k}/{scene}_{frame}/0.npy with 'bev_seg' (agent0 = RSU)
+        from torch.utils.data import DataLoader
+        from v2x_sim_amd.datasets import V2XSimSeg, seg_batch_on_device
+        first = 0 if args.rsu else 1
+        roots = [os.path.join(args.data, "agent%d" % k) for k in range(first, first + A)]
+        dataset = V2XSimSeg(dataset_roots=roots, config=config, split="train", densify="none")
+        loader = DataLoader(dataset, batch_size=args.batch, shuffle=True, collate_fn=lambda x: x,
+                            generator=torch.Generator().manual_seed(args.seed))
+        print("training on %d frames x %d agents from %s" % (len(dataset), A, args.data))
+    # one optimizer for the whole run, kept in the checkpoint (same rule as tools/det/train_codet.py)
     opt = torch.optim.Adam(model.parameters(), lr=args.lr)
+    start = 1
+    if ckpt is not None and "optimizer_state_dict" in ckpt:
+        opt.load_state_dict(ckpt["optimizer_state_dict"])
+    if ckpt is not None and "epoch" in ckpt:
+        start = int(ckpt["epoch"]) + 1
     module = SegModule(model, None, config, opt, 0)
     grid = ops.VoxelGrid(config.voxel_size, config.area_extents)
-    for epoch in range(1, args.nepoch + 1):
+    for epoch in range(start, args.nepoch + 1):
         losses = []
-        for it in range(args.steps):
-            losses.append(module.step(seg_batch(config, args.batch, A, (args.seed + epoch) * 1000003 + it, device, grid), A, args.batch))
-            if args.log and it % 20 == 0:
-                print("step %4d  loss %.4f" % (it, losses[-1]), flush=True)
+        if loader is not None:
+            for samples in loader:
+                losses.append(module.step(seg_batch_on_device(samples, grid, device), len(samples[0]), len(samples)))
+        else:
+            for it in range(args.steps):
+                losses.append(module.step(seg_batch(config, args.batch, A, (args.seed + epoch) * 1000003 + it, device, grid), A, args.batch))
+                if args.log and it % 20 == 0:
+                    print("step %4d  loss %.4f" % (it, losses[-1]), flush=True)
         print("epoch %d: mean loss of the last 20 steps %.4f" % (epoch, float(np.mean(losses[-20:]))))
         if args.logpath:
             os.makedirs(args.logpath, exist_ok=True)
-            torch.save({"epoch": epoch, "model_state_dict": model.state_dict()}, os.path.join(args.logpath, "epoch_%d.pth" % epoch))
+            torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optimizer_state_dict": opt.state_dict()},
+                       os.path.join(args.logpath, "epoch_%d.pth" % epoch))
     model.eval()
     return model
 
