@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 6
+#define V2X_AMD_ABI_VERSION 7
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -264,6 +264,29 @@ int v2x_det_postprocess(const float *cls, const float *loc, const float *anchors
                         float nms_thr, int cap, float *out_boxes, float *out_scores, int32_t *out_index,
                         int32_t *out_count, unsigned long long *key_scratch, int32_t *count_scratch,
                         v2x_stream_t stream);
+
+/* Same, but the greedy suppression compares the ROTATED boxes (convex-polygon IoU in fp64; the stand-up overlap is only the
+ * cheap reject).  Upstream's apply_nms_det suppresses on stand-up boxes (v2x_det_postprocess); this is the variant SURVEY.md
+ * row f-1 lists ("rotated-box NMS"). */
+int v2x_det_postprocess_rotated(const float *cls, const float *loc, const float *anchors, int n, int M, float score_thr,
+                                float nms_thr, int cap, float *out_boxes, float *out_scores, int32_t *out_index,
+                                int32_t *out_count, unsigned long long *key_scratch, int32_t *count_scratch,
+                                v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- f-1: the metric (coperception/utils/mean_ap.py::eval_map)
+ * Upstream intersects shapely polygons on the host; here the IoU of rotated boxes (x, y, w, h, yaw) is a convex clip in
+ * fp64 on the device.
+ * v2x_rotated_iou: boxes_a fp32 [na][5], boxes_b fp32 [nb][5] -> iou fp32 [na][nb]. */
+int v2x_rotated_iou(const float *boxes_a, int na, const float *boxes_b, int nb, float *iou, v2x_stream_t stream);
+/* v2x_match_detections: eval_map's per-image matching (mmdet tpfp_default).  det_boxes fp32 [n_img][det_cap][5] in DESCENDING
+ * score order (what v2x_det_postprocess emits), det_count int32 [n_img]; gt_boxes fp32 [n_img][gt_cap][5], gt_count int32
+ * [n_img] (gt_cap <= 8192).  Each detection takes the ground truth of highest IoU (lowest index on ties) and is a true positive
+ * iff IoU >= iou_thr and that box is still free.  tp int32 [n_img][det_cap] (1 / 0; entries >= det_count untouched),
+ * best_iou fp32 [n_img][det_cap] or NULL.  AP itself = a sort + two cumulative sums over (score, tp) of all images: the
+ * caller's (v2x_sim_amd/utils/postprocess.py::average_precision). */
+int v2x_match_detections(const float *det_boxes, const int32_t *det_count, int det_cap, const float *gt_boxes,
+                         const int32_t *gt_count, int gt_cap, int n_img, float iou_thr, int32_t *tp, float *best_iou,
+                         v2x_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -68,11 +68,11 @@ def aabb_iou(a, b):
     return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
 
 
-def detect(cls, loc, anchors, score_thr=SCORE_THR, nms_thr=NMS_THR):
+def detect(cls, loc, anchors, score_thr=SCORE_THR, nms_thr=NMS_THR, rotated=False):
     """One map.  cls [M][2] logits, loc [M][6] codes, anchors [M][6] (any nested sequence / array).
     -> list of dict(index, score, box (x, y, w, h, yaw), corners) in the order the detections are kept:
     score descending, ties by anchor index ascending; a candidate is dropped iff its stand-up box overlaps an
-    already KEPT one with IoU > nms_thr."""
+    already KEPT one with IoU > nms_thr.  rotated=True (not upstream's default): the IoU of the rotated boxes themselves."""
     cand = []
     for i in range(len(cls)):
         s = fg_score(float(cls[i][0]), float(cls[i][1]))
@@ -84,7 +84,10 @@ def detect(cls, loc, anchors, score_thr=SCORE_THR, nms_thr=NMS_THR):
         box = decode_faf(loc[i], anchors[i])
         cor = corners_of(box)
         sb = standup_of(cor)
-        if any(aabb_iou(sb, k["standup"]) > nms_thr for k in kept):
+        if rotated:
+            if any(aabb_iou(sb, k["standup"]) > 0.0 and rotated_iou(cor, k["corners"]) > nms_thr for k in kept):
+                continue
+        elif any(aabb_iou(sb, k["standup"]) > nms_thr for k in kept):
             continue
         kept.append({"index": i, "score": -neg_s, "box": box, "corners": cor, "standup": sb})
     return kept

@@ -72,9 +72,18 @@ def test_device_postprocess_equals_oracle(device):
         dev.append({"boxes": b, "scores": scores[i, :count[i]].cpu().numpy(),
                     "corners": P.box_corners(b) if count[i] else np.zeros((0, 4, 2), np.float32)})
     ref = [_oracle_dets(cls[i], loc[i], anchors, 0.7, 0.01) for i in range(n)]
+    for i in range(n):
+        # the kept ANCHORS are the comparison key: the kernel ranks by its fp32 score, the oracle by a float64 one, so two
+        # candidates whose scores agree to the last fp32 bit may swap places -- allowed only there
+        di, ri = index[i, :count[i]].cpu().numpy().astype(np.int64), ref[i]["index"]
+        assert np.array_equal(np.sort(di), np.sort(ri)), "map %d: kept anchor sets differ" % i
+        pos = {int(a): k for k, a in enumerate(ri)}
+        perm = np.array([pos[int(a)] for a in di], dtype=np.int64)
+        moved = np.nonzero(perm != np.arange(perm.size))[0]
+        for k in moved:
+            assert abs(ref[i]["scores"][perm[k]] - ref[i]["scores"][k]) < 2e-7, (i, k, perm[k])
+        dev[i] = {key: (v[np.argsort(perm)] if v.shape[0] == perm.size else v) for key, v in dev[i].items()}
     _compare(dev, ref)
-    for i in range(n):    # the kept anchors themselves, in order
-        assert np.array_equal(index[i, :count[i]].cpu().numpy(), ref[i]["index"]), i
 
 
 def test_candidate_overflow_is_reported(device):
@@ -138,3 +147,86 @@ def test_device_postprocess_golden(device):
     assert np.allclose(boxes[0, :n].cpu().numpy(), g["boxes"], atol=1e-4)
     assert np.allclose(scores[0, :n].cpu().numpy(), g["scores"], atol=1e-6)
     assert np.array_equal(index[0, :n].cpu().numpy(), g["index"])
+
+
+def _rand_boxes(rng, n, spread=3.0):
+    import math
+    return np.stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n), rng.uniform(0.5, 5.0, n),
+                     rng.uniform(0.5, 5.0, n), rng.uniform(-math.pi, math.pi, n)], 1).astype(np.float32)
+
+
+def test_rotated_iou_kernel_vs_oracle(device):
+    """v2x_rotated_iou (Sutherland-Hodgman in fp64 on the device) against the oracle's vertex-collection IoU on 60 x 50 random
+    box pairs + the degenerate poses (identical, contained, edge contact, 90-degree turns)."""
+    from v2x_sim_amd import ops
+    rng = np.random.default_rng(0)
+    a, b = _rand_boxes(rng, 60), _rand_boxes(rng, 50)
+    a[:4] = [[0, 0, 2, 4, 0.3]] * 4
+    b[:4] = [[0, 0, 2, 4, 0.3], [0, 0, 1, 2, 0.3], [0, 0, 4, 2, 0.3 + np.pi / 2], [2 * np.cos(0.3), 2 * np.sin(0.3), 2, 4, 0.3]]
+    got = ops.rotated_iou(torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)).cpu().numpy()
+    want = np.array([[PR.rotated_iou(PR.corners_of(tuple(float(v) for v in x)), PR.corners_of(tuple(float(v) for v in y))) for y in b] for x in a])
+    assert np.abs(got - want).max() < 1e-6, float(np.abs(got - want).max())
+    assert abs(got[0, 0] - 1.0) < 1e-6 and abs(got[1, 1] - 0.25) < 1e-6 and abs(got[2, 2] - 1.0) < 1e-6 and got[3, 3] < 1e-6
+    assert (got > 0).mean() > 0.3
+    assert ops.rotated_iou(torch.zeros((0, 5), device=device), torch.from_numpy(b).to(device)).shape == (0, 50)
+
+
+def test_match_detections_and_map_on_device_vs_oracle(device):
+    """eval_map with IoU + greedy matching on the device (v2x_match_detections) = the oracle's from-the-definition AP, on
+    random detection sets around jittered ground truth: duplicates on one GT, tied scores, images without GT / detections."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.utils import postprocess as P
+    rng = np.random.default_rng(7)
+    for trial in range(4):
+        n_img, det_cap = 16, 64
+        det = np.zeros((n_img, det_cap, 5), np.float32)
+        sc = np.zeros((n_img, det_cap), np.float32)
+        cnt = np.zeros((n_img,), np.int32)
+        gts, dets_o, gts_o = [], [], []
+        for i in range(n_img):
+            ng = int(rng.integers(0, 9))
+            gt = _rand_boxes(rng, ng, spread=20.0)
+            picks = [gt[g] for g in range(ng) for _ in range(int(rng.integers(0, 3)))] + list(_rand_boxes(rng, int(rng.integers(0, 5)), 20.0))
+            d = np.asarray(picks, np.float32).reshape(-1, 5).copy()
+            d[:, :2] += rng.normal(0, 0.4, (d.shape[0], 2)).astype(np.float32)
+            d[:, 2:4] *= rng.uniform(0.8, 1.25, (d.shape[0], 2)).astype(np.float32)
+            d[:, 4] += rng.normal(0, 0.15, d.shape[0]).astype(np.float32)
+            s = np.round(rng.uniform(0.7, 1.0, d.shape[0]), 2).astype(np.float32)
+            order = np.argsort(-s, kind="stable")                  # the device contract: descending score per image
+            d, s = d[order], s[order]
+            det[i, :d.shape[0]], sc[i, :d.shape[0]], cnt[i] = d, s, d.shape[0]
+            gts.append(gt)
+            dets_o.append([(float(s[j]), PR.corners_of(tuple(float(v) for v in d[j]))) for j in range(d.shape[0])])
+            gts_o.append([PR.corners_of(tuple(float(v) for v in g)) for g in gt])
+        for thr in (0.5, 0.7):
+            ap_d, info = P.eval_map_device(torch.from_numpy(det).to(device), torch.from_numpy(sc).to(device),
+                                           torch.from_numpy(cnt).to(device), gts, thr)
+            ap_o, ngt, ndet = PR.eval_map(dets_o, gts_o, thr)
+            assert abs(ap_d - ap_o) < 1e-9 and info["num_gt"] == ngt and info["num_det"] == ndet, (trial, thr, ap_d, ap_o)
+    # flags themselves on a hand case: two detections on one GT -> the better-scored one wins, the other is a false positive
+    det = torch.tensor([[[0, 0, 2, 4, 0.0], [0.1, 0, 2, 4, 0.0], [9, 9, 2, 4, 0.0]]], device=device)
+    gt = torch.tensor([[[0, 0, 2, 4, 0.0]]], device=device)
+    tp, best = ops.match_detections(det, torch.tensor([3], dtype=torch.int32, device=device), gt,
+                                    torch.tensor([1], dtype=torch.int32, device=device), 0.5, want_iou=True)
+    assert tp[0].tolist() == [1, 0, 0] and abs(float(best[0, 0]) - 1.0) < 1e-6 and float(best[0, 2]) == 0.0
+
+
+def test_rotated_nms_on_device_vs_oracle(device):
+    """v2x_det_postprocess_rotated: suppression on the rotated boxes' polygon IoU (SURVEY row f-1 'rotated-box NMS').  Same kept
+    anchors as the oracle's rotated greedy NMS, and strictly more detections survive than with the stand-up boxes (elongated
+    boxes at 45 degrees have large stand-up overlaps but small true overlaps)."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.utils import postprocess as P
+    anchors = P.build_anchor_map(Config("test"))
+    X, Y, A = anchors.shape[:3]
+    cls, loc = _synthetic_logits(2, X, Y, A, n_obj=60, seed=11)
+    args = (torch.from_numpy(cls).to(device), torch.from_numpy(loc).to(device), torch.from_numpy(anchors.reshape(-1, 6)).to(device))
+    nms_thr = 0.1
+    _, _, index_r, count_r = ops.det_postprocess(*args, 0.7, nms_thr, 4096, rotated=True)
+    _, _, _, count_s = ops.det_postprocess(*args, 0.7, nms_thr, 4096, rotated=False)
+    for i in range(2):
+        ref = PR.detect(cls[i], loc[i].reshape(-1, 6), anchors.reshape(-1, 6), 0.7, nms_thr, rotated=True)
+        got = index_r[i, :int(count_r[i])].cpu().numpy()
+        assert np.array_equal(np.sort(got), np.sort([d["index"] for d in ref])), i
+    assert int(count_r.sum()) > int(count_s.sum())

@@ -469,6 +469,31 @@ def test_halo_conv_vs_torch(device, cfg):
     assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 16, 32), (3, 64, 96), (40, 256, 256), (1, 8, 64)])
+def test_halo_pingpong_equals_4wave_kernel_bitwise(device, monkeypatch, N, H, W):
+    """conv8_1's 8-wave ping-pong form (two 4-wave groups on one resident weight copy, default) against the 4-wave kernel
+    (V2X_HALO_PP=0): same K order and fragment mapping -> bit-identical, for one tile pair, ragged persistent walks (tile
+    pairs not a multiple of the grid), image borders, and the bench's 256x256 maps (40 maps = 10 240 tiles, 20 per workgroup);
+    repeated launches are bit-identical too (no race between the groups' phases)."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(N * 1000 + H + W)
+    x = bf16r(torch.randn(N, 32, H, W, generator=g))
+    x_up = bf16r(torch.randn(N, 64, H // 2, W // 2, generator=g))
+    w = torch.randn(32, 96, 3, 3, generator=g) * (2.0 / (96 * 9)) ** 0.5
+    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
+    pc = packing.pack_conv_halo("t", w, scale, shift, C0=64, C1=32, relu=True, device=device)
+    xu, xs = to_nhwc_bf16(x_up, device), to_nhwc_bf16(x, device)
+    monkeypatch.setenv("V2X_HALO_PP", "0")
+    old = ops.conv2d(pc, xu, xs).clone()
+    monkeypatch.setenv("V2X_HALO_PP", "1")
+    new = [ops.conv2d(pc, xu, xs).clone() for _ in range(3)]
+    monkeypatch.delenv("V2X_HALO_PP")
+    assert all(torch.equal(old.view(torch.int16), y.view(torch.int16)) for y in new)
+    if N <= 3:
+        ref = _halo_ref(x, w, scale, shift, True, x_up)
+        assert torch.allclose(from_nhwc(new[0]), ref, atol=2e-3, rtol=2 ** -7)
+
+
 def test_halo_equals_gather_kernel_bitwise(device):
     """Same operands, same fp32 accumulation order per output?  Not guaranteed (different K walk), so the
     two kernels are compared at 1 bf16 ulp; both against the same torch reference elsewhere."""

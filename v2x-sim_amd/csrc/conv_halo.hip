@@ -482,6 +482,259 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     conv3x3_halo_body<C0, C1, COUT, COUT2, EPI2, false, BITS>(a);
 }
 
+// ---- 8-wave "ping-pong" form (conv8_1) -----------------------------------------------------------------
+// conv8_1 (cat(up(x_7) [64 ch], x [32 ch]) -> 32) keeps 54 KiB of weights resident; with a double-buffered 36-KiB patch
+// that is 126 KiB, i.e. ONE 4-wave workgroup per CU = one wave per SIMD.  Per tile such a wave spends ~3.5k cycles issuing
+// MFMAs and as much again on everything that cannot overlap them when nobody else is resident: the fragment reads'
+// issue slots, 8 output stores with their conversions, ~10 LDS-DMA instructions (60-185 issue cycles each next to
+// MFMAs), counted waits and the barrier (SQ counters of the 4-wave form: MfmaUtil 41.6 %, 4.0 waves/CU).
+// Here ONE 512-thread workgroup per CU holds ONE copy of the weights and two SINGLE-buffered patches, one per
+// 4-wave group; the groups own consecutive tiles (x-neighbours) and run half a period out of phase:
+//
+//      interval   2k                          2k+1
+//      group 0    C(k)  MFMAs of its tile     E(k): stores of tile k;  L(k+1): patch DMAs of its next tile, wait
+//      group 1    E(k-1), L(k), wait          C(k)
+//
+// with one s_barrier between intervals, so that on every SIMD the MFMA stream of one wave runs beside the store /
+// DMA / wait phase of the other.  Hazards: a group's patch is overwritten (L) only in the interval after its own
+// C finished reading it (barrier in between); C(k) of a group starts after the barrier that closes its own L(k), before
+// which every wave waited for its own DMA pieces (vmcnt(N_STORES): the DMAs are issued BEFORE the stores of E, so the
+// stores may stay in flight).  The accumulators live across the barrier from C to E.  K order, fragment mapping and
+// epilogue arithmetic are those of conv3x3_halo_kernel: results are bit-identical.
+template <int C0, int C1, int COUT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_pp_kernel(const HaloArgs a) {
+    constexpr int SPP0 = C0 / 8, SPP1 = C1 / 8;
+    constexpr int NS1 = round64(PH * PW * SPP1);
+    constexpr int NS0 = C0 ? round64(PH0 * PW0 * SPP0) : 0;
+    constexpr int PATCH_BYTES = (NS0 + NS1) * 16;
+    constexpr int KSLOTS = 9 * (SPP0 + SPP1);
+    constexpr int W_BYTES = KSLOTS * COUT * 16;
+    constexpr int TCO = COUT / 16;
+    static_assert(C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && TCO == 2, "ping-pong form: two sources, 32 output channels");
+    static_assert(W_BYTES % 1024 == 0, "weights are moved 1 KiB per wave instruction");
+    constexpr int N_STORES = TCO * 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_w = smem;
+    char *s_patch = smem + W_BYTES;                       // [group][PATCH_BYTES]
+    float *s_ss = reinterpret_cast<float *>(smem + W_BYTES + 2 * PATCH_BYTES);
+    for (int i = threadIdx.x; i < COUT; i += 512) {
+        s_ss[i] = a.scale[i];
+        s_ss[COUT + i] = a.shift[i];
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int grp = wave >> 2, wv = wave & 3;
+    const int fj = lane & 15, fq = lane >> 4;
+    char *pb = s_patch + grp * PATCH_BYTES;
+
+    for (int off = wave * 1024; off < W_BYTES; off += 8192)
+        glds16h(reinterpret_cast<const char *>(a.w) + off + lane * 16, s_w + off);
+
+    // per-lane DMA tables (see conv3x3_halo_body): piece t of wave wv of a group covers patch slots [wv*64 + t*256, +64)
+    constexpr int NP1 = (NS1 + 255) / 256, NP0 = (NS0 + 255) / 256;
+    int tb1[NP1], tb0[NP0];
+#pragma unroll
+    for (int t = 0; t < NP1; ++t) {
+        const int L = wv * 64 + t * 256 + lane;
+        const int pix = L / SPP1, phys = L - pix * SPP1;
+        const int pr = pix / PW, pc = pix - pr * PW;
+        tb1[t] = pix < PH * PW ? (((pr * a.W + pc) * C1 + swz<SPP1>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < NP0; ++t) {
+        const int L = wv * 64 + t * 256 + lane;
+        const int pix = L / SPP0, phys = L - pix * SPP0;
+        const int pr = pix / PW0, pc = pix - pr * PW0;
+        tb0[t] = pix < PH0 * PW0 ? (((pr * (a.W >> 1) + pc) * C0 + swz<SPP0>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
+    }
+
+    const int txy = a.tiles_x * a.tiles_y;
+    auto coords = [&](int tile, int &n, int &y0, int &x0) {
+        n = tile / txy;
+        const int r = tile - n * txy;
+        const int ty = r / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (r - ty * a.tiles_x) * TW;
+    };
+    auto load_patch = [&](int tile) {   // this group's patch <- tile; <= NP1 + NP0 DMAs per wave
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+        {
+            const unsigned base = ((unsigned)(n * a.H + y0 - 1) * (unsigned)a.W + (unsigned)(x0 - 1)) * (unsigned)C1;
+#pragma unroll
+            for (int t = 0; t < NP1; ++t) {
+                if (wv * 64 + t * 256 >= NS1) break;   // wave-uniform
+                const int y = y0 - 1 + ((tb1[t] >> 20) & 15), x = x0 - 1 + ((tb1[t] >> 24) & 63);
+                const bool ok = tb1[t] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                glds16h(ok ? (const void *)(a.in1 + (base + (unsigned)(tb1[t] & 0xfffff))) : (const void *)g_zero_page_h,
+                        pb + NS0 * 16 + (wv * 64 + t * 256) * 16);
+            }
+        }
+        {
+            const int Hs = a.H >> 1, Ws = a.W >> 1;
+            const unsigned base = ((unsigned)(n * Hs + (y0 >> 1) - 1) * (unsigned)Ws + (unsigned)((x0 >> 1) - 1)) * (unsigned)C0;
+#pragma unroll
+            for (int t = 0; t < NP0; ++t) {
+                if (wv * 64 + t * 256 >= NS0) break;   // wave-uniform
+                const int y = (y0 >> 1) - 1 + ((tb0[t] >> 20) & 15), x = (x0 >> 1) - 1 + ((tb0[t] >> 24) & 63);
+                const bool ok = tb0[t] >= 0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+                glds16h(ok ? (const void *)(a.in0 + (base + (unsigned)(tb0[t] & 0xfffff))) : (const void *)g_zero_page_h,
+                        pb + (wv * 64 + t * 256) * 16);
+            }
+        }
+    };
+
+    f32x4_t acc[TCO][4];
+    constexpr int KC0 = C0 / 32, KC1 = C1 / 32, KC = KC0 + KC1, NG = 3 * KC;
+    struct Frags {
+        bf16x8_t A[3][TCO];
+        bf16x8_t B[8];
+    };
+    auto load_group = [&](int g, Frags &F) {
+        const int kx = g / KC, kk = g - kx * KC;
+        if (kk < KC0) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int kslot = (ky * 3 + kx) * (SPP0 + SPP1) + kk * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    F.A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+            }
+#pragma unroll
+            for (int hr = 0; hr < 3; ++hr)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const int pr = wv + hr;
+                    const int pc = ((ch * 16 + fj + kx - 1) >> 1) + 1;
+                    F.B[hr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + ((pr * PW0 + pc) * SPP0 + swz<SPP0>(kk * 4 + fq, pc)) * 16);
+                }
+        } else {
+            const int kc = kk - KC0;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int kslot = (ky * 3 + kx) * (SPP0 + SPP1) + SPP0 + kc * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    F.A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const int pr = 2 * wv + rr;
+                    const int pc = ch * 16 + fj + kx;
+                    F.B[rr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + NS0 * 16 + ((pr * PW + pc) * SPP1 + swz<SPP1>(kc * 4 + fq, pc)) * 16);
+                }
+        }
+    };
+    auto mma_group = [&](int g, const Frags &F) {
+        const bool half = (g % KC) < KC0;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int r = f >> 1, ch = f & 1;
+                    const int row = half ? (((r + ky - 1) >> 1) + 1) : (r + ky);
+                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.A[ky][i], F.B[row * 2 + ch], acc[i][f], 0, 0, 0);
+                }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        Frags fr[2];
+        load_group(0, fr[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, fr[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(g, fr[g & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto epilogue = [&](int tile) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int co = i * 16 + fq * 4;
+            const float4 sc = *reinterpret_cast<const float4 *>(s_ss + co);
+            const float4 sf = *reinterpret_cast<const float4 *>(s_ss + COUT + co);
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
+                float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
+                float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
+                if (a.relu) {
+                    v0 = fmaxf(v0, 0.f);
+                    v1 = fmaxf(v1, 0.f);
+                    v2 = fmaxf(v2, 0.f);
+                    v3 = fmaxf(v3, 0.f);
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co;
+                *reinterpret_cast<uint2 *>(dst) = o;
+            }
+        }
+    };
+
+    // pairs of tiles (2p, 2p + 1): group g owns tile 2p + g;  p = blockIdx.x + k * gridDim.x
+    const int n_pairs = a.n_tiles >> 1;
+    const int K = (n_pairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= n_pairs)
+    auto tile_of = [&](int k) { return 2 * ((int)blockIdx.x + k * (int)gridDim.x) + grp; };
+
+    if (grp == 0) load_patch(tile_of(0));
+    __syncthreads();   // weights, scale/shift and group 0's first patch have landed
+
+    // interval i: group g computes tile k = i >> 1 when (i & 1) == g; otherwise it stores tile m (computed in the previous
+    // interval) and fetches the patch of tile m + 1 (computed in the next one), m = (i - g - 1) / 2.  ONE call site per role:
+    // two inlined copies of compute() cost ~45 spilled registers, and scratch traffic would also corrupt the vmcnt counts.
+    for (int i = 0; i <= 2 * K; ++i) {
+        if ((i & 1) == grp) {
+            if ((i >> 1) < K) compute();
+        } else {
+            const int m = (i - grp - 1) / 2;               // -1 in group 1's first interval (truncating division)
+            if (m + 1 < K) load_patch(tile_of(m + 1));     // its previous compute is behind the last barrier
+            if (m >= 0) {
+                epilogue(tile_of(m));
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the DMAs are OLDER than the 8 stores: they have landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(N_STORES == 8, "the counted waits above assume 8 stores per tile and wave");
+}
+
+template <int C0, int C1, int COUT>
+static int launch_halo_pp(const HaloArgs &a, hipStream_t s) {
+    constexpr int NS1 = round64(PH * PW * (C1 / 8));
+    constexpr int NS0 = round64(PH0 * PW0 * (C0 / 8));
+    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16 + 2 * COUT * 4;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static v2x_once_per_device attr_once;
+    auto kern = &conv3x3_halo_pp_kernel<C0, C1, COUT>;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    int grid = 256;                       // one 8-wave workgroup per CU, persistent over tile pairs
+    if (grid > a.n_tiles / 2) grid = a.n_tiles / 2;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_halo_pp_kernel");
+    return V2X_OK;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 template <int C0, int C1, int COUT, int COUT2, int EPI2, bool BITS>
 static int launch_halo_sb(const HaloArgs &a, hipStream_t s) {
@@ -568,6 +821,11 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     if (C0 == 0 && C1 == 32 && d->Cout == 32 && co2 == 0 && e2 == 0)
         return d->in_format == 1 ? launch_halo_sb<0, 32, 32, 0, 0, true>(a, s) : launch_halo_sb<0, 32, 32, 0, 0, false>(a, s);
     if (d->in_format == 1) return 1;  // bit-grid input exists for the 32 -> 32 first layer only
+    if (C0 == 64 && C1 == 32 && d->Cout == 32 && co2 == 0 && e2 == 0 && a.n_tiles >= 2 && a.n_tiles % 2 == 0) {
+        // conv8_1: 8-wave ping-pong form (V2X_HALO_PP=0 keeps the 4-wave kernel: A/B runs and the bitwise-equality test)
+        const char *e = getenv("V2X_HALO_PP");
+        if (!(e && e[0] == '0')) return launch_halo_pp<64, 32, 32>(a, s);
+    }
     HALO_CASE(64, 32, 32, 0, 0)   // conv8_1: cat(up(x_7), x)
     HALO_CASE(0, 64, 64, 0, 0)    // conv7_2
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits

@@ -20,6 +20,146 @@
 
 constexpr int DET_MAX_CAP = 4096;
 
+// ---- rotated-box IoU (row f-1: upstream's eval_map intersects shapely polygons; here: convex clipping in fp64) ----------
+// Corners of (x, y, w, h, yaw), counter-clockwise, first = (+w/2, +h/2) rotated (the order of utils/postprocess.box_corners).
+__device__ __forceinline__ void box_corners_d(const float *b, double (&cx)[4], double (&cy)[4]) {
+    const double x = b[0], y = b[1], w = b[2], h = b[3], yaw = b[4];
+    const double c = cos(yaw), s = sin(yaw);
+    const double dx[4] = {0.5 * w, -0.5 * w, -0.5 * w, 0.5 * w}, dy[4] = {0.5 * h, 0.5 * h, -0.5 * h, -0.5 * h};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        cx[q] = x + dx[q] * c - dy[q] * s;
+        cy[q] = y + dx[q] * s + dy[q] * c;
+    }
+}
+
+// Area of (quad 1) intersected with (quad 2): Sutherland-Hodgman, quad 1 clipped by the four edges of quad 2.  A convex
+// polygon gains at most one vertex per clip: 4 + 4 = 8.
+__device__ double quad_intersection_area(const double (&ax)[4], const double (&ay)[4], const double (&bx)[4], const double (&by)[4]) {
+    double px[10], py[10], qx[10], qy[10];
+    int n = 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        px[i] = ax[i];
+        py[i] = ay[i];
+    }
+    for (int e = 0; e < 4 && n > 0; ++e) {
+        const double ex0 = bx[e], ey0 = by[e], ex1 = bx[(e + 1) & 3], ey1 = by[(e + 1) & 3];
+        int m = 0;
+        for (int i = 0; i < n; ++i) {
+            const int j = (i + 1 == n) ? 0 : i + 1;
+            const double sp = (ex1 - ex0) * (py[i] - ey0) - (ey1 - ey0) * (px[i] - ex0);
+            const double sq = (ex1 - ex0) * (py[j] - ey0) - (ey1 - ey0) * (px[j] - ex0);
+            if (sp >= 0.0) {
+                qx[m] = px[i];
+                qy[m] = py[i];
+                ++m;
+            }
+            if ((sp >= 0.0) != (sq >= 0.0)) {
+                const double t = sp / (sp - sq);
+                qx[m] = px[i] + t * (px[j] - px[i]);
+                qy[m] = py[i] + t * (py[j] - py[i]);
+                ++m;
+            }
+        }
+        n = m;
+        for (int i = 0; i < n; ++i) {
+            px[i] = qx[i];
+            py[i] = qy[i];
+        }
+    }
+    if (n < 3) return 0.0;
+    double a2 = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        a2 += px[i] * py[j] - px[j] * py[i];
+    }
+    return 0.5 * fabs(a2);
+}
+
+__device__ double rotated_iou_d(const float *a, const float *b) {
+    double ax[4], ay[4], bx[4], by[4];
+    box_corners_d(a, ax, ay);
+    box_corners_d(b, bx, by);
+    // stand-up boxes first: disjoint -> 0 without clipping
+    double a0 = ax[0], a1 = ax[0], a2 = ay[0], a3 = ay[0], b0 = bx[0], b1 = bx[0], b2 = by[0], b3 = by[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        a0 = fmin(a0, ax[q]); a1 = fmax(a1, ax[q]); a2 = fmin(a2, ay[q]); a3 = fmax(a3, ay[q]);
+        b0 = fmin(b0, bx[q]); b1 = fmax(b1, bx[q]); b2 = fmin(b2, by[q]); b3 = fmax(b3, by[q]);
+    }
+    if (a1 < b0 || b1 < a0 || a3 < b2 || b3 < a2) return 0.0;
+    const double inter = quad_intersection_area(ax, ay, bx, by);
+    const double uni = (double)a[2] * a[3] + (double)b[2] * b[3] - inter;   // |w*h| of each rectangle
+    return uni > 0.0 ? inter / uni : 0.0;
+}
+
+__global__ __launch_bounds__(256) void rotated_iou_kernel(const float *__restrict__ a, int na, const float *__restrict__ b, int nb,
+                                                          float *__restrict__ iou) {
+    const long long total = (long long)na * nb;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (long long)gridDim.x * blockDim.x) {
+        const int i = (int)(p / nb), j = (int)(p - (long long)i * nb);
+        iou[p] = (float)rotated_iou_d(a + (size_t)i * 5, b + (size_t)j * 5);
+    }
+}
+
+// ---- eval_map's matching step on the device --------------------------------------------------------------------------
+// One workgroup per image.  Detections arrive in descending-score order (the order v2x_det_postprocess emits); each in turn
+// takes the ground-truth box of highest rotated IoU (lowest index on ties) and is a true positive iff that IoU >= thr and
+// the box is still free -- mmdet's tpfp_default as upstream's mean_ap.py uses it; there is no second choice.  The serial
+// depth is the number of detections; the IoUs of one detection against all ground truths run in parallel.
+__global__ __launch_bounds__(256) void match_detections_kernel(const float *__restrict__ det, const int32_t *__restrict__ det_count,
+                                                               int det_cap, const float *__restrict__ gt,
+                                                               const int32_t *__restrict__ gt_count, int gt_cap, float thr,
+                                                               int32_t *__restrict__ tp, float *__restrict__ best_iou) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int *taken = reinterpret_cast<int *>(smem);                 // [gt_cap]
+    __shared__ double s_best[256];
+    __shared__ int s_arg[256];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    int nd = det_count[img];
+    nd = nd < 0 ? 0 : (nd > det_cap ? det_cap : nd);
+    int ng = gt_count[img];
+    ng = ng < 0 ? 0 : (ng > gt_cap ? gt_cap : ng);
+    for (int g = tid; g < ng; g += 256) taken[g] = 0;
+    __syncthreads();
+    for (int j = 0; j < nd; ++j) {
+        const float *d = det + ((size_t)img * det_cap + j) * 5;
+        double best = 0.0;
+        int arg = -1;
+        for (int g = tid; g < ng; g += 256) {
+            const double v = rotated_iou_d(d, gt + ((size_t)img * gt_cap + g) * 5);
+            if (v > best) {
+                best = v;
+                arg = g;
+            }
+        }
+        s_best[tid] = best;
+        s_arg[tid] = arg;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (tid < st) {
+                const double o = s_best[tid + st];
+                const int oa = s_arg[tid + st];
+                // larger IoU wins; equal IoU: the lower ground-truth index (a sequential scan keeps the first maximum)
+                if (o > s_best[tid] || (o == s_best[tid] && oa >= 0 && (s_arg[tid] < 0 || oa < s_arg[tid]))) {
+                    s_best[tid] = o;
+                    s_arg[tid] = oa;
+                }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const int a0 = s_arg[0];
+            const bool hit = a0 >= 0 && s_best[0] >= (double)thr && !taken[a0];
+            if (hit) taken[a0] = 1;
+            tp[(size_t)img * det_cap + j] = hit ? 1 : 0;
+            if (best_iou) best_iou[(size_t)img * det_cap + j] = (float)s_best[0];
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void det_candidates_kernel(const float *__restrict__ cls, int n, int M, float thr,
                                                              int cap, unsigned long long *__restrict__ keys,
                                                              int32_t *__restrict__ counts) {
@@ -38,6 +178,7 @@ __global__ __launch_bounds__(256) void det_candidates_kernel(const float *__rest
     }
 }
 
+template <bool ROTATED>
 __global__ __launch_bounds__(256) void det_nms_kernel(const float *__restrict__ loc, const float *__restrict__ anchors,
                                                       int M, int cap, float nms_thr, const unsigned long long *__restrict__ keys,
                                                       const int32_t *__restrict__ counts, float *__restrict__ out_boxes,
@@ -126,7 +267,13 @@ __global__ __launch_bounds__(256) void det_nms_kernel(const float *__restrict__ 
             const float inter = iw * ih;
             const float area_k = (bk.z - bk.x) * (bk.w - bk.y);
             const float iou = inter / (area_k + area_i - inter + 1e-12f);
-            if (iou > nms_thr) sup = 1;
+            if constexpr (ROTATED) {
+                // rotated mode: the stand-up overlap is only the cheap reject; the decision is the polygon IoU of the decoded
+                // boxes (staged in global memory in sorted order)
+                if (inter > 0.0f && (float)rotated_iou_d(stage + (size_t)skept[k] * 5, stage + (size_t)i * 5) > nms_thr) sup = 1;
+            } else {
+                if (iou > nms_thr) sup = 1;
+            }
         }
         sup = __syncthreads_or(sup);
         if (!sup && tid == 0) {
@@ -158,10 +305,10 @@ __global__ __launch_bounds__(256) void det_nms_kernel(const float *__restrict__ 
     if (tid == 0) out_count[map] = nk;
 }
 
-extern "C" int v2x_det_postprocess(const float *cls, const float *loc, const float *anchors, int n, int M,
-                                   float score_thr, float nms_thr, int cap, float *out_boxes, float *out_scores,
-                                   int32_t *out_index, int32_t *out_count, unsigned long long *key_scratch,
-                                   int32_t *count_scratch, v2x_stream_t stream) {
+static int det_postprocess_impl(bool rotated, const float *cls, const float *loc, const float *anchors, int n, int M,
+                                float score_thr, float nms_thr, int cap, float *out_boxes, float *out_scores,
+                                int32_t *out_index, int32_t *out_count, unsigned long long *key_scratch,
+                                int32_t *count_scratch, v2x_stream_t stream) {
     V2X_REQUIRE(cls && loc && anchors && out_boxes && out_scores && out_index && out_count && key_scratch && count_scratch,
                 "v2x_det_postprocess: null pointer");
     V2X_REQUIRE(n >= 0 && M > 0, "v2x_det_postprocess: bad sizes");
@@ -179,10 +326,55 @@ extern "C" int v2x_det_postprocess(const float *cls, const float *loc, const flo
     const int smem = cap * 28;   // keys 8 B + stand-up boxes 16 B + kept list 4 B per candidate
     static v2x_once_per_device attr_once;
     if (v2x_first_use_on_device(attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX_CAP * 28);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX_CAP * 28);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX_CAP * 28);
     }
-    hipLaunchKernelGGL(det_nms_kernel, dim3(n), dim3(256), smem, s, loc, anchors, M, cap, nms_thr, key_scratch, count_scratch,
-                       out_boxes, out_scores, out_index, out_count);
+    if (rotated)
+        hipLaunchKernelGGL(det_nms_kernel<true>, dim3(n), dim3(256), smem, s, loc, anchors, M, cap, nms_thr, key_scratch, count_scratch,
+                           out_boxes, out_scores, out_index, out_count);
+    else
+        hipLaunchKernelGGL(det_nms_kernel<false>, dim3(n), dim3(256), smem, s, loc, anchors, M, cap, nms_thr, key_scratch, count_scratch,
+                           out_boxes, out_scores, out_index, out_count);
     V2X_CHECK_LAUNCH("det_nms_kernel");
+    return V2X_OK;
+}
+
+extern "C" int v2x_det_postprocess(const float *cls, const float *loc, const float *anchors, int n, int M,
+                                   float score_thr, float nms_thr, int cap, float *out_boxes, float *out_scores,
+                                   int32_t *out_index, int32_t *out_count, unsigned long long *key_scratch,
+                                   int32_t *count_scratch, v2x_stream_t stream) {
+    return det_postprocess_impl(false, cls, loc, anchors, n, M, score_thr, nms_thr, cap, out_boxes, out_scores, out_index, out_count,
+                                key_scratch, count_scratch, stream);
+}
+
+extern "C" int v2x_det_postprocess_rotated(const float *cls, const float *loc, const float *anchors, int n, int M,
+                                           float score_thr, float nms_thr, int cap, float *out_boxes, float *out_scores,
+                                           int32_t *out_index, int32_t *out_count, unsigned long long *key_scratch,
+                                           int32_t *count_scratch, v2x_stream_t stream) {
+    return det_postprocess_impl(true, cls, loc, anchors, n, M, score_thr, nms_thr, cap, out_boxes, out_scores, out_index, out_count,
+                                key_scratch, count_scratch, stream);
+}
+
+extern "C" int v2x_rotated_iou(const float *boxes_a, int na, const float *boxes_b, int nb, float *iou, v2x_stream_t stream) {
+    V2X_REQUIRE(na >= 0 && nb >= 0, "v2x_rotated_iou: negative count");
+    if (na == 0 || nb == 0) return V2X_OK;
+    V2X_REQUIRE(boxes_a && boxes_b && iou, "v2x_rotated_iou: null pointer");
+    const long long total = (long long)na * nb;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(rotated_iou_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, boxes_a, na, boxes_b, nb, iou);
+    V2X_CHECK_LAUNCH("rotated_iou_kernel");
+    return V2X_OK;
+}
+
+extern "C" int v2x_match_detections(const float *det_boxes, const int32_t *det_count, int det_cap, const float *gt_boxes,
+                                    const int32_t *gt_count, int gt_cap, int n_img, float iou_thr, int32_t *tp, float *best_iou,
+                                    v2x_stream_t stream) {
+    V2X_REQUIRE(n_img >= 0 && det_cap > 0 && gt_cap > 0 && gt_cap <= 8192, "v2x_match_detections: bad sizes (gt_cap <= 8192)");
+    if (n_img == 0) return V2X_OK;
+    V2X_REQUIRE(det_boxes && det_count && gt_boxes && gt_count && tp, "v2x_match_detections: null pointer");
+    hipLaunchKernelGGL(match_detections_kernel, dim3(n_img), dim3(256), (size_t)gt_cap * sizeof(int), (hipStream_t)stream, det_boxes,
+                       det_count, det_cap, gt_boxes, gt_count, gt_cap, iou_thr, tp, best_iou);
+    V2X_CHECK_LAUNCH("match_detections_kernel");
     return V2X_OK;
 }

@@ -65,6 +65,8 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         e2 = 0 if not pc.Cout2 else (2 if pc.epilogue == V2X_EPI_F32 else 1)
         if (c0, c1, pc.Cout, co2) == (0, 32, 32, 0):  # HBM-bound layers: single-buffer form (+ bit-grid input)
             return "conv3x3_halo_sb_kernel<0, 32, 32, 0, 0, %s>" % ("true" if bits else "false")
+        if (c0, c1, pc.Cout, co2) == (64, 32, 32, 0) and os.environ.get("V2X_HALO_PP", "1")[:1] != "0":
+            return "conv3x3_halo_pp_kernel<64, 32, 32>"   # conv8_1: 8-wave ping-pong form
         return "conv3x3_halo_kernel<%d, %d, %d, %d, %d>" % (c0, c1, pc.Cout, co2, e2)
     rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
     return "conv_igemm_kernel<%d, %d, %d, %d, %d>" % (_CONV_TILES[rows] + (pc.epilogue,))
@@ -410,9 +412,10 @@ def pixel_weighted_fuse(scores, valid, maps):
 
 
 # ------------------------------------------------------------------ f-1
-def det_postprocess(cls, loc, anchors, score_thr=0.7, nms_thr=0.01, cap=4096):
+def det_postprocess(cls, loc, anchors, score_thr=0.7, nms_thr=0.01, cap=4096, rotated=False):
     """cls (n, M, 2) fp32, loc (n, ..., 6) fp32 with M anchors per map, anchors (M, 6) fp32 on the device ->
-    (boxes (n, cap, 5), scores (n, cap), index (n, cap) int32, count (n,) int32); count < 0: more than `cap` candidates."""
+    (boxes (n, cap, 5), scores (n, cap), index (n, cap) int32, count (n,) int32); count < 0: more than `cap` candidates.
+    rotated=True: suppression on the rotated boxes' polygon IoU instead of upstream's stand-up boxes."""
     lib = _lib.load()
     n, M = cls.shape[0], cls.shape[1]
     loc = loc.reshape(n, M, 6)
@@ -424,13 +427,41 @@ def det_postprocess(cls, loc, anchors, score_thr=0.7, nms_thr=0.01, cap=4096):
     count = torch.empty((n,), dtype=torch.int32, device=dev)
     keys = torch.empty((n, cap), dtype=torch.int64, device=dev)
     cnt = torch.empty((n,), dtype=torch.int32, device=dev)
-    _lib.check(lib.v2x_det_postprocess(_dev(cls, torch.float32, "cls"), _dev(loc, torch.float32, "loc"),
+    fn = lib.v2x_det_postprocess_rotated if rotated else lib.v2x_det_postprocess
+    _lib.check(fn(_dev(cls, torch.float32, "cls"), _dev(loc, torch.float32, "loc"),
                                        _dev(anchors, torch.float32, "anchors"), n, M, C.c_float(score_thr),
                                        C.c_float(nms_thr), cap, _dev(boxes, torch.float32, "boxes"),
                                        _dev(scores, torch.float32, "scores"), _dev(index, torch.int32, "index"),
                                        _dev(count, torch.int32, "count"), _dev(keys, torch.int64, "keys"),
                                        _dev(cnt, torch.int32, "cnt"), _stream()), "v2x_det_postprocess")
     return boxes, scores, index, count
+
+
+def rotated_iou(boxes_a, boxes_b):
+    """boxes (na, 5), (nb, 5) fp32 (x, y, w, h, yaw) on the device -> (na, nb) fp32 IoU of the rotated rectangles."""
+    lib = _lib.load()
+    na, nb = boxes_a.shape[0], boxes_b.shape[0]
+    out = torch.zeros((na, nb), dtype=torch.float32, device=boxes_a.device)
+    if na and nb:
+        _lib.check(lib.v2x_rotated_iou(_dev(boxes_a, torch.float32, "boxes_a"), na, _dev(boxes_b, torch.float32, "boxes_b"), nb,
+                                       _dev(out, torch.float32, "iou"), _stream()), "v2x_rotated_iou")
+    return out
+
+
+def match_detections(det_boxes, det_count, gt_boxes, gt_count, iou_thr, want_iou=False):
+    """eval_map's matching on the device.  det_boxes (n, det_cap, 5) fp32 in descending-score order, det_count (n,) int32,
+    gt_boxes (n, gt_cap, 5) fp32, gt_count (n,) int32 -> tp (n, det_cap) int32 [, best_iou (n, det_cap) fp32]."""
+    lib = _lib.load()
+    n, det_cap, _ = det_boxes.shape
+    gt_cap = gt_boxes.shape[1]
+    tp = torch.zeros((n, det_cap), dtype=torch.int32, device=det_boxes.device)
+    best = torch.zeros((n, det_cap), dtype=torch.float32, device=det_boxes.device) if want_iou else None
+    _lib.check(lib.v2x_match_detections(_dev(det_boxes, torch.float32, "det_boxes"), _dev(det_count, torch.int32, "det_count"), det_cap,
+                                        _dev(gt_boxes, torch.float32, "gt_boxes"), _dev(gt_count, torch.int32, "gt_count"), gt_cap, n,
+                                        C.c_float(iou_thr), _dev(tp, torch.int32, "tp"),
+                                        _dev(best, torch.float32, "best_iou") if best is not None else None, _stream()),
+               "v2x_match_detections")
+    return (tp, best) if want_iou else tp
 
 
 # ------------------------------------------------------------------ a8

@@ -147,7 +147,7 @@ def eval_map(det_results, annotations, iou_thr=0.5):
     det_results: list (one per sample) of dict(corners (M,4,2), scores (M,));
     annotations: list of (G, 4, 2) ground-truth corner arrays.
     Returns (ap, dict(recall, precision, num_gt, num_det))."""
-    scores, tps, fps = [], [], []
+    scores, tps = [], []
     num_gt = 0
     for det, gt in zip(det_results, annotations):
         gt = np.asarray(gt, dtype=np.float64).reshape(-1, 4, 2)
@@ -170,15 +170,20 @@ def eval_map(det_results, annotations, iou_thr=0.5):
             if best >= iou_thr and not taken[best_g]:
                 taken[best_g] = True
                 tps.append(1)
-                fps.append(0)
             else:
                 tps.append(0)
-                fps.append(1)
-    if num_gt == 0 or not scores:
-        return 0.0, {"recall": np.zeros(0), "precision": np.zeros(0), "num_gt": num_gt, "num_det": len(scores)}
-    order = np.argsort(-np.asarray(scores), kind="stable")
-    tp = np.cumsum(np.asarray(tps)[order])
-    fp = np.cumsum(np.asarray(fps)[order])
+    return average_precision(scores, tps, num_gt)
+
+
+def average_precision(scores, tps, num_gt):
+    """mmdet 'area' AP from per-detection (score, true-positive flag) pairs of ALL images (image-major, per image in descending
+    score order) and the number of ground-truth boxes.  -> (ap, info) like eval_map."""
+    scores, tps = np.asarray(scores, dtype=np.float64).reshape(-1), np.asarray(tps).reshape(-1).astype(np.int64)
+    if num_gt == 0 or scores.size == 0:
+        return 0.0, {"recall": np.zeros(0), "precision": np.zeros(0), "num_gt": num_gt, "num_det": int(scores.size)}
+    order = np.argsort(-scores, kind="stable")
+    tp = np.cumsum(tps[order])
+    fp = np.cumsum(1 - tps[order])
     recall = tp / num_gt
     precision = tp / np.maximum(tp + fp, 1e-12)
     mrec = np.concatenate([[0.0], recall, [1.0]])
@@ -187,4 +192,27 @@ def eval_map(det_results, annotations, iou_thr=0.5):
         mpre[i] = max(mpre[i], mpre[i + 1])
     idx = np.nonzero(mrec[1:] != mrec[:-1])[0]
     ap = float(np.sum((mrec[idx + 1] - mrec[idx]) * mpre[idx + 1]))
-    return ap, {"recall": recall, "precision": precision, "num_gt": num_gt, "num_det": len(scores)}
+    return ap, {"recall": recall, "precision": precision, "num_gt": num_gt, "num_det": int(scores.size)}
+
+
+def eval_map_device(det_boxes, det_scores, det_count, gt_boxes_list, iou_thr=0.5):
+    """eval_map with the IoU + matching step on the MI355X (v2x_match_detections): det_boxes (n, cap, 5), det_scores (n, cap),
+    det_count (n,) as v2x_det_postprocess leaves them ON THE DEVICE (descending score per map), gt_boxes_list = per image a
+    (G, 5) host array.  Only (score, tp) pairs come back to the host for the final sort + cumulative sums."""
+    import torch
+    from .. import ops
+    n = det_boxes.shape[0]
+    gt_cap = max(1, max((len(g) for g in gt_boxes_list), default=1))
+    gt = np.zeros((n, gt_cap, 5), np.float32)
+    gcount = np.zeros((n,), np.int32)
+    for i, g in enumerate(gt_boxes_list):
+        g = np.asarray(g, np.float32).reshape(-1, 5)
+        gt[i, :g.shape[0]] = g
+        gcount[i] = g.shape[0]
+    dev = det_boxes.device
+    cnt = det_count.clamp(min=0).to(torch.int32).contiguous()
+    tp = ops.match_detections(det_boxes.contiguous(), cnt, torch.from_numpy(gt).to(dev), torch.from_numpy(gcount).to(dev), iou_thr)
+    cnt_h, tp_h, sc_h = cnt.cpu().numpy(), tp.cpu().numpy(), det_scores.cpu().numpy()
+    scores = np.concatenate([sc_h[i, :cnt_h[i]] for i in range(n)]) if n else np.zeros(0)
+    tps = np.concatenate([tp_h[i, :cnt_h[i]] for i in range(n)]) if n else np.zeros(0, np.int64)
+    return average_precision(scores, tps, int(gcount.sum()))
