@@ -188,10 +188,13 @@ def test_stream8_persistent_equals_one_tile_per_workgroup_bitwise(device, cfg, m
 
 
 @pytest.mark.parametrize("cfg", [
-    # (C, Cout, N, H, W): H % 8 == 0, W % 64 == 0
+    # (C, Cout, N, H, W): H % 8 == 0, W % 64 == 0 (4 x 32 output tiles) or H % 16 == 0, W % 32 == 0 (8 x 16)
     (32, 64, 3, 16, 64),      # conv1_1 class (one chunk, BCO = 64)
     (64, 128, 2, 24, 128),    # conv2_1 class (two chunks, BCO = 128)
     (128, 256, 2, 8, 64),     # conv3_1 class (two channel tiles)
+    (256, 512, 3, 32, 32),    # conv4_1: 16 x 16 outputs -> the 8 x 16 output-tile form (four channel tiles, 8 chunks)
+    (64, 64, 2, 16, 32),      # 8 x 16 form with BCO = 64, one tile per map, every border is padding
+    (128, 128, 1, 48, 96),    # 8 x 16 form, 3 x 3 tiles per map (interior + border tiles)
 ])
 def test_stride2_stream_conv_vs_torch_and_gather(device, cfg):
     """Stride-2 streamed kernel (conv_stream_s2.hip: parity-de-interleaved patch) vs torch fp32 on the same bf16 operands

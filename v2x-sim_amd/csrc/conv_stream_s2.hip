@@ -45,13 +45,29 @@ constexpr int S2_PPW = (S2_PIECES + 3) / 4;                  // pieces per wave 
 constexpr int S2_PATCH_BYTES = S2_PIECES * 1024;             // 37 KiB (pieces 37..39 of the per-wave loop are never issued)
 constexpr int S2_RING = 4;
 
+// Output-tile geometry of the streamed kernel.  4 x 32 (the 128^2 / 64^2 / 32^2 outputs of conv1_1 .. conv3_1) or 8 x 16
+// (conv4_1: 16 x 16 outputs -- before, that layer fell back to the gather kernel, 31 % of the MFMA peak).  Both are 128
+// output pixels = two 16-pixel fragments per wave, and both patches fit the same 37-KiB buffer (9 x 65 vs 17 x 33 pixels).
+template <int TH, int TW>
+struct S2Geom {
+    static constexpr int PH = 2 * TH + 1;
+    static constexpr int NE = TW + 1, NO = TW;
+    static constexpr int ROW_SLOTS = (NE + NO) * 4;
+    static constexpr int SLOTS = PH * ROW_SLOTS;
+    static constexpr int PIECES = (SLOTS + 63) / 64;
+    static constexpr int PPW = (PIECES + 3) / 4;
+    static_assert(TH * TW == 128 && (TW == 32 || TW == 16), "128 output pixels: 4 x 32 or 8 x 16");
+    static_assert(PIECES * 1024 <= S2_PATCH_BYTES, "patch must fit the common buffer");
+};
+
 template <int N>
 __device__ __forceinline__ void s2_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BCO>
+template <int BCO, int TH = S2_TH, int TW = S2_TW>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv3x3_s2_stream_kernel(const S2Args a) {
+    using G = S2Geom<TH, TW>;
     constexpr int TCO = BCO / 16;
     constexpr int W_PIECES = BCO / 16;           // 1 KiB pieces per weight slice
     constexpr int NW = W_PIECES / 4;             // weight DMAs per wave and step (1 or 2)
@@ -79,7 +95,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int trem = px_tile - n * txy;
     const int ty = trem / a.tiles_x;
     const int tx = trem - ty * a.tiles_x;
-    const int y0 = ty * S2_TH, x0 = tx * S2_TW;       // output coordinates
+    const int y0 = ty * TH, x0 = tx * TW;       // output coordinates
 
     const int nchunks = a.C >> 5;
     const int S = nchunks * 9;
@@ -96,29 +112,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     // per-lane DMA descriptors of this wave's patch pieces (piece = wave + 4t): (input pixel index << 5) | (logical 16-B
     // slot * 8 elements), -1 = zero page (outside the image, or the padding slots behind the patch)
-    int pd[S2_PPW];
+    int pd[G::PPW];
 #pragma unroll
-    for (int t = 0; t < S2_PPW; ++t) {
+    for (int t = 0; t < G::PPW; ++t) {
         const int L = (wave + 4 * t) * 64 + lane;
-        const int r = L / S2_ROW_SLOTS, q = L - r * S2_ROW_SLOTS;
+        const int r = L / G::ROW_SLOTS, q = L - r * G::ROW_SLOTS;
         const int ent = q >> 2, phys = q & 3;
-        const bool odd = ent >= S2_NE;
-        const int idx = odd ? ent - S2_NE : ent;
+        const bool odd = ent >= G::NE;
+        const int idx = odd ? ent - G::NE : ent;
         const int pc = 2 * idx + (odd ? 1 : 0);               // patch column
         const int y = 2 * y0 - 1 + r, x = 2 * x0 - 1 + pc;   // input pixel
-        const bool ok = L < S2_SLOTS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const bool ok = L < G::SLOTS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
         pd[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((idx >> 1) & 3)) << 3)) : -1;
     }
-    // fragment column offsets: fragment f covers output columns f*16 + fj; tap kx reads entry (f*16 + fj + (kx == 2)) of the
-    // even (kx = 0, 2) or odd (kx = 1) half
+    // fragment f of a wave: 4 x 32 tile -> output row `wave`, columns f*16 + fj;  8 x 16 tile -> output row 2*wave + f,
+    // columns fj.  Column offsets: tap kx reads entry (col + (kx == 2)) of the even (kx = 0, 2) or odd (kx = 1) half
     int ct[2][3];
 #pragma unroll
     for (int f = 0; f < 2; ++f)
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int idx = f * 16 + fj + (kx == 2 ? 1 : 0);
-            ct[f][kx] = (((kx == 1 ? S2_NE : 0) + idx) * 4 + (fq ^ ((idx >> 1) & 3))) * 16;
+            const int idx = (TW == 32 ? f * 16 : 0) + fj + (kx == 2 ? 1 : 0);
+            ct[f][kx] = (((kx == 1 ? G::NE : 0) + idx) * 4 + (fq ^ ((idx >> 1) & 3))) * 16;
         }
+    const int frow0 = (TW == 32) ? wave : 2 * wave, frow1 = (TW == 32) ? wave : 2 * wave + 1;   // output row of fragment 0 / 1
 
     const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
     auto issue_weights = [&](int s) {   // NW DMAs
@@ -129,8 +146,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     };
     auto issue_patch = [&](int kc) {    // this wave's pieces of chunk kc (pieces >= S2_PIECES do not exist)
 #pragma unroll
-        for (int t = 0; t < S2_PPW; ++t) {
-            if (wave + 4 * t >= S2_PIECES) break;            // wave-uniform
+        for (int t = 0; t < G::PPW; ++t) {
+            if (wave + 4 * t >= G::PIECES) break;            // wave-uniform
             const int d = pd[t];
             const unsigned off = (unsigned)(d >> 5) * (unsigned)a.C + (unsigned)(kc * 32 + (d & 31));
             glds16q(d >= 0 ? (const void *)(a.in + off) : zero_page, s_patch + (wave + 4 * t) * 1024);
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         __builtin_amdgcn_s_barrier();
 #pragma unroll 1
         for (int ky = 0; ky < 3; ++ky) {
-            const int rowoff = (2 * wave + ky) * (S2_ROW_SLOTS * 16);
+            const int rowoff0 = (2 * frow0 + ky) * (G::ROW_SLOTS * 16), rowoff1 = (2 * frow1 + ky) * (G::ROW_SLOTS * 16);
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx, ++s) {
                 const int tap = ky * 3 + kx;
@@ -171,7 +188,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 const char *ws = s_ring + (s & (S2_RING - 1)) * SLICE_BYTES;
                 bf16x8_t fa[TCO], fb[2];
 #pragma unroll
-                for (int f = 0; f < 2; ++f) fb[f] = *reinterpret_cast<const bf16x8_t *>(s_patch + rowoff + ct[f][kx]);
+                for (int f = 0; f < 2; ++f) fb[f] = *reinterpret_cast<const bf16x8_t *>(s_patch + (f ? rowoff1 : rowoff0) + ct[f][kx]);
 #pragma unroll
                 for (int i = 0; i < TCO; ++i)
                     fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             uint2 o;
             o.x = pack_bf16x2(v0, v1);
             o.y = pack_bf16x2(v2, v3);
-            const size_t pix = (size_t)(n * Ho + y0 + wave) * Wo + x0 + f * 16 + fj;
+            const size_t pix = (size_t)(n * Ho + y0 + (f ? frow1 : frow0)) * Wo + x0 + (TW == 32 ? f * 16 : 0) + fj;
             *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
         }
     }
@@ -353,11 +370,11 @@ static int launch_s2_resident(const S2Args &a, hipStream_t s) {
     return V2X_OK;
 }
 
-template <int BCO>
+template <int BCO, int TH = S2_TH, int TW = S2_TW>
 static int launch_s2(const S2Args &a, hipStream_t s) {
     constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES + 2 * BCO * 4;
     static v2x_once_per_device attr_once;
-    auto kern = &conv3x3_s2_stream_kernel<BCO>;
+    auto kern = &conv3x3_s2_stream_kernel<BCO, TH, TW>;
     if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     }
@@ -369,7 +386,9 @@ static int launch_s2(const S2Args &a, hipStream_t s) {
 // Returns V2X_OK if handled, 1 if the shape is not covered (caller reports).
 int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     if (d->C1 != 0 || d->up0 != 0 || d->Cout2 != 0 || d->epilogue != V2X_EPI_BF16) return 1;
-    if (d->H % (2 * S2_TH) != 0 || d->W % (2 * S2_TW) != 0) return 1;
+    const bool t32 = d->H % (2 * S2_TH) == 0 && d->W % (2 * S2_TW) == 0;     // 4 x 32 output tiles
+    const bool t16 = !t32 && d->H % 16 == 0 && d->W % 32 == 0;                // 8 x 16 output tiles (16 x 16 outputs: conv4_1)
+    if (!t32 && !t16) return 1;
     const int rows = (d->Cout % 128 == 0) ? 128 : ((d->Cout % 64 == 0) ? 64 : 0);
     if (rows == 0 || d->w_rows != d->Cout) return 1;
     S2Args a;
@@ -386,10 +405,11 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.out_cstride = d->out_cstride;
     a.out_coff = d->out_coff;
     a.Cout = d->Cout;
-    a.tiles_x = (d->W / 2) / S2_TW;
-    a.tiles_y = (d->H / 2) / S2_TH;
+    a.tiles_x = (d->W / 2) / (t32 ? S2_TW : 16);
+    a.tiles_y = (d->H / 2) / (t32 ? S2_TH : 8);
     a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
     a.n_co_tiles = d->Cout / rows;
+    if (t16) return rows == 128 ? launch_s2<128, 8, 16>(a, s) : launch_s2<64, 8, 16>(a, s);
     if (rows == 64 && a.n_co_tiles == 1 && d->C0 == 32) {   // one chunk, one channel tile: resident weights (conv1_1)
         const char *e = getenv("V2X_S2_RESIDENT");
         if (!(e && e[0] == '0')) return launch_s2_resident(a, s);

@@ -47,7 +47,10 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
     if pc.w_layout == 2 and pc.stride == 2:
         if pc.Cout == 64 and pc.C0 == 32 and os.environ.get("V2X_S2_RESIDENT", "1") != "0":
             return "conv3x3_s2_resident_kernel<64>"
-        return "conv3x3_s2_stream_kernel<%d>" % (128 if pc.Cout % 128 == 0 else 64)
+        rows = 128 if pc.Cout % 128 == 0 else 64
+        if not (H % 8 == 0 and W % 64 == 0):
+            return "conv3x3_s2_stream_kernel<%d, 8, 16>" % rows    # 16 x 16 outputs (conv4_1)
+        return "conv3x3_s2_stream_kernel<%d, 4, 32>" % rows
     if pc.w_layout == 2:
         rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
         th, tw = (8, 32) if W % 32 == 0 else (16, 16)
@@ -511,8 +514,8 @@ def run_layer(layer, in0, in1=None, zbits=0):
         H, W = in0.shape[1], in0.shape[2]
     h = layer.halo
     if h is not None and h.stride == 2:
-        # stride-2 streamed kernel: 4x32 output tiles.  16x16 outputs (conv4_1) stay on the gather kernel.
-        if H % 8 == 0 and W % 64 == 0:
+        # stride-2 streamed kernel: 4x32 output tiles, or 8x16 ones for narrow maps (conv4_1: 16x16 outputs)
+        if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and os.environ.get("V2X_S2_T16", "1")[:1] != "0"):
             return conv2d(h, in0, in1, split=layer.split)
     elif h is not None and halo_eligible(H, W, h.w_layout):
         use = True
