@@ -469,29 +469,61 @@ def test_halo_conv_vs_torch(device, cfg):
     assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 16, 32), (3, 64, 96), (40, 256, 256), (1, 8, 64)])
-def test_halo_pingpong_equals_4wave_kernel_bitwise(device, monkeypatch, N, H, W):
-    """conv8_1's 8-wave ping-pong form (two 4-wave groups on one resident weight copy, default) against the 4-wave kernel
+@pytest.mark.parametrize("cup,c,cout,N,H,W", [(64, 32, 32, 2, 16, 32), (64, 32, 32, 3, 64, 96), (64, 32, 32, 40, 256, 256), (64, 32, 32, 1, 8, 64),
+                                               (0, 64, 64, 2, 16, 32), (0, 64, 64, 3, 40, 96), (0, 64, 64, 40, 128, 128)])
+def test_halo_pingpong_equals_4wave_kernel_bitwise(device, monkeypatch, cup, c, cout, N, H, W):
+    """The 8-wave ping-pong form of conv8_1 / conv7_2 (two 4-wave groups on one resident weight copy, default) against the 4-wave kernel
     (V2X_HALO_PP=0): same K order and fragment mapping -> bit-identical, for one tile pair, ragged persistent walks (tile
     pairs not a multiple of the grid), image borders, and the bench's 256x256 maps (40 maps = 10 240 tiles, 20 per workgroup);
     repeated launches are bit-identical too (no race between the groups' phases)."""
     from v2x_sim_amd import ops, packing
-    g = torch.Generator().manual_seed(N * 1000 + H + W)
-    x = bf16r(torch.randn(N, 32, H, W, generator=g))
-    x_up = bf16r(torch.randn(N, 64, H // 2, W // 2, generator=g))
-    w = torch.randn(32, 96, 3, 3, generator=g) * (2.0 / (96 * 9)) ** 0.5
-    scale, shift = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.2
-    pc = packing.pack_conv_halo("t", w, scale, shift, C0=64, C1=32, relu=True, device=device)
-    xu, xs = to_nhwc_bf16(x_up, device), to_nhwc_bf16(x, device)
+    g = torch.Generator().manual_seed(N * 1000 + H + W + cup)
+    x = bf16r(torch.randn(N, c, H, W, generator=g))
+    x_up = bf16r(torch.randn(N, cup, H // 2, W // 2, generator=g)) if cup else None
+    w = torch.randn(cout, cup + c, 3, 3, generator=g) * (2.0 / ((cup + c) * 9)) ** 0.5
+    scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    pc = packing.pack_conv_halo("t", w, scale, shift, C0=cup if cup else c, C1=c if cup else 0, relu=True, device=device)
+    xs = to_nhwc_bf16(x, device)
+    run = (lambda xu=to_nhwc_bf16(x_up, device): ops.conv2d(pc, xu, xs)) if cup else (lambda: ops.conv2d(pc, xs))
     monkeypatch.setenv("V2X_HALO_PP", "0")
-    old = ops.conv2d(pc, xu, xs).clone()
+    old = run().clone()
     monkeypatch.setenv("V2X_HALO_PP", "1")
-    new = [ops.conv2d(pc, xu, xs).clone() for _ in range(3)]
+    new = [run().clone() for _ in range(3)]
     monkeypatch.delenv("V2X_HALO_PP")
+    assert ops.conv_kernel_name(pc, H, W) == "conv3x3_halo_pp_kernel<%d, %d, %d, 0>" % (cup, c, cout)
     assert all(torch.equal(old.view(torch.int16), y.view(torch.int16)) for y in new)
     if N <= 3:
         ref = _halo_ref(x, w, scale, shift, True, x_up)
         assert torch.allclose(from_nhwc(new[0]), ref, atol=2e-3, rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 16, 32), (3, 48, 96), (40, 128, 128)])
+def test_halo_pingpong_chained_1x1(device, N, H, W):
+    """conv1_2 -> conv3d_1 on the ping-pong kernel: 3x3 64 -> 64 (+BN+ReLU, rounded to bf16) chained with the 1x1 64 -> 64
+    (+BN+ReLU) in the store phase.  vs torch fp32 on the same bf16 operands and vs the wide streamed kernel's chained epilogue,
+    at the tolerance of tests/test_gpu_stream.py::test_stream_chain_conv1x1 (the hidden map is one bf16 rounding apart between
+    implementations with different K walks, and 64 such values feed every output); bit-stable over launches."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(N + H + W)
+    x = bf16r(torch.randn(N, 64, H, W, generator=g))
+    w1 = torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5
+    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    w2 = torch.randn(64, 64, 1, 1, generator=g) * 0.2
+    s2, t2 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    pp = packing.pack_conv_halo("c", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
+    st = packing.pack_conv_stream("c", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
+    xs = to_nhwc_bf16(x, device)
+    assert ops.conv_kernel_name(pp, H, W) == "conv3x3_halo_pp_kernel<0, 64, 64, 64>"
+    a = ops.conv2d(pp, xs)
+    assert all(torch.equal(a, ops.conv2d(pp, xs)) for _ in range(3))
+    b = ops.conv2d(st, xs)
+    d = (a.float() - b.float()).abs()
+    assert torch.allclose(a.float(), b.float(), atol=3e-2, rtol=2 ** -6) and float(d.mean()) < 2e-3, (float(d.max()), float(d.mean()))
+    if N <= 3:
+        hid = bf16r(_halo_ref(x, w1, s1, t1, True))
+        ref = F.relu(F.conv2d(hid, bf16r(w2)) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1))
+        e = (from_nhwc(a) - ref).abs()
+        assert torch.allclose(from_nhwc(a), ref, atol=3e-2, rtol=2 ** -6) and float(e.mean()) < 2e-3, (float(e.max()), float(e.mean()))
 
 
 def test_halo_equals_gather_kernel_bitwise(device):

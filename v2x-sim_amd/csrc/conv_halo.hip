@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // which every wave waited for its own DMA pieces (vmcnt(N_STORES): the DMAs are issued BEFORE the stores of E, so the
 // stores may stay in flight).  The accumulators live across the barrier from C to E.  K order, fragment mapping and
 // epilogue arithmetic are those of conv3x3_halo_kernel: results are bit-identical.
-template <int C0, int C1, int COUT>
+template <int C0, int C1, int COUT, int COUT2 = 0>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_pp_kernel(const HaloArgs a) {
     constexpr int SPP0 = C0 / 8, SPP1 = C1 / 8;
     constexpr int NS1 = round64(PH * PW * SPP1);
@@ -510,9 +510,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int KSLOTS = 9 * (SPP0 + SPP1);
     constexpr int W_BYTES = KSLOTS * COUT * 16;
     constexpr int TCO = COUT / 16;
-    static_assert(C0 > 0 && C0 % 32 == 0 && C1 % 32 == 0 && TCO == 2, "ping-pong form: two sources, 32 output channels");
+    static_assert(C0 % 32 == 0 && C1 % 32 == 0 && (TCO == 2 || TCO == 4), "ping-pong form: 32 or 64 output channels");
     static_assert(W_BYTES % 1024 == 0, "weights are moved 1 KiB per wave instruction");
-    constexpr int N_STORES = TCO * 4;
+    constexpr int TCO2 = COUT2 / 16;
+    static_assert(COUT2 == 0 || (COUT2 == 64 && COUT == 64), "chained 1x1: 64 -> 64 (conv1_2 -> conv3d_1)");
+    constexpr int N_STORES = (COUT2 ? TCO2 : TCO) * 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_w = smem;
@@ -521,6 +523,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int i = threadIdx.x; i < COUT; i += 512) {
         s_ss[i] = a.scale[i];
         s_ss[COUT + i] = a.shift[i];
+    }
+    if constexpr (COUT2 > 0) {   // [scale | shift | scale2 | shift2]
+        for (int i = threadIdx.x; i < COUT2; i += 512) {
+            s_ss[2 * COUT + i] = a.scale2[i];
+            s_ss[2 * COUT + COUT2 + i] = a.shift2[i];
+        }
     }
 
     const int tid = threadIdx.x;
@@ -534,21 +542,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         glds16h(reinterpret_cast<const char *>(a.w) + off + lane * 16, s_w + off);
 
     // per-lane DMA tables (see conv3x3_halo_body): piece t of wave wv of a group covers patch slots [wv*64 + t*256, +64)
+    // (the chained form recomputes them per piece instead: its store phase has slack next to the other group's MFMA interval,
+    // its register budget has none)
+    constexpr bool TABLES = (COUT2 == 0);
     constexpr int NP1 = (NS1 + 255) / 256, NP0 = (NS0 + 255) / 256;
-    int tb1[NP1], tb0[NP0];
+    int tb1[TABLES ? NP1 : 1], tb0[NP0 ? NP0 : 1];
 #pragma unroll
-    for (int t = 0; t < NP1; ++t) {
+    for (int t = 0; t < (TABLES ? NP1 : 0); ++t) {
         const int L = wv * 64 + t * 256 + lane;
         const int pix = L / SPP1, phys = L - pix * SPP1;
         const int pr = pix / PW, pc = pix - pr * PW;
         tb1[t] = pix < PH * PW ? (((pr * a.W + pc) * C1 + swz<SPP1>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
     }
+    if constexpr (C0 > 0) {
+        constexpr int S0 = SPP0 ? SPP0 : 1;
 #pragma unroll
-    for (int t = 0; t < NP0; ++t) {
-        const int L = wv * 64 + t * 256 + lane;
-        const int pix = L / SPP0, phys = L - pix * SPP0;
-        const int pr = pix / PW0, pc = pix - pr * PW0;
-        tb0[t] = pix < PH0 * PW0 ? (((pr * (a.W >> 1) + pc) * C0 + swz<SPP0>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
+        for (int t = 0; t < NP0; ++t) {
+            const int L = wv * 64 + t * 256 + lane;
+            const int pix = L / S0, phys = L - pix * S0;
+            const int pr = pix / PW0, pc = pix - pr * PW0;
+            tb0[t] = pix < PH0 * PW0 ? (((pr * (a.W >> 1) + pc) * C0 + swz<(SPP0 ? SPP0 : 4)>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
+        }
     }
 
     const int txy = a.tiles_x * a.tiles_y;
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     auto load_patch = [&](int tile) {   // this group's patch <- tile; <= NP1 + NP0 DMAs per wave
         int n, y0, x0;
         coords(tile, n, y0, x0);
-        {
+        if constexpr (TABLES) {
             const unsigned base = ((unsigned)(n * a.H + y0 - 1) * (unsigned)a.W + (unsigned)(x0 - 1)) * (unsigned)C1;
 #pragma unroll
             for (int t = 0; t < NP1; ++t) {
@@ -572,8 +586,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 glds16h(ok ? (const void *)(a.in1 + (base + (unsigned)(tb1[t] & 0xfffff))) : (const void *)g_zero_page_h,
                         pb + NS0 * 16 + (wv * 64 + t * 256) * 16);
             }
+        } else {
+            for (int base = wv * 64; base < NS1; base += 256) {
+                const int L = base + lane;
+                const int pix = L / SPP1, phys = L - pix * SPP1;
+                const int pr = pix / PW, pc = pix - pr * PW;
+                const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+                const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                const unsigned off = ((unsigned)(n * a.H + y) * (unsigned)a.W + (unsigned)x) * (unsigned)C1 + swz<SPP1>(phys, pc) * 8;
+                glds16h(ok ? (const void *)(a.in1 + off) : (const void *)g_zero_page_h, pb + NS0 * 16 + base * 16);
+            }
         }
-        {
+        if constexpr (C0 > 0) {
             const int Hs = a.H >> 1, Ws = a.W >> 1;
             const unsigned base = ((unsigned)(n * Hs + (y0 >> 1) - 1) * (unsigned)Ws + (unsigned)((x0 >> 1) - 1)) * (unsigned)C0;
 #pragma unroll
@@ -609,7 +633,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int ch = 0; ch < 2; ++ch) {
                     const int pr = wv + hr;
                     const int pc = ((ch * 16 + fj + kx - 1) >> 1) + 1;
-                    F.B[hr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + ((pr * PW0 + pc) * SPP0 + swz<SPP0>(kk * 4 + fq, pc)) * 16);
+                    F.B[hr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + ((pr * PW0 + pc) * (SPP0 ? SPP0 : 1) + swz<(SPP0 ? SPP0 : 4)>(kk * 4 + fq, pc)) * 16);
                 }
         } else {
             const int kc = kk - KC0;
@@ -648,24 +672,134 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int i = 0; i < TCO; ++i)
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        Frags fr[2];
-        load_group(0, fr[0]);
+        if constexpr (TCO == 2) {   // fragments of group g+1 are read while the MFMAs of group g issue (register double-buffer)
+            Frags fr[2];
+            load_group(0, fr[0]);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) load_group(g + 1, fr[(g + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_group(g, fr[g & 1]);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) load_group(g + 1, fr[(g + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                mma_group(g, fr[g & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            // 64 output channels: the group's 8 pixel fragments in one register set, its weight fragments per tap row ky in
+            // two alternating sets of 4 (the reads of row ky+1 are issued before the 16 MFMAs of row ky): 64 fragment
+            // registers instead of 80 -- what the chained epilogue needs to stay inside the 256-VGPR budget
+            static_assert(C0 == 0 || TCO == 2, "the 64-channel form has one full-resolution source");
+            bf16x8_t B[8], A[2][TCO];
+            auto load_A = [&](int g, int ky, bf16x8_t (&Ak)[TCO]) {
+                const int kx = g / KC, kc = g - kx * KC;
+                const int kslot = (ky * 3 + kx) * (SPP0 + SPP1) + SPP0 + kc * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < TCO; ++i) Ak[i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
+            };
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int kx = g / KC, kc = g - kx * KC;
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ++ch) {
+                        const int pr = 2 * wv + rr, pc = ch * 16 + fj + kx;
+                        B[rr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + NS0 * 16 + ((pr * PW + pc) * SPP1 + swz<SPP1>(kc * 4 + fq, pc)) * 16);
+                    }
+                load_A(g, 0, A[0]);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (ky < 2) load_A(g, ky + 1, A[(ky + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                        for (int f = 0; f < 4; ++f)
+                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky & 1][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     };
     auto epilogue = [&](int tile) {
         int n, y0, x0;
         coords(tile, n, y0, x0);
+        // opaque zero: the scale/shift reads below are loop-invariant LDS loads; hoisted out of the interval loop they would
+        // sit in 32-64 registers across the MFMA phase (the chained form spilled)
+        int zo = 0;
+        asm volatile("" : "+v"(zo));
+        const float *ss = s_ss + zo;
+        if constexpr (COUT2 > 0) {
+            // chained 1x1 (rows of the first GEMM in kappa order: a lane's accumulators ARE its B fragment of the second GEMM,
+            // see conv3x3_halo_body).  The second GEMM's weights (8 KiB, L1/L2-resident) are read from global memory -- the LDS
+            // is full -- and this whole phase runs beside the other group's MFMA interval.
+            bf16x8_t w2f[TCO2][COUT / 32];
+            int w2off = fj * COUT + fq * 8;
+            asm volatile("" : "+v"(w2off));   // opaque: the loads are loop-invariant and would be hoisted across the MFMA interval
+                                              // (32 more live registers on top of the 234 of the compute phase: it spilled)
+#pragma unroll
+            for (int i2 = 0; i2 < TCO2; ++i2)
+#pragma unroll
+                for (int ks = 0; ks < COUT / 32; ++ks)
+                    w2f[i2][ks] = *reinterpret_cast<const bf16x8_t *>(a.w2 + w2off + i2 * 16 * COUT + ks * 32);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // w2 fragments (and the patch DMAs issued before them) have landed
+            // one pixel fragment at a time: its hidden activations (8 registers) -> the four output-channel tiles
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                bf16x8_t hb[COUT / 32];
+#pragma unroll
+                for (int ks = 0; ks < COUT / 32; ++ks) {
+                    float h[8];
+#pragma unroll
+                    for (int hf = 0; hf < 2; ++hf) {
+                        const int i = 2 * ks + hf;
+                        const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
+                        const float4 sc = *reinterpret_cast<const float4 *>(ss + kappa);
+                        const float4 sf = *reinterpret_cast<const float4 *>(ss + COUT + kappa);
+                        h[hf * 4 + 0] = acc[i][f][0] * sc.x + sf.x;
+                        h[hf * 4 + 1] = acc[i][f][1] * sc.y + sf.y;
+                        h[hf * 4 + 2] = acc[i][f][2] * sc.z + sf.z;
+                        h[hf * 4 + 3] = acc[i][f][3] * sc.w + sf.w;
+                    }
+                    if (a.relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) h[e] = fmaxf(h[e], 0.f);
+                    }
+                    uint4 p;
+                    p.x = pack_bf16x2(h[0], h[1]);
+                    p.y = pack_bf16x2(h[2], h[3]);
+                    p.z = pack_bf16x2(h[4], h[5]);
+                    p.w = pack_bf16x2(h[6], h[7]);
+                    hb[ks] = __builtin_bit_cast(bf16x8_t, p);
+                }
+                const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
+                uint16_t *prow = reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff;
+#pragma unroll
+                for (int i2 = 0; i2 < TCO2; ++i2) {
+                    const int co = i2 * 16 + fq * 4;
+                    const float4 s2 = *reinterpret_cast<const float4 *>(ss + 2 * COUT + co);
+                    const float4 t2 = *reinterpret_cast<const float4 *>(ss + 2 * COUT + COUT2 + co);
+                    f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ks = 0; ks < COUT / 32; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][ks], hb[ks], d, 0, 0, 0);
+                    float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
+                    if (a.relu2) {
+                        v0 = fmaxf(v0, 0.f);
+                        v1 = fmaxf(v1, 0.f);
+                        v2 = fmaxf(v2, 0.f);
+                        v3 = fmaxf(v3, 0.f);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v0, v1);
+                    o.y = pack_bf16x2(v2, v3);
+                    *reinterpret_cast<uint2 *>(prow + co) = o;
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
             const int co = i * 16 + fq * 4;
-            const float4 sc = *reinterpret_cast<const float4 *>(s_ss + co);
-            const float4 sf = *reinterpret_cast<const float4 *>(s_ss + COUT + co);
+            const float4 sc = *reinterpret_cast<const float4 *>(ss + co);
+            const float4 sf = *reinterpret_cast<const float4 *>(ss + COUT + co);
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
                 const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
@@ -705,7 +839,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (m + 1 < K) load_patch(tile_of(m + 1));     // its previous compute is behind the last barrier
             if (m >= 0) {
                 epilogue(tile_of(m));
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // the DMAs are OLDER than the 8 stores: they have landed
+                // the DMAs are OLDER than the N_STORES stores: they have landed, the stores may stay in flight
+                if constexpr (N_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -714,17 +850,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     }
-    static_assert(N_STORES == 8, "the counted waits above assume 8 stores per tile and wave");
+    static_assert(N_STORES == 8 || N_STORES == 16, "the counted waits above know 8 or 16 stores per tile and wave");
 }
 
-template <int C0, int C1, int COUT>
+template <int C0, int C1, int COUT, int COUT2 = 0>
 static int launch_halo_pp(const HaloArgs &a, hipStream_t s) {
     constexpr int NS1 = round64(PH * PW * (C1 / 8));
-    constexpr int NS0 = round64(PH0 * PW0 * (C0 / 8));
-    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16 + 2 * COUT * 4;
+    constexpr int NS0 = C0 ? round64(PH0 * PW0 * (C0 / 8)) : 0;
+    constexpr int smem = 9 * (C0 + C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16 + 2 * COUT * 4 + 2 * COUT2 * 4;
     static_assert(smem <= 160 * 1024, "LDS budget");
     static v2x_once_per_device attr_once;
-    auto kern = &conv3x3_halo_pp_kernel<C0, C1, COUT>;
+    auto kern = &conv3x3_halo_pp_kernel<C0, C1, COUT, COUT2>;
     if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     }
@@ -827,7 +963,15 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
         if (!(e && e[0] == '0')) return launch_halo_pp<64, 32, 32>(a, s);
     }
     HALO_CASE(64, 32, 32, 0, 0)   // conv8_1: cat(up(x_7), x)
+    if (C0 == 0 && C1 == 64 && d->Cout == 64 && co2 == 0 && e2 == 0 && a.n_tiles >= 2 && a.n_tiles % 2 == 0) {
+        // conv7_2: resident 72-KiB weights + two single-buffered 43-KiB patches = 158.5 KiB, 8-wave ping-pong form
+        const char *e = getenv("V2X_HALO_PP");
+        if (!(e && e[0] == '0')) return launch_halo_pp<0, 64, 64>(a, s);
+    }
     HALO_CASE(0, 64, 64, 0, 0)    // conv7_2
+    if (C0 == 0 && C1 == 64 && d->Cout == 64 && co2 == 64 && e2 == 1 && d->Cout2 == 64 && a.n_tiles >= 2 && a.n_tiles % 2 == 0 &&
+        d->split == 0)
+        return launch_halo_pp<0, 64, 64, 64>(a, s);   // conv1_2 -> conv3d_1 chained (ping-pong form only)
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
 #undef HALO_CASE
     return 1;

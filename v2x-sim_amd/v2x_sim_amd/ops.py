@@ -68,8 +68,10 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         e2 = 0 if not pc.Cout2 else (2 if pc.epilogue == V2X_EPI_F32 else 1)
         if (c0, c1, pc.Cout, co2) == (0, 32, 32, 0):  # HBM-bound layers: single-buffer form (+ bit-grid input)
             return "conv3x3_halo_sb_kernel<0, 32, 32, 0, 0, %s>" % ("true" if bits else "false")
-        if (c0, c1, pc.Cout, co2) == (64, 32, 32, 0) and os.environ.get("V2X_HALO_PP", "1")[:1] != "0":
-            return "conv3x3_halo_pp_kernel<64, 32, 32>"   # conv8_1: 8-wave ping-pong form
+        if (c0, c1, pc.Cout, co2, e2) == (0, 64, 64, 64, 1):
+            return "conv3x3_halo_pp_kernel<0, 64, 64, 64>"   # conv1_2 -> conv3d_1 chained: ping-pong form only
+        if (c0, c1, pc.Cout, co2) in ((64, 32, 32, 0), (0, 64, 64, 0)) and os.environ.get("V2X_HALO_PP", "1")[:1] != "0":
+            return "conv3x3_halo_pp_kernel<%d, %d, %d, 0>" % (c0, c1, pc.Cout)   # conv8_1 / conv7_2: 8-wave ping-pong form
         return "conv3x3_halo_kernel<%d, %d, %d, %d, %d>" % (c0, c1, pc.Cout, co2, e2)
     rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
     return "conv_igemm_kernel<%d, %d, %d, %d, %d>" % (_CONV_TILES[rows] + (pc.epilogue,))

@@ -9,6 +9,8 @@
   * ConvGRU (h0 = 0): W_ih rows regrouped as (r,z,n) triples of 16 hidden channels so one
     wave owns all three gates of its channels; biases packed float4 per hidden channel.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -187,7 +189,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
         cin_h = _ceil_to(cin_p, 32)
         key = (fb.C0 if fb.C1 else 0, fb.C1 if fb.C1 else cin_h, conv.out_channels)
-        if key in ((0, 32, 32), (64, 32, 32)) or (key == (0, 64, 64) and not STREAM_64):
+        if key in ((0, 32, 32), (64, 32, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
         elif (cin_p >= (64 if STREAM_64 else 128) and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
@@ -204,6 +206,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
 CHAIN_STREAM = True   # conv1_2 -> conv3d_1 and conv2_2 -> conv3d_2: 1x1 chained in the streamed kernel's epilogue (False: separate launches for conv3d_2)
 STREAM_64 = True      # 64 -> 64 layers (conv7_2): streamed (wide 4-wave) kernel instead of the resident-weights halo kernel (471 vs 495 us)
+PP_64 = os.environ.get("V2X_PP_64", "1")[:1] != "0"   # 64 -> 64 layers (conv7_2): resident-weights 8-wave ping-pong halo kernel instead of the wide streamed one
 STREAM_S2 = True      # stride-2 3x3 layers (conv1_1, conv2_1, conv3_1): patch-based stride-2 kernel instead of the gather kernel
 
 
