@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 7
+#define V2X_AMD_ABI_VERSION 8
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -199,6 +199,19 @@ int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
  * first->in_format = 1 (bit grid, in_zbits <= 16); H % 8 == 0, W % 32 == 0.  first->out is ignored; the result is
  * bit-identical to v2x_conv2d(first) followed by v2x_conv2d(second). */
 int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- f-3: backward of the 3x3 stride-1 convolutions
+ * Upstream trains through torch.autograd (cuDNN / MIOpen kernels behind nn.Conv2d.backward, tools/det/train_codet.py).
+ *   data gradient:   dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] -- a forward convolution: v2x_conv2d
+ *                    on the re-packed weights (v2x_sim_amd/train/hip_conv.py);
+ *   weight gradient: v2x_conv3x3_wgrad, an MFMA kernel contracting over pixels (conv_wgrad.hip).
+ * x bf16 NHWC [N][H][W][Cin], dy bf16 NHWC [N][H][W][Cout]; H % 8 == 0, W % 32 == 0, Cin % 32 == 0, Cout % 64 == 0.
+ * workspace fp32 [n_split][Cout][3][3][Cin]: partial sums, every element written; dW = sum over the first axis (the caller
+ * adds them in a fixed order: deterministic).  n_split in [1, number of 8x32 pixel tiles]; v2x_conv3x3_wgrad_splits gives
+ * the library's choice (0 = unsupported extent). */
+int v2x_conv3x3_wgrad_splits(int N, int H, int W);
+int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, int H, int W, int Cin, int Cout, float *workspace,
+                      int n_split, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- a3 (+ the sum of a4/a5): warp + fuse
  * Replaces DetModelBase.py::feature_transformation (affine_grid + grid_sample twice,

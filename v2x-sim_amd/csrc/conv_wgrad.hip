@@ -1,0 +1,170 @@
+// Weight gradient of the 3x3 stride-1 pad-1 convolutions (the first hand-written backward
+// kernel -- until now the whole backward pass was MIOpen's through torch.autograd).
+//
+//     dW[co][ky][kx][ci] = sum over (n, y, x) of  dY[n][y][x][co] * X[n][y + ky - 1][x + kx - 1][ci]        (zero padding)
+//
+// As a GEMM this contracts over PIXELS: M = Cout, N = 9*Cin, K = N*H*W, while both operands live in HBM channel-contiguous
+// (NHWC).  The MFMA wants 8 consecutive k per lane, so both operands are TRANSPOSED on their way into LDS (16-B global
+// loads, eight ds_write_b16 each): dY tile as [co][pixel], the input patch as [ci][patch row][column] in THREE copies
+// shifted by the tap column kx, so that every fragment read is an aligned ds_read_b128 of 8 consecutive pixels.
+//
+// Work split: block = (64 output channels) x (32 input channels) x (a share of the 8x32-pixel tiles).  Wave w owns 16
+// output channels x 9 taps x 2 input-channel sub-tiles = 18 accumulator tiles (72 VGPRs) that stay in registers over all
+// the block's pixel tiles.  Per patch row pr the wave reads 6 B fragments (3 tap columns x 2 ci sub-tiles) and one new A
+// fragment and issues the MFMAs of the (output row r, tap row ky) pairs with r + ky = pr: 7 fragment reads per 18 MFMAs.
+// The partial sums of the blocks that share (co tile, ci tile) go to a workspace [split][Cout][9][Cin] fp32 and are added
+// up by the caller in a fixed order -- deterministic, unlike an atomicAdd reduction (and unlike MIOpen's wgrad).
+#include "common.h"
+
+constexpr int WG_TH = 8, WG_TW = 32;                 // pixel tile
+constexpr int WG_CO = 64, WG_CI = 32;                // channel block
+constexpr int WG_PX = WG_TH * WG_TW;                 // 256 pixels = k extent of one tile
+constexpr int WG_DY_ROW = WG_PX * 2 + 16;            // bytes per output channel of the transposed dY tile (+16: bank spread)
+constexpr int WG_X_ROW = (WG_TH + 2) * WG_TW * 2 + 16;  // bytes per input channel of one shifted patch copy
+constexpr int WG_SMEM = WG_CO * WG_DY_ROW + 3 * WG_CI * WG_X_ROW;
+
+struct WgradArgs {
+    const uint16_t *x;    // [N][H][W][Cin] bf16
+    const uint16_t *dy;   // [N][H][W][Cout] bf16
+    float *ws;            // [n_split][Cout][9][Cin] fp32 partial sums (every element written)
+    int N, H, W, Cin, Cout;
+    int tiles_x, tiles_y, n_tiles, n_split;
+};
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_dy = smem;                                 // [64 co][256 px]
+    char *s_x = smem + WG_CO * WG_DY_ROW;              // [3 kx][32 ci][10 rows][32 cols]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15, fq = lane >> 4;
+    const int n_ci_t = a.Cin / WG_CI;
+    const int blk = blockIdx.x;
+    const int split = blk % a.n_split;
+    const int cc = blk / a.n_split;
+    const int ci_t = cc % n_ci_t, co_t = cc / n_ci_t;
+    const int txy = a.tiles_x * a.tiles_y;
+
+    f32x4_t acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = split; tile < a.n_tiles; tile += a.n_split) {
+        const int n = tile / txy;
+        const int r0 = tile - n * txy;
+        const int ty = r0 / a.tiles_x;
+        const int y0 = ty * WG_TH, x0 = (r0 - ty * a.tiles_x) * WG_TW;
+        __syncthreads();   // everyone is done reading the previous tile
+        // ---- dY tile, transposed: thread = pixel, loop over the 8 groups of 8 output channels
+        {
+            const int pr = tid >> 5, pc = tid & 31;
+            const uint16_t *src = a.dy + ((size_t)(n * a.H + y0 + pr) * a.W + x0 + pc) * a.Cout + co_t * WG_CO;
+#pragma unroll
+            for (int cg = 0; cg < WG_CO / 8; ++cg) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + cg * 8);
+                const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *reinterpret_cast<uint16_t *>(s_dy + (cg * 8 + e) * WG_DY_ROW + tid * 2) = (uint16_t)(wds[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+        // ---- input patch (10 x 34 pixels x 32 channels), transposed into the three kx-shifted copies
+        for (int p = tid; p < (WG_TH + 2) * (WG_TW + 2); p += 256) {
+            const int pr = p / (WG_TW + 2), pc = p - pr * (WG_TW + 2);
+            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+            const bool ok = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const uint16_t *src = a.x + ((size_t)(n * a.H + (ok ? y : 0)) * a.W + (ok ? x : 0)) * a.Cin + ci_t * WG_CI;
+#pragma unroll
+            for (int cg = 0; cg < WG_CI / 8; ++cg) {
+                uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                if (ok) v = *reinterpret_cast<const uint4 *>(src + cg * 8);
+                const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int c = pc - kx;   // copy kx holds patch column c + kx at column c
+                    if (c < 0 || c >= WG_TW) continue;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        *reinterpret_cast<uint16_t *>(s_x + (kx * WG_CI + cg * 8 + e) * WG_X_ROW + (pr * WG_TW + c) * 2) =
+                            (uint16_t)(wds[e >> 1] >> ((e & 1) * 16));
+                }
+            }
+        }
+        __syncthreads();
+        // ---- MFMAs: patch row pr serves (r, ky) with r + ky = pr
+        bf16x8_t A[3];   // A[(pr) % 3] = dY^T fragment of output row pr (16 co x 32 px)
+#pragma unroll
+        for (int pr = 0; pr < WG_TH + 2; ++pr) {
+            if (pr < WG_TH)
+                A[pr % 3] = *reinterpret_cast<const bf16x8_t *>(s_dy + (wave * 16 + fj) * WG_DY_ROW + (pr * WG_TW + fq * 8) * 2);
+            bf16x8_t B[3][2];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    B[kx][j] = *reinterpret_cast<const bf16x8_t *>(s_x + (kx * WG_CI + j * 16 + fj) * WG_X_ROW + (pr * WG_TW + fq * 8) * 2);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int r = pr - ky;
+                if (r < 0 || r >= WG_TH) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ky * 3 + kx][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r % 3], B[kx][j], acc[ky * 3 + kx][j], 0, 0, 0);
+            }
+        }
+    }
+    // ---- partial result of this block: ws[split][co][tap][ci]; lane (fj, fq) holds rows co = 4*fq + e, column ci = fj
+    float *dst = a.ws + (size_t)split * a.Cout * 9 * a.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co_t * WG_CO + wave * 16 + fq * 4 + e;
+                const int ci = ci_t * WG_CI + j * 16 + fj;
+                dst[((size_t)co * 9 + t) * a.Cin + ci] = acc[t][j][e];
+            }
+}
+
+extern "C" int v2x_conv3x3_wgrad_splits(int N, int H, int W) {
+    // pixel tiles per (co tile, ci tile) pair are shared by up to 64 blocks; fewer when the batch is small
+    if (N <= 0 || H <= 0 || W <= 0 || H % WG_TH || W % WG_TW) return 0;
+    const long long tiles = (long long)N * (H / WG_TH) * (W / WG_TW);
+    return (int)(tiles < 64 ? tiles : 64);
+}
+
+extern "C" int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, int H, int W, int Cin, int Cout, float *workspace,
+                                 int n_split, v2x_stream_t stream) {
+    V2X_REQUIRE(x && dy && workspace, "v2x_conv3x3_wgrad: null pointer");
+    V2X_REQUIRE(N > 0 && H % WG_TH == 0 && W % WG_TW == 0 && Cin % WG_CI == 0 && Cout % WG_CO == 0,
+                "v2x_conv3x3_wgrad: needs H %% 8 == 0, W %% 32 == 0, Cin %% 32 == 0, Cout %% 64 == 0");
+    WgradArgs a;
+    a.x = x;
+    a.dy = dy;
+    a.ws = workspace;
+    a.N = N;
+    a.H = H;
+    a.W = W;
+    a.Cin = Cin;
+    a.Cout = Cout;
+    a.tiles_x = W / WG_TW;
+    a.tiles_y = H / WG_TH;
+    a.n_tiles = N * a.tiles_x * a.tiles_y;
+    V2X_REQUIRE(n_split >= 1 && n_split <= a.n_tiles, "v2x_conv3x3_wgrad: n_split=%d outside [1, %d]", n_split, a.n_tiles);
+    a.n_split = n_split;
+    static v2x_once_per_device attr_once;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+    }
+    const int grid = (Cout / WG_CO) * (Cin / WG_CI) * n_split;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(256), WG_SMEM, (hipStream_t)stream, a);
+    V2X_CHECK_LAUNCH("conv3x3_wgrad_kernel");
+    return V2X_OK;
+}

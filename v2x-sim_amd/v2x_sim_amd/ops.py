@@ -363,6 +363,26 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
     return out
 
 
+def conv3x3_wgrad(x, dy):
+    """Weight gradient of a 3x3 stride-1 pad-1 conv.  x (N, H, W, Cin), dy (N, H, W, Cout) bf16 NHWC -> dW (Cout, Cin, 3, 3) fp32
+    (the parameter's own layout).  MFMA kernel contracting over pixels + a fixed-order sum of the per-block partials."""
+    lib = _lib.load()
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    if tuple(dy.shape[:3]) != (N, H, W):
+        raise ValueError("x %s and dy %s disagree" % (tuple(x.shape), tuple(dy.shape)))
+    ns = lib.v2x_conv3x3_wgrad_splits(N, H, W)
+    if ns == 0:
+        raise ValueError("v2x_conv3x3_wgrad needs H % 8 == 0 and W % 32 == 0")
+    ws = torch.empty((ns, Cout, 3, 3, Cin), dtype=torch.float32, device=x.device)
+    prof = _Prof("conv3x3_wgrad_kernel", 2.0 * N * H * W * Cout * 9 * Cin, (x.numel() + dy.numel()) * 2 + ws.numel() * 4)
+    rc = lib.v2x_conv3x3_wgrad(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"), N, H, W, Cin, Cout,
+                               _dev(ws, torch.float32, "workspace"), ns, _stream())
+    prof.done()
+    _lib.check(rc, "v2x_conv3x3_wgrad")
+    return ws.sum(0).permute(0, 3, 1, 2).contiguous()
+
+
 # ------------------------------------------------------------------ a3
 def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
     """feat (A*Bt, H, W, C) bf16; trans (Bt, A, A, 4, 4) fp32; items (n_out, 2) int32; coef (n_out, A) fp32."""

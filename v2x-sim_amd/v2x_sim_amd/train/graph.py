@@ -15,8 +15,23 @@ import torch
 import torch.nn.functional as F
 
 
+def _hip_train():
+    import os
+    return os.environ.get("V2X_TRAIN_HIP_CONV", "0")[:1] == "1"
+
+
+def _conv(x, conv):
+    """nn.Conv2d forward + backward: MIOpen through torch.autograd (default), or -- V2X_TRAIN_HIP_CONV=1, eligible 3x3 stride-1
+    layers on the MI355X -- the hand-written HIP forward / dgrad / wgrad kernels (train/hip_conv.py)."""
+    if x.is_cuda and _hip_train():
+        from . import hip_conv
+        if hip_conv.eligible(conv.weight, conv.stride, conv.padding, x.shape[2], x.shape[3]):
+            return hip_conv.conv2d_nchw(x, conv)
+    return conv(x)
+
+
 def _cbr(x, conv, bn):
-    return F.relu(bn(conv(x)))
+    return F.relu(bn(_conv(x, conv)))
 
 
 def _cbr_each(x, conv, bn, order=None):
