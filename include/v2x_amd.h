@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 8
+#define V2X_AMD_ABI_VERSION 9
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -199,6 +199,14 @@ int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
  * first->in_format = 1 (bit grid, in_zbits <= 16); H % 8 == 0, W % 32 == 0.  first->out is ignored; the result is
  * bit-identical to v2x_conv2d(first) followed by v2x_conv2d(second). */
 int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream);
+
+/* The decoder's last layer and the detection heads in one launch (conv_tail.hip): replaces Backbone.py::LidarDecoder's
+ * conv8_2 + bn8_2 + relu followed by DetModelBase.py::ClassificationHead / SingleRegressionHead.  first: 3x3, stride 1, pad 1,
+ * w_layout 1, 32 -> 32, bf16 epilogue, bf16 NHWC input; second: the fused heads descriptor v2x_conv2d takes (w_layout 1, 32 -> 64
+ * hidden rows in chain order, Cout2 = 48, V2X_EPI_F32, optional split into two fp32 tensors).  H % 8 == 0, W % 32 == 0, an even
+ * number of 8x32 tiles.  first->out is ignored -- the 32-channel map never reaches memory; the logits are bit-identical to
+ * v2x_conv2d(first) followed by v2x_conv2d(second). */
+int v2x_conv2d_tail(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-3: backward of the 3x3 stride-1 convolutions
  * Upstream trains through torch.autograd (cuDNN / MIOpen kernels behind nn.Conv2d.backward, tools/det/train_codet.py).

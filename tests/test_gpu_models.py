@@ -68,6 +68,24 @@ def test_fafnet_lowerbound(device):
     assert got["cls"].shape == (2, 256 * 256 * 6, 2) and got["loc"].shape == (2, 256, 256, 6, 1, 6)
 
 
+def test_fused_tail_equals_unfused_models_bitwise(device, monkeypatch):
+    """DetModelBase.decode_heads: conv8_2 + heads as one launch (default) vs V2X_CONV_TAIL=0 (LidarDecoder.run +
+    get_cls_loc_result): the same bits for FaFNet and V2VNet end to end."""
+    from v2x_sim_amd.models.det import FaFNet, V2VNet
+    A, B = 5, 1
+    _, bev, T = make_inputs(A, B, n_pts=8000, seed=3)
+    nat = torch.full((B, A), A)
+    for P, O in ((FaFNet, R.FaFNet), (V2VNet, R.V2VNet)):
+        pm, _ = build(P, O, device)
+        outs = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("V2X_CONV_TAIL", flag)
+            with torch.no_grad():
+                outs[flag] = pm(bev.to(device)) if P is FaFNet else pm(bev.to(device), T.to(device), nat, batch_size=B)
+        monkeypatch.delenv("V2X_CONV_TAIL")
+        assert torch.equal(outs["0"]["cls"], outs["1"]["cls"]) and torch.equal(outs["0"]["loc"], outs["1"]["loc"]), P.__name__
+
+
 def test_upperbound_full_size_points_to_logits(device):
     """BASELINE.json config 1 at its full size, end to end: 5 agents x 65 536 points, every ego grid = the union of all five
     sweeps moved into the ego frame (25 transform + scatter jobs, ONE launch) -> FaFNet on the HIP path.  The occupancy

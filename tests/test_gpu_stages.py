@@ -526,6 +526,32 @@ def test_halo_pingpong_chained_1x1(device, N, H, W):
         assert torch.allclose(from_nhwc(a), ref, atol=3e-2, rtol=2 ** -6) and float(e.mean()) < 2e-3, (float(e.max()), float(e.mean()))
 
 
+@pytest.mark.parametrize("N,H,W", [(2, 16, 32), (3, 64, 96), (1, 8, 64), (40, 256, 256)])
+def test_tail_equals_two_launches(device, monkeypatch, N, H, W):
+    """conv_tail.hip: conv8_2 -> fused det heads in ONE launch (the 32-channel map stays in LDS) against the two v2x_conv2d
+    launches it replaces: bit-identical cls / loc logits -- one tile pair, ragged persistent walks, image borders (the
+    intermediate must be ZERO outside the image, not conv8_2 of padding), the bench's 256x256 maps; bit-stable over launches."""
+    from v2x_sim_amd import ops, packing
+    monkeypatch.setenv("V2X_CONV_TAIL", "1")     # the fused launch is opt-in (measured slower than the two launches)
+    g = torch.Generator().manual_seed(N * 100 + H + W)
+    x = torch.randn(N, H, W, 32, generator=g).to(torch.bfloat16).to(device)
+    wa = torch.randn(32, 32, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
+    sa, ta = torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.3     # a shift: conv8_2 of pure padding is NOT zero
+    w1 = torch.randn(64, 32, 3, 3, generator=g) * (2.0 / (32 * 9)) ** 0.5
+    s1, t1 = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    w2 = torch.randn(48, 64, 1, 1, generator=g) * 0.2
+    b2 = torch.randn(48, generator=g)
+    pa = packing.pack_conv_halo("conv8_2", wa, sa, ta, relu=True, device=device)
+    pb = packing.pack_conv_halo("heads", w1, s1, t1, relu=True, chain=(w2, torch.ones(48), b2, False), epilogue=ops.V2X_EPI_F32, device=device)
+    assert ops.tail_eligible(pa, pb, x)
+    ref_cls, ref_loc = ops.conv2d(pb, ops.conv2d(pa, x), split=12)
+    for _ in range(3):
+        cls, loc = ops.conv2d_tail(pa, pb, x, 12)
+        assert cls.shape == (N, H, W, 12) and loc.shape == (N, H, W, 36)
+        assert torch.equal(cls, ref_cls) and torch.equal(loc, ref_loc)
+    assert not ops.tail_eligible(pa, pb, x[:1, :8, :32])        # a single 8x32 tile: no tile pair -> the two launches
+
+
 def test_halo_equals_gather_kernel_bitwise(device):
     """Same operands, same fp32 accumulation order per output?  Not guaranteed (different K walk), so the
     two kernels are compared at 1 bf16 ulp; both against the same torch reference elsewhere."""

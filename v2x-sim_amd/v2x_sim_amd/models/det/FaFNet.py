@@ -29,8 +29,7 @@ class FaFNet(NonIntermediateModelBase):
     def forward_nhwc(self, x0):
         pk = self.packed(x0.device)
         feats = LidarEncoder.run(pk["enc"], x0)
-        x = LidarDecoder.run(pk["dec"], *feats)
-        return self.get_cls_loc_result(x, pk["heads"])
+        return self.decode_heads(pk, feats)
 
     def forward(self, bevs, maps=None, vis=None, batch_size=None):
         """bevs: (batch*agents, 1, 256, 256, 13) dense occupancy, as the reference Dataset yields."""

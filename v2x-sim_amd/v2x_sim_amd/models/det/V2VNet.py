@@ -102,8 +102,7 @@ class V2VNet(IntermediateModelBase):
         if plan is None:
             plan = self.make_plan(num_agent_tensor, batch_size, x0.device)
         feats[self.layer] = self.fuse(feats[self.layer], trans_matrices, plan, batch_size, pk)
-        x = LidarDecoder.run(pk["dec"], *feats)
-        return self.get_cls_loc_result(x, pk["heads"])
+        return self.decode_heads(pk, feats)
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
         """bevs (A*B, 1, 256, 256, 13) agent-major; trans_matrices (B, A, A, 4, 4); num_agent_tensor (B, A)."""

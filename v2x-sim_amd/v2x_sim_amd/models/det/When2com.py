@@ -156,8 +156,7 @@ class When2com(IntermediateModelBase):
             fused = torch.zeros_like(feat)
             fused.index_copy_(0, plan["rows"], fused_items)
         feats[self.layer] = fused
-        x = LidarDecoder.run(pk["dec"], *feats)
-        res = self.get_cls_loc_result(x, pk["heads"])
+        res = self.decode_heads(pk, feats)
         res["prob_action"] = prob
         res["coef"] = coef
         return res

@@ -147,11 +147,14 @@ class LidarDecoder(_ParamsOnly):
         return plan
 
     @staticmethod
-    def run(plan, x, x_1, x_2, x_3, x_4):
+    def run(plan, x, x_1, x_2, x_3, x_4, last=True):
+        """last=False stops before conv8_2 (DetModelBase.decode_heads then runs conv8_2 + the heads as one launch)."""
         it = iter(plan)
         y = x_4
         for skip in (x_3, x_2, x_1, x):
             y = ops.run_layer(next(it), y, skip)
+            if skip is x and not last:
+                return y
             y = ops.run_layer(next(it), y)
         return y
 
@@ -249,6 +252,22 @@ class DetModelBase(nn.Module):
         if bevs.dim() != 5 or bevs.shape[1] != 1:
             raise ValueError("bevs must be (batch*agents, 1, X, Y, Z); got %s" % (tuple(bevs.shape),))
         return ops.dense_to_nhwc(bevs[:, 0].to(torch.float32).contiguous(), INPUT_C_PAD)
+
+    def decode_heads(self, pk, feats):
+        """Decoder + heads on the (possibly fused) pyramid `feats` -> {'loc', 'cls'}.  When the extent allows, conv8_2 and the
+        heads are ONE launch (conv_tail.hip: the decoder's 32-channel output map never reaches HBM); otherwise, or with
+        V2X_CONV_TAIL=0, LidarDecoder.run + get_cls_loc_result as before -- bit-identical either way."""
+        plan, heads = pk["dec"], pk["heads"]
+        y = LidarDecoder.run(plan, *feats, last=False)
+        if heads.split and ops.tail_eligible(plan[-1].halo, heads.halo, y):
+            cls, loc = ops.conv2d_tail(plan[-1].halo, heads.halo, y, heads.split)
+            return self._shape_cls_loc(cls, loc)
+        return self.get_cls_loc_result(ops.run_layer(plan[-1], y), heads)
+
+    def _shape_cls_loc(self, cls, loc):
+        n = cls.shape[0]
+        return {"loc": loc.view(-1, loc.size(1), loc.size(2), self.anchor_num_per_loc, self.out_seq_len, self.box_code_size),
+                "cls": cls.view(n, -1, self.category_num)}
 
     def get_cls_loc_result(self, x, heads):
         cls, loc = ops.run_layer(heads, x)  # fp32 NHWC == upstream's permute(0, 2, 3, 1)

@@ -57,7 +57,7 @@ class FusionBase(IntermediateModelBase):
         if plan is None:
             plan = self.make_plan(num_agent_tensor, batch_size, x0.device)
         feats[self.layer] = self.fuse(feats[self.layer], trans_matrices, plan, batch_size, pk)
-        return self.get_cls_loc_result(LidarDecoder.run(pk["dec"], *feats), pk["heads"])
+        return self.decode_heads(pk, feats)
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
         return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)

@@ -383,6 +383,48 @@ def conv3x3_wgrad(x, dy):
     return ws.sum(0).permute(0, 3, 1, 2).contiguous()
 
 
+def tail_eligible(pa, pb, x):
+    """conv_tail.hip covers: halo-packed conv8_2 (32 -> 32, bf16) followed by the fused det heads (32 -> 64 chained to 48 fp32),
+    bf16 NHWC input with H % 8 == 0, W % 32 == 0 and an even number of 8x32 tiles.  OFF by default (V2X_CONV_TAIL=1 enables it):
+    bit-identical to the two launches and 2.7 GB per 320 maps lighter on HBM, but measured SLOWER (1.93-1.96 vs 1.67 ms same-box:
+    the fused kernel is bound by LDS reads and issue slots, not by HBM -- DESIGN.md section 9)."""
+    if pa is None or pb is None or os.environ.get("V2X_CONV_TAIL", "0")[:1] != "1":
+        return False
+    ok_a = (pa.w_layout == 1 and pa.ksize == 3 and pa.stride == 1 and pa.C0 == 32 and not pa.C1 and pa.Cout == 32 and not pa.Cout2
+            and pa.epilogue == V2X_EPI_BF16)
+    ok_b = (pb.w_layout == 1 and pb.ksize == 3 and pb.stride == 1 and pb.C0 == 32 and not pb.C1 and pb.Cout == 64 and pb.Cout2 == 48
+            and pb.epilogue == V2X_EPI_F32)
+    if not (ok_a and ok_b and x.dtype == torch.bfloat16 and x.dim() == 4):
+        return False
+    N, H, W, _ = x.shape
+    return H % 8 == 0 and W % 32 == 0 and (N * (H // 8) * (W // 32)) % 2 == 0 and N * H * W < (1 << 26)
+
+
+def conv2d_tail(pa, pb, x, split):
+    """heads(conv8_2(x)) in one launch, the 32-channel map stays in LDS.  x (N, H, W, 32) bf16 -> (cls (N, H, W, split),
+    loc (N, H, W, 48 - split)) fp32, bit-identical to the two v2x_conv2d launches."""
+    lib = _lib.load()
+    N, H, W, _ = x.shape
+    da, db = _pair_desc(pa, N, H, W), _pair_desc(pb, N, H, W)
+    da.in0 = _dev(x, torch.bfloat16, "x").value
+    out = torch.empty((N, H, W, split), dtype=torch.float32, device=x.device)
+    out2 = torch.empty((N, H, W, pb.Cout2 - split), dtype=torch.float32, device=x.device)
+    db.out, db.out_cstride, db.out_coff = out.data_ptr(), split, 0
+    db.out2, db.split, db.out2_cstride = out2.data_ptr(), split, out2.shape[3]
+    db.Cout2, db.relu2 = pb.Cout2, int(bool(pb.relu2))
+    db.weight2, db.scale2, db.shift2 = pb.weight2.data_ptr(), pb.scale2.data_ptr(), pb.shift2.data_ptr()
+    prof = None
+    if PROFILE is not None:
+        M = N * H * W
+        prof = _Prof("conv3x3_tail_kernel", 2.0 * M * (9 * 32 * 32 + 9 * 32 * 64 + 64 * 48),
+                     x.numel() * 2 + (out.numel() + out2.numel()) * 4 + (pa.weight.numel() + pb.weight.numel()) * 2, pa.name + "+" + pb.name)
+    rc = lib.v2x_conv2d_tail(C.byref(da), C.byref(db), _stream())
+    if prof is not None:
+        prof.done()
+    _lib.check(rc, "v2x_conv2d_tail(%s, %s)" % (pa.name, pb.name))
+    return out, out2
+
+
 # ------------------------------------------------------------------ a3
 def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
     """feat (A*Bt, H, W, C) bf16; trans (Bt, A, A, 4, 4) fp32; items (n_out, 2) int32; coef (n_out, A) fp32."""

@@ -189,8 +189,7 @@ class ShardedV2VNet:
         pk = m.packed(gathered.device)
         feats = list(feats)
         feats[m.layer] = self.fuse_local(feats, trans, plan, pk, gathered0=gathered)
-        x = LidarDecoder.run(pk["dec"], *feats)
-        return m.get_cls_loc_result(x, pk["heads"])
+        return m.decode_heads(pk, feats)
 
     def encode_points(self, points, n_pts, pk):
         """points (L, max_pts, stride) fp32 of this rank's items -> encoder pyramid."""
@@ -235,8 +234,7 @@ class ShardedV2VNet:
         pk = m.packed(points.device)
         feats = self.encode_points(points, n_pts, pk)
         feats[m.layer] = self.fuse_local(feats, trans, plan, pk)
-        x = LidarDecoder.run(pk["dec"], *feats)
-        return m.get_cls_loc_result(x, pk["heads"])
+        return m.decode_heads(pk, feats)
 
 
 def when2com_needs(shard, coef, counts):
@@ -339,7 +337,6 @@ class ShardedWhen2com:
             fused = torch.zeros_like(feats[m.layer])
             fused.index_copy_(0, plan["local_rows"], fused_items)
         feats[m.layer] = fused
-        x = LidarDecoder.run(pk["dec"], *feats)
-        res = m.get_cls_loc_result(x, pk["heads"])
+        res = m.decode_heads(pk, feats)
         res["prob_action"], res["coef"] = prob, coef
         return res
