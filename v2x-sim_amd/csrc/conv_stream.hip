@@ -18,6 +18,7 @@
 // LDS layouts as conv_halo.hip (conflict-free: patch slot ^ ((x>>1)&3), weights k-slot-major).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -47,6 +48,14 @@ constexpr int PATCH_BYTES = PATCH_PIECES * 1024;
 constexpr int RING = 4;                      // weight slices in flight + 1 being read
 
 enum { SEPI_BF16 = 0, SEPI_CHAIN = 1, SEPI_GRU = 2 };
+
+// TIMING EXPERIMENTS ONLY (tools/stream8_phase_probe.sh builds the library with -DV2X_STREAM_DBG_BUILD=n): which part of the
+// 8-wave kernel's step is the long pole?  1 = no weight DMAs, 2 = no patch DMAs, 4 = no fragment reads, 8 = no MFMAs.  Results are
+// garbage in those builds; the default build (0) compiles every branch away.
+#ifndef V2X_STREAM_DBG_BUILD
+#define V2X_STREAM_DBG_BUILD 0
+#endif
+constexpr int SDBG = V2X_STREAM_DBG_BUILD;
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -506,6 +515,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
     auto issue_dummy = [&]() { glds16s(zero_page, s_dummy); };
     auto issue_slice = [&](int slice, int slot, bool real) {  // exactly one DMA
+        if constexpr ((SDBG & 1) != 0) return;
         if (has_w && real) glds16s(wsrc + (size_t)slice * (BCO * 32), s_ring + slot * SLICE_BYTES + wave * 1024);
         else issue_dummy();
     };
@@ -587,7 +597,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const int s3 = s + 3;
                         issue_slice(s3 < S ? s3 : s3 - S, (g + 3) & (RING - 1), s3 < S || has_next);
                     }
-                    if (tap < 5 && fill) {
+                    if constexpr ((SDBG & 2) != 0) {
+                    } else if (tap < 5 && fill) {
                         int d = pd[0];
 #pragma unroll
                         for (int u = 1; u < 5; ++u) d = (tap == u) ? pd[u] : d;
@@ -597,12 +608,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     const char *ws = s_ring + (g & (RING - 1)) * SLICE_BYTES;
                     bf16x8_t fa[TCO], fb[4];
+                    if constexpr ((SDBG & 4) == 0) {
 #pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + ct[f][kx]);
+                        for (int f = 0; f < 4; ++f)
+                            fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + ct[f][kx]);
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i)
-                        fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+                        for (int i = 0; i < TCO; ++i)
+                            fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) fb[f] = __builtin_bit_cast(bf16x8_t, make_uint4(s, s, s, s));
+#pragma unroll
+                        for (int i = 0; i < TCO; ++i) fa[i] = __builtin_bit_cast(bf16x8_t, make_uint4(g, g, g, g));
+                    }
                     // own pieces of slice s+1 (and older) have landed; right after an epilogue its stores are younger
                     // than that group and may stay in flight
                     if (relaxed > 0) {
@@ -616,11 +634,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- M(s)
+                    if constexpr ((SDBG & 8) == 0) {
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i)
+                        for (int i = 0; i < TCO; ++i)
 #pragma unroll
-                        for (int f = 0; f < 4; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                            for (int f = 0; f < 4; ++f)
+                                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < TCO; ++i) acc[i][0] += __builtin_bit_cast(f32x4_t, fa[i]) + __builtin_bit_cast(f32x4_t, fb[i & 3]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -647,6 +670,342 @@ int v2x_num_cus() {   // also used by conv_halo_pair.hip
     if (n[dev] == 0)
         n[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     return n[dev];
+}
+
+// ---- 8-wave form with THREE taps per synchronisation ("stream8g") ------------------------------------------------------------
+// tools/stream8_phase_probe.sh (one phase compiled out at a time, dominant kernel at 320 maps): full step 550 us; without the
+// MFMAs 519; without the DMAs 414; without the fragment reads 410; with neither 382 -- the 8-wave kernel above is bound by its
+// LOAD phase (per step and wave: 2 LDS-DMA instructions, 12 ds_read_b128, address selects, a counted wait and two barriers
+// ~ 825 cycles) against 512 cycles of MFMAs.  Here a step is a TAP COLUMN of a 32-channel chunk -- the three taps (ky = 0..2) of
+// one kx -- so a synchronisation interval carries 96 MFMAs per wave instead of 32:
+//   * pixel operands are shared between the tap rows: the wave's two output rows need 4 patch rows (3 at half resolution)
+//     -> 8 B fragments per step instead of 12, read in the load phase;
+//   * weight operands stream through registers in HALF taps (TCO/2 fragments): the reads of half h+1 are issued before the
+//     MFMAs of half h, inside the MFMA phase (two alternating sets; a whole tap would not fit beside 128 accumulators);
+//   * the weight ring holds 3 steps of 3 slices (72 KiB at 128 rows).  Group 0's waves DMA their pieces of step s+1, group 1's
+//     waves theirs of step s+2, each in its own load phase L(s); every wave drains its own DMAs (vmcnt(0)) at the end of its
+//     MFMA phase, one full phase later.  With the half-step offset of the two groups this is hazard-free with THREE slots:
+//     slot (s+1)%3 is written by group 0 in interval 2s, its old content (step s-2) was last read by group 1 in interval 2s-2;
+//     slot (s+2)%3 is written by group 1 in interval 2s+1, its old content (step s-1) was last read by group 0 in interval
+//     2s-1 and by group 1 itself in interval 2s.  Pieces of step s+1 are drained by interval 2s+1 (group 0) / 2s (group 1),
+//     first read in interval 2s+2.  The next chunk's patch is DMA'd during the steps kx = 0, 1 (drained by interval 6kc+4, first
+//     read in 6kc+6) into the buffer last read in the load phases of chunk kc-1 (interval 6kc-1 at the latest).
+//   No counted waits, no dummy DMAs.  Persistent over tiles like the kernel above (the ring and the patch fill wrap into the
+//   next tile).  K order is (chunk, kx, ky): the fp32 sums differ from the other streamed kernels in their last bits, so this
+//   form replaces them for a layer everywhere or nowhere (the choice depends on the layer's shape only).
+template <int BCO, int EPI>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8g_kernel(const StreamArgs a) {
+    constexpr int TH = 16, TW = 32;
+    constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
+    constexpr int TCO = BCO / 16, HCO = TCO / 2;            // channel tiles per tap / per half tap
+    constexpr int W_PIECES = BCO / 16;                     // 1-KiB pieces per tap slice
+    constexpr int SLICE_BYTES = BCO * 64;
+    constexpr int STEP_BYTES = 3 * SLICE_BYTES;            // one tap column of a chunk
+    constexpr int NWD = (3 * W_PIECES + 3) / 4;            // weight DMAs per wave of GROUP 1 and step (6 at 128 rows, 5 at 96)
+    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;   // output-store instructions per wave and tile
+    static_assert(EPI != SEPI_CHAIN, "the chained epilogue stays on conv3x3_stream8_kernel (its operands need the LDS)");
+    static_assert(TCO % 2 == 0 && PH * PW * 4 <= (PATCH8_PIECES - 1) * 64, "half taps; patch fits its buffer");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_ring = smem;                                   // 3 x STEP_BYTES
+    char *s_patch = smem + 3 * STEP_BYTES;                 // 2 x PATCH8_BYTES
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int grp = wave >> 2, wv = wave & 3;
+    const int fj = lane & 15, fq = lane >> 4;
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int n_tiles = a.n_px_tiles * a.n_co_tiles;
+    const int co_tile = bid % a.n_co_tiles;
+    const int txy = a.tiles_x * a.tiles_y;
+    const int nc0 = a.C0 >> 5, nchunks = (a.C0 + a.C1) >> 5;
+    const int S3 = nchunks * 3;                            // steps (tap columns) per tile
+    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+
+    auto tile_coords = [&](int t, int &n, int &y0, int &x0) {
+        const int px_tile = t / a.n_co_tiles;
+        n = px_tile / txy;
+        const int trem = px_tile - n * txy;
+        const int ty = trem / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (trem - ty * a.tiles_x) * TW;
+    };
+    // lane id from VOLATILE asm: values derived from it cannot be hoisted out of the tile / chunk / step loops (as lane constants
+    // they would be -- dozens of registers kept, and spilled, across the MFMA phases)
+    auto fresh_lane = [&]() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto desc = [&](int n, int y0, int x0, int t, bool hf) -> int {   // DMA source descriptor of patch piece (wv + 4t) (group 0 fills the patch)
+        const int L = (wv + 4 * t) * 64 + fresh_lane();
+        const int pix = L >> 2, phys = L & 3;
+        if (!hf) {
+            const int pr = pix / PW, pc = pix - pr * PW;
+            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+            const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            return ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+        }
+        const int Hs = a.H >> 1, Ws = a.W >> 1;
+        const int pr = pix / PW0, pc = pix - pr * PW0;
+        const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+        const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        return ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+    };
+    auto issue_piece = [&](int d, int kc, int t, int buf) {
+        const bool first = kc < nc0;
+        const uint16_t *src = first ? a.in0 : a.in1;
+        const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
+        const unsigned off = (unsigned)(d >> 5) * cs + (unsigned)((first ? kc : kc - nc0) * 32 + (d & 31));
+        glds16s(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + buf * PATCH8_BYTES + (wv + 4 * t) * 1024);
+    };
+    // weight pieces of step `st` (chunk st / 3, tap column st % 3): piece p = wq + NQ * u, p < 3 * W_PIECES, for worker wq of NQ
+    // (the prologue spreads a step over all 8 waves, the steady state over the 4 waves of group 1);
+    // piece p = (tap row ky = p / W_PIECES, 1-KiB piece p % W_PIECES of that tap's slice)
+    auto issue_weights = [&](int st, int slot, int wq, int NQ) -> int {   // -> number of DMAs issued (wave-uniform)
+        const int kc = st / 3, kx = st - kc * 3;
+        const int lane_w = fresh_lane();
+        int cnt = 0;
+#pragma unroll
+        for (int u = 0; u < NWD; ++u) {
+            const int p = wq + NQ * u;
+            if (p >= 3 * W_PIECES) break;                  // wave-uniform (96-row tiles: 18 pieces)
+            ++cnt;
+            if constexpr ((SDBG & 1) != 0) continue;
+            const int ky = p / W_PIECES, pis = p - ky * W_PIECES;
+            glds16s(wbase + (size_t)(kc * 9 + ky * 3 + kx) * (BCO * 32) + pis * 512 + lane_w * 8,
+                    s_ring + slot * STEP_BYTES + ky * SLICE_BYTES + pis * 1024);
+        }
+        return cnt;
+    };
+    // wait until at most `keep` vector-memory operations are outstanding, keep in {0, NWD-1, NWD} (+ N_ST): the immediate must be
+    // a constant, the choice is wave-uniform
+    auto wait_keep = [&](int keep, bool plus_stores) {
+        if (plus_stores) {
+            if (keep == NWD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWD + N_ST) : "memory");
+            else if (keep == NWD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWD - 1 + N_ST) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_ST) : "memory");
+        } else {
+            if (keep == NWD) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWD) : "memory");
+            else if (keep == NWD - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NWD - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    };
+
+    int frow[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) frow[f] = 8 * grp + 2 * wv + (f >> 1);
+    const int R0 = 8 * grp + 2 * wv;                       // the wave's first output row (even)
+    const bool chunk0_half = (nc0 > 0) && a.up0;
+
+    int tile = bid;
+    int n, y0, x0;
+    tile_coords(tile, n, y0, x0);
+    // Division of labour in the steady state: GROUP 0 fills the next chunk's patch (10 pieces per wave: t = 0..4 at kx = 0, 5..9 at
+    // kx = 1, drained at the end of its load phase of kx = 2), GROUP 1 streams the weights: ALL pieces of step s+2 in its load phase
+    // L(s) (interval 2s+1) into slot (s+2)%3 -- last read by group 0 in interval 2s-1 and by group 1 itself in interval 2s -- and
+    // waits for them at the end of its NEXT load phase L(s+1) (interval 2s+3; counted: the NWD newest DMAs are that phase's own),
+    // one interval before group 0 reads them.  A weight DMA thus has an MFMA phase plus a load phase (~1.1 us) to land, a patch
+    // DMA two to four intervals; the first form of this kernel drained every wave's DMAs after one MFMA phase (0.7 us) and the
+    // 128-row layers gained nothing.
+    int pd[10];
+    bool pd_half = chunk0_half;
+    if (grp == 0) {
+#pragma unroll
+        for (int t = 0; t < 10; ++t) pd[t] = desc(n, y0, x0, t, pd_half);
+#pragma unroll
+        for (int t = 0; t < 10; ++t) issue_piece(pd[t], 0, t, 0);
+    }
+    // prologue: patch of chunk 0 (group 0), weights of steps 0 and 1 (all 8 waves share them)
+    {
+        constexpr int NP8 = (3 * W_PIECES + 7) / 8;
+        for (int stp = 0; stp < (S3 > 1 ? 2 : 1); ++stp) {
+            const int lane_w = fresh_lane();
+#pragma unroll
+            for (int u = 0; u < NP8; ++u) {
+                const int p = wave + 8 * u;
+                if (p >= 3 * W_PIECES) break;
+                const int ky = p / W_PIECES, pis = p - ky * W_PIECES;
+                glds16s(wbase + (size_t)((stp / 3) * 9 + ky * 3 + (stp % 3)) * (BCO * 32) + pis * 512 + lane_w * 8,
+                        s_ring + stp * STEP_BYTES + ky * SLICE_BYTES + pis * 1024);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();            // half-step offset
+
+    int g = 0;     // global step counter
+    bool relaxed = false;
+    int slot = 0;  // ring slot of the current step = g % 3
+    int gc = 0;    // global chunk counter: patch buffer = gc & 1
+    for (;;) {
+        const int next = tile + nwg;
+        const bool has_next = next < n_tiles;
+        int nn = 0, ny0 = 0, nx0 = 0;
+        if (has_next) tile_coords(next, nn, ny0, nx0);
+
+        f32x4_t acc[TCO][4];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+        for (int kc = 0; kc < nchunks; ++kc, ++gc) {
+            const char *pb = s_patch + (gc & 1) * PATCH8_BYTES;
+            const bool half = (kc < nc0) && a.up0;
+            const bool last_chunk = kc + 1 == nchunks;
+            const int kcn = last_chunk ? 0 : kc + 1;
+            const bool fill = !last_chunk || has_next;
+            const bool hfn = (kcn < nc0) && a.up0;
+            if (grp == 0 && ((last_chunk && has_next) || (fill && hfn != pd_half))) {
+                const int dn = last_chunk ? nn : n, dy = last_chunk ? ny0 : y0, dx = last_chunk ? nx0 : x0;
+#pragma unroll
+                for (int t = 0; t < 10; ++t) {
+                    pd[t] = desc(dn, dy, dx, t, hfn);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                pd_half = hfn;
+            }
+            // one chunk = three steps (tap columns).  ONE code path for both source resolutions: the pixel fragment a (row r, tap row
+            // ky) pair uses is always B[r + ky]; at half resolution (nearest x2 upsample) the four entries are loaded from the patch
+            // rows {0, 1, 1, 2} -- the resolution only enters address arithmetic (a run-time choice between REGISTERS would be selects
+            // on 32 of them, and two specialised copies of this body made the allocator shuffle accumulators through scratch).
+            const int sh = half ? 1 : 0;
+            const int row_bytes = (half ? PW0 : PW) * 64;
+            const int row0 = (R0 >> sh) * row_bytes;            // the wave's first patch row
+#pragma unroll 1   // rolled: unrolled copies of this body hoist ~100 lane constants and spill
+            for (int kx = 0; kx < 3; ++kx, ++g, slot = (slot == 2 ? 0 : slot + 1)) {
+                const int st = kc * 3 + kx;
+                const int ln = fresh_lane();
+                const int fjl = ln & 15, fql = ln >> 4;
+                // ---- L: group 1 streams the weights of step st+2 (wrapping into the next tile), group 0 the next chunk's patch
+                int nw = 0;   // weight DMAs this wave issues in this phase
+                if (grp == 1) {
+                    const int ahead = st + 2;
+                    const int wslot = slot == 0 ? 2 : slot - 1;   // (slot + 2) % 3
+                    if (ahead < S3) nw = issue_weights(ahead, wslot, wv, 4);
+                    else if (has_next && ahead - S3 < S3) nw = issue_weights(ahead - S3, wslot, wv, 4);
+                } else if (fill && kx < 2) {
+                    const int npieces = hfn ? (PH0 * PW0 * 4 + 63) / 64 : PATCH8_PIECES;   // the half-resolution patch is 3x smaller
+#pragma unroll
+                    for (int t = 0; t < 5; ++t) {
+                        const int tt = kx * 5 + t;
+                        if (wv + 4 * tt >= npieces) break;       // wave-uniform
+                        int d = pd[0];                          // select by the wave-uniform tt (a run-time index would go to scratch)
+#pragma unroll
+                        for (int u = 1; u < 10; ++u) d = (tt == u) ? pd[u] : d;
+                        if constexpr ((SDBG & 2) == 0) issue_piece(d, kcn, tt, (gc + 1) & 1);
+                    }
+                }
+                // pixel fragments of the tap column: B[q * 2 + ch], q = r + ky = 0..3
+                bf16x8_t B[8];
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const int col = ch * 16 + fjl + kx;
+                    const int pc = ((col - sh) >> sh) + sh;     // full: col + kx;  half: ((col + kx - 1) >> 1) + 1
+                    const int coff = ((pc << 2) + (fql ^ ((pc >> 1) & 3))) * 16;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if constexpr ((SDBG & 4) == 0) B[q * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + row0 + (((q - sh) >> sh) + sh) * row_bytes + coff);
+                        else B[q * 2 + ch] = __builtin_bit_cast(bf16x8_t, make_uint4(coff, q, st, ch));
+                    }
+                }
+                const char *ws = s_ring + slot * STEP_BYTES + (fql * BCO + fjl) * 16;   // + compile-time offsets below
+                bf16x8_t A[2][HCO];
+#pragma unroll
+                for (int i = 0; i < HCO; ++i) {
+                    if constexpr ((SDBG & 4) == 0) A[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+                    else A[0][i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, slot, ln));
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): fragments in registers before the patch / ring may be overwritten
+                // drain: group 1 -- the weights issued one step ago (everything but this phase's own NWD DMAs; right after an epilogue
+                // the tile's output stores are younger than those and may stay in flight); group 0 -- at kx = 2, the patch it issued
+                // during kx = 0, 1 (two to four intervals ago), together with any older stores
+                if (grp == 1) {
+                    wait_keep(nw, relaxed);
+                    relaxed = false;
+                } else if (kx == 2) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- M: six half taps.  The weight fragments of half h+1 are read in the MIDDLE of half h's MFMA block: the compiler
+                // waits for them with lgkmcnt(0) before their first use (it does not count LDS reads individually here), so reads
+                // issued right before a block would be waited for at once -- six exposed LDS latencies per step (the first form:
+                // MFMA phases alone 458 us against 318 us of MFMA work).  Issued after the first part of the block they land under
+                // its second part.
+                constexpr int H1 = (HCO + 1) / 2;   // channel tiles of the first part
+#pragma unroll
+                for (int h = 0; h < 6; ++h) {
+                    const int ky = h >> 1, hh = h & 1;
+                    auto mma_part = [&](int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int i = i0; i < i1; ++i)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) {
+                                if constexpr ((SDBG & 8) == 0)
+                                    acc[hh * HCO + i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[h & 1][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[hh * HCO + i][f], 0, 0, 0);
+                                else if (f == 0)
+                                    acc[hh * HCO + i][0] += __builtin_bit_cast(f32x4_t, A[h & 1][i]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
+                            }
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(0, H1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (h + 1 < 6) {
+                        const int ky1 = (h + 1) >> 1, hh1 = (h + 1) & 1;
+#pragma unroll
+                        for (int i = 0; i < HCO; ++i) {
+                            if constexpr ((SDBG & 4) == 0) A[(h + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (hh1 * HCO + i) * 256);
+                            else A[(h + 1) & 1][i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, h, ln));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma_part(H1, HCO);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        stream_epilogue<BCO, TW, EPI, 4, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr);
+        if (!has_next) break;
+        tile = next;
+        n = nn;
+        y0 = ny0;
+        x0 = nx0;
+        relaxed = true;   // the stores just issued are younger than the weight DMAs the next load phase waits for
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the offset barrier of group 1
+}
+
+template <int BCO, int EPI>
+static int launch_stream8g(const StreamArgs &a, hipStream_t s) {
+    constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES;   // 152 KiB at 128 rows, 134 KiB at 96
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static v2x_once_per_device attr_once;
+    auto kern = &conv3x3_stream8g_kernel<BCO, EPI>;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    const int n_tiles = a.n_px_tiles * a.n_co_tiles;
+    int grid = n_tiles;
+    int g = v2x_num_cus() / a.n_co_tiles * a.n_co_tiles;   // persistent: a workgroup's tiles share one channel tile
+    if (g > 0 && g < n_tiles) grid = g;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_stream8g_kernel");
+    return V2X_OK;
 }
 
 template <int BCO, int EPI>
@@ -929,9 +1288,12 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
         if (!(e && e[0] == '4')) {
             a.tiles_y = d->H / 16;
             a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
-            if (d->epilogue == V2X_EPI_GRU) return launch_stream8<96, SEPI_GRU>(a, s);
+            // three taps per synchronisation (stream8g) unless V2X_STREAM_G=0 (A/B runs); the chained epilogue keeps the 1-tap form
+            const char *eg = getenv("V2X_STREAM_G");
+            const bool grouped = !(eg && eg[0] == '0') && !chain && a.n_co_tiles <= v2x_num_cus();
+            if (d->epilogue == V2X_EPI_GRU) return grouped ? launch_stream8g<96, SEPI_GRU>(a, s) : launch_stream8<96, SEPI_GRU>(a, s);
             if (chain) return launch_stream8<128, SEPI_CHAIN>(a, s);
-            return launch_stream8<128, SEPI_BF16>(a, s);
+            return grouped ? launch_stream8g<128, SEPI_BF16>(a, s) : launch_stream8<128, SEPI_BF16>(a, s);
         }
     }
     // 64-row layers on maps that tile into 16x32: the wide 4-wave form (V2X_STREAM_WIDE=0 keeps the 256-pixel kernel: A/B)
