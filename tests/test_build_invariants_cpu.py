@@ -37,11 +37,14 @@ def _kernels(asm):
 @pytest.mark.parametrize("src,kernel_prefix,min_kernels", [
     ("conv_stream.hip", "_Z21conv3x3_stream_kernel", 6),
     ("conv_stream.hip", "_Z22conv3x3_stream8_kernel", 3),
+    ("conv_stream.hip", "_Z23conv3x3_stream8g_kernel", 2),
     ("conv_stream_s2.hip", "_Z24conv3x3_s2_stream_kernel", 2),
     ("conv_stream.hip", "_Z19conv3x3_wide_kernel", 2),
     ("conv_stream_s2.hip", "_Z26conv3x3_s2_resident_kernel", 1),
     ("conv_halo.hip", "_Z19conv3x3_halo_kernel", 3),
     ("conv_halo.hip", "_Z22conv3x3_halo_sb_kernel", 2),
+    ("conv_halo.hip", "_Z22conv3x3_halo_pp_kernel", 3),
+    ("conv_tail.hip", "_Z19conv3x3_tail_kernel", 1),
     ("conv_halo_pair.hip", "_Z24conv3x3_pair_bits_kernel", 1),
     ("conv_igemm.hip", "_Z17conv_igemm_kernel", 9),
 ])

@@ -1,0 +1,60 @@
+// What does the MI355X sustain on PURE register-resident bf16 MFMA work?  (The roofline fractions in bench.py are priced against
+// the 2.5 PFLOP/s dense peak at 2.4 GHz; the chip runs the step power-limited.)  Every wave issues back-to-back independent
+// v_mfma_f32_16x16x32_bf16 on operands that never leave registers: no LDS, no memory.  Variants: 1 or 2 waves per SIMD, constant or
+// random operand bits (toggle rate -> power).   hipcc --offload-arch=gfx950 -O3 tools/mfma_clock_probe.hip -o /tmp/mfma_probe && /tmp/mfma_probe
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+template <int NACC>
+__global__ __launch_bounds__(512) void mfma_loop(float *out, int iters, uint32_t seed) {
+    f32x4_t acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) { acc[i] = (f32x4_t){(float)i, 0.f, 0.f, 0.f}; asm volatile("" : "+v"(acc[i])); }   // opaque: no CSE across tiles
+    uint32_t r = seed ? (seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x) : 0x3f803f80u;
+    uint4 ua, ub;
+    ua.x = r; ua.y = r * 3u + 1u; ua.z = r * 5u + 2u; ua.w = r * 7u + 3u;
+    ub.x = r ^ 0x5555u; ub.y = r * 11u; ub.z = r * 13u; ub.w = r * 17u;
+    if (!seed) { ua = make_uint4(r, r, r, r); ub = ua; }
+    // keep the exponents small so that nothing overflows: clear the top exponent bits of every bf16
+    ua.x &= 0x3fff3fffu; ua.y &= 0x3fff3fffu; ua.z &= 0x3fff3fffu; ua.w &= 0x3fff3fffu;
+    ub.x &= 0x3fff3fffu; ub.y &= 0x3fff3fffu; ub.z &= 0x3fff3fffu; ub.w &= 0x3fff3fffu;
+    bf16x8_t a = __builtin_bit_cast(bf16x8_t, ua), b = __builtin_bit_cast(bf16x8_t, ub);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i]) : "v"(a), "v"(b));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) sum += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (sum == 12345.678f) out[threadIdx.x] = sum;
+}
+
+int main() {
+    float *out;
+    (void)hipMalloc(&out, 4096);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int iters = 20000;
+    for (int random = 0; random < 2; ++random)
+        for (int wps = 1; wps <= 2; ++wps) {
+            const int threads = 256 * wps, grid = 256;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(e0, 0);
+                hipLaunchKernelGGL(mfma_loop<16>, dim3(grid), dim3(threads), 0, 0, out, iters, random ? 12345u + rep : 0u);
+                (void)hipEventRecord(e1, 0);
+                (void)hipEventSynchronize(e1);
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                const double flop = (double)grid * (threads / 64) * iters * 16.0 * 16384.0;
+                // cycles per MFMA per SIMD if issue were back to back: time * clock / (MFMAs per SIMD)
+                const double mfma_per_simd = (double)wps * iters * 16.0;
+                printf("%s operands, %d wave(s)/SIMD: %8.3f ms  %7.1f TFLOP/s  => %.2f GHz if one MFMA per 16 cycles\n", random ? "random  " : "constant",
+                       wps, ms, flop / ms / 1e9, mfma_per_simd * 16.0 / (ms * 1e-3) / 1e9);
+            }
+        }
+    return 0;
+}

@@ -1298,6 +1298,8 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     }
     // 64-row layers on maps that tile into 16x32: the wide 4-wave form (V2X_STREAM_WIDE=0 keeps the 256-pixel kernel: A/B)
     if (!t16 && d->H % 16 == 0 && rows == 64 && d->epilogue == V2X_EPI_BF16 && ((d->C0 + d->C1) >> 5) >= 2) {
+        // (measured and rejected: the three-taps-per-synchronisation 8-wave form at 64 rows -- 1 172-1 187 us for conv7_1 against
+        // 965-979 us for the wide form: 48 MFMAs per step do not cover its load phase)
         const char *e = getenv("V2X_STREAM_WIDE");
         if (!(e && e[0] == '0')) {
             a.tiles_y = d->H / 16;
