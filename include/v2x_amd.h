@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 9
+#define V2X_AMD_ABI_VERSION 10
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -213,13 +213,34 @@ int v2x_conv2d_tail(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x
  *   data gradient:   dX = conv3x3(dY, W') with W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx] -- a forward convolution: v2x_conv2d
  *                    on the re-packed weights (v2x_sim_amd/train/hip_conv.py);
  *   weight gradient: v2x_conv3x3_wgrad, an MFMA kernel contracting over pixels (conv_wgrad.hip).
- * x bf16 NHWC [N][H][W][Cin], dy bf16 NHWC [N][H][W][Cout]; H % 8 == 0, W % 32 == 0, Cin % 32 == 0, Cout % 64 == 0.
+ * x bf16 NHWC [N][H][W][Cin], dy bf16 NHWC [N][H][W][Cout]; H % 8 == 0, W % 32 == 0, Cin % 32 == 0, Cout % 32 == 0.
  * workspace fp32 [n_split][Cout][3][3][Cin]: partial sums, every element written; dW = sum over the first axis (the caller
- * adds them in a fixed order: deterministic).  n_split in [1, number of 8x32 pixel tiles]; v2x_conv3x3_wgrad_splits gives
- * the library's choice (0 = unsupported extent). */
-int v2x_conv3x3_wgrad_splits(int N, int H, int W);
+ * adds them in a fixed order: deterministic).  Cout % 64 == 0: n_split in [1, number of 8x32 pixel tiles]; otherwise (the 32-row
+ * form, two workspace slots per block) n_split even, in [2, 2 x tiles].  v2x_conv3x3_wgrad_splits gives the library's choice
+ * (0 = unsupported shape).  Stride-2 layers: pass dy with zeros inserted between its pixels (dy_z[2y][2x] = dy[y][x]) and the
+ * layer's input x -- the same sum (v2x_sim_amd/train/hip_conv.py). */
+int v2x_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout);
 int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, int H, int W, int Cin, int Cout, float *workspace,
                       int n_split, v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- f-3: batch-statistics BatchNorm + ReLU on bf16 NHWC maps
+ * Replaces nn.BatchNorm2d / nn.BatchNorm3d in TRAIN mode followed by F.relu as Backbone.py applies them after every convolution
+ * (`F.relu(self.bn1_1(self.conv1_1(x)))`), forward and backward (bn_train.hip).  x [M][C] bf16 with M = N*H*W pixels: the
+ * convolution's output as v2x_conv2d wrote it.  C / 8 must divide 256 (C = 8, 16, 32, ..., 2048).
+ *   forward:  mean / biased variance over the M pixels (fp32 partials, fp64 finish, fixed order), y = relu((x - mean) * invstd *
+ *             gamma + beta) -> bf16; save_mean / save_invstd [C] for the backward; running_mean / running_var (both or neither)
+ *             updated as nn.BatchNorm does (momentum, unbiased variance).  relu = 0 leaves the ReLU out.
+ *   backward: g = dy * [y > 0] (y recomputed from x), dbeta = sum g, dgamma = sum g * xhat,
+ *             dx = gamma * invstd * (g - dbeta / M - xhat * dgamma / M) -> bf16.
+ * workspace: v2x_bn_train_workspace_size(M, C) bytes of device memory (per-workgroup partial sums; 0 = unsupported shape).
+ * No atomics: results are bit-reproducible run to run. */
+long long v2x_bn_train_workspace_size(long long M, int C);
+int v2x_bn_train_forward(const uint16_t *x, long long M, int C, const float *gamma, const float *beta, float eps, float momentum,
+                         float *running_mean, float *running_var, int relu, uint16_t *y, float *save_mean, float *save_invstd,
+                         float *workspace, v2x_stream_t stream);
+int v2x_bn_train_backward(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
+                          const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma, float *dbeta,
+                          float *workspace, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- a3 (+ the sum of a4/a5): warp + fuse
  * Replaces DetModelBase.py::feature_transformation (affine_grid + grid_sample twice,

@@ -14,7 +14,7 @@ HEADER = os.path.join(ROOT, "include", "v2x_amd.h")
 def declared_functions():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"^\s*(?:const\s+)?(?:int|size_t|char\s*\*|const char\s*\*)\s*\**\s*(v2x_[a-z0-9_]+)\s*\(", src, flags=re.M)
+    names = re.findall(r"^\s*(?:const\s+)?(?:int|size_t|long long|char\s*\*|const char\s*\*)\s*\**\s*(v2x_[a-z0-9_]+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.v2x_abi_version() == _lib.ABI_VERSION == 9
+    assert lib.v2x_abi_version() == _lib.ABI_VERSION == 10
 
 
 def test_conv_desc_mirror_matches_header():

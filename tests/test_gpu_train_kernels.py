@@ -110,3 +110,156 @@ def test_training_step_on_hip_conv_kernels(device, monkeypatch):
             worst, worst_k = d, k
     print("worst relative gradient difference %.3e (%s)" % (worst, worst_k))
     assert worst < 5e-2, (worst, worst_k)
+
+
+# ------------------------------------------------------------------ batch-statistics BN + ReLU kernels (bn_train.hip)
+@pytest.mark.parametrize("M,C,relu", [(2 * 256 * 256, 32, True), (3 * 64 * 64, 128, True), (5 * 16 * 16, 512, True), (1000, 64, False),
+                                      (7, 8, True)])
+def test_bn_train_kernels_vs_autograd(device, M, C, relu):
+    """v2x_bn_train_forward / backward against F.batch_norm(training=True) (+ relu) in fp32 on the same bf16 inputs: statistics and
+    parameter gradients to 1e-5 / 2e-4 of their scale, y and dx within one bf16 rounding, running statistics as nn.BatchNorm updates
+    them, and bit-identical results on a second run (no atomics)."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = (torch.randn(M, C, generator=g) * (0.5 + torch.rand(C, generator=g)) + torch.randn(C, generator=g)).to(torch.bfloat16)
+    dy = torch.randn(M, C, generator=g).to(torch.bfloat16)
+    gamma = (0.5 + torch.rand(C, generator=g)).requires_grad_(True)
+    beta = (0.3 * torch.randn(C, generator=g)).requires_grad_(True)
+    rm0, rv0 = torch.randn(C, generator=g), 0.5 + torch.rand(C, generator=g)
+    # reference: fp32 on the CPU
+    xr = x.float().requires_grad_(True)
+    rm, rv = rm0.clone(), rv0.clone()
+    yr = F.batch_norm(xr, rm, rv, gamma, beta, True, 0.1, 1e-5)
+    if relu:
+        yr = F.relu(yr)
+    yr.backward(dy.float())
+    # device
+    xd, dyd = x.to(device), dy.to(device)
+    gd, bd = gamma.detach().to(device), beta.detach().to(device)
+    rmd, rvd = rm0.to(device), rv0.to(device)
+    y, mean, invstd = ops.bn_train_forward(xd, gd, bd, rmd, rvd, 1e-5, 0.1, relu)
+    dx, dgamma, dbeta = ops.bn_train_backward(xd, dyd, gd, bd, mean, invstd, relu)
+    mu_ref = x.float().mean(0)
+    var_ref = x.float().var(0, unbiased=False)
+    assert torch.allclose(mean.cpu(), mu_ref, rtol=1e-5, atol=1e-5)
+    assert torch.allclose(invstd.cpu(), 1.0 / torch.sqrt(var_ref + 1e-5), rtol=2e-5)
+    assert torch.allclose(rmd.cpu(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(rvd.cpu(), rv, rtol=2e-5, atol=1e-6)
+    ybf = yr.detach().to(torch.bfloat16).float()
+    tol_y = 2.0 ** -7 * ybf.abs().clamp(min=2.0 ** -6)            # one bf16 rounding step of the value
+    assert bool(((y.cpu().float() - ybf).abs() <= tol_y).all())
+    sg, sb = float(gamma.grad.abs().max()), float(beta.grad.abs().max())
+    assert float((dgamma.cpu() - gamma.grad).abs().max()) <= 2e-4 * sg + 1e-4, (dgamma.cpu() - gamma.grad).abs().max()
+    assert float((dbeta.cpu() - beta.grad).abs().max()) <= 2e-4 * sb + 1e-4
+    dxr = xr.grad
+    err = (dx.cpu().float() - dxr).abs()
+    # a ReLU decided on the fp32 value vs on the value recomputed in another order can differ only where y ~ 0
+    near_kink = yr.detach().abs() < 1e-5 if relu else torch.zeros_like(err, dtype=torch.bool)
+    tol_dx = 2.0 ** -7 * dxr.abs() + 2.0 ** -8 * float(dxr.abs().max()) * 2.0 ** -4 + 1e-6
+    assert bool(((err <= tol_dx) | near_kink).all()), float((err - tol_dx).max())
+    y2, mean2, invstd2 = ops.bn_train_forward(xd, gd, bd, None, None, 1e-5, 0.1, relu)
+    dx2, dgamma2, dbeta2 = ops.bn_train_backward(xd, dyd, gd, bd, mean2, invstd2, relu)
+    assert torch.equal(y2, y) and torch.equal(mean2, mean) and torch.equal(dx2, dx) and torch.equal(dgamma2, dgamma) and torch.equal(dbeta2, dbeta)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 64, 64, 32, 32), (1, 32, 64, 96, 32), (3, 8, 32, 64, 96)])
+def test_wgrad_32_row_form_vs_autograd(device, N, H, W, Cin, Cout):
+    """Cout % 64 == 32: the 32-row form of conv3x3_wgrad_kernel (wave pairs split the tile's rows, two workspace slots per block)."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(N * H + Cout)
+    x = torch.randn(N, Cin, H, W, generator=g).to(torch.bfloat16).float()
+    dy = torch.randn(N, Cout, H, W, generator=g).to(torch.bfloat16).float()
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    got = ops.conv3x3_wgrad(x.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device),
+                            dy.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(device)).cpu()
+    err = float((got - w.grad).abs().max()) / float(w.grad.abs().max())
+    print("wgrad32 %s: %.2e" % ((N, H, W, Cin, Cout), err))
+    assert err < 2e-5
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,cin_store", [(2, 64, 64, 32, 64, 2, 32), (1, 32, 32, 256, 512, 2, 256), (2, 64, 64, 13, 32, 1, 32),
+                                                             (1, 64, 64, 96, 32, 1, 96), (2, 32, 32, 64, 128, 1, 64)])
+def test_hip_graph_conv_function_vs_autograd(device, N, H, W, Cin, Cout, stride, cin_store):
+    """train/hip_graph.py::_Conv3x3 (forward, data gradient, weight gradient, bias gradient) for stride 1 and 2, 32-channel layers and the
+    13-channel first layer stored as 32, against torch.autograd in fp32 on the same bf16-rounded operands."""
+    from v2x_sim_amd.train import hip_graph
+    g = torch.Generator().manual_seed(Cin + Cout + stride)
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16)
+    conv_r = torch.nn.Conv2d(Cin, Cout, 3, stride, 1)
+    with torch.no_grad():
+        conv_r.weight.copy_((conv_r.weight * 2).to(torch.bfloat16).float())
+    conv_d = torch.nn.Conv2d(Cin, Cout, 3, stride, 1).to(device)
+    conv_d.load_state_dict(conv_r.state_dict())
+    Ho, Wo = H // stride, W // stride
+    dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(torch.bfloat16)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = conv_r(xr)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    xd = F.pad(x, (0, cin_store - Cin)).to(device).requires_grad_(cin_store == Cin)   # the padded first layer's input takes no gradient
+    assert hip_graph.hip_eligible(conv_d.weight, stride, H, W)
+    yd = hip_graph.conv3x3(xd, conv_d)
+    yd.backward(dy.to(device))
+    ybf = yr.detach().permute(0, 2, 3, 1)
+    assert float((yd.detach().cpu().float() - ybf).abs().max()) <= 2.0 ** -7 * float(ybf.abs().max())
+    if cin_store == Cin:
+        dxr = xr.grad.permute(0, 2, 3, 1)
+        assert float((xd.grad.cpu().float() - dxr).abs().max()) <= 2.0 ** -7 * float(dxr.abs().max())
+    assert float((conv_d.weight.grad.cpu() - conv_r.weight.grad).abs().max()) <= 2e-5 * float(conv_r.weight.grad.abs().max())
+    assert torch.allclose(conv_d.bias.grad.cpu(), conv_r.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
+    """V2X_TRAIN_HIP=1: a FaFNet training step (batch-statistics BN) on the bf16 NHWC HIP graph against the fp32 MIOpen graph: the
+    loss within 2 %, the running statistics of every BN within 2 % of their scale, and parameter gradients that point the same way
+    (cosine > 0.98 over all parameters together; individual ReLU flips make per-element comparisons meaningless in train mode, see
+    tests/test_gpu_train.py).  Then 30 SGD steps on either graph from the same start: both reduce the loss, to within 15 % of each other."""
+    import copy
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.loop import synthetic_batch_on_device
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    cfg = Config("train")
+    base = init_synthetic_weights(FaFNet(cfg, kd_flag=0, num_agent=2), seed=3).to(device)
+    data = synthetic_batch_on_device(cfg, 1, 2, seed=5, device=device)
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+        model = copy.deepcopy(base)
+        model.train()
+        res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
+        loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+        loss.backward()
+        out[flag] = (float(loss.detach()), {k: p.grad.detach().float().clone() for k, p in model.named_parameters() if p.grad is not None},
+                     {k: b.detach().float().clone() for k, b in model.named_buffers() if "running" in k})
+    l0, g0, b0 = out["0"]
+    l1, g1, b1 = out["1"]
+    print("loss: fp32 graph %.5f, HIP graph %.5f" % (l0, l1))
+    assert abs(l1 - l0) <= 2e-2 * abs(l0)
+    assert set(g0) == set(g1)
+    for k in b0:
+        assert float((b1[k] - b0[k]).abs().max()) <= 2e-2 * max(float(b0[k].abs().max()), 1e-3), k
+    dot = sum(float((g0[k] * g1[k]).sum()) for k in g0)
+    n0 = sum(float((g0[k] ** 2).sum()) for k in g0) ** 0.5
+    n1 = sum(float((g1[k] ** 2).sum()) for k in g0) ** 0.5
+    print("gradient cosine %.4f, norms %.4e / %.4e" % (dot / (n0 * n1), n0, n1))
+    assert dot / (n0 * n1) > 0.98 and abs(n1 - n0) <= 0.1 * n0
+    finals = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+        model = copy.deepcopy(base)
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=2e-3, momentum=0.9)
+        first = None
+        for _ in range(30):
+            res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
+            loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            first = float(loss.detach()) if first is None else first
+        finals[flag] = (first, float(loss.detach()))
+    monkeypatch.delenv("V2X_TRAIN_HIP")
+    print("30 SGD steps: fp32 graph %.4f -> %.4f, HIP graph %.4f -> %.4f" % (finals["0"] + finals["1"]))
+    assert finals["0"][1] < 0.7 * finals["0"][0] and finals["1"][1] < 0.7 * finals["1"][0]
+    assert abs(finals["1"][1] - finals["0"][1]) <= 0.15 * finals["0"][1]

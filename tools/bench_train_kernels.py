@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Row f-3 kernels next to MIOpen: weight gradient, data gradient and forward of the backbone's 3x3 stride-1 layers at the
-training batch (2 frames x 5 agents = 10 maps), and one FaFNet training step with / without V2X_TRAIN_HIP_CONV=1.
+training batch (2 frames x 5 agents = 10 maps), one FaFNet forward + backward with / without V2X_TRAIN_HIP_CONV=1, and a whole
+training step on the fp32 MIOpen graph against the bf16 NHWC HIP graph (V2X_TRAIN_HIP=1, train/hip_graph.py).
 
     python tools/bench_train_kernels.py"""
 import os
@@ -62,6 +63,35 @@ def main():
     for flag in ("0", "1"):
         os.environ["V2X_TRAIN_HIP_CONV"] = flag
         print("FaFNet forward + backward, 10 maps, V2X_TRAIN_HIP_CONV=%s: %.1f ms" % (flag, timed(step, 5) / 1e3))
+    os.environ["V2X_TRAIN_HIP_CONV"] = "0"
+    # the bf16 NHWC graph on the HIP kernels (train/hip_graph.py) against the fp32 MIOpen graph, optimizer step included
+    # (the HIP graph re-packs every layer's weights on the GPU after each step -- that cost is inside the number)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+    def full_step():
+        res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 2)
+        loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+    for flag in ("0", "1"):
+        os.environ["V2X_TRAIN_HIP"] = flag
+        print("FaFNet training step (fwd + bwd + Adam), 10 maps, V2X_TRAIN_HIP=%s: %.1f ms" % (flag, timed(full_step, 5) / 1e3))
+    os.environ["V2X_TRAIN_HIP"] = "1"
+    ops.PROFILE = []
+    full_step()
+    torch.cuda.synchronize()
+    agg = {}
+    for name, flops, nbytes, e0, e1, layer in ops.PROFILE:
+        t = e0.elapsed_time(e1) * 1e3
+        a = agg.setdefault(name, [0, 0.0])
+        a[0] += 1
+        a[1] += t
+    ops.PROFILE = None
+    print("HIP launches of one training step (us, by kernel family):")
+    for k, (n, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("  %-58s x%-3d %9.1f" % (k, n, t))
+    print("  total %.1f ms in %d launches" % (sum(v[1] for v in agg.values()) / 1e3, sum(v[0] for v in agg.values())))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,284 @@
+// Batch-statistics BatchNorm + ReLU for TRAINING on bf16 NHWC maps.
+//
+// Upstream trains through nn.BatchNorm2d / nn.BatchNorm3d in train mode followed by F.relu (Backbone.py's
+// `F.relu(self.bnK_J(self.convK_J(x)))`); on ROCm that is MIOpen's BN kernels over NCHW fp32.  Here a map is [M][C] bf16 with
+// M = N*H*W pixels and the channel index fastest, the way every conv kernel of this library reads and writes it, so BN is four
+// streaming passes -- all HBM-bound, 16-B accesses, no layout change:
+//
+//   forward   (1) bn_partial_kernel<STATS>   per-channel sum x, sum x^2           read x
+//             (2) bn_finish_stats_kernel     mean, biased var -> 1/sqrt(var+eps); running statistics as nn.BatchNorm does
+//             (3) bn_apply_kernel            y = relu(x * a + b) -> bf16          read x, write y     (a = gamma/std, b = beta - mean a)
+//   backward  (1) bn_partial_kernel<GRADS>   sum g, sum g xhat,  g = dy * [y > 0] read x, dy          (y recomputed, never stored twice)
+//             (2) bn_finish_grads_kernel     dbeta, dgamma
+//             (3) bn_bwd_apply_kernel        dx = a (g - dbeta/M - xhat dgamma/M) read x, dy, write dx
+//
+// Determinism: a workgroup owns a contiguous run of pixels and writes ONE partial per channel; the finish kernels add the partials
+// in index order in fp64.  No atomics anywhere, so two runs give the same bits (MIOpen's BN backward does not promise that).
+// var = E[x^2] - mean^2 is formed in fp64 from fp32 partials of <= 4096 pixels each.
+#include "common.h"
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_BLOCKS = 2048;
+
+struct BnArgs {
+    const uint16_t *x;     // [M][C] bf16: the convolution's output
+    const uint16_t *dy;    // [M][C] bf16 (backward)
+    uint16_t *out;         // y (forward) or dx (backward)
+    const float *gamma, *beta;
+    float *mean, *invstd;  // [C] saved statistics
+    float *running_mean, *running_var;   // may be null
+    float *dgamma, *dbeta;
+    float *partial;        // [n_blocks][2][C]
+    long long M;
+    int C, G;              // G = C / 8 channel groups
+    int n_blocks;
+    long long vec_per_block;   // 16-B vectors per workgroup (a multiple of BN_THREADS)
+    float eps, momentum;
+    int relu;
+};
+
+__device__ __forceinline__ void unpack8(const uint4 v, float f[8]) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+
+// MODE 0: sum x, sum x^2.   MODE 1: sum g, sum g * xhat with g = dy masked by the recomputed ReLU.
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const BnArgs a) {
+    __shared__ float red[BN_THREADS][17];
+    const int t = threadIdx.x;
+    const int g = t % a.G;                 // BN_THREADS % G == 0: a thread keeps its channel group over the whole run
+    const long long total = a.M * a.G;
+    const long long v0 = (long long)blockIdx.x * a.vec_per_block;
+    long long v1 = v0 + a.vec_per_block;
+    if (v1 > total) v1 = total;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s0[i] = s1[i] = 0.f;
+    float mu[8], is[8], ga[8], be[8];
+    if (MODE == 1) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int c = g * 8 + i;
+            mu[i] = a.mean[c];
+            is[i] = a.invstd[c];
+            ga[i] = a.gamma[c];
+            be[i] = a.beta[c];
+        }
+    }
+    const uint4 *xv = reinterpret_cast<const uint4 *>(a.x);
+    const uint4 *dv = reinterpret_cast<const uint4 *>(a.dy);
+    for (long long v = v0 + t; v < v1; v += BN_THREADS) {
+        float x[8];
+        unpack8(xv[v], x);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s0[i] += x[i];
+                s1[i] = fmaf(x[i], x[i], s1[i]);
+            }
+        } else {
+            float d[8];
+            unpack8(dv[v], d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float xh = (x[i] - mu[i]) * is[i];
+                const float y = fmaf(xh, ga[i], be[i]);
+                const float gr = (a.relu && !(y > 0.f)) ? 0.f : d[i];
+                s0[i] += gr;
+                s1[i] = fmaf(gr, xh, s1[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[t][i] = s0[i];
+        red[t][8 + i] = s1[i];
+    }
+    __syncthreads();
+    // thread (g, i) for g < G, i < 16 adds the BN_THREADS / G rows of its channel group in row order
+    for (int o = t; o < a.G * 16; o += BN_THREADS) {
+        const int gg = o >> 4, i = o & 15;
+        float s = 0.f;
+        for (int r = gg; r < BN_THREADS; r += a.G) s += red[r][i];
+        a.partial[((size_t)blockIdx.x * 2 + (i >> 3)) * a.C + gg * 8 + (i & 7)] = s;
+    }
+}
+
+__global__ void bn_finish_stats_kernel(const BnArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < a.n_blocks; ++b) {
+        s += (double)a.partial[((size_t)b * 2) * a.C + c];
+        q += (double)a.partial[((size_t)b * 2 + 1) * a.C + c];
+    }
+    const double m = s / (double)a.M;
+    double var = q / (double)a.M - m * m;
+    if (var < 0.0) var = 0.0;
+    a.mean[c] = (float)m;
+    a.invstd[c] = (float)(1.0 / sqrt(var + (double)a.eps));
+    if (a.running_mean) a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)m;
+    if (a.running_var) {
+        const double unbiased = a.M > 1 ? var * (double)a.M / (double)(a.M - 1) : var;
+        a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+    }
+}
+
+__global__ void bn_finish_grads_kernel(const BnArgs a) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= a.C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < a.n_blocks; ++b) {
+        s += (double)a.partial[((size_t)b * 2) * a.C + c];
+        q += (double)a.partial[((size_t)b * 2 + 1) * a.C + c];
+    }
+    a.dbeta[c] = (float)s;
+    a.dgamma[c] = (float)q;
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const BnArgs a) {
+    const int t = threadIdx.x;
+    const int g = t % a.G;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = g * 8 + i;
+        sc[i] = a.gamma[c] * a.invstd[c];
+        sh[i] = fmaf(-a.mean[c], sc[i], a.beta[c]);
+    }
+    const long long total = a.M * a.G;
+    const uint4 *xv = reinterpret_cast<const uint4 *>(a.x);
+    uint4 *yv = reinterpret_cast<uint4 *>(a.out);
+    for (long long v = (long long)blockIdx.x * BN_THREADS + t; v < total; v += (long long)gridDim.x * BN_THREADS) {
+        float x[8];
+        unpack8(xv[v], x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i] = fmaf(x[i], sc[i], sh[i]);
+            if (a.relu) x[i] = fmaxf(x[i], 0.f);
+        }
+        yv[v] = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+    }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnArgs a) {
+    const int t = threadIdx.x;
+    const int g = t % a.G;
+    float mu[8], is[8], ga[8], be[8], k0[8], k1[8];
+    const float inv_m = 1.f / (float)a.M;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int c = g * 8 + i;
+        mu[i] = a.mean[c];
+        is[i] = a.invstd[c];
+        ga[i] = a.gamma[c];
+        be[i] = a.beta[c];
+        k0[i] = a.dbeta[c] * inv_m;
+        k1[i] = a.dgamma[c] * inv_m;
+    }
+    const long long total = a.M * a.G;
+    const uint4 *xv = reinterpret_cast<const uint4 *>(a.x);
+    const uint4 *dv = reinterpret_cast<const uint4 *>(a.dy);
+    uint4 *ov = reinterpret_cast<uint4 *>(a.out);
+    for (long long v = (long long)blockIdx.x * BN_THREADS + t; v < total; v += (long long)gridDim.x * BN_THREADS) {
+        float x[8], d[8];
+        unpack8(xv[v], x);
+        unpack8(dv[v], d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float xh = (x[i] - mu[i]) * is[i];
+            const float y = fmaf(xh, ga[i], be[i]);
+            const float gr = (a.relu && !(y > 0.f)) ? 0.f : d[i];
+            x[i] = ga[i] * is[i] * (gr - k0[i] - xh * k1[i]);
+        }
+        ov[v] = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+    }
+}
+
+static int bn_plan(long long M, int C, BnArgs &a) {
+    a.M = M;
+    a.C = C;
+    a.G = C / 8;
+    const long long total = M * a.G;
+    // <= 4096 pixels' worth per partial would need too many blocks for big maps; bound the block count instead and keep the
+    // per-thread run short enough for fp32 (a thread adds total / (n_blocks * 256) values per channel)
+    long long per = (total + BN_MAX_BLOCKS - 1) / BN_MAX_BLOCKS;
+    per = (per + BN_THREADS - 1) / BN_THREADS * BN_THREADS;
+    if (per < BN_THREADS) per = BN_THREADS;
+    a.vec_per_block = per;
+    a.n_blocks = (int)((total + per - 1) / per);
+    return a.n_blocks;
+}
+
+static bool bn_shape_ok(long long M, int C) { return M > 0 && C >= 8 && C % 8 == 0 && BN_THREADS % (C / 8) == 0; }
+
+extern "C" long long v2x_bn_train_workspace_size(long long M, int C) {
+    if (!bn_shape_ok(M, C)) return 0;
+    BnArgs a;
+    return (long long)bn_plan(M, C, a) * 2 * C * (long long)sizeof(float);
+}
+
+extern "C" int v2x_bn_train_forward(const uint16_t *x, long long M, int C, const float *gamma, const float *beta, float eps,
+                                    float momentum, float *running_mean, float *running_var, int relu, uint16_t *y,
+                                    float *save_mean, float *save_invstd, float *workspace, v2x_stream_t stream) {
+    V2X_REQUIRE(x && gamma && beta && y && save_mean && save_invstd && workspace, "v2x_bn_train_forward: null pointer");
+    V2X_REQUIRE(bn_shape_ok(M, C), "v2x_bn_train_forward: needs M > 0 and C in {8, 16, 32, ..., 2048} (C / 8 divides 256), got M=%lld C=%d", M, C);
+    V2X_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "v2x_bn_train_forward: running_mean and running_var go together");
+    BnArgs a = {};
+    bn_plan(M, C, a);
+    a.x = x;
+    a.out = y;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.mean = save_mean;
+    a.invstd = save_invstd;
+    a.running_mean = running_mean;
+    a.running_var = running_var;
+    a.partial = workspace;
+    a.eps = eps;
+    a.momentum = momentum;
+    a.relu = relu;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(a.n_blocks), dim3(BN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, s, a);
+    const long long total = M * a.G;
+    long long blocks = (total + BN_THREADS - 1) / BN_THREADS;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, a);
+    V2X_CHECK_LAUNCH("bn_train_forward");
+    return V2X_OK;
+}
+
+extern "C" int v2x_bn_train_backward(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
+                                     const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma,
+                                     float *dbeta, float *workspace, v2x_stream_t stream) {
+    V2X_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "v2x_bn_train_backward: null pointer");
+    V2X_REQUIRE(bn_shape_ok(M, C), "v2x_bn_train_backward: needs M > 0 and C in {8, 16, 32, ..., 2048} (C / 8 divides 256), got M=%lld C=%d", M, C);
+    BnArgs a = {};
+    bn_plan(M, C, a);
+    a.x = x;
+    a.dy = dy;
+    a.out = dx;
+    a.gamma = gamma;
+    a.beta = beta;
+    a.mean = const_cast<float *>(save_mean);
+    a.invstd = const_cast<float *>(save_invstd);
+    a.dgamma = dgamma;
+    a.dbeta = dbeta;
+    a.partial = workspace;
+    a.relu = relu;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(a.n_blocks), dim3(BN_THREADS), 0, s, a);
+    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, a);
+    const long long total = M * a.G;
+    long long blocks = (total + BN_THREADS - 1) / BN_THREADS;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, a);
+    V2X_CHECK_LAUNCH("bn_train_backward");
+    return V2X_OK;
+}

@@ -14,10 +14,14 @@
 // fragment and issues the MFMAs of the (output row r, tap row ky) pairs with r + ky = pr: 7 fragment reads per 18 MFMAs.
 // The partial sums of the blocks that share (co tile, ci tile) go to a workspace [split][Cout][9][Cin] fp32 and are added
 // up by the caller in a fixed order -- deterministic, unlike an atomicAdd reduction (and unlike MIOpen's wgrad).
+//
+// 32-row form (Cout % 64 == 32: the full-resolution 32-channel layers conv_pre_2 / conv8_1 / conv8_2 and the head hiddens): the block
+// covers 32 output channels; waves 0-1 take the tile's output rows 0-3, waves 2-3 rows 4-7 and write to two DIFFERENT workspace
+// slots (2*split, 2*split + 1), so the halves meet in the caller's fixed-order sum like any other pair of partials.
 #include "common.h"
 
 constexpr int WG_TH = 8, WG_TW = 32;                 // pixel tile
-constexpr int WG_CO = 64, WG_CI = 32;                // channel block
+constexpr int WG_CO = 64, WG_CI = 32;                // channel block (WG_CO: the 64-row form; LDS is sized for it)
 constexpr int WG_PX = WG_TH * WG_TW;                 // 256 pixels = k extent of one tile
 constexpr int WG_DY_ROW = WG_PX * 2 + 16;            // bytes per output channel of the transposed dY tile (+16: bank spread)
 constexpr int WG_X_ROW = (WG_TH + 2) * WG_TW * 2 + 16;  // bytes per input channel of one shifted patch copy
@@ -28,10 +32,12 @@ struct WgradArgs {
     const uint16_t *dy;   // [N][H][W][Cout] bf16
     float *ws;            // [n_split][Cout][9][Cin] fp32 partial sums (every element written)
     int N, H, W, Cin, Cout;
-    int tiles_x, tiles_y, n_tiles, n_split;
+    int tiles_x, tiles_y, n_tiles, n_split;   // n_split = number of blocks that share one (co tile, ci tile) pair
 };
 
+template <int CO>   // 64: wave w owns co 16w..16w+15, all 8 tile rows;  32: wave w owns co 16(w&1).., rows 4(w>>1)..4(w>>1)+3
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
+    constexpr int RT = CO == 64 ? WG_TH : WG_TH / 2;   // output rows of the tile one wave contracts over
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_dy = smem;                                 // [64 co][256 px]
     char *s_x = smem + WG_CO * WG_DY_ROW;              // [3 kx][32 ci][10 rows][32 cols]
@@ -40,6 +46,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fj = lane & 15, fq = lane >> 4;
+    const int wco = CO == 64 ? wave : (wave & 1);      // the wave's 16-channel sub-tile
+    const int row0 = CO == 64 ? 0 : (wave >> 1) * RT;  // its first output row
     const int n_ci_t = a.Cin / WG_CI;
     const int blk = blockIdx.x;
     const int split = blk % a.n_split;
@@ -62,9 +70,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
         // ---- dY tile, transposed: thread = pixel, loop over the 8 groups of 8 output channels
         {
             const int pr = tid >> 5, pc = tid & 31;
-            const uint16_t *src = a.dy + ((size_t)(n * a.H + y0 + pr) * a.W + x0 + pc) * a.Cout + co_t * WG_CO;
+            const uint16_t *src = a.dy + ((size_t)(n * a.H + y0 + pr) * a.W + x0 + pc) * a.Cout + co_t * CO;
 #pragma unroll
-            for (int cg = 0; cg < WG_CO / 8; ++cg) {
+            for (int cg = 0; cg < CO / 8; ++cg) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(src + cg * 8);
                 const uint32_t wds[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -95,22 +103,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
             }
         }
         __syncthreads();
-        // ---- MFMAs: patch row pr serves (r, ky) with r + ky = pr
-        bf16x8_t A[3];   // A[(pr) % 3] = dY^T fragment of output row pr (16 co x 32 px)
+        // ---- MFMAs: patch row row0 + pr serves (r, ky) with r + ky = pr, r = output row relative to row0
+        bf16x8_t A[3];   // A[pr % 3] = dY^T fragment of output row row0 + pr (16 co x 32 px)
 #pragma unroll
-        for (int pr = 0; pr < WG_TH + 2; ++pr) {
-            if (pr < WG_TH)
-                A[pr % 3] = *reinterpret_cast<const bf16x8_t *>(s_dy + (wave * 16 + fj) * WG_DY_ROW + (pr * WG_TW + fq * 8) * 2);
+        for (int pr = 0; pr < RT + 2; ++pr) {
+            if (pr < RT)
+                A[pr % 3] = *reinterpret_cast<const bf16x8_t *>(s_dy + (wco * 16 + fj) * WG_DY_ROW + ((row0 + pr) * WG_TW + fq * 8) * 2);
             bf16x8_t B[3][2];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    B[kx][j] = *reinterpret_cast<const bf16x8_t *>(s_x + (kx * WG_CI + j * 16 + fj) * WG_X_ROW + (pr * WG_TW + fq * 8) * 2);
+                    B[kx][j] = *reinterpret_cast<const bf16x8_t *>(s_x + (kx * WG_CI + j * 16 + fj) * WG_X_ROW + ((row0 + pr) * WG_TW + fq * 8) * 2);
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int r = pr - ky;
-                if (r < 0 || r >= WG_TH) continue;
+                if (r < 0 || r >= RT) continue;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
@@ -120,31 +128,39 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
         }
     }
     // ---- partial result of this block: ws[split][co][tap][ci]; lane (fj, fq) holds rows co = 4*fq + e, column ci = fj
-    float *dst = a.ws + (size_t)split * a.Cout * 9 * a.Cin;
+    const int slot = CO == 64 ? split : 2 * split + (wave >> 1);
+    float *dst = a.ws + (size_t)slot * a.Cout * 9 * a.Cin;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int co = co_t * WG_CO + wave * 16 + fq * 4 + e;
+                const int co = co_t * CO + wco * 16 + fq * 4 + e;
                 const int ci = ci_t * WG_CI + j * 16 + fj;
                 dst[((size_t)co * 9 + t) * a.Cin + ci] = acc[t][j][e];
             }
 }
 
-extern "C" int v2x_conv3x3_wgrad_splits(int N, int H, int W) {
-    // pixel tiles per (co tile, ci tile) pair are shared by up to 64 blocks; fewer when the batch is small
-    if (N <= 0 || H <= 0 || W <= 0 || H % WG_TH || W % WG_TW) return 0;
+extern "C" int v2x_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
+    // number of workspace slots the library would use: enough blocks for two rounds of the 256 CUs, at most one block per pixel tile
+    if (N <= 0 || H <= 0 || W <= 0 || H % WG_TH || W % WG_TW || Cin <= 0 || Cin % WG_CI || Cout <= 0 || Cout % 32) return 0;
+    const bool rows32 = Cout % WG_CO != 0;
     const long long tiles = (long long)N * (H / WG_TH) * (W / WG_TW);
-    return (int)(tiles < 64 ? tiles : 64);
+    const long long pairs = (long long)(Cout / (rows32 ? 32 : WG_CO)) * (Cin / WG_CI);
+    long long n = (512 + pairs - 1) / pairs;
+    if (n > 256) n = 256;
+    if (n > tiles) n = tiles;
+    if (n < 1) n = 1;
+    return (int)(rows32 ? 2 * n : n);
 }
 
 extern "C" int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, int H, int W, int Cin, int Cout, float *workspace,
                                  int n_split, v2x_stream_t stream) {
     V2X_REQUIRE(x && dy && workspace, "v2x_conv3x3_wgrad: null pointer");
-    V2X_REQUIRE(N > 0 && H % WG_TH == 0 && W % WG_TW == 0 && Cin % WG_CI == 0 && Cout % WG_CO == 0,
-                "v2x_conv3x3_wgrad: needs H %% 8 == 0, W %% 32 == 0, Cin %% 32 == 0, Cout %% 64 == 0");
+    V2X_REQUIRE(N > 0 && H > 0 && W > 0 && H % WG_TH == 0 && W % WG_TW == 0 && Cin > 0 && Cin % WG_CI == 0 && Cout > 0 && Cout % 32 == 0,
+                "v2x_conv3x3_wgrad: needs H %% 8 == 0, W %% 32 == 0, Cin %% 32 == 0, Cout %% 32 == 0");
+    const bool rows32 = Cout % WG_CO != 0;
     WgradArgs a;
     a.x = x;
     a.dy = dy;
@@ -157,14 +173,24 @@ extern "C" int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, i
     a.tiles_x = W / WG_TW;
     a.tiles_y = H / WG_TH;
     a.n_tiles = N * a.tiles_x * a.tiles_y;
-    V2X_REQUIRE(n_split >= 1 && n_split <= a.n_tiles, "v2x_conv3x3_wgrad: n_split=%d outside [1, %d]", n_split, a.n_tiles);
-    a.n_split = n_split;
+    if (rows32) {
+        V2X_REQUIRE(n_split >= 2 && n_split % 2 == 0 && n_split / 2 <= a.n_tiles,
+                    "v2x_conv3x3_wgrad: Cout %% 64 != 0 takes an even n_split in [2, %d] (two workspace slots per block), got %d", 2 * a.n_tiles, n_split);
+        a.n_split = n_split / 2;
+    } else {
+        V2X_REQUIRE(n_split >= 1 && n_split <= a.n_tiles, "v2x_conv3x3_wgrad: n_split=%d outside [1, %d]", n_split, a.n_tiles);
+        a.n_split = n_split;
+    }
     static v2x_once_per_device attr_once;
     if (v2x_first_use_on_device(attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
     }
-    const int grid = (Cout / WG_CO) * (Cin / WG_CI) * n_split;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3(grid), dim3(256), WG_SMEM, (hipStream_t)stream, a);
+    const int grid = (Cout / (rows32 ? 32 : WG_CO)) * (Cin / WG_CI) * a.n_split;
+    if (rows32)
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(grid), dim3(256), WG_SMEM, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(conv3x3_wgrad_kernel<64>, dim3(grid), dim3(256), WG_SMEM, (hipStream_t)stream, a);
     V2X_CHECK_LAUNCH("conv3x3_wgrad_kernel");
     return V2X_OK;
 }

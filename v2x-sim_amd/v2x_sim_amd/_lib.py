@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU = 0, 1, 2
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(C.Structure):
@@ -69,9 +69,14 @@ SIGNATURES = {
     "v2x_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "v2x_conv2d_pair": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
     "v2x_conv2d_tail": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
-    "v2x_conv3x3_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "v2x_conv3x3_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v2x_conv3x3_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p]),
+    "v2x_bn_train_workspace_size": (C.c_longlong, [C.c_longlong, C.c_int]),
+    "v2x_bn_train_forward": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p,
+                                       C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_bn_train_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_warp_fuse": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_attn_handshake": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -90,6 +90,10 @@ def _dev(t, dtype, name):
     return C.c_void_p(t.data_ptr())
 
 
+def _dev_opt(t, dtype, name):
+    return None if t is None else _dev(t, dtype, name)
+
+
 # ------------------------------------------------------------------ a1
 class VoxelGrid:
     """Geometry of the BEV grid (upstream Config.voxel_size / area_extents)."""
@@ -373,9 +377,9 @@ def conv3x3_wgrad(x, dy):
     Cout = dy.shape[3]
     if tuple(dy.shape[:3]) != (N, H, W):
         raise ValueError("x %s and dy %s disagree" % (tuple(x.shape), tuple(dy.shape)))
-    ns = lib.v2x_conv3x3_wgrad_splits(N, H, W)
+    ns = lib.v2x_conv3x3_wgrad_splits(N, H, W, Cin, Cout)
     if ns == 0:
-        raise ValueError("v2x_conv3x3_wgrad needs H % 8 == 0 and W % 32 == 0")
+        raise ValueError("v2x_conv3x3_wgrad needs H % 8 == 0, W % 32 == 0, Cin % 32 == 0 and Cout % 32 == 0")
     ws = torch.empty((ns, Cout, 3, 3, Cin), dtype=torch.float32, device=x.device)
     prof = _Prof("conv3x3_wgrad_kernel", 2.0 * N * H * W * Cout * 9 * Cin, (x.numel() + dy.numel()) * 2 + ws.numel() * 4)
     rc = lib.v2x_conv3x3_wgrad(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"), N, H, W, Cin, Cout,
@@ -383,6 +387,53 @@ def conv3x3_wgrad(x, dy):
     prof.done()
     _lib.check(rc, "v2x_conv3x3_wgrad")
     return ws.sum(0).permute(0, 3, 1, 2).contiguous()
+
+
+def bn_train_forward(x, gamma, beta, running_mean, running_var, eps, momentum, relu=True):
+    """Batch-statistics BN (+ ReLU) of a bf16 NHWC map on the HIP kernels (bn_train.hip).  x (..., C) bf16; gamma / beta (C,) fp32;
+    running_mean / running_var fp32 (updated in place) or None.  -> (y bf16 like x, save_mean, save_invstd)."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    M = x.numel() // C
+    nbytes = lib.v2x_bn_train_workspace_size(M, C)
+    if nbytes == 0:
+        raise ValueError("v2x_bn_train_forward: unsupported shape M=%d C=%d (C / 8 must divide 256)" % (M, C))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    prof = _Prof("bn_train_forward", 0.0, x.numel() * 2 * 3)
+    rc = lib.v2x_bn_train_forward(_dev(x, torch.bfloat16, "x"), M, C, _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
+                                  float(eps), float(momentum), _dev_opt(running_mean, torch.float32, "running_mean"),
+                                  _dev_opt(running_var, torch.float32, "running_var"), 1 if relu else 0, _dev(y, torch.bfloat16, "y"),
+                                  _dev(mean, torch.float32, "save_mean"), _dev(invstd, torch.float32, "save_invstd"),
+                                  _dev(ws, torch.float32, "workspace"), _stream())
+    prof.done()
+    _lib.check(rc, "v2x_bn_train_forward")
+    return y, mean, invstd
+
+
+def bn_train_backward(x, dy, gamma, beta, mean, invstd, relu=True):
+    """Backward of bn_train_forward: -> (dx bf16 like x, dgamma (C,), dbeta (C,)) fp32."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    M = x.numel() // C
+    nbytes = lib.v2x_bn_train_workspace_size(M, C)
+    if nbytes == 0:
+        raise ValueError("v2x_bn_train_backward: unsupported shape M=%d C=%d" % (M, C))
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
+    prof = _Prof("bn_train_backward", 0.0, x.numel() * 2 * 5)
+    rc = lib.v2x_bn_train_backward(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"), M, C, _dev(gamma, torch.float32, "gamma"),
+                                   _dev(beta, torch.float32, "beta"), _dev(mean, torch.float32, "save_mean"),
+                                   _dev(invstd, torch.float32, "save_invstd"), 1 if relu else 0, _dev(dx, torch.bfloat16, "dx"),
+                                   _dev(dgamma, torch.float32, "dgamma"), _dev(dbeta, torch.float32, "dbeta"),
+                                   _dev(ws, torch.float32, "workspace"), _stream())
+    prof.done()
+    _lib.check(rc, "v2x_bn_train_backward")
+    return dx, dgamma, dbeta
 
 
 def tail_eligible(pa, pb, x):

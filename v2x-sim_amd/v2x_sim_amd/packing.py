@@ -21,11 +21,39 @@ def _ceil_to(x, m):
     return (x + m - 1) // m * m
 
 
+# Where the re-ordering runs.  None: on the host (inference packs once per checkpoint).  A device: the training path re-packs every
+# layer after every optimizer step, so the permutes / pads / casts run on the GPU and nothing crosses PCIe (train/hip_graph.py).
+PACK_DEVICE = None
+
+
+class on_device:
+    """with packing.on_device(dev): ... -- pack_conv / pack_conv_halo / pack_conv_stream build their buffers on `dev`."""
+
+    def __init__(self, device):
+        self.device, self.prev = device, None
+
+    def __enter__(self):
+        global PACK_DEVICE
+        self.prev, PACK_DEVICE = PACK_DEVICE, self.device
+
+    def __exit__(self, *exc):
+        global PACK_DEVICE
+        PACK_DEVICE = self.prev
+
+
+def _home(t):
+    return t.detach().float().cpu() if PACK_DEVICE is None else t.detach().float().to(PACK_DEVICE)
+
+
+def _zeros(*shape):
+    return torch.zeros(shape, dtype=torch.float32, device="cpu" if PACK_DEVICE is None else PACK_DEVICE)
+
+
 def fold_bn(conv_bias, bn, cout):
     """-> (scale, shift) fp32 on CPU for y = acc*scale + shift."""
     if bn is None:
-        scale = torch.ones(cout, dtype=torch.float32)
-        shift = conv_bias.detach().float().cpu() if conv_bias is not None else torch.zeros(cout)
+        scale = _zeros(cout) + 1.0
+        shift = _home(conv_bias) if conv_bias is not None else _zeros(cout)
         return scale, shift
     g, b = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
     mu, var = bn.running_mean.detach().float().cpu(), bn.running_var.detach().float().cpu()
@@ -39,7 +67,7 @@ def pack_conv(name, weight, scale, shift, *, stride=1, pad=None, C0=None, C1=0, 
               epilogue=V2X_EPI_BF16, cin_pad=None, device="cuda"):
     """weight [Cout, Cin, k, k] (any float dtype, CPU or device) -> PackedConv on `device`."""
     lib = _lib.load()
-    w = weight.detach().float().cpu()
+    w = _home(weight)
     cout, cin, k, _ = w.shape
     if pad is None:
         pad = (k - 1) // 2
@@ -54,10 +82,10 @@ def pack_conv(name, weight, scale, shift, *, stride=1, pad=None, C0=None, C1=0, 
     K = k * k * cin_p
     tile = lib.v2x_conv_tile_rows(cout, epilogue)
     rows, kpad = _ceil_to(cout, tile), _ceil_to(K, 64)
-    wp = torch.zeros((rows, kpad), dtype=torch.float32)
+    wp = _zeros(rows, kpad)
     wp[:cout, :K] = w.reshape(cout, K)
-    sc = torch.zeros(rows, dtype=torch.float32)
-    sf = torch.zeros(rows, dtype=torch.float32)
+    sc = _zeros(rows)
+    sf = _zeros(rows)
     sc[:cout] = scale
     sf[:cout] = shift
     return PackedConv(name=name, weight=wp.to(torch.bfloat16).to(device).contiguous(), scale=sc.to(device),
@@ -139,7 +167,7 @@ def pack_conv_halo(name, weight, scale, shift, *, C0=None, C1=0, relu=True, cin_
     """3x3 stride-1 conv for the halo kernel: weights k-slot-major [9*Cin/8][Cout][8].
     chain = (weight2 [Cout2, Cout, 1, 1], scale2, shift2, relu2): 1x1 conv fused in the epilogue; the
     hidden rows are then stored in the kernel's chain order (scale/shift stay in natural order)."""
-    w = weight.detach().float().cpu()
+    w = _home(weight)
     cout, cin, k, _ = w.shape
     if k != 3:
         raise ValueError("halo kernel is 3x3 only")
@@ -217,7 +245,7 @@ def _stream_layout(wk, rows_tile, cin):
     n_tiles, n_chunks = rows // rows_tile, cin // 32
     w = wk.view(n_tiles, rows_tile, 9, n_chunks, 4, 8)            # [tile][row][tap][chunk][slot][8]
     flat = w.permute(0, 3, 2, 4, 1, 5).contiguous().view(-1)      # [tile][chunk][tap][slot][row][8]
-    return torch.cat([flat, torch.zeros(32, dtype=flat.dtype)])   # + 64 B of zeros: the kernel's zero page
+    return torch.cat([flat, torch.zeros(32, dtype=flat.dtype, device=flat.device)])   # + 64 B of zeros: the kernel's zero page
 
 
 def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=True, chain=None, stride=1, device="cuda"):
@@ -226,7 +254,7 @@ def pack_conv_stream(name, weight, scale, shift, *, C0=None, C1=0, up0=0, relu=T
     chain = (weight2 [Cout, Cout, 1, 1], scale2, shift2, relu2): 1x1 conv fused in the epilogue (Cout == 64 or 128: all
     channels in one workgroup); the hidden rows are stored in the chain order of conv_halo.hip."""
     lib = _lib.load()
-    w = weight.detach().float().cpu()
+    w = _home(weight)
     cout, cin, k, _ = w.shape
     if C0 is None:
         C0 = cin

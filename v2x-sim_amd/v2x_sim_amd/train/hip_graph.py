@@ -1,0 +1,209 @@
+"""The detection backbone's TRAINING graph on the hand-written HIP kernels, bf16 NHWC end to end.
+
+`train/graph.py` is upstream's graph on PyTorch-ROCm ops (MIOpen convolutions and BatchNorm over fp32 NCHW, autograd).  This module
+is the same graph -- Backbone.py's lidar_encoder / lidar_decoder and DetModelBase.py's heads: conv -> batch-statistics BN -> ReLU,
+nearest x2 upsample + concat -- over the SAME parameter tree, with
+
+    3x3 convolutions   forward           v2x_conv2d (the inference kernels, bias in the epilogue, no activation)
+                       data gradient     v2x_conv2d on W'[ci][co][ky][kx] = W[co][ci][2-ky][2-kx]; stride 2: on dy with zeros inserted
+                       weight gradient   v2x_conv3x3_wgrad (conv_wgrad.hip; stride 2: the same zero-inserted dy)
+    BatchNorm + ReLU   forward/backward  v2x_bn_train_forward / v2x_bn_train_backward (bn_train.hip), running statistics updated
+                                         exactly as nn.BatchNorm does
+
+and the maps staying bf16 NHWC between layers (no layout or precision conversion).  Left on PyTorch-ROCm ops, by design: the 1x1
+layers (conv3d_1/2 and the heads' last layers are plain GEMMs: hipBLASLt through F.linear), upsample/concat and their backward
+(views, copies and a 2x2 sum), bias gradients (a reduction), the one 3x3 layer whose map is narrower than a 32-pixel tile (conv4_2
+at 16x16: MIOpen), the cross-agent fusion of V2VNet (converted to the fp32 graph at the fusion layer and back) and the loss.
+Packed weights are rebuilt on the GPU after every optimizer step (packing.on_device): nothing crosses PCIe inside a step.
+
+Mixed precision: activations, activation gradients and the MFMA operands are bf16; every sum, the BN statistics, the weight
+gradients and the master weights are fp32.  Enabled with V2X_TRAIN_HIP=1 (FaFModule.step / train_forward); there is no CPU path.
+"""
+import types
+
+import torch
+import torch.nn.functional as F
+
+from .. import ops, packing
+
+BF16 = torch.bfloat16
+
+
+# ------------------------------------------------------------------ packed weights, rebuilt when the parameter changed
+_CACHE = {}
+
+
+def _conv_like(weight, bias, stride):
+    k = weight.shape[-1]
+    return types.SimpleNamespace(weight=weight, bias=bias, kernel_size=(k, k), stride=(stride, stride), padding=(k // 2, k // 2),
+                                 out_channels=weight.shape[0])
+
+
+def _layer(kind, weight, bias, stride, cin_pad):
+    key = (kind, weight.data_ptr(), stride, cin_pad)
+    ver = (weight._version, None if bias is None else bias._version)
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    with packing.on_device(weight.device):
+        if kind == "fwd":
+            layer = packing.layer_conv_bn("train.fwd", _conv_like(weight, bias, stride), None, device=weight.device, relu=False,
+                                          cin_pad=cin_pad)
+        else:   # data gradient: stride-1 convolution with the flipped, transposed weights (no bias)
+            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
+            layer = packing.layer_conv_bn("train.dgrad", _conv_like(wt, None, 1), None, device=weight.device, relu=False)
+    if len(_CACHE) > 512:
+        _CACHE.clear()
+    _CACHE[key] = (ver, layer)
+    return layer
+
+
+def _zero_insert(dy):
+    """dy (N, Ho, Wo, C) of a stride-2 layer -> (N, 2Ho, 2Wo, C) with dy at the even positions."""
+    N, Ho, Wo, C = dy.shape
+    z = torch.zeros((N, 2 * Ho, 2 * Wo, C), dtype=dy.dtype, device=dy.device)
+    z[:, ::2, ::2] = dy
+    return z
+
+
+def hip_eligible(weight, stride, H, W):
+    """3x3, stride 1 or 2, pad 1; the INPUT map tiles into 8x32-pixel tiles; Cout % 32 == 0 (Cin is padded to 32)."""
+    cout, cin, kh, kw = weight.shape
+    return kh == 3 and kw == 3 and stride in (1, 2) and cout % 32 == 0 and H % 8 == 0 and W % 32 == 0
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride):
+        cin = weight.shape[1]
+        cin_pad = x.shape[-1] if x.shape[-1] != cin else None          # conv_pre_1: 13 channels stored as 32
+        y = ops.run_layer(_layer("fwd", weight, bias, stride, cin_pad), x)
+        ctx.save_for_backward(x, weight)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        dyz = _zero_insert(dy) if ctx.stride == 2 else dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.run_layer(_layer("dgrad", weight, None, 1, None), dyz)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv3x3_wgrad(x, dyz)[:, :weight.shape[1]]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.float().sum((0, 1, 2))
+        return dx, dw, db, None
+
+
+class _BnRelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        y, mean, invstd = ops.bn_train_forward(x, gamma.detach(), beta.detach(), running_mean, running_var, eps, momentum, relu)
+        ctx.save_for_backward(x, gamma, beta, mean, invstd)
+        ctx.relu = relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, invstd = ctx.saved_tensors
+        dx, dgamma, dbeta = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def conv3x3(x, conv):
+    """nn.Conv2d (3x3) on a bf16 NHWC map: the HIP kernels where the map tiles, MIOpen through a layout round trip otherwise."""
+    s = conv.stride[0]
+    if hip_eligible(conv.weight, s, x.shape[1], x.shape[2]):
+        return _Conv3x3.apply(x.contiguous(), conv.weight, conv.bias, s)
+    y = F.conv2d(x.permute(0, 3, 1, 2).float(), conv.weight, conv.bias, conv.stride, conv.padding)
+    return y.permute(0, 2, 3, 1).to(BF16).contiguous()
+
+
+def bn_relu(x, bn, relu=True):
+    """nn.BatchNorm2d / nn.BatchNorm3d in train mode (+ ReLU) on a bf16 NHWC map."""
+    if not bn.training:
+        raise RuntimeError("hip_graph is the TRAINING graph (batch statistics); evaluation runs the inference engine")
+    rm = bn.running_mean if bn.track_running_stats else None
+    rv = bn.running_var if bn.track_running_stats else None
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    if bn.momentum is None:
+        raise NotImplementedError("cumulative-average BatchNorm (momentum=None)")
+    return _BnRelu.apply(x.contiguous(), bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, relu)
+
+
+def cbr(x, conv, bn):
+    return bn_relu(conv3x3(x, conv), bn)
+
+
+def conv1x1(x, weight, bias):
+    """1x1 layer = a plain GEMM over the pixels: hipBLASLt (F.linear), fp32 accumulate and fp32 weight gradient."""
+    w = weight.reshape(weight.shape[0], weight.shape[1])
+    return F.linear(x.float(), w, bias)
+
+
+def conv3d_1x1(x, m):
+    """upstream Conv3D on a length-1 sequence: 1x1x1 conv3d + BatchNorm3d + ReLU."""
+    return bn_relu(conv1x1(x, m.conv3d.weight, m.conv3d.bias).to(BF16), m.bn3d)
+
+
+def upcat(lo, skip):
+    """cat(nearest x2 upsample of lo, skip) along the channels, NHWC."""
+    up = lo.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    return torch.cat((up, skip), dim=3)
+
+
+# ------------------------------------------------------------------ the graph (Backbone.py)
+def nhwc_input(bevs):
+    """bevs (A*B, 1, X, Y, Z) dense occupancy -> (A*B, X, Y, 32) bf16 (the Z heights are the channels; zero-padded to 32)."""
+    x = bevs[:, 0]
+    return F.pad(x, (0, 32 - x.shape[-1])).to(BF16).contiguous()
+
+
+def encoder(e, x):
+    x = cbr(x, e.conv_pre_1, e.bn_pre_1)
+    x = cbr(x, e.conv_pre_2, e.bn_pre_2)
+    x_1 = cbr(x, e.conv1_1, e.bn1_1)
+    x_1 = conv3d_1x1(cbr(x_1, e.conv1_2, e.bn1_2), e.conv3d_1)
+    x_2 = cbr(x_1, e.conv2_1, e.bn2_1)
+    x_2 = conv3d_1x1(cbr(x_2, e.conv2_2, e.bn2_2), e.conv3d_2)
+    x_3 = cbr(cbr(x_2, e.conv3_1, e.bn3_1), e.conv3_2, e.bn3_2)
+    x_4 = cbr(cbr(x_3, e.conv4_1, e.bn4_1), e.conv4_2, e.bn4_2)
+    return [x, x_1, x_2, x_3, x_4]
+
+
+def decoder(d, x, x_1, x_2, x_3, x_4):
+    y = cbr(cbr(upcat(x_4, x_3), d.conv5_1, d.bn5_1), d.conv5_2, d.bn5_2)
+    y = cbr(cbr(upcat(y, x_2), d.conv6_1, d.bn6_1), d.conv6_2, d.bn6_2)
+    y = cbr(cbr(upcat(y, x_1), d.conv7_1, d.bn7_1), d.conv7_2, d.bn7_2)
+    return cbr(cbr(upcat(y, x), d.conv8_1, d.bn8_1), d.conv8_2, d.bn8_2)
+
+
+def heads(model, x):
+    c, bp = model.classification, model.regression.box_prediction
+    cls = conv1x1(cbr(x, c.conv1, c.bn1), c.conv2.weight, c.conv2.bias)           # fp32 NHWC logits
+    loc = conv1x1(cbr(x, bp[0], bp[1]), bp[3].weight, bp[3].bias)
+    return {"cls": cls.reshape(cls.shape[0], -1, model.category_num),
+            "loc": loc.reshape(-1, loc.size(1), loc.size(2), model.anchor_num_per_loc, model.out_seq_len, model.box_code_size)}
+
+
+def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1):
+    """bevs (A*B, 1, X, Y, Z) on the MI355X -> {'loc', 'cls'} fp32, shapes as train/graph.py::train_forward.
+    FaFNet (lowerbound / upperbound) and V2VNet; model.training must be on."""
+    if not bevs.is_cuda:
+        raise RuntimeError("train/hip_graph.py runs on the MI355X (no CPU path)")
+    x = nhwc_input(bevs)
+    if hasattr(model, "outc"):
+        raise NotImplementedError("hip_graph: segmentation variants train through train/graph.py")
+    if hasattr(model, "stpn"):
+        return heads(model, decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x)))
+    if hasattr(model, "convgru"):
+        from . import graph
+        feats = encoder(model.u_encoder, x)
+        f = feats[model.layer].permute(0, 3, 1, 2).float()                        # the fusion runs on the fp32 graph
+        f = graph.v2v_fuse(model, f, trans_matrices.to(x.device), num_agent_tensor, batch_size)
+        feats[model.layer] = f.permute(0, 2, 3, 1).to(BF16).contiguous()
+        return heads(model, decoder(model.decoder, *feats))
+    raise NotImplementedError("hip_graph covers FaFNet and V2VNet; the other baselines train through train/graph.py")
