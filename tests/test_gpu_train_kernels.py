@@ -210,9 +210,10 @@ def test_hip_graph_conv_function_vs_autograd(device, N, H, W, Cin, Cout, stride,
 
 def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
     """V2X_TRAIN_HIP=1: a FaFNet training step (batch-statistics BN) on the bf16 NHWC HIP graph against the fp32 MIOpen graph: the
-    loss within 2 %, the running statistics of every BN within 2 % of their scale, and parameter gradients that point the same way
-    (cosine > 0.98 over all parameters together; individual ReLU flips make per-element comparisons meaningless in train mode, see
-    tests/test_gpu_train.py).  Then 30 SGD steps on either graph from the same start: both reduce the loss, to within 15 % of each other."""
+    loss within 2 %, the running statistics of every BN within 2 % of their scale, and parameter gradients that point the same way:
+    cosine over all parameters together > 0.95 and no worse than 0.02 below a CONTROL -- the fp32 graph itself with its weights rounded to
+    bf16 (measured 0.973 vs 0.978: individual ReLU flips under batch statistics make per-element comparisons meaningless in train
+    mode, see tests/test_gpu_train.py).  Then 30 SGD steps on either graph from the same start: both reduce the loss, to within 15 % of each other."""
     import copy
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import FaFNet
@@ -223,10 +224,14 @@ def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
     base = init_synthetic_weights(FaFNet(cfg, kd_flag=0, num_agent=2), seed=3).to(device)
     data = synthetic_batch_on_device(cfg, 1, 2, seed=5, device=device)
     out = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+    for flag in ("0", "1", "0r"):
+        monkeypatch.setenv("V2X_TRAIN_HIP", flag[0])
         model = copy.deepcopy(base)
         model.train()
+        if flag == "0r":   # control: the fp32 graph with its weights rounded to bf16 -- the noise floor of this comparison
+            with torch.no_grad():
+                for p in model.parameters():
+                    p.copy_(p.to(torch.bfloat16).float())
         res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
         loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
         loss.backward()
@@ -234,16 +239,21 @@ def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
                      {k: b.detach().float().clone() for k, b in model.named_buffers() if "running" in k})
     l0, g0, b0 = out["0"]
     l1, g1, b1 = out["1"]
-    print("loss: fp32 graph %.5f, HIP graph %.5f" % (l0, l1))
+    print("loss: fp32 graph %.5f, HIP graph %.5f, fp32 graph on bf16-rounded weights %.5f" % (l0, l1, out["0r"][0]))
     assert abs(l1 - l0) <= 2e-2 * abs(l0)
     assert set(g0) == set(g1)
     for k in b0:
         assert float((b1[k] - b0[k]).abs().max()) <= 2e-2 * max(float(b0[k].abs().max()), 1e-3), k
-    dot = sum(float((g0[k] * g1[k]).sum()) for k in g0)
-    n0 = sum(float((g0[k] ** 2).sum()) for k in g0) ** 0.5
-    n1 = sum(float((g1[k] ** 2).sum()) for k in g0) ** 0.5
-    print("gradient cosine %.4f, norms %.4e / %.4e" % (dot / (n0 * n1), n0, n1))
-    assert dot / (n0 * n1) > 0.98 and abs(n1 - n0) <= 0.1 * n0
+
+    def cosine(ga, gb):
+        dot = sum(float((ga[k] * gb[k]).sum()) for k in ga)
+        na = sum(float((ga[k] ** 2).sum()) for k in ga) ** 0.5
+        nb = sum(float((gb[k] ** 2).sum()) for k in ga) ** 0.5
+        return dot / (na * nb), na, nb
+    c_hip, n0, n1 = cosine(g0, g1)
+    c_ctl, _, _ = cosine(g0, out["0r"][1])
+    print("gradient cosine vs the fp32 graph: HIP graph %.4f, control (bf16-rounded weights) %.4f; norms %.4e / %.4e" % (c_hip, c_ctl, n0, n1))
+    assert c_hip > 0.95 and c_hip >= c_ctl - 0.02 and abs(n1 - n0) <= 0.1 * n0
     finals = {}
     for flag in ("0", "1"):
         monkeypatch.setenv("V2X_TRAIN_HIP", flag)
@@ -263,3 +273,68 @@ def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
     print("30 SGD steps: fp32 graph %.4f -> %.4f, HIP graph %.4f -> %.4f" % (finals["0"] + finals["1"]))
     assert finals["0"][1] < 0.7 * finals["0"][0] and finals["1"][1] < 0.7 * finals["1"][0]
     assert abs(finals["1"][1] - finals["0"][1]) <= 0.15 * finals["0"][1]
+
+
+def test_hip_graph_v2vnet_step(device, monkeypatch):
+    """V2VNet on the HIP training graph (encoder / decoder / heads on the kernels, warp + ConvGRU fusion on the fp32 graph in between):
+    loss within 2 % of the fp32 graph's, every parameter that is in the graph (the ConvGRU's input weights included) receives a finite gradient,
+    and FaFModule.step runs."""
+    import copy
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.loop import synthetic_batch_on_device
+    from v2x_sim_amd.utils.CoDetModule import FaFModule
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    cfg = Config("train")
+    base = init_synthetic_weights(V2VNet(cfg, num_agent=2), seed=4).to(device)
+    data = synthetic_batch_on_device(cfg, 1, 2, seed=6, device=device)
+    losses = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+        model = copy.deepcopy(base)
+        model.train()
+        res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
+        loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+        loss.backward()
+        losses[flag] = float(loss.detach())
+        for k, p in model.named_parameters():
+            if "weight_hh" in k:      # h0 = 0: W_hh never enters the graph (DESIGN.md section 3.4), on either path
+                assert p.grad is None
+                continue
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    print("V2VNet loss: fp32 graph %.5f, HIP graph %.5f" % (losses["0"], losses["1"]))
+    assert abs(losses["1"] - losses["0"]) <= 2e-2 * abs(losses["0"])
+    model = copy.deepcopy(base)
+    module = FaFModule(model, None, cfg, torch.optim.Adam(model.parameters(), lr=1e-4), 0)
+    first = module.step(data, 1, num_agent=2)[0]
+    for _ in range(9):
+        last = module.step(data, 1, num_agent=2)[0]
+    monkeypatch.delenv("V2X_TRAIN_HIP")
+    print("FaFModule.step on the HIP graph: loss %.4f -> %.4f in 10 steps" % (first, last))
+    assert np.isfinite(last) and last < first
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,f32_out", [(2, 64, 64, 64, 64, False), (1, 64, 64, 32, 12, True), (2, 32, 32, 32, 36, True),
+                                                     (1, 32, 64, 128, 128, False)])
+def test_hip_graph_conv1x1_vs_autograd(device, N, H, W, Cin, Cout, f32_out):
+    """1x1 layers of the training graph (conv3d_1/2, the heads' last layers): forward / dgrad on v2x_conv2d, weight gradient = centre tap
+    of v2x_conv3x3_wgrad, against F.linear autograd in fp32 on the same bf16-rounded operands."""
+    from v2x_sim_amd.train import hip_graph
+    g = torch.Generator().manual_seed(Cin * 3 + Cout)
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.2).to(torch.bfloat16).float()
+    b = torch.randn(Cout, generator=g)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(torch.bfloat16)
+    xr, wr, br = x.float().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.linear(xr, wr.view(Cout, Cin), br)
+    yr.backward(dy.float())
+    xd, wd, bd = x.to(device).requires_grad_(True), w.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    yd = hip_graph.conv1x1(xd, wd, bd, f32_out=f32_out)
+    assert yd.dtype == (torch.float32 if f32_out else torch.bfloat16)
+    yd.backward(dy.to(device).float() if f32_out else dy.to(device))
+    tol = 1e-5 if f32_out else 2.0 ** -7
+    assert float((yd.detach().cpu().float() - yr.detach()).abs().max()) <= tol * float(yr.abs().max()) + 1e-5
+    assert float((xd.grad.cpu().float() - xr.grad).abs().max()) <= 2.0 ** -7 * float(xr.grad.abs().max())
+    assert float((wd.grad.cpu() - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
+    assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-3)

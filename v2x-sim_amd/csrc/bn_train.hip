@@ -13,8 +13,8 @@
 //             (3) bn_bwd_apply_kernel        dx = a (g - dbeta/M - xhat dgamma/M) read x, dy, write dx
 //
 // Determinism: a workgroup owns a contiguous run of pixels and writes ONE partial per channel; the finish kernels add the partials
-// in index order in fp64.  No atomics anywhere, so two runs give the same bits (MIOpen's BN backward does not promise that).
-// var = E[x^2] - mean^2 is formed in fp64 from fp32 partials of <= 4096 pixels each.
+// in a fixed order in fp64.  No atomics anywhere, so two runs give the same bits (MIOpen's BN backward does not promise that).
+// var = E[x^2] - mean^2 is formed in fp64 from the fp32 partials (a thread adds at most M * C / (8 * 256 * n_blocks) values per channel).
 #include "common.h"
 
 constexpr int BN_THREADS = 256;
@@ -109,14 +109,35 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const BnArgs a) 
     }
 }
 
-__global__ void bn_finish_stats_kernel(const BnArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.C) return;
+// One workgroup per channel: thread t adds partials t, t + 256, ... in fp64, then a fixed-shape tree over the 256 threads (the same
+// association every run).  A single thread walking all <= 2048 partials was 0.3 ms of dependent loads per launch.
+__device__ __forceinline__ void bn_sum_partials(const BnArgs &a, int c, double &s_out, double &q_out) {
+    __shared__ double rs[BN_THREADS], rq[BN_THREADS];
+    const int t = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = 0; b < a.n_blocks; ++b) {
+    for (int b = t; b < a.n_blocks; b += BN_THREADS) {
         s += (double)a.partial[((size_t)b * 2) * a.C + c];
         q += (double)a.partial[((size_t)b * 2 + 1) * a.C + c];
     }
+    rs[t] = s;
+    rq[t] = q;
+    __syncthreads();
+    for (int w = BN_THREADS / 2; w > 0; w >>= 1) {
+        if (t < w) {
+            rs[t] += rs[t + w];
+            rq[t] += rq[t + w];
+        }
+        __syncthreads();
+    }
+    s_out = rs[0];
+    q_out = rq[0];
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_finish_stats_kernel(const BnArgs a) {
+    const int c = blockIdx.x;
+    double s, q;
+    bn_sum_partials(a, c, s, q);
+    if (threadIdx.x != 0) return;
     const double m = s / (double)a.M;
     double var = q / (double)a.M - m * m;
     if (var < 0.0) var = 0.0;
@@ -129,14 +150,11 @@ __global__ void bn_finish_stats_kernel(const BnArgs a) {
     }
 }
 
-__global__ void bn_finish_grads_kernel(const BnArgs a) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= a.C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < a.n_blocks; ++b) {
-        s += (double)a.partial[((size_t)b * 2) * a.C + c];
-        q += (double)a.partial[((size_t)b * 2 + 1) * a.C + c];
-    }
+__global__ __launch_bounds__(BN_THREADS) void bn_finish_grads_kernel(const BnArgs a) {
+    const int c = blockIdx.x;
+    double s, q;
+    bn_sum_partials(a, c, s, q);
+    if (threadIdx.x != 0) return;
     a.dbeta[c] = (float)s;
     a.dgamma[c] = (float)q;
 }
@@ -245,7 +263,7 @@ extern "C" int v2x_bn_train_forward(const uint16_t *x, long long M, int C, const
     a.relu = relu;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<0>, dim3(a.n_blocks), dim3(BN_THREADS), 0, s, a);
-    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(bn_finish_stats_kernel, dim3(C), dim3(BN_THREADS), 0, s, a);
     const long long total = M * a.G;
     long long blocks = (total + BN_THREADS - 1) / BN_THREADS;
     if (blocks > 8192) blocks = 8192;
@@ -274,7 +292,7 @@ extern "C" int v2x_bn_train_backward(const uint16_t *x, const uint16_t *dy, long
     a.relu = relu;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_partial_kernel<1>, dim3(a.n_blocks), dim3(BN_THREADS), 0, s, a);
-    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3((C + 63) / 64), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(C), dim3(BN_THREADS), 0, s, a);
     const long long total = M * a.G;
     long long blocks = (total + BN_THREADS - 1) / BN_THREADS;
     if (blocks > 8192) blocks = 8192;

@@ -14,6 +14,8 @@ W % 32 == 0 (conv1_2 ... conv7_2 of the backbone at the training resolutions).  
 V2X_TRAIN_HIP_CONV=1; everything else (BatchNorm with batch statistics, ReLU, the stride-2 / 13- and 32-channel layers, the
 heads) stays on PyTorch-ROCm ops.  There is no CPU path.
 """
+import weakref
+
 import torch
 
 from .. import ops, packing
@@ -43,10 +45,10 @@ _PACK_CACHE = {}
 
 def _packed(kind, weight, bias, device):
     """Packed forward / dgrad weights of a parameter, re-packed only when the parameter changed (optimizer step)."""
-    key = (kind, weight.data_ptr(), str(device))
+    key = (kind, id(weight), str(device))   # the parameter OBJECT (weak reference checked on a hit): a data_ptr can be reused
     ver = (weight._version, None if bias is None else bias._version)
     hit = _PACK_CACHE.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]
     if kind == "fwd":
         layer = _pack_plain("train.fwd", weight, bias, device)
@@ -54,7 +56,7 @@ def _packed(kind, weight, bias, device):
         layer = _pack_plain("train.dgrad", weight.detach().flip(2, 3).transpose(0, 1).contiguous(), None, device)   # W'[ci][co][ky][kx]
     if len(_PACK_CACHE) > 256:
         _PACK_CACHE.clear()
-    _PACK_CACHE[key] = (ver, layer)
+    _PACK_CACHE[key] = (ver, layer, weakref.ref(weight))
     return layer
 
 

@@ -10,16 +10,20 @@ nearest x2 upsample + concat -- over the SAME parameter tree, with
     BatchNorm + ReLU   forward/backward  v2x_bn_train_forward / v2x_bn_train_backward (bn_train.hip), running statistics updated
                                          exactly as nn.BatchNorm does
 
-and the maps staying bf16 NHWC between layers (no layout or precision conversion).  Left on PyTorch-ROCm ops, by design: the 1x1
-layers (conv3d_1/2 and the heads' last layers are plain GEMMs: hipBLASLt through F.linear), upsample/concat and their backward
-(views, copies and a 2x2 sum), bias gradients (a reduction), the one 3x3 layer whose map is narrower than a 32-pixel tile (conv4_2
-at 16x16: MIOpen), the cross-agent fusion of V2VNet (converted to the fp32 graph at the fusion layer and back) and the loss.
+    1x1 layers         forward, dgrad    v2x_conv2d (ksize 1: conv3d_1/2, the heads' last layers with fp32 logits)
+                       weight gradient   the centre tap of v2x_conv3x3_wgrad
+
+and the maps staying bf16 NHWC between layers (no layout or precision conversion).  Left on PyTorch-ROCm ops, by design:
+upsample/concat and their backward (views, copies and a 2x2 sum), bias gradients (a reduction), the one 3x3 layer whose map is
+narrower than a 32-pixel tile (conv4_2 at 16x16: MIOpen), the cross-agent fusion of V2VNet (converted to the fp32 graph at the
+fusion layer and back) and the loss.
 Packed weights are rebuilt on the GPU after every optimizer step (packing.on_device): nothing crosses PCIe inside a step.
 
 Mixed precision: activations, activation gradients and the MFMA operands are bf16; every sum, the BN statistics, the weight
 gradients and the master weights are fp32.  Enabled with V2X_TRAIN_HIP=1 (FaFModule.step / train_forward); there is no CPU path.
 """
 import types
+import weakref
 
 import torch
 import torch.nn.functional as F
@@ -40,10 +44,11 @@ def _conv_like(weight, bias, stride):
 
 
 def _layer(kind, weight, bias, stride, cin_pad):
-    key = (kind, weight.data_ptr(), stride, cin_pad)
+    # keyed on the parameter OBJECT (weak reference checked on a hit): a data_ptr can be reused by another model's tensor
+    key = (kind, id(weight), stride, cin_pad)
     ver = (weight._version, None if bias is None else bias._version)
     hit = _CACHE.get(key)
-    if hit is not None and hit[0] == ver:
+    if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]
     with packing.on_device(weight.device):
         if kind == "fwd":
@@ -54,7 +59,7 @@ def _layer(kind, weight, bias, stride, cin_pad):
             layer = packing.layer_conv_bn("train.dgrad", _conv_like(wt, None, 1), None, device=weight.device, relu=False)
     if len(_CACHE) > 512:
         _CACHE.clear()
-    _CACHE[key] = (ver, layer)
+    _CACHE[key] = (ver, layer, weakref.ref(weight))
     return layer
 
 
@@ -138,15 +143,68 @@ def cbr(x, conv, bn):
     return bn_relu(conv3x3(x, conv), bn)
 
 
-def conv1x1(x, weight, bias):
-    """1x1 layer = a plain GEMM over the pixels: hipBLASLt (F.linear), fp32 accumulate and fp32 weight gradient."""
-    w = weight.reshape(weight.shape[0], weight.shape[1])
-    return F.linear(x.float(), w, bias)
+def _layer_1x1(kind, weight, bias, f32_out, cout_pad):
+    key = (kind, id(weight), f32_out, cout_pad)
+    ver = (weight._version, None if bias is None else bias._version)
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is weight:
+        return hit[1]
+    from .._lib import V2X_EPI_BF16, V2X_EPI_F32
+    cout, cin = weight.shape[0], weight.shape[1]
+    w2 = weight.detach().reshape(cout, cin)
+    with packing.on_device(weight.device):
+        if kind == "fwd":
+            scale, shift = packing.fold_bn(bias, None, cout)
+            pc = packing.pack_conv("train.fwd1x1", w2[:, :, None, None], scale, shift, stride=1, pad=0, relu=False,
+                                   epilogue=V2X_EPI_F32 if f32_out else V2X_EPI_BF16, device=weight.device)
+        else:   # dx = dy . W: a 1x1 layer with the transposed weights, the gradient's channels zero-padded to cout_pad
+            wt = F.pad(w2.t(), (0, cout_pad - cout))                                    # [Cin][cout_pad]
+            scale, shift = packing.fold_bn(None, None, cin)
+            pc = packing.pack_conv("train.dgrad1x1", wt[:, :, None, None], scale, shift, stride=1, pad=0, relu=False,
+                                   epilogue=V2X_EPI_BF16, device=weight.device)
+    _CACHE[key] = (ver, pc, weakref.ref(weight))
+    return pc
+
+
+class _Conv1x1(torch.autograd.Function):
+    """1x1 layer on the HIP kernels: forward and data gradient on the implicit-GEMM kernel (v2x_conv2d, ksize 1); the weight gradient
+    is the CENTRE TAP of v2x_conv3x3_wgrad (8/9 of its MFMAs are wasted, and it is still 5-10x faster than the fp32 library GEMM
+    with K = N*H*W that autograd would run: 58 us against 0.4-1.1 ms per layer at 10 maps)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, f32_out):
+        y = ops.conv2d(_layer_1x1("fwd", weight, bias, f32_out, 0), x)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        cout = weight.shape[0]
+        cp = (cout + 31) // 32 * 32
+        db = dy.float().sum((0, 1, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        dyp = F.pad(dy, (0, cp - cout)).to(BF16).contiguous() if (cp != cout or dy.dtype != BF16) else dy.contiguous()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d(_layer_1x1("dgrad", weight, None, False, cp), dyp)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv3x3_wgrad(x, dyp)[:cout, :, 1, 1].reshape(weight.shape)
+        return dx, dw, db, None
+
+
+def conv1x1(x, weight, bias, f32_out=False):
+    """1x1 layer (nn.Conv2d 1x1 or upstream's Conv3D 1x1x1 on a length-1 sequence) on a bf16 NHWC map."""
+    N, H, W, cin = x.shape
+    if H % 8 == 0 and W % 32 == 0 and cin % 32 == 0:
+        return _Conv1x1.apply(x.contiguous(), weight, bias, f32_out)
+    y = F.linear(x.float(), weight.reshape(weight.shape[0], weight.shape[1]), bias)      # odd extent: the library GEMM
+    return y if f32_out else y.to(BF16)
 
 
 def conv3d_1x1(x, m):
     """upstream Conv3D on a length-1 sequence: 1x1x1 conv3d + BatchNorm3d + ReLU."""
-    return bn_relu(conv1x1(x, m.conv3d.weight, m.conv3d.bias).to(BF16), m.bn3d)
+    return bn_relu(conv1x1(x, m.conv3d.weight, m.conv3d.bias), m.bn3d)
 
 
 def upcat(lo, skip):
@@ -183,8 +241,8 @@ def decoder(d, x, x_1, x_2, x_3, x_4):
 
 def heads(model, x):
     c, bp = model.classification, model.regression.box_prediction
-    cls = conv1x1(cbr(x, c.conv1, c.bn1), c.conv2.weight, c.conv2.bias)           # fp32 NHWC logits
-    loc = conv1x1(cbr(x, bp[0], bp[1]), bp[3].weight, bp[3].bias)
+    cls = conv1x1(cbr(x, c.conv1, c.bn1), c.conv2.weight, c.conv2.bias, f32_out=True)           # fp32 NHWC logits
+    loc = conv1x1(cbr(x, bp[0], bp[1]), bp[3].weight, bp[3].bias, f32_out=True)
     return {"cls": cls.reshape(cls.shape[0], -1, model.category_num),
             "loc": loc.reshape(-1, loc.size(1), loc.size(2), model.anchor_num_per_loc, model.out_seq_len, model.box_code_size)}
 
