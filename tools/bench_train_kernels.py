@@ -78,6 +78,11 @@ def main():
         os.environ["V2X_TRAIN_HIP"] = flag
         print("FaFNet training step (fwd + bwd + Adam), 10 maps, V2X_TRAIN_HIP=%s: %.1f ms" % (flag, timed(full_step, 5) / 1e3))
     os.environ["V2X_TRAIN_HIP"] = "1"
+    from v2x_sim_amd.train.graph_step import GraphedTrainStep
+    opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True)
+    gstep = GraphedTrainStep(model, opt_c, data, 2)
+    print("FaFNet training step, 10 maps, HIP graph of train/hip_graph.py replayed as ONE hipGraph (train/graph_step.py): %.1f ms"
+          % (timed(lambda: gstep(data), 10) / 1e3))
     ops.PROFILE = []
     full_step()
     torch.cuda.synchronize()

@@ -32,6 +32,69 @@ __global__ __launch_bounds__(512) void mfma_loop(float *out, int iters, uint32_t
     if (sum == 12345.678f) out[threadIdx.x] = sum;
 }
 
+// The conv kernels' MFMA block: acc[i][f] += A[i] * B[f] with 4 (or 8) different A fragments and 4 different B fragments in registers.
+// ORDER 0: i outer, f inner (A reused by 4 consecutive MFMAs);  1: f outer, i inner;  NA = number of A fragments (acc tiles = NA x 4).
+template <int NA, int ORDER>
+__global__ __launch_bounds__(512) void mfma_block(float *out, int iters, uint32_t seed) {
+    f32x4_t acc[NA][4];
+    bf16x8_t A[NA], B[4];
+    uint32_t r = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        uint4 u = make_uint4((r * (i + 3)) & 0x3fff3fffu, (r * (i + 5)) & 0x3fff3fffu, (r * (i + 7)) & 0x3fff3fffu, (r * (i + 11)) & 0x3fff3fffu);
+        A[i] = __builtin_bit_cast(bf16x8_t, u);
+        asm volatile("" : "+v"(A[i]));
+#pragma unroll
+        for (int f = 0; f < 4; ++f) { acc[i][f] = (f32x4_t){(float)(i * 4 + f), 0.f, 0.f, 0.f}; asm volatile("" : "+v"(acc[i][f])); }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        uint4 u = make_uint4((r * (f + 13)) & 0x3fff3fffu, (r * (f + 17)) & 0x3fff3fffu, (r * (f + 19)) & 0x3fff3fffu, (r * (f + 23)) & 0x3fff3fffu);
+        B[f] = __builtin_bit_cast(bf16x8_t, u);
+        asm volatile("" : "+v"(B[f]));
+    }
+    for (int it = 0; it < iters; ++it) {
+        if (ORDER == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][f]) : "v"(A[i]), "v"(B[f]));
+        } else {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int i = 0; i < NA; ++i) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][f]) : "v"(A[i]), "v"(B[f]));
+        }
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) sum += acc[i][f][0] + acc[i][f][1] + acc[i][f][2] + acc[i][f][3];
+    if (sum == 12345.678f) out[threadIdx.x] = sum;
+}
+
+template <int NA, int ORDER>
+static void run_block(float *out, hipEvent_t e0, hipEvent_t e1) {
+    const int iters = 20000;
+    for (int wps = 1; wps <= 2; ++wps) {
+        const int threads = 256 * wps, grid = 256;
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; ++rep) {
+            (void)hipEventRecord(e0, 0);
+            hipLaunchKernelGGL((mfma_block<NA, ORDER>), dim3(grid), dim3(threads), 0, 0, out, iters, 99u + rep);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        const double n = (double)iters * NA * 4;
+        printf("block acc[%d][4] += A[i]*B[f], %s, %d wave(s)/SIMD: %7.1f TFLOP/s\n", NA, ORDER ? "f outer" : "i outer", wps,
+               (double)grid * (threads / 64) * n * 16384.0 / best / 1e9);
+    }
+}
+
 int main() {
     float *out;
     (void)hipMalloc(&out, 4096);
@@ -56,5 +119,24 @@ int main() {
                        wps, ms, flop / ms / 1e9, mfma_per_simd * 16.0 / (ms * 1e-3) / 1e9);
             }
         }
+    run_block<4, 0>(out, e0, e1);
+    run_block<4, 1>(out, e0, e1);
+    run_block<8, 0>(out, e0, e1);
+    run_block<8, 1>(out, e0, e1);
+    // sustained: the same kernel back to back for ~4 s (the power manager needs far longer than one 5-ms burst to settle)
+    for (int random = 0; random < 2; ++random) {
+        const int threads = 512, grid = 256;
+        const double flop = (double)grid * (threads / 64) * iters * 16.0 * 16384.0;
+        for (int sec = 0; sec < 4; ++sec) {
+            (void)hipEventRecord(e0, 0);
+            const int launches = 200;
+            for (int l = 0; l < launches; ++l) hipLaunchKernelGGL(mfma_loop<16>, dim3(grid), dim3(threads), 0, 0, out, iters, random ? 777u + l : 0u);
+            (void)hipEventRecord(e1, 0);
+            (void)hipEventSynchronize(e1);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("sustained, %s operands, 2 waves/SIMD, window %d (%.0f ms): %7.1f TFLOP/s\n", random ? "random  " : "constant", sec, ms, flop * launches / ms / 1e9);
+        }
+    }
     return 0;
 }

@@ -56,6 +56,21 @@ enum { SEPI_BF16 = 0, SEPI_CHAIN = 1, SEPI_GRU = 2 };
 #define V2X_STREAM_DBG_BUILD 0
 #endif
 constexpr int SDBG = V2X_STREAM_DBG_BUILD;
+// bit 16: TIMESTAMPS.  Lane 0 of waves 0 and 4 (one wave per group) of workgroup 0 records s_memrealtime (100 MHz) at four points of
+// each of its first 128 steps into 4 KiB of extra LDS, dumped to this buffer when the workgroup ends: [group][step][point], points =
+// top of the load phase, before the first barrier (loads issued, waits done), after it (MFMA phase begins), end of the MFMA phase.
+// tools/stream8g_timeline.py fetches it through v2x_debug_stream_timeline (exported by these builds only).
+constexpr int SDBG_T_STEPS = 128;
+__device__ unsigned v2x_stream_timeline[2 * SDBG_T_STEPS * 4];
+extern "C" int v2x_debug_stream_timeline(unsigned *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2x_stream_timeline), sizeof(unsigned) * 2 * SDBG_T_STEPS * 4);
+}
+#ifndef V2X_STREAM_PRIO_BUILD
+#define V2X_STREAM_PRIO_BUILD 0
+#endif
+#ifndef V2X_STREAM_H1_BUILD
+#define V2X_STREAM_H1_BUILD 1
+#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -846,6 +861,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int g = 0;     // global step counter
     bool relaxed = false;
     int slot = 0;  // ring slot of the current step = g % 3
+    int dbg_n = 0; // (SDBG & 16) steps stamped so far
     int gc = 0;    // global chunk counter: patch buffer = gc & 1
     for (;;) {
         const int next = tile + nwg;
@@ -886,6 +902,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int kx = 0; kx < 3; ++kx, ++g, slot = (slot == 2 ? 0 : slot + 1)) {
                 const int st = kc * 3 + kx;
                 const int ln = fresh_lane();
+                auto stamp = [&](int point) __attribute__((always_inline)) {
+                    if constexpr ((SDBG & 16) != 0) {
+                        if (blockIdx.x == 0 && (wave & 3) == 0 && dbg_n < SDBG_T_STEPS) {
+                            const unsigned t = (unsigned)__builtin_amdgcn_s_memrealtime();
+                            if (fresh_lane() == 0) *reinterpret_cast<unsigned *>(smem + 3 * STEP_BYTES + 2 * PATCH8_BYTES + ((grp * SDBG_T_STEPS + dbg_n) * 4 + point) * 4) = t;
+                        }
+                    }
+                };
+                stamp(0);
                 const int fjl = ln & 15, fql = ln >> 4;
                 // ---- L: group 1 streams the weights of step st+2 (wrapping into the next tile), group 0 the next chunk's patch
                 int nw = 0;   // weight DMAs this wave issues in this phase
@@ -936,15 +961,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 } else if (kx == 2) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                stamp(1);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(2);
                 // ---- M: six half taps.  The weight fragments of half h+1 are read in the MIDDLE of half h's MFMA block: the compiler
                 // waits for them with lgkmcnt(0) before their first use (it does not count LDS reads individually here), so reads
                 // issued right before a block would be waited for at once -- six exposed LDS latencies per step (the first form:
                 // MFMA phases alone 458 us against 318 us of MFMA work).  Issued after the first part of the block they land under
                 // its second part.
-                constexpr int H1 = (HCO + 1) / 2;   // channel tiles of the first part
+                constexpr int H1 = V2X_STREAM_H1_BUILD < 0 ? (HCO + 1) / 2 : V2X_STREAM_H1_BUILD;   // channel tiles of the first part
+                if constexpr (V2X_STREAM_PRIO_BUILD > 0) __builtin_amdgcn_s_setprio(V2X_STREAM_PRIO_BUILD);
 #pragma unroll
                 for (int h = 0; h < 6; ++h) {
                     const int ky = h >> 1, hh = h & 1;
@@ -974,6 +1002,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     mma_part(H1, HCO);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if constexpr (V2X_STREAM_PRIO_BUILD > 0) __builtin_amdgcn_s_setprio(0);
+                stamp(3);
+                if constexpr ((SDBG & 16) != 0) ++dbg_n;
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -988,11 +1019,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         relaxed = true;   // the stores just issued are younger than the weight DMAs the next load phase waits for
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the offset barrier of group 1
+    if constexpr ((SDBG & 16) != 0) {
+        __syncthreads();
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < 2 * SDBG_T_STEPS * 4; i += 512)
+                v2x_stream_timeline[i] = *reinterpret_cast<const unsigned *>(smem + 3 * STEP_BYTES + 2 * PATCH8_BYTES + i * 4);
+    }
 }
 
 template <int BCO, int EPI>
 static int launch_stream8g(const StreamArgs &a, hipStream_t s) {
-    constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES;   // 152 KiB at 128 rows, 134 KiB at 96
+    constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0);   // 152 KiB at 128 rows, 134 KiB at 96
     static_assert(smem <= 160 * 1024, "LDS budget");
     static v2x_once_per_device attr_once;
     auto kern = &conv3x3_stream8g_kernel<BCO, EPI>;

@@ -14,9 +14,9 @@ nearest x2 upsample + concat -- over the SAME parameter tree, with
                        weight gradient   the centre tap of v2x_conv3x3_wgrad
 
 and the maps staying bf16 NHWC between layers (no layout or precision conversion).  Left on PyTorch-ROCm ops, by design:
-upsample/concat and their backward (views, copies and a 2x2 sum), bias gradients (a reduction), the one 3x3 layer whose map is
-narrower than a 32-pixel tile (conv4_2 at 16x16: MIOpen), the cross-agent fusion of V2VNet (converted to the fp32 graph at the
-fusion layer and back) and the loss.
+upsample/concat and their backward (views, copies and a 2x2 sum), bias gradients (a reduction), the cross-agent fusion of V2VNet
+(converted to the fp32 graph at the fusion layer and back) and the loss.  conv4_2's 16x16 map is widened to 16x32 with zero
+columns (exact: see conv3x3); maps that do not tile even then fall back to MIOpen.  No atomics anywhere in a FaFNet step.
 Packed weights are rebuilt on the GPU after every optimizer step (packing.on_device): nothing crosses PCIe inside a step.
 
 Mixed precision: activations, activation gradients and the MFMA operands are bf16; every sum, the BN statistics, the weight
@@ -122,6 +122,11 @@ def conv3x3(x, conv):
     s = conv.stride[0]
     if hip_eligible(conv.weight, s, x.shape[1], x.shape[2]):
         return _Conv3x3.apply(x.contiguous(), conv.weight, conv.bias, s)
+    if s == 1 and x.shape[2] % 32 == 16 and hip_eligible(conv.weight, s, x.shape[1], x.shape[2] + 16):
+        # a 16-pixel-wide map (conv4_2): widen it with 16 zero columns -- a zero column IS the layer's padding, so columns 0..W-1 of
+        # the output, of dx and the whole of dW are unchanged (the slice's backward zero-fills dy over the extra columns)
+        W = x.shape[2]
+        return _Conv3x3.apply(F.pad(x, (0, 0, 0, 16)).contiguous(), conv.weight, conv.bias, s)[:, :, :W]
     y = F.conv2d(x.permute(0, 3, 1, 2).float(), conv.weight, conv.bias, conv.stride, conv.padding)
     return y.permute(0, 2, 3, 1).to(BF16).contiguous()
 
@@ -209,7 +214,8 @@ def conv3d_1x1(x, m):
 
 def upcat(lo, skip):
     """cat(nearest x2 upsample of lo, skip) along the channels, NHWC."""
-    up = lo.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    N, H, W, C = lo.shape
+    up = lo[:, :, None, :, None, :].expand(N, H, 2, W, 2, C).reshape(N, 2 * H, 2 * W, C)   # backward = a 2x2 sum (no atomics: deterministic)
     return torch.cat((up, skip), dim=3)
 
 

@@ -53,7 +53,14 @@ def make_optimizer(model, lr, total_steps):
     """Adam + the step-wise MultiStepLR (x0.3 at 60 % and 85 % of `total_steps`) every loop here uses.  Drivers that
     train for several epochs create the pair ONCE over the whole run and hand it to the loops, so that Adam's moments and
     the decay schedule survive epoch boundaries (and checkpoints)."""
-    opt = torch.optim.Adam(model.parameters(), lr=lr)
+    import os
+    if os.environ.get("V2X_TRAIN_GRAPH", "0")[:1] == "1" and next(model.parameters()).is_cuda:
+        # hipGraph-captured steps (train/graph_step.py): step counter and learning rate live on the device; the scheduler updates the
+        # lr tensor in place, so the captured optimizer step sees every decay
+        dev = next(model.parameters()).device
+        opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(float(lr), device=dev), capturable=True)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=lr)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(total_steps * 0.6), int(total_steps * 0.85)], gamma=0.3)
     return opt, sched
 

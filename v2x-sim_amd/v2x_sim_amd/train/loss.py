@@ -26,8 +26,10 @@ def detection_loss(result, labels, reg_targets, reg_loss_mask):
     lab = labels.reshape(n, -1, 2).to(result["cls"].dtype)
     n_pos = lab[..., 1].sum().clamp(min=1.0)
     cls_loss = focal_loss(result["cls"], lab).sum() / n_pos
-    m = reg_loss_mask.reshape(n, -1)
-    pred = result["loc"].reshape(n, -1, 6)[m]
-    tgt = reg_targets.reshape(n, -1, 6)[m]
-    loc_loss = F.smooth_l1_loss(pred, tgt, reduction="sum", beta=1.0 / (SIGMA * SIGMA)) / n_pos
+    # masked SUM instead of boolean indexing: the same terms, but no data-dependent shape -- no host synchronisation, and the step can be
+    # captured in a hipGraph (train/graph_step.py).  Unselected anchors contribute exactly 0 (their terms are finite: targets are 0 there).
+    m = reg_loss_mask.reshape(n, -1, 1).to(result["loc"].dtype)
+    per = F.smooth_l1_loss(result["loc"].reshape(n, -1, 6), reg_targets.reshape(n, -1, 6).to(result["loc"].dtype), reduction="none",
+                           beta=1.0 / (SIGMA * SIGMA))
+    loc_loss = (per * m).sum() / n_pos
     return cls_loss + loc_loss, cls_loss, loc_loss

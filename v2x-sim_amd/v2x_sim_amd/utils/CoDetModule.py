@@ -25,6 +25,7 @@ class FaFModule(object):
         self.device_postprocess = True    # False: upstream's host-side numpy path (utils/postprocess.apply_nms_det)
         self.cap = 4096                   # candidate capacity per map of the device path
         self._anchors_dev = None
+        self._graphed = None              # (batch-shape key, GraphedTrainStep) when V2X_TRAIN_GRAPH=1
 
     def step(self, data, batch_size, num_agent=5):
         """One optimisation step.  data: 'bev_seq' (A*B, 1, X, Y, Z), 'labels' (A*B, X, Y, A', 2), 'reg_targets'
@@ -37,12 +38,28 @@ class FaFModule(object):
         if not bev.is_cuda or next(self.model.parameters()).device != bev.device:
             raise RuntimeError("FaFModule.step trains on the MI355X: move the model and the batch to 'cuda'")
         self.model.train()
+        if self._graph_ok(data):
+            # V2X_TRAIN_HIP=1 V2X_TRAIN_GRAPH=1: the whole step as one hipGraph (train/graph_step.py), rebuilt when the batch shape changes
+            from ..train.graph_step import GraphedTrainStep
+            key = tuple(tuple(data[k].shape) for k in ("bev_seq", "labels", "reg_targets", "reg_loss_mask")) + (batch_size,)
+            if self._graphed is None or self._graphed[0] != key:
+                self._graphed = (key, GraphedTrainStep(self.model, self.optimizer, data, batch_size))
+            loss, cls_loss, loc_loss = self._graphed[1](data)
+            return loss.item(), cls_loss.item(), loc_loss.item()
         result = train_forward(self.model, bev, data.get("trans_matrices"), data.get("num_agent"), batch_size)
         loss, cls_loss, loc_loss = detection_loss(result, data["labels"], data["reg_targets"], data["reg_loss_mask"])
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
         return loss.item(), cls_loss.item(), loc_loss.item()
+
+    def _graph_ok(self, data):
+        import os
+        if os.environ.get("V2X_TRAIN_HIP", "0")[:1] != "1" or os.environ.get("V2X_TRAIN_GRAPH", "0")[:1] != "1":
+            return False
+        if not hasattr(self.model, "stpn") or hasattr(self.model, "outc"):      # FaFNet: no per-batch host plan in its graph
+            return False
+        return all(g.get("capturable", True) for g in self.optimizer.param_groups)
 
     def postprocess(self, result):
         """Device-side score / threshold / decode / NMS (v2x_det_postprocess) for every map of `result` -> list of
