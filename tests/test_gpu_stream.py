@@ -159,6 +159,16 @@ def test_stream8_equals_stream4_bitwise(device, cfg, monkeypatch):
     assert float((yg != y8).float().mean()) < 0.02
     for _ in range(10):
         assert torch.equal(run(), yg)
+    # the two wave tilings of stream8g (all channels x 64 pixels per wave / half the channels x 128 pixels) walk K in the same order:
+    # bit-identical, for the plain layers (default: new tiling) and the ConvGRU (default: old tiling)
+    monkeypatch.setenv("V2X_STREAM_WT", "0")
+    assert ops.conv_kernel_name(pc, H, W).endswith("false>")
+    y_old = run()
+    monkeypatch.setenv("V2X_STREAM_WT", "2")
+    assert ops.conv_kernel_name(pc, H, W).endswith("true>")
+    y_new = run()
+    monkeypatch.delenv("V2X_STREAM_WT")
+    assert torch.equal(y_old, yg) and torch.equal(y_new, yg)
 
 
 @pytest.mark.parametrize("cfg", [

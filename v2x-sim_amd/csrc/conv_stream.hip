@@ -708,7 +708,11 @@ int v2x_num_cus() {   // also used by conv_halo_pair.hip
 //   No counted waits, no dummy DMAs.  Persistent over tiles like the kernel above (the ring and the patch fill wrap into the
 //   next tile).  K order is (chunk, kx, ky): the fp32 sums differ from the other streamed kernels in their last bits, so this
 //   form replaces them for a layer everywhere or nowhere (the choice depends on the layer's shape only).
-template <int BCO, int EPI>
+//   WT (wave tiling): false -- a wave owns ALL BCO channels x 64 pixels (2 rows) of its group's 8x32 pixels: 24 weight + 8 pixel fragment
+//   reads per step; true -- a wave owns HALF the channels x 128 pixels (4 rows): 12 + 12 reads per step for the same 96 MFMAs (-25 % LDS
+//   reads; the step timeline, tools/stream8g_timeline.sh, showed the MFMA phase stretched 1.6x by LDS queueing: 165 KiB of LDS traffic
+//   per interval = 84 % of what the LDS moves in an ideal interval).  Same K order, bit-identical results.
+template <int BCO, int EPI, bool WT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8g_kernel(const StreamArgs a) {
     constexpr int TH = 16, TW = 32;
     constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
@@ -720,6 +724,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;   // output-store instructions per wave and tile
     static_assert(EPI != SEPI_CHAIN, "the chained epilogue stays on conv3x3_stream8_kernel (its operands need the LDS)");
     static_assert(TCO % 2 == 0 && PH * PW * 4 <= (PATCH8_PIECES - 1) * 64, "half taps; patch fits its buffer");
+    constexpr int AT = WT ? HCO : TCO;                     // accumulator tiles of a wave: channel tiles x pixel fragments
+    constexpr int NF = WT ? 8 : 4;
+    constexpr int NB = WT ? 12 : 8;                        // pixel fragments a wave reads per step
+    constexpr int BT = (HCO % 2 == 0) ? 2 : HCO;           // WT: channel tiles per MFMA block (2 -> blocks of 16 MFMAs, 3 -> of 24)
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_ring = smem;                                   // 3 x STEP_BYTES
@@ -815,10 +823,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    int frow[4];
+    const int coh = WT ? (wv & 1) : 0;                     // WT: the wave's channel half
+    const int R0 = WT ? 8 * grp + 4 * (wv >> 1) : 8 * grp + 2 * wv;   // the wave's first output row (even)
+    int frow[NF];
 #pragma unroll
-    for (int f = 0; f < 4; ++f) frow[f] = 8 * grp + 2 * wv + (f >> 1);
-    const int R0 = 8 * grp + 2 * wv;                       // the wave's first output row (even)
+    for (int f = 0; f < NF; ++f) frow[f] = R0 + (f >> 1);
     const bool chunk0_half = (nc0 > 0) && a.up0;
 
     int tile = bid;
@@ -869,11 +878,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int nn = 0, ny0 = 0, nx0 = 0;
         if (has_next) tile_coords(next, nn, ny0, nx0);
 
-        f32x4_t acc[TCO][4];
+        f32x4_t acc[AT][NF];
 #pragma unroll
-        for (int i = 0; i < TCO; ++i)
+        for (int i = 0; i < AT; ++i)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < NF; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
         for (int kc = 0; kc < nchunks; ++kc, ++gc) {
             const char *pb = s_patch + (gc & 1) * PATCH8_BYTES;
@@ -932,22 +941,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 // pixel fragments of the tap column: B[q * 2 + ch], q = r + ky = 0..3
-                bf16x8_t B[8];
+                bf16x8_t B[NB];
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch) {
                     const int col = ch * 16 + fjl + kx;
                     const int pc = ((col - sh) >> sh) + sh;     // full: col + kx;  half: ((col + kx - 1) >> 1) + 1
                     const int coff = ((pc << 2) + (fql ^ ((pc >> 1) & 3))) * 16;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < NB / 2; ++q) {
                         if constexpr ((SDBG & 4) == 0) B[q * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + row0 + (((q - sh) >> sh) + sh) * row_bytes + coff);
                         else B[q * 2 + ch] = __builtin_bit_cast(bf16x8_t, make_uint4(coff, q, st, ch));
                     }
                 }
-                const char *ws = s_ring + slot * STEP_BYTES + (fql * BCO + fjl) * 16;   // + compile-time offsets below
-                bf16x8_t A[2][HCO];
+                const char *ws = s_ring + slot * STEP_BYTES + (fql * BCO + fjl) * 16 + coh * (HCO * 256);   // + compile-time offsets below
+                bf16x8_t A[2][WT ? BT : HCO];
 #pragma unroll
-                for (int i = 0; i < HCO; ++i) {
+                for (int i = 0; i < (WT ? BT : HCO); ++i) {
                     if constexpr ((SDBG & 4) == 0) A[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
                     else A[0][i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, slot, ln));
                 }
@@ -971,8 +980,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // issued right before a block would be waited for at once -- six exposed LDS latencies per step (the first form:
                 // MFMA phases alone 458 us against 318 us of MFMA work).  Issued after the first part of the block they land under
                 // its second part.
-                constexpr int H1 = V2X_STREAM_H1_BUILD < 0 ? (HCO + 1) / 2 : V2X_STREAM_H1_BUILD;   // channel tiles of the first part
                 if constexpr (V2X_STREAM_PRIO_BUILD > 0) __builtin_amdgcn_s_setprio(V2X_STREAM_PRIO_BUILD);
+                if constexpr (WT) {
+                    // blocks of BT channel tiles x 8 pixel fragments; the next block's BT weight fragments are read after the first
+                    // tile's 8 MFMAs and land under the rest of the block
+                    constexpr int NBLK = 3 * HCO / BT;
+#pragma unroll
+                    for (int b = 0; b < NBLK; ++b) {
+                        const int ky = (b * BT) / HCO, i0 = (b * BT) % HCO;
+                        auto mma_tiles = [&](int j0, int j1) __attribute__((always_inline)) {
+#pragma unroll
+                            for (int j = j0; j < j1; ++j)
+#pragma unroll
+                                for (int f = 0; f < 8; ++f) {
+                                    if constexpr ((SDBG & 8) == 0)
+                                        acc[i0 + j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b & 1][j], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i0 + j][f], 0, 0, 0);
+                                    else if (f == 0)
+                                        acc[i0 + j][0] += __builtin_bit_cast(f32x4_t, A[b & 1][j]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
+                                }
+                        };
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_tiles(0, 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (b + 1 < NBLK) {
+                            const int ky1 = ((b + 1) * BT) / HCO, j1 = ((b + 1) * BT) % HCO;
+#pragma unroll
+                            for (int j = 0; j < BT; ++j) {
+                                if constexpr ((SDBG & 4) == 0) A[(b + 1) & 1][j] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (j1 + j) * 256);
+                                else A[(b + 1) & 1][j] = __builtin_bit_cast(bf16x8_t, make_uint4(st, j, b, ln));
+                            }
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_tiles(1, BT);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                constexpr int H1 = V2X_STREAM_H1_BUILD < 0 ? (HCO + 1) / 2 : V2X_STREAM_H1_BUILD;   // channel tiles of the first part
 #pragma unroll
                 for (int h = 0; h < 6; ++h) {
                     const int ky = h >> 1, hh = h & 1;
@@ -1002,6 +1045,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     mma_part(H1, HCO);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                }
                 if constexpr (V2X_STREAM_PRIO_BUILD > 0) __builtin_amdgcn_s_setprio(0);
                 stamp(3);
                 if constexpr ((SDBG & 16) != 0) ++dbg_n;
@@ -1010,7 +1054,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        stream_epilogue<BCO, TW, EPI, 4, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr);
+        if constexpr (WT) stream_epilogue<BCO / 2, TW, EPI, 8, false>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr);
+        else stream_epilogue<BCO, TW, EPI, 4, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr);
         if (!has_next) break;
         tile = next;
         n = nn;
@@ -1027,12 +1072,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int BCO, int EPI>
+template <int BCO, int EPI, bool WT = false>
 static int launch_stream8g(const StreamArgs &a, hipStream_t s) {
     constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0);   // 152 KiB at 128 rows, 134 KiB at 96
     static_assert(smem <= 160 * 1024, "LDS budget");
     static v2x_once_per_device attr_once;
-    auto kern = &conv3x3_stream8g_kernel<BCO, EPI>;
+    auto kern = &conv3x3_stream8g_kernel<BCO, EPI, WT>;
     if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     }
@@ -1328,6 +1373,14 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
             // three taps per synchronisation (stream8g) unless V2X_STREAM_G=0 (A/B runs); the chained epilogue keeps the 1-tap form
             const char *eg = getenv("V2X_STREAM_G");
             const bool grouped = !(eg && eg[0] == '0') && !chain && a.n_co_tiles <= v2x_num_cus();
+            // wave tiling of stream8g: half the channels x 128 pixels per wave for the 128-row layers (-25 % LDS fragment reads: conv5_1
+            // 750 -> 710 us, conv6_1 799 -> 751, conv3_2 301 -> 279 per 320 maps, bit-identical); the ConvGRU keeps all channels x 64
+            // pixels (with the new tiling 1 685 -> 1 699 us inside the step although +7 % in isolation).  V2X_STREAM_WT=0: old tiling
+            // everywhere, =2: new tiling for the GRU too (A/B runs).
+            const char *ew = getenv("V2X_STREAM_WT");
+            const int wt = ew ? ew[0] - '0' : 1;
+            if (grouped && wt >= 1 && d->epilogue != V2X_EPI_GRU) return launch_stream8g<128, SEPI_BF16, true>(a, s);
+            if (grouped && wt >= 2 && d->epilogue == V2X_EPI_GRU) return launch_stream8g<96, SEPI_GRU, true>(a, s);
             if (d->epilogue == V2X_EPI_GRU) return grouped ? launch_stream8g<96, SEPI_GRU>(a, s) : launch_stream8<96, SEPI_GRU>(a, s);
             if (chain) return launch_stream8<128, SEPI_CHAIN>(a, s);
             return grouped ? launch_stream8g<128, SEPI_BF16>(a, s) : launch_stream8<128, SEPI_BF16>(a, s);

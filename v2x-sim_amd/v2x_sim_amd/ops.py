@@ -61,7 +61,9 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         if W % 32 == 0 and H % 16 == 0 and rows in (96, 128) \
                 and not os.environ.get("V2X_STREAM_WAVES", "").startswith("4"):
             if epi != 1 and os.environ.get("V2X_STREAM_G", "1")[:1] != "0":
-                return "conv3x3_stream8g_kernel<%d, %d>" % (rows, epi)  # 8 waves, three taps per synchronisation
+                wt = int(os.environ.get("V2X_STREAM_WT", "1")[:1] or 1)   # wave tiling: half the channels x 128 pixels per wave
+                tiled = (wt >= 1 and epi == 0) or (wt >= 2 and epi == 2)
+                return "conv3x3_stream8g_kernel<%d, %d, %s>" % (rows, epi, "true" if tiled else "false")  # 8 waves, three taps per synchronisation
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
         return "conv3x3_stream_kernel<%d, %d, %d, %d>" % (rows, th, tw, epi)
     if pc.w_layout == 1:
