@@ -6,7 +6,8 @@
  *                                  against the index formulas documented in include/v2x_amd.h ("weight layouts")
  *   ./c_abi_smoke                  + uploads them, runs v2x_conv2d through the gather, halo and streamed kernels and
  *                                  compares the three results with each other (<= 1 bf16 ulp: the K walks differ) and with a
- *                                  float loop on the host
+ *                                  float loop on the host; then v2x_bn_train_forward / _backward on that output against a
+ *                                  double loop on the host (statistics, running averages, y, dgamma, dbeta, dx)
  *
  * The layer: 3x3 stride-1 conv 64 -> 64 + folded BN + ReLU on 2 x 32 x 64 NHWC bf16 maps (all three kernels cover it).
  * Driven by tests/test_c_abi.py (build + --pack-only on the CPU box, full run under -m gpu). */
@@ -173,6 +174,84 @@ int main(int argc, char **argv) {
     /* the kernels walk K in different orders: fp32 sums may differ in the last bit and flip a bf16 rounding now and then */
     CHECK(ulp_diff_01 == 0 && diff_01 * 100 < n_out, "gather and halo kernels differ by more than rounding flips (%zu > 1 ulp, %zu differ)", ulp_diff_01, diff_01);
     CHECK(ulp_diff_12 == 0, "streamed kernel differs from the halo kernel by more than one bf16 ulp");
+    /* ---- row f-3 from C: batch-statistics BN + ReLU forward / backward on the halo kernel's output (M = NB*HH*WW pixels x COUT) */
+    {
+        const long long M = (long long)NB * HH * WW;
+        const long long ws_bytes = v2x_bn_train_workspace_size(M, COUT);
+        CHECK(ws_bytes > 0, "v2x_bn_train_workspace_size rejected M=%lld C=%d", M, COUT);
+        CHECK(v2x_bn_train_workspace_size(M, 24) == 0, "C = 24 (C / 8 does not divide 256) must be reported as unsupported");
+        float *gamma = (float *)malloc(COUT * 4), *beta = (float *)malloc(COUT * 4), *rm = (float *)malloc(COUT * 4), *rv = (float *)malloc(COUT * 4);
+        uint16_t *dy = (uint16_t *)malloc(n_out * 2), *bn_y = (uint16_t *)malloc(n_out * 2), *bn_dx = (uint16_t *)malloc(n_out * 2);
+        for (int c = 0; c < COUT; ++c) {
+            gamma[c] = 1.0f + 0.5f * frand();
+            beta[c] = 0.3f * frand();
+            rm[c] = 0.0f;
+            rv[c] = 1.0f;
+        }
+        for (size_t i = 0; i < n_out; ++i) dy[i] = to_bf16(frand());
+        void *d_g, *d_b, *d_rm, *d_rv, *d_dy, *d_by, *d_dx, *d_mean, *d_istd, *d_dg, *d_db, *d_ws;
+        HIPOK(hipMalloc(&d_g, COUT * 4)); HIPOK(hipMalloc(&d_b, COUT * 4)); HIPOK(hipMalloc(&d_rm, COUT * 4)); HIPOK(hipMalloc(&d_rv, COUT * 4));
+        HIPOK(hipMalloc(&d_mean, COUT * 4)); HIPOK(hipMalloc(&d_istd, COUT * 4)); HIPOK(hipMalloc(&d_dg, COUT * 4)); HIPOK(hipMalloc(&d_db, COUT * 4));
+        HIPOK(hipMalloc(&d_dy, n_out * 2)); HIPOK(hipMalloc(&d_by, n_out * 2)); HIPOK(hipMalloc(&d_dx, n_out * 2)); HIPOK(hipMalloc(&d_ws, (size_t)ws_bytes));
+        HIPOK(hipMemcpy(d_g, gamma, COUT * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(d_b, beta, COUT * 4, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(d_rm, rm, COUT * 4, hipMemcpyHostToDevice)); HIPOK(hipMemcpy(d_rv, rv, COUT * 4, hipMemcpyHostToDevice));
+        HIPOK(hipMemcpy(d_dy, dy, n_out * 2, hipMemcpyHostToDevice));
+        CHECK(v2x_bn_train_forward((const uint16_t *)d_y[1], M, COUT, (const float *)d_g, (const float *)d_b, 1e-5f, 0.1f, (float *)d_rm, (float *)d_rv, 1,
+                                   (uint16_t *)d_by, (float *)d_mean, (float *)d_istd, (float *)d_ws, NULL) == V2X_OK, "v2x_bn_train_forward: %s", v2x_last_error());
+        CHECK(v2x_bn_train_backward((const uint16_t *)d_y[1], (const uint16_t *)d_dy, M, COUT, (const float *)d_g, (const float *)d_b, (const float *)d_mean,
+                                    (const float *)d_istd, 1, (uint16_t *)d_dx, (float *)d_dg, (float *)d_db, (float *)d_ws, NULL) == V2X_OK,
+              "v2x_bn_train_backward: %s", v2x_last_error());
+        CHECK(v2x_bn_train_forward((const uint16_t *)d_y[1], M, COUT, (const float *)d_g, (const float *)d_b, 1e-5f, 0.1f, (float *)d_rm, NULL, 1, (uint16_t *)d_by,
+                                   (float *)d_mean, (float *)d_istd, (float *)d_ws, NULL) == V2X_EINVAL, "running_mean without running_var must be rejected");
+        HIPOK(hipDeviceSynchronize());
+        float mean[COUT], istd[COUT], dg[COUT], db[COUT];
+        HIPOK(hipMemcpy(mean, d_mean, COUT * 4, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(istd, d_istd, COUT * 4, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(dg, d_dg, COUT * 4, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(db, d_db, COUT * 4, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(rm, d_rm, COUT * 4, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(rv, d_rv, COUT * 4, hipMemcpyDeviceToHost));
+        HIPOK(hipMemcpy(bn_y, d_by, n_out * 2, hipMemcpyDeviceToHost)); HIPOK(hipMemcpy(bn_dx, d_dx, n_out * 2, hipMemcpyDeviceToHost));
+        double worst_stat = 0, worst_y = 0, worst_dx = 0, worst_g = 0;
+        for (int c = 0; c < COUT; ++c) {
+            double s1 = 0, s2 = 0;
+            for (long long m = 0; m < M; ++m) {
+                const double v = from_bf16(y[1][m * COUT + c]);
+                s1 += v;
+                s2 += v * v;
+            }
+            const double mu = s1 / M, var = s2 / M - mu * mu, is = 1.0 / sqrt(var + 1e-5);
+            double e = fabs(mean[c] - mu) / (fabs(mu) + 1e-3);
+            if (e > worst_stat) worst_stat = e;
+            e = fabs(istd[c] - is) / is;
+            if (e > worst_stat) worst_stat = e;
+            e = fabs(rm[c] - 0.1 * mu) / (fabs(0.1 * mu) + 1e-3);
+            if (e > worst_stat) worst_stat = e;
+            e = fabs(rv[c] - (0.9 + 0.1 * var * M / (M - 1))) / rv[c];
+            if (e > worst_stat) worst_stat = e;
+            double sg = 0, sgx = 0;
+            for (long long m = 0; m < M; ++m) {
+                const double xh = (from_bf16(y[1][m * COUT + c]) - mu) * is, yv = xh * gamma[c] + beta[c];
+                const double g = yv > 0 ? from_bf16(dy[m * COUT + c]) : 0.0;
+                sg += g;
+                sgx += g * xh;
+                const double yr = yv > 0 ? yv : 0.0;
+                e = fabs(from_bf16(bn_y[m * COUT + c]) - yr) / (fabs(yr) + 1e-2);
+                if (e > worst_y) worst_y = e;
+            }
+            e = fabs(db[c] - sg) / (fabs(sg) + 1.0);
+            if (e > worst_g) worst_g = e;
+            e = fabs(dg[c] - sgx) / (fabs(sgx) + 1.0);
+            if (e > worst_g) worst_g = e;
+            for (long long m = 0; m < M; ++m) {
+                const double xh = (from_bf16(y[1][m * COUT + c]) - mu) * is, yv = xh * gamma[c] + beta[c];
+                if (fabs(yv) < 1e-4) continue; /* the ReLU decision of a value this close to 0 may differ in the last bit */
+                const double g = yv > 0 ? from_bf16(dy[m * COUT + c]) : 0.0;
+                const double dxr = gamma[c] * is * (g - sg / M - xh * sgx / M);
+                e = fabs(from_bf16(bn_dx[m * COUT + c]) - dxr) / (fabs(dxr) + 1e-2);
+                if (e > worst_dx) worst_dx = e;
+            }
+        }
+        printf("BN train kernels vs host double loop: statistics %.1e, dgamma/dbeta %.1e, y %.1e, dx %.1e (bf16 ulp = 7.8e-3)\n", worst_stat, worst_g, worst_y, worst_dx);
+        CHECK(worst_stat < 1e-4 && worst_g < 1e-3 && worst_y < 1.2e-2 && worst_dx < 1.2e-2, "BN training kernels disagree with the host reference");
+    }
     printf("C ABI smoke OK\n");
     return 0;
 }

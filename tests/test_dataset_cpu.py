@@ -47,6 +47,30 @@ def test_layout_and_roundtrip(tmp_path):
     assert np.array_equal(idx, idx[np.lexsort((idx[:, 2], idx[:, 1], idx[:, 0]))])  # stored sorted
 
 
+def test_training_target_fields_of_the_tuple(tmp_path):
+    """targets=True fills positions 2-5 of upstream's per-agent tuple (label_one_hot, reg_target, reg_loss_mask, anchors_map), dense, and
+    they are the same targets the GPU loop scatters from the sparse form (train/loop.py::dataset_batch_on_device)."""
+    from v2x_sim_amd.utils import postprocess, synthetic_scene
+    cfg = Config("train")
+    pts = synthetic_points(1, 2000, seed=5)
+    _, idx = VR.voxelize_occupy(pts[0], return_indices=True)
+    boxes = np.array([[4.0, -6.0, 2.0, 4.5, 0.3], [-12.0, 9.0, 1.9, 4.2, -1.2]], np.float32)
+    write_sample(str(tmp_path), "train", 0, 1, 0, idx, np.eye(4, dtype=np.float32)[None], 1, gt_boxes=boxes)
+    ds = V2XSimDet(dataset_roots=[os.path.join(str(tmp_path), "train", "agent0")], config=cfg, split="train", targets=True)
+    t = ds[0][0]
+    assert len(t) == 13
+    label, reg, mask, anchors = t[2], t[3], t[4], t[5]
+    X, Y, A = anchors.shape[:3]
+    assert label.shape == (X, Y, A, 2) and reg.shape == (X, Y, A, 1, 6) and mask.shape == (X, Y, A, 1) and mask.dtype == bool
+    assert np.array_equal(anchors, postprocess.build_anchor_map(cfg))
+    pos, code = synthetic_scene.anchor_targets_sparse(boxes, anchors)
+    assert pos.shape[0] > 0 and int(mask.sum()) == pos.shape[0] == int(label[..., 1].sum())
+    assert np.array_equal(np.argwhere(mask[..., 0]), pos) and np.allclose(reg[mask[..., 0]][:, 0], code)
+    assert np.all(label.sum(-1) == 1.0) and not reg[~mask[..., 0]].any()
+    # without the flag the fields stay None (the GPU loops build the targets on the device)
+    assert V2XSimDet(dataset_roots=[os.path.join(str(tmp_path), "train", "agent0")], config=cfg, split="train")[0][0][2] is None
+
+
 def test_errors(tmp_path):
     with pytest.raises(ValueError):
         V2XSimDet(dataset_roots=None, config=Config("test"), split="test")

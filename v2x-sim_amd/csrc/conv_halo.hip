@@ -58,10 +58,28 @@ struct HaloArgs {
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
 constexpr int PH0 = TH / 2 + 2, PW0 = TW / 2 + 2;
 
+// Patch swizzle (slot permutation per pixel x).  Chosen by TIMING the fragment reads (tools/lds_conflict_probe.hip: lane (fj, fq) reads
+// 16 bytes of pixel x0 + fj -- or ((c + fj) >> 1) + 1 for a half-resolution source -- at slot 4*kc + fq; 8 reads in flight per wave):
+//   4 slots per pixel:  (x >> 2) & 3             17.5 ns per read at every alignment of both forms;  the round-1 choice (x >> 1) & 3:
+//                                                22.9 ns for EVERY full-resolution read, 22.6 for two of three half-resolution alignments
+//   8 slots per pixel:  ((x >> 1) & 1) * 4 ^ ((x >> 2) & 3)   17.2-17.5 ns;  round 1's x & 7: 22.7 / 19.2 ns
+// SQ_LDS_BANK_CONFLICT reads 0 for the slow full-resolution patterns: the counter does not see whatever pairing rule ds_read_b128
+// applies, which is how round 1's search (driven by that counter) settled on them.  INSIDE the kernels the faster reads change nothing
+// (same-box A/B, two runs each: heads 1 132-1 154 vs 1 133-1 139 us, conv8_1 967-974 vs 975-977, pair kernel 687-713 vs 723-727 (worse: its
+// layer-A epilogue WRITES this layout), conv7_2 365-367 vs 364-369): the fragment reads are not what these kernels wait for.  Default stays
+// the round-1 swizzle (V2X_HALO_PSWZ_BUILD=1); =2 builds the timing-derived one.
+#ifndef V2X_HALO_PSWZ_BUILD
+#define V2X_HALO_PSWZ_BUILD 1
+#endif
 template <int SPP>
 __device__ __forceinline__ int swz(int slot, int x) {
-    if constexpr (SPP == 8) return slot ^ (x & 7);
-    else return slot ^ ((x >> 1) & 3);  // SPP 4 or 12: permute inside each aligned group of 4 slots
+    if constexpr (V2X_HALO_PSWZ_BUILD == 1) {
+        if constexpr (SPP == 8) return slot ^ (x & 7);
+        else return slot ^ ((x >> 1) & 3);
+    } else {
+        if constexpr (SPP == 8) return slot ^ ((((x >> 1) & 1) << 2) ^ ((x >> 2) & 3));
+        else return slot ^ ((x >> 2) & 3);  // SPP 4 or 12: permute inside each aligned group of 4 slots
+    }
 }
 
 constexpr int round64(int v) { return (v + 63) / 64 * 64; }

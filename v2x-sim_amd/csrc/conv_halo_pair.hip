@@ -56,7 +56,11 @@ constexpr int IN_BYTES = 2 * IN_PLANE; // 13 824: channels 0..7 | 8..15, planar 
 constexpr int MID_BYTES = NMID * 64;    // 21 760
 constexpr int LUT_BYTES = 256 * 16;     // byte of occupancy bits -> 8 bf16 {0,1}: the expansion is one ds_read_b128 instead of ~60 VALU ops
 constexpr int SMEM = 2 * W_BYTES + IN_BYTES + MID_BYTES + LUT_BYTES;
-__device__ __forceinline__ int swz4(int slot, int x) { return slot ^ ((x >> 1) & 3); }
+#ifndef V2X_HALO_PSWZ_BUILD
+#define V2X_HALO_PSWZ_BUILD 1
+#endif
+// 1: (x >> 1) & 3 (round 1);  2: (x >> 2) & 3, whose fragment reads time 30 % faster in isolation and change nothing here (conv_halo.hip)
+__device__ __forceinline__ int swz4(int slot, int x) { return slot ^ ((x >> V2X_HALO_PSWZ_BUILD) & 3); }
 // ReLU on two packed bf16: as 16-bit integers a negative bf16 (sign bit) is a negative short, so max(x, 0) per half is
 // ONE v_pk_max_i16 for two values (fmaxf on the fp32 values costs two instructions EACH: it canonicalises first).
 // relu(round(v)) == round(relu(v)): rounding is monotone and -0 maps to +0 either way.

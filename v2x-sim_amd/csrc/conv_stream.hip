@@ -56,6 +56,18 @@ enum { SEPI_BF16 = 0, SEPI_CHAIN = 1, SEPI_GRU = 2 };
 #define V2X_STREAM_DBG_BUILD 0
 #endif
 constexpr int SDBG = V2X_STREAM_DBG_BUILD;
+// Patch swizzle: pixel pc's channel slot s (16 bytes) lives at physical slot s ^ PSWZ(pc) of its 64 bytes.  A pixel-fragment read is
+// lane (fj, fq) -> pixel pc0 + fj (full resolution) or ((c + fj) >> 1) + 1 (half resolution), slot fq.  tools/lds_conflict_probe.hip times
+// candidate swizzles with eight reads in flight: (pc >> 2) & 3 serves every alignment of both forms at 17.5 ns per read, the round-1 choice
+// (pc >> 1) & 3 at 22.5 ns for EVERY full-resolution read and for two of three half-resolution alignments -- although SQ_LDS_BANK_CONFLICT
+// reads 0 for the full-resolution case (the counter does not see whatever pairing rule ds_read_b128 applies).  Inside the kernels the
+// effect is at the noise level (same-box A/B: stream8g 465 -> 455 us, wide 954 -> 926, with unrelated kernels drifting 3 % between the
+// runs): LDS read throughput is not what they wait for.  Kept because it removes the half-resolution conflicts the counter does see
+// (11-20 % of LDS cycles on conv5_1 / conv6_1).  V2X_STREAM_PSWZ_BUILD=1 restores the old swizzle for A/B runs.
+#ifndef V2X_STREAM_PSWZ_BUILD
+#define V2X_STREAM_PSWZ_BUILD 2
+#endif
+#define PSWZ(pc) (((pc) >> V2X_STREAM_PSWZ_BUILD) & 3)
 // bit 16: TIMESTAMPS.  Lane 0 of waves 0 and 4 (one wave per group) of workgroup 0 records s_memrealtime (100 MHz) at four points of
 // each of its first 128 steps into 4 KiB of extra LDS, dumped to this buffer when the workgroup ends: [group][step][point], points =
 // top of the load phase, before the first barrier (loads issued, waits done), after it (MFMA phase begins), end of the MFMA phase.
@@ -289,14 +301,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int pr = pix / PW, pc = pix - pr * PW;
             const int y = y0 - 1 + pr, x = x0 - 1 + pc;
             const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            pd_full[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+            pd_full[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
         }
         {
             const int Hs = a.H >> 1, Ws = a.W >> 1;
             const int pr = pix / PW0, pc = pix - pr * PW0;
             const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
             const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-            pd_half[t] = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+            pd_half[t] = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
         }
     }
     // (b) byte offset inside a patch row of this lane's B fragment f for tap column kx (pixel slot + swizzled k-slot)
@@ -309,8 +321,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int kx = 0; kx < 3; ++kx) {
             const int pcf = col + kx;                    // full res: column col + kx
             const int pch = ((col + kx - 1) >> 1) + 1;   // half res: floor((col + kx - 1) / 2) + 1
-            ct_full[f][kx] = ((pcf << 2) + (fq ^ ((pcf >> 1) & 3))) * 16;
-            ct_half[f][kx] = ((pch << 2) + (fq ^ ((pch >> 1) & 3))) * 16;
+            ct_full[f][kx] = ((pcf << 2) + (fq ^ PSWZ(pcf))) * 16;
+            ct_half[f][kx] = ((pch << 2) + (fq ^ PSWZ(pch))) * 16;
         }
     }
 
@@ -499,13 +511,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int pr = pix / PW, pc = pix - pr * PW;
             const int y = y0 - 1 + pr, x = x0 - 1 + pc;
             const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            return ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+            return ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
         }
         const int Hs = a.H >> 1, Ws = a.W >> 1;
         const int pr = pix / PW0, pc = pix - pr * PW0;
         const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
         const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-        return ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+        return ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
     };
 
     // per-lane fragment tables.  ONE column-offset table, valid for the resolution of the chunk being computed (it is
@@ -521,7 +533,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int pc = hf ? (((col + kx - 1) >> 1) + 1) : (col + kx);
-                ct[f][kx] = ((pc << 2) + (fq ^ ((pc >> 1) & 3))) * 16;
+                ct[f][kx] = ((pc << 2) + (fq ^ PSWZ(pc))) * 16;
             }
         }
     };
@@ -775,13 +787,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int pr = pix / PW, pc = pix - pr * PW;
             const int y = y0 - 1 + pr, x = x0 - 1 + pc;
             const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            return ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+            return ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
         }
         const int Hs = a.H >> 1, Ws = a.W >> 1;
         const int pr = pix / PW0, pc = pix - pr * PW0;
         const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
         const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-        return ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+        return ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
     };
     auto issue_piece = [&](int d, int kc, int t, int buf) {
         const bool first = kc < nc0;
@@ -946,7 +958,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int ch = 0; ch < 2; ++ch) {
                     const int col = ch * 16 + fjl + kx;
                     const int pc = ((col - sh) >> sh) + sh;     // full: col + kx;  half: ((col + kx - 1) >> 1) + 1
-                    const int coff = ((pc << 2) + (fql ^ ((pc >> 1) & 3))) * 16;
+                    const int coff = ((pc << 2) + (fql ^ PSWZ(pc))) * 16;
 #pragma unroll
                     for (int q = 0; q < NB / 2; ++q) {
                         if constexpr ((SDBG & 4) == 0) B[q * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + row0 + (((q - sh) >> sh) + sh) * row_bytes + coff);
@@ -1182,13 +1194,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int pr = pix / PW, pc = pix - pr * PW;
                 const int y = y0 - 1 + pr, x = x0 - 1 + pc;
                 const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                d = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+                d = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
             } else {
                 const int Hs = a.H >> 1, Ws = a.W >> 1;
                 const int pr = pix / PW0, pc = pix - pr * PW0;
                 const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
                 const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
-                d = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ ((pc >> 1) & 3)) << 3)) : -1;
+                d = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
             }
             pd[t] = d;
             __builtin_amdgcn_sched_barrier(0);
@@ -1205,7 +1217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int pc = hf ? (((col + kx - 1) >> 1) + 1) : (col + kx);
-                ct[c][kx] = ((pc << 2) + (fq ^ ((pc >> 1) & 3))) * 16;
+                ct[c][kx] = ((pc << 2) + (fq ^ PSWZ(pc))) * 16;
             }
         }
     };

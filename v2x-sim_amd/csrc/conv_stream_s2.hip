@@ -15,6 +15,9 @@
 // One patch buffer (37 KiB) + ring (16 / 32 KiB) = 53 / 69 KiB -> three / two workgroups per CU; the patch refill at a
 // chunk boundary (everything drains there) is what the other workgroups cover.
 #include "common.h"
+#ifndef V2X_S2_PSWZ_BUILD
+#define V2X_S2_PSWZ_BUILD 1   // patch swizzle (entry >> 1) & 3; 2 = (entry >> 2) & 3 (conv_stream.hip PSWZ): measured no different here (297 vs 299 us)
+#endif
 #include <cstdlib>
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         const int pc = 2 * idx + (odd ? 1 : 0);               // patch column
         const int y = 2 * y0 - 1 + r, x = 2 * x0 - 1 + pc;   // input pixel
         const bool ok = L < G::SLOTS && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-        pd[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((idx >> 1) & 3)) << 3)) : -1;
+        pd[t] = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ ((idx >> V2X_S2_PSWZ_BUILD) & 3)) << 3)) : -1;
     }
     // fragment f of a wave: 4 x 32 tile -> output row `wave`, columns f*16 + fj;  8 x 16 tile -> output row 2*wave + f,
     // columns fj.  Column offsets: tap kx reads entry (col + (kx == 2)) of the even (kx = 0, 2) or odd (kx = 1) half
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int idx = (TW == 32 ? f * 16 : 0) + fj + (kx == 2 ? 1 : 0);
-            ct[f][kx] = (((kx == 1 ? G::NE : 0) + idx) * 4 + (fq ^ ((idx >> 1) & 3))) * 16;
+            ct[f][kx] = (((kx == 1 ? G::NE : 0) + idx) * 4 + (fq ^ ((idx >> V2X_S2_PSWZ_BUILD) & 3))) * 16;
         }
     const int frow0 = (TW == 32) ? wave : 2 * wave, frow1 = (TW == 32) ? wave : 2 * wave + 1;   // output row of fragment 0 / 1
 
@@ -270,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int idx = f * 16 + fj + (kx == 2 ? 1 : 0);
-            ct[f][kx] = (((kx == 1 ? S2_NE : 0) + idx) * 4 + (fq ^ ((idx >> 1) & 3))) * 16;
+            ct[f][kx] = (((kx == 1 ? S2_NE : 0) + idx) * 4 + (fq ^ ((idx >> V2X_S2_PSWZ_BUILD) & 3))) * 16;
         }
     // tile-independent part of the patch descriptors: (patch row << 20) | (patch column << 8) | (swizzled slot << 3), -1 = padding
     int pdt[S2_PPW];
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const bool odd = ent >= S2_NE;
         const int idx = odd ? ent - S2_NE : ent;
         const int pc = 2 * idx + (odd ? 1 : 0);
-        pdt[t] = L < S2_SLOTS ? ((r << 20) | (pc << 8) | ((phys ^ ((idx >> 1) & 3)) << 3)) : -1;
+        pdt[t] = L < S2_SLOTS ? ((r << 20) | (pc << 8) | ((phys ^ ((idx >> V2X_S2_PSWZ_BUILD) & 3)) << 3)) : -1;
     }
     const int txy = a.tiles_x * a.tiles_y;
     const int Ho = a.H >> 1, Wo = a.W >> 1;

@@ -50,7 +50,7 @@ def write_sample(root, split, agent, scene, frame, voxel_indices, trans_matrices
 
 class V2XSimDet(Dataset):
     def __init__(self, dataset_roots=None, config=None, config_global=None, agent_list=None, split=None, val=False,
-                 bound=None, kd_flag=False, rsu=False, densify="cpu"):
+                 bound=None, kd_flag=False, rsu=False, densify="cpu", targets=False):
         if split is None or dataset_roots is None or config is None:
             raise ValueError("dataset_roots, config and split are required")
         if kd_flag:
@@ -61,6 +61,12 @@ class V2XSimDet(Dataset):
         self.config, self.config_global = config, config_global
         self.split, self.val, self.bound, self.rsu = split, val, bound, rsu
         self.densify = densify
+        # targets=True: fill the training fields of upstream's per-agent tuple -- label_one_hot (X, Y, A, 2), reg_target (X, Y, A, 1, 6),
+        # reg_loss_mask (X, Y, A, 1), anchors_map (X, Y, A, 6) -- dense, as upstream's Dataset returns them (built from the stored
+        # ground-truth boxes with the assignment rule of DESIGN.md section 3.7).  The GPU training loops keep targets=False and scatter
+        # the sparse targets on the device instead (train/loop.py::dataset_batch_on_device).
+        self.targets = targets
+        self._anchors = None
         self.dims = tuple(config.map_dims)
         self.num_agent = len(self.dataset_roots)
         # frames present for EVERY agent, in (scene, frame) order
@@ -90,10 +96,17 @@ class V2XSimDet(Dataset):
                 padded_voxel_points = vox[None].astype(np.float32)         # (1, X, Y, Z)
             else:
                 padded_voxel_points = indices
-            res.append((padded_voxel_points, None, None, None, None, None, None, None,
+            boxes = np.asarray(gt.get("gt_boxes", np.zeros((0, 5), np.float32)), dtype=np.float32)
+            label_one_hot = reg_target = reg_loss_mask = anchors_map = None
+            if self.targets:
+                from ..utils import postprocess, synthetic_scene
+                if self._anchors is None:
+                    self._anchors = postprocess.build_anchor_map(self.config)
+                anchors_map = self._anchors
+                label_one_hot, reg_target, reg_loss_mask = synthetic_scene.anchor_targets(boxes, anchors_map)
+            res.append((padded_voxel_points, None, label_one_hot, reg_target, reg_loss_mask, anchors_map, None, None,
                         os.path.join(root, name), int(gt["target_agent_id"]), int(gt["num_sensor"]),
-                        np.asarray(gt["trans_matrices"], dtype=np.float32),
-                        np.asarray(gt.get("gt_boxes", np.zeros((0, 5), np.float32)), dtype=np.float32)))
+                        np.asarray(gt["trans_matrices"], dtype=np.float32), boxes))
         return res
 
 
