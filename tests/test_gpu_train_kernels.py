@@ -414,3 +414,62 @@ def test_fafmodule_step_graphed_with_scheduler(device, monkeypatch):
     first, last = np.mean([h[0] for h in hist[:5]]), np.mean([h[0] for h in hist[-5:]])
     print("graphed FaFModule.step: mean loss of the first / last 5 of 40 steps: %.4f / %.4f" % (first, last))
     assert np.isfinite(last) and last < 0.8 * first
+
+
+@pytest.mark.parametrize("family", ["when2com", "max", "cat", "disco", "v2v_seg", "faf_seg"])
+def test_hip_graph_other_baselines_loss_parity(device, monkeypatch, family):
+    """V2X_TRAIN_HIP=1 for the other detection baselines and the segmentation variants: encoder / decoder / heads on the kernels, their
+    cross-agent fusion on the fp32 graph at the fusion layer.  One training-mode step: loss within 2 % of the all-fp32 graph's, finite
+    gradients for the same set of parameters, and 15 Adam steps reduce the loss."""
+    import copy
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models import det as D
+    from v2x_sim_amd.models import seg as S
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    cfg = Config("train")
+    A = 3
+    seg = family.endswith("_seg")
+    if seg:
+        cls = {"v2v_seg": S.V2VNetSeg, "faf_seg": S.FaFNetSeg}[family]
+        base = cls(cfg, num_agent=A) if family == "v2v_seg" else cls(cfg)
+        from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+        base = init_synthetic_weights(base, seed=2).to(device)
+    else:
+        cls = {"when2com": D.When2com, "max": D.MaxFusion, "cat": D.CatFusion, "disco": D.DiscoNet}[family]
+        base = init_for_training(cls(cfg, num_agent=A), seed=2).to(device)
+    data = synthetic_batch_on_device(cfg, 1, A, seed=8, device=device)
+    if seg:
+        g = torch.Generator().manual_seed(3)
+        target = torch.randint(0, 8, (A, 256, 256), generator=g).to(device)
+
+    def loss_of(model):
+        res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
+        if seg:
+            return torch.nn.functional.cross_entropy(res.reshape(-1, res.shape[-1]), target.reshape(-1))
+        return detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+    out = {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+        model = copy.deepcopy(base).train()
+        loss = loss_of(model)
+        loss.backward()
+        out[flag] = (float(loss.detach()), {k for k, p in model.named_parameters() if p.grad is not None})
+        for k, p in model.named_parameters():
+            assert p.grad is None or bool(torch.isfinite(p.grad).all()), k
+    print("%s: loss fp32 graph %.5f, HIP graph %.5f" % (family, out["0"][0], out["1"][0]))
+    assert abs(out["1"][0] - out["0"][0]) <= 2e-2 * abs(out["0"][0])
+    assert out["0"][1] == out["1"][1]
+    monkeypatch.setenv("V2X_TRAIN_HIP", "1")
+    model = copy.deepcopy(base).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    first = None
+    for _ in range(15):
+        loss = loss_of(model)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        first = float(loss.detach()) if first is None else first
+    monkeypatch.delenv("V2X_TRAIN_HIP")
+    print("%s: 15 Adam steps on the HIP graph %.4f -> %.4f" % (family, first, float(loss.detach())))
+    assert float(loss.detach()) < first

@@ -235,12 +235,11 @@ def disco_fuse(model, feat, trans, num_agent_tensor, B):
 def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
     """bevs (A*B, 1, X, Y, Z) dense occupancy (the Dataset format) -> {'loc', 'cls'} with the shapes of the HIP path.
     Uses batch-statistics BN when model.training, running statistics otherwise.
-    V2X_TRAIN_HIP=1: FaFNet / V2VNet in train mode run the bf16 NHWC graph on the hand-written kernels (train/hip_graph.py)."""
+    V2X_TRAIN_HIP=1: in train mode encoder, decoder and heads run as the bf16 NHWC graph on the hand-written kernels (train/hip_graph.py)."""
     import os
-    if (os.environ.get("V2X_TRAIN_HIP", "0")[:1] == "1" and model.training and bevs.is_cuda and not hasattr(model, "outc")
-            and (hasattr(model, "stpn") or hasattr(model, "convgru"))):
+    if os.environ.get("V2X_TRAIN_HIP", "0")[:1] == "1" and model.training and bevs.is_cuda:
         from . import hip_graph
-        return hip_graph.train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size)
+        return hip_graph.train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size, inference)
     x = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)
     if hasattr(model, "outc"):                      # segmentation variants: det backbone + 1x1 head, NHWC fp32 logits
         if hasattr(model, "stpn"):

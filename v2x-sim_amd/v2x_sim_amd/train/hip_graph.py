@@ -253,21 +253,50 @@ def heads(model, x):
             "loc": loc.reshape(-1, loc.size(1), loc.size(2), model.anchor_num_per_loc, model.out_seq_len, model.box_code_size)}
 
 
-def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1):
-    """bevs (A*B, 1, X, Y, Z) on the MI355X -> {'loc', 'cls'} fp32, shapes as train/graph.py::train_forward.
-    FaFNet (lowerbound / upperbound) and V2VNet; model.training must be on."""
+def _fused_on_fp32_graph(fuse, model, feat, *args):
+    """The cross-agent fusion runs on the fp32 NCHW graph (train/graph.py): convert the fusion-layer maps, fuse, convert back."""
+    out = fuse(model, feat.permute(0, 3, 1, 2).float(), *args)
+    extra = ()
+    if isinstance(out, tuple):
+        out, extra = out[0], out[1:]
+    return (out.permute(0, 2, 3, 1).to(BF16).contiguous(),) + tuple(extra)
+
+
+def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
+    """bevs (A*B, 1, X, Y, Z) on the MI355X -> {'loc', 'cls'} fp32 (segmentation variants: NHWC fp32 logits), shapes as
+    train/graph.py::train_forward.  Every detection / segmentation baseline: encoder, decoder and heads on the kernels; the cross-agent
+    fusion (V2VNet's warp + ConvGRU, when2com's handshake, sum / mean / max / cat / DiscoNet) on the fp32 graph at the fusion layer.
+    model.training must be on."""
+    from . import graph
     if not bevs.is_cuda:
         raise RuntimeError("train/hip_graph.py runs on the MI355X (no CPU path)")
     x = nhwc_input(bevs)
-    if hasattr(model, "outc"):
-        raise NotImplementedError("hip_graph: segmentation variants train through train/graph.py")
-    if hasattr(model, "stpn"):
+    T = None if trans_matrices is None else trans_matrices.to(x.device)
+    if hasattr(model, "outc"):                      # segmentation variants: det backbone + 1x1 head, NHWC fp32 logits
+        if hasattr(model, "stpn"):
+            y = decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x))
+        else:
+            feats = encoder(model.u_encoder, x)
+            feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size)
+            y = decoder(model.decoder, *feats)
+        return conv1x1(y, model.outc.conv.weight, model.outc.conv.bias, f32_out=True)
+    if hasattr(model, "stpn"):                      # FaFNet: lowerbound / upperbound
         return heads(model, decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x)))
-    if hasattr(model, "convgru"):
-        from . import graph
-        feats = encoder(model.u_encoder, x)
-        f = feats[model.layer].permute(0, 3, 1, 2).float()                        # the fusion runs on the fp32 graph
-        f = graph.v2v_fuse(model, f, trans_matrices.to(x.device), num_agent_tensor, batch_size)
-        feats[model.layer] = f.permute(0, 2, 3, 1).to(BF16).contiguous()
-        return heads(model, decoder(model.decoder, *feats))
-    raise NotImplementedError("hip_graph covers FaFNet and V2VNet; the other baselines train through train/graph.py")
+    feats = encoder(model.u_encoder, x)
+    res_extra = {}
+    if hasattr(model, "convgru"):                   # V2VNet
+        feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size)
+    elif hasattr(model, "query_key_net"):           # when2com / who2com: its key / query tower reads the input on the fp32 graph
+        x32 = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)
+        fused, prob, coef = _fused_on_fp32_graph(lambda m, f: graph.when2com_fuse(m, x32, f, T, num_agent_tensor, batch_size, model.training, inference),
+                                                 model, feats[model.layer])
+        feats[model.layer] = fused
+        res_extra = {"prob_action": prob, "coef": coef}
+    elif hasattr(model, "FUSE_MODE"):               # Sum / Mean / Max / Cat fusion, DiscoNet (no teacher)
+        fuse = graph.disco_fuse if hasattr(model, "pixel_weighted_fusion") else graph.simple_fuse
+        feats[model.layer], = _fused_on_fp32_graph(fuse, model, feats[model.layer], T, num_agent_tensor, batch_size)
+    else:
+        raise NotImplementedError("hip_graph: unknown model family")
+    res = heads(model, decoder(model.decoder, *feats))
+    res.update(res_extra)
+    return res
