@@ -77,6 +77,20 @@ def main():
     for flag in ("0", "1"):
         os.environ["V2X_TRAIN_HIP"] = flag
         print("FaFNet training step (fwd + bwd + Adam), 10 maps, V2X_TRAIN_HIP=%s: %.1f ms" % (flag, timed(full_step, 5) / 1e3))
+    # V2VNet (the fusion -- warp + ConvGRU -- between the HIP encoder and decoder)
+    from v2x_sim_amd.models.det import V2VNet
+    vmodel = init_for_training(V2VNet(cfg, num_agent=5), seed=0).to(dev).train()
+    vopt = torch.optim.Adam(vmodel.parameters(), lr=1e-4)
+
+    def v_step():
+        res = train_forward(vmodel, data["bev_seq"], data["trans_matrices"], data["num_agent"], 2)
+        loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+        vopt.zero_grad(set_to_none=True)
+        loss.backward()
+        vopt.step()
+    for flag in ("0", "1"):
+        os.environ["V2X_TRAIN_HIP"] = flag
+        print("V2VNet training step (fwd + bwd + Adam), 10 maps, V2X_TRAIN_HIP=%s: %.1f ms" % (flag, timed(v_step, 5) / 1e3))
     os.environ["V2X_TRAIN_HIP"] = "1"
     from v2x_sim_amd.train.graph_step import GraphedTrainStep
     opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True)
