@@ -414,6 +414,21 @@ def test_fafmodule_step_graphed_with_scheduler(device, monkeypatch):
     first, last = np.mean([h[0] for h in hist[:5]]), np.mean([h[0] for h in hist[-5:]])
     print("graphed FaFModule.step: mean loss of the first / last 5 of 40 steps: %.4f / %.4f" % (first, last))
     assert np.isfinite(last) and last < 0.8 * first
+    # the inference engine must see the weights the replays produced (they do not bump the parameters' version counters): a model that
+    # was used for inference BEFORE training, then trained by replays, must answer like a fresh copy holding the same state_dict
+    from v2x_sim_amd.train.loop import synthetic_batch_on_device
+    data = synthetic_batch_on_device(cfg, 1, 2, seed=41, device=device, with_targets=False)
+    model2 = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=2).to(device).eval()
+    with torch.no_grad():
+        before = model2(data["bev_seq"], batch_size=1)["cls"].clone()           # packs the initial weights
+    opt2, _ = make_optimizer(model2, 1e-3, 10)
+    train_synthetic(model2, cfg, 10, frames_per_step=1, seed=4, device=device, agents=2, opt=opt2, sched=None)   # ends with model.eval()
+    fresh = FaFNet(cfg, kd_flag=0, num_agent=2).to(device).eval()
+    fresh.load_state_dict(model2.state_dict())
+    with torch.no_grad():
+        after = model2(data["bev_seq"], batch_size=1)["cls"]
+        ref = fresh(data["bev_seq"], batch_size=1)["cls"]
+    assert torch.equal(after, ref) and not torch.equal(after, before)
 
 
 @pytest.mark.parametrize("family", ["when2com", "max", "cat", "disco", "v2v_seg", "faf_seg"])

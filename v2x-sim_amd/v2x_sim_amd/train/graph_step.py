@@ -81,4 +81,8 @@ class GraphedTrainStep:
                 raise ValueError("GraphedTrainStep: %s has shape %s, captured %s" % (k, tuple(data[k].shape), tuple(v.shape)))
             v.copy_(data[k])
         self.graph.replay()
+        # a replay changes the parameters without bumping their version counters, which is what the inference engine's packed-weights
+        # cache looks at (DetModelBase.packed): drop that cache so that the next model(...) call re-packs
+        if hasattr(self.model, "repack"):
+            self.model.repack()
         return self.losses
