@@ -77,6 +77,15 @@ __device__ unsigned v2x_stream_timeline[2 * SDBG_T_STEPS * 4];
 extern "C" int v2x_debug_stream_timeline(unsigned *dst) {
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2x_stream_timeline), sizeof(unsigned) * 2 * SDBG_T_STEPS * 4);
 }
+// Compile-time experiment switches of stream8g, all measured and left at their neutral values (tools/ab_build.sh):
+//   LPRIO: s_setprio for the load phase (0 = off; 1, 3: no effect beyond box drift);  PF: weight fragments read 1 or 2 blocks ahead (2 =
+//   inline-asm reads with counted lgkmcnt waits: 482 -> 503-507 us, slower);  PRIO: s_setprio for the MFMA phase (no effect);  H1: prefetch point.
+#ifndef V2X_STREAM_LPRIO_BUILD
+#define V2X_STREAM_LPRIO_BUILD 0
+#endif
+#ifndef V2X_STREAM_PF_BUILD
+#define V2X_STREAM_PF_BUILD 1
+#endif
 #ifndef V2X_STREAM_PRIO_BUILD
 #define V2X_STREAM_PRIO_BUILD 0
 #endif
@@ -932,6 +941,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 };
                 stamp(0);
+                if constexpr (V2X_STREAM_LPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(V2X_STREAM_LPRIO_BUILD);   // load phase: win the issue arbitration
                 const int fjl = ln & 15, fql = ln >> 4;
                 // ---- L: group 1 streams the weights of step st+2 (wrapping into the next tile), group 0 the next chunk's patch
                 int nw = 0;   // weight DMAs this wave issues in this phase
@@ -966,11 +976,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 const char *ws = s_ring + slot * STEP_BYTES + (fql * BCO + fjl) * 16 + coh * (HCO * 256);   // + compile-time offsets below
-                bf16x8_t A[2][WT ? BT : HCO];
+                constexpr int PFD = WT ? V2X_STREAM_PF_BUILD : 1;   // WT: weight fragments are read PFD blocks ahead (A is a ring of PFD + 1 blocks)
+                bf16x8_t A[PFD + 1][WT ? BT : HCO];
 #pragma unroll
                 for (int i = 0; i < (WT ? BT : HCO); ++i) {
                     if constexpr ((SDBG & 4) == 0) A[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
                     else A[0][i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, slot, ln));
+                }
+                if constexpr (WT && PFD == 2) {   // block 1 as well (tap 0, tiles BT.. or tap 1)
+#pragma unroll
+                    for (int i = 0; i < BT; ++i)
+                        A[1][i] = *reinterpret_cast<const bf16x8_t *>(ws + (BT / HCO) * SLICE_BYTES + ((BT % HCO) + i) * 256);
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): fragments in registers before the patch / ring may be overwritten
                 // drain: group 1 -- the weights issued one step ago (everything but this phase's own NWD DMAs; right after an epilogue
@@ -983,6 +999,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 stamp(1);
+                if constexpr (V2X_STREAM_LPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -994,9 +1011,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // its second part.
                 if constexpr (V2X_STREAM_PRIO_BUILD > 0) __builtin_amdgcn_s_setprio(V2X_STREAM_PRIO_BUILD);
                 if constexpr (WT) {
-                    // blocks of BT channel tiles x 8 pixel fragments; the next block's BT weight fragments are read after the first
-                    // tile's 8 MFMAs and land under the rest of the block
+                    // blocks of BT channel tiles x 8 pixel fragments.  PFD = 1: the next block's BT weight fragments are read after the
+                    // first tile's 8 MFMAs and land under the rest of the block (the compiler waits lgkmcnt(0) before their first use).
+                    // PFD = 2: fragments are read TWO blocks ahead.  The compiler only ever waits lgkmcnt(0) here, which would also
+                    // wait for the younger read, so these reads and their waits are inline asm it does not track: LDS returns in
+                    // order, lgkmcnt(BT) = "everything but the BT newest reads has arrived".
                     constexpr int NBLK = 3 * HCO / BT;
+                    const uint32_t ws32 = (uint32_t)(uintptr_t)(lptr_t)const_cast<char *>(ws);
 #pragma unroll
                     for (int b = 0; b < NBLK; ++b) {
                         const int ky = (b * BT) / HCO, i0 = (b * BT) % HCO;
@@ -1006,20 +1027,34 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                                 for (int f = 0; f < 8; ++f) {
                                     if constexpr ((SDBG & 8) == 0)
-                                        acc[i0 + j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b & 1][j], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i0 + j][f], 0, 0, 0);
+                                        acc[i0 + j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b % (PFD + 1)][j], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i0 + j][f], 0, 0, 0);
                                     else if (f == 0)
-                                        acc[i0 + j][0] += __builtin_bit_cast(f32x4_t, A[b & 1][j]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
+                                        acc[i0 + j][0] += __builtin_bit_cast(f32x4_t, A[b % (PFD + 1)][j]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
                                 }
                         };
                         __builtin_amdgcn_sched_barrier(0);
+                        if constexpr (PFD == 2) {
+                            // operands of block b: read two blocks ago (b >= 2) -- younger in flight: the reads of block b + 1, if any
+                            if (b >= 2) {
+                                if (b + 1 < NBLK) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(BT) : "memory");
+                                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         mma_tiles(0, 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (b + 1 < NBLK) {
-                            const int ky1 = ((b + 1) * BT) / HCO, j1 = ((b + 1) * BT) % HCO;
+                        if (b + PFD < NBLK) {
+                            const int ky1 = ((b + PFD) * BT) / HCO, j1 = ((b + PFD) * BT) % HCO;
 #pragma unroll
                             for (int j = 0; j < BT; ++j) {
-                                if constexpr ((SDBG & 4) == 0) A[(b + 1) & 1][j] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (j1 + j) * 256);
-                                else A[(b + 1) & 1][j] = __builtin_bit_cast(bf16x8_t, make_uint4(st, j, b, ln));
+                                if constexpr (PFD == 2) {
+                                    const uint32_t ad = ws32 + ky1 * SLICE_BYTES + (j1 + j) * 256;
+                                    asm volatile("ds_read_b128 %0, %1" : "=v"(A[(b + PFD) % (PFD + 1)][j]) : "v"(ad) : "memory");
+                                } else if constexpr ((SDBG & 4) == 0) {
+                                    A[(b + PFD) % (PFD + 1)][j] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (j1 + j) * 256);
+                                } else {
+                                    A[(b + PFD) % (PFD + 1)][j] = __builtin_bit_cast(bf16x8_t, make_uint4(st, j, b, ln));
+                                }
                             }
                         }
                         __builtin_amdgcn_sched_barrier(0);
