@@ -60,12 +60,11 @@ constexpr int SDBG = V2X_STREAM_DBG_BUILD;
 // lane (fj, fq) -> pixel pc0 + fj (full resolution) or ((c + fj) >> 1) + 1 (half resolution), slot fq.  tools/lds_conflict_probe.hip times
 // candidate swizzles with eight reads in flight: (pc >> 2) & 3 serves every alignment of both forms at 17.5 ns per read, the round-1 choice
 // (pc >> 1) & 3 at 22.5 ns for EVERY full-resolution read and for two of three half-resolution alignments -- although SQ_LDS_BANK_CONFLICT
-// reads 0 for the full-resolution case (the counter does not see whatever pairing rule ds_read_b128 applies).  Inside the kernels the
-// effect is at the noise level (same-box A/B: stream8g 465 -> 455 us, wide 954 -> 926, with unrelated kernels drifting 3 % between the
-// runs): LDS read throughput is not what they wait for.  Kept because it removes the half-resolution conflicts the counter does see
-// (11-20 % of LDS cycles on conv5_1 / conv6_1).  V2X_STREAM_PSWZ_BUILD=1 restores the old swizzle for A/B runs.
+// reads 0 for the full-resolution case (the counter does not see whatever pairing rule ds_read_b128 applies).  INSIDE the kernels the
+// faster reads lose: paired in-process A/B (tools/ab_inproc.sh, s.e. 0.1-0.2 %): every streamed layer is 1.0-3.0 % SLOWER with
+// (pc >> 2) & 3 (conv3_2 289 -> 298 us, ConvGRU 1 570 -> 1 611 us).  Default = the round-1 swizzle (1); 2 builds the other one.
 #ifndef V2X_STREAM_PSWZ_BUILD
-#define V2X_STREAM_PSWZ_BUILD 2
+#define V2X_STREAM_PSWZ_BUILD 1
 #endif
 #define PSWZ(pc) (((pc) >> V2X_STREAM_PSWZ_BUILD) & 3)
 // bit 16: TIMESTAMPS.  Lane 0 of waves 0 and 4 (one wave per group) of workgroup 0 records s_memrealtime (100 MHz) at four points of
