@@ -488,3 +488,40 @@ def test_hip_graph_other_baselines_loss_parity(device, monkeypatch, family):
     monkeypatch.delenv("V2X_TRAIN_HIP")
     print("%s: 15 Adam steps on the HIP graph %.4f -> %.4f" % (family, first, float(loss.detach())))
     assert float(loss.detach()) < first
+
+
+def test_graphed_v2vnet_step(device, monkeypatch):
+    """The captured step for V2VNet (fixed agent table): the frame plan's index tensors come from the warm-up calls' cache, so the capture
+    contains no host -> device copy.  Five replays track five eager steps (the fp32 fusion's index_add uses atomics: 1e-3, not bitwise),
+    a batch with another agent table is refused, and FaFModule.step falls back to eager for it."""
+    import copy
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.graph_step import GraphedTrainStep
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    monkeypatch.setenv("V2X_TRAIN_HIP", "1")
+    cfg = Config("train")
+    base = init_for_training(V2VNet(cfg, num_agent=3), seed=1).to(device)
+    batches = [synthetic_batch_on_device(cfg, 1, 3, seed=20 + i, device=device) for i in range(5)]
+    eager = copy.deepcopy(base).train()
+    opt_e = torch.optim.SGD(eager.parameters(), lr=1e-3)
+    losses_e = []
+    for d in batches:
+        res = train_forward(eager, d["bev_seq"], d["trans_matrices"], d["num_agent"], 1)
+        loss = detection_loss(res, d["labels"], d["reg_targets"], d["reg_loss_mask"])[0]
+        opt_e.zero_grad(set_to_none=True)
+        loss.backward()
+        opt_e.step()
+        losses_e.append(float(loss.detach()))
+    graphed = copy.deepcopy(base).train()
+    step = GraphedTrainStep(graphed, torch.optim.SGD(graphed.parameters(), lr=1e-3), batches[0], 1)
+    losses_g = [float(step(d)[0]) for d in batches]
+    print("eager  ", ["%.5f" % v for v in losses_e])
+    print("graphed", ["%.5f" % v for v in losses_g])
+    assert np.allclose(losses_g, losses_e, rtol=2e-3)
+    other = dict(batches[0])
+    other["num_agent"] = batches[0]["num_agent"].clone()
+    other["num_agent"][0, :] = 2
+    with pytest.raises(ValueError):
+        step(other)

@@ -78,9 +78,13 @@ extern "C" int v2x_debug_stream_timeline(unsigned *dst) {
 }
 // Compile-time experiment switches of stream8g, all measured and left at their neutral values (tools/ab_build.sh):
 //   LPRIO: s_setprio for the load phase (0 = off; 1, 3: no effect beyond box drift);  PF: weight fragments read 1 or 2 blocks ahead (2 =
-//   inline-asm reads with counted lgkmcnt waits: 482 -> 503-507 us, slower);  PRIO: s_setprio for the MFMA phase (no effect);  H1: prefetch point.
+//   inline-asm reads with counted lgkmcnt waits: +2.8-3.7 %, slower);  PRIO: s_setprio for the MFMA phase (-0.3 %);  H1: prefetch point (0.0 %);
+//   XCDCO: one channel tile per XCD instead of all channel tiles on every XCD (+0.1-0.7 %: weight locality in L2 does not matter).
 #ifndef V2X_STREAM_LPRIO_BUILD
 #define V2X_STREAM_LPRIO_BUILD 0
+#endif
+#ifndef V2X_STREAM_XCDCO_BUILD
+#define V2X_STREAM_XCDCO_BUILD 0
 #endif
 #ifndef V2X_STREAM_PF_BUILD
 #define V2X_STREAM_PF_BUILD 1
@@ -764,6 +768,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        if constexpr (V2X_STREAM_XCDCO_BUILD != 0) {
+            // EXPERIMENT: one channel tile per XCD (its weights stay in that XCD's L2) instead of all channel tiles on every XCD
+            const int nco = a.n_co_tiles;
+            if (r == 0 && nco > 1 && (8 % nco == 0 || nco % 8 == 0) && nco <= 8) {
+                const int x = bid / q, j = bid - x * q;          // XCD and index inside it
+                const int co = x % nco, slot = (x / nco) * q + j;
+                bid = slot * nco + co;
+            }
+        }
     }
     const int n_tiles = a.n_px_tiles * a.n_co_tiles;
     const int co_tile = bid % a.n_co_tiles;

@@ -112,13 +112,21 @@ def v2v_fuse(model, feat, trans, num_agent_tensor, B):
     counts, items, rows = model.frame_plan(num_agent_tensor, B, A)
     if min(counts) < 2:
         raise RuntimeError("V2VNet needs >= 2 agents in every frame (stack expects a non-empty TensorList)")
-    pairs = [(m, j * B + f, f, a, j) for m, (a, f) in enumerate(items) for j in range(counts[f]) if j != a]
     dev = feat.device
-    src = torch.tensor([p[1] for p in pairs], device=dev)
-    dst = torch.tensor([p[0] for p in pairs], device=dev)
-    Tp = torch.stack([trans[f, a, j] for (_, _, f, a, j) in pairs]).to(feat.dtype)
-    cnt = torch.tensor([counts[f] - 1 for (_, f) in items], device=dev, dtype=feat.dtype).view(-1, 1, 1, 1)
-    rows_t = torch.tensor(rows, device=dev)
+    # the plan's index tensors are cached per (agent table, B, device): building them is a host -> device copy, which must not happen
+    # inside a hipGraph capture (train/graph_step.py captures the step after warm-up calls have filled this cache)
+    A1, A2 = trans.shape[1], trans.shape[2]
+    key = (tuple(counts), B, A, A1, A2, str(dev), str(feat.dtype))
+    cache = model.__dict__.setdefault("_v2v_plan_cache", {})
+    if key not in cache:
+        pairs = [(m, j * B + f, f, a, j) for m, (a, f) in enumerate(items) for j in range(counts[f]) if j != a]
+        cache.clear()
+        cache[key] = (torch.tensor([p[1] for p in pairs], device=dev), torch.tensor([p[0] for p in pairs], device=dev),
+                      torch.tensor([(f * A1 + a) * A2 + j for (_, _, f, a, j) in pairs], device=dev),
+                      torch.tensor([counts[f] - 1 for (_, f) in items], device=dev, dtype=feat.dtype).view(-1, 1, 1, 1),
+                      torch.tensor(rows, device=dev))
+    src, dst, tsel, cnt, rows_t = cache[key]
+    Tp = trans.reshape(-1, 4, 4).index_select(0, tsel).to(feat.dtype)        # trans[f, a, j] of every (ego item, neighbour) pair
     cur = feat
     for _ in range(model.gnn_iter_num):
         base = feat if model.neighbor_source == "initial" else cur

@@ -57,7 +57,12 @@ class FaFModule(object):
         import os
         if os.environ.get("V2X_TRAIN_HIP", "0")[:1] != "1" or os.environ.get("V2X_TRAIN_GRAPH", "0")[:1] != "1":
             return False
-        if not hasattr(self.model, "stpn") or hasattr(self.model, "outc"):      # FaFNet: no per-batch host plan in its graph
+        if hasattr(self.model, "outc"):
+            return False
+        if hasattr(self.model, "convgru"):          # V2VNet: the frame plan is baked into the graph -- only for the agent table it was captured with
+            if self._graphed is not None and not torch.equal(data["num_agent"].cpu(), self._graphed[1].num_agent):
+                return False
+        elif not hasattr(self.model, "stpn"):       # FaFNet has no per-batch host plan; the other baselines stay eager
             return False
         return all(g.get("capturable", True) for g in self.optimizer.param_groups)
 
