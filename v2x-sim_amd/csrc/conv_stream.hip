@@ -79,9 +79,15 @@ extern "C" int v2x_debug_stream_timeline(unsigned *dst) {
 // Compile-time experiment switches of stream8g, all measured and left at their neutral values (tools/ab_build.sh):
 //   LPRIO: s_setprio for the load phase (0 = off; 1, 3: no effect beyond box drift);  PF: weight fragments read 1 or 2 blocks ahead (2 =
 //   inline-asm reads with counted lgkmcnt waits: +2.8-3.7 %, slower);  PRIO: s_setprio for the MFMA phase (-0.3 %);  H1: prefetch point (0.0 %);
-//   XCDCO: one channel tile per XCD instead of all channel tiles on every XCD (+0.1-0.7 %: weight locality in L2 does not matter).
+//   XCDCO: one channel tile per XCD instead of all channel tiles on every XCD (+0.1-0.7 %: weight locality in L2 does not matter);
+//   LORDER: 1 = the load phase reads its fragments first and issues its DMAs while they are in flight (+0.2-0.5 %: the LDS latency of the
+//   load phase is not on the critical path either).  What moves these kernels is the NUMBER of instructions per MFMA (taps per barrier,
+//   fragment reads per wave tile), not where their latencies fall.
 #ifndef V2X_STREAM_LPRIO_BUILD
 #define V2X_STREAM_LPRIO_BUILD 0
+#endif
+#ifndef V2X_STREAM_LORDER_BUILD
+#define V2X_STREAM_LORDER_BUILD 0
 #endif
 #ifndef V2X_STREAM_XCDCO_BUILD
 #define V2X_STREAM_XCDCO_BUILD 0
@@ -732,10 +738,28 @@ int v2x_num_cus() {   // also used by conv_halo_pair.hip
 //   No counted waits, no dummy DMAs.  Persistent over tiles like the kernel above (the ring and the patch fill wrap into the
 //   next tile).  K order is (chunk, kx, ky): the fp32 sums differ from the other streamed kernels in their last bits, so this
 //   form replaces them for a layer everywhere or nowhere (the choice depends on the layer's shape only).
+// the load phase's DMA issue of conv3x3_stream8g_kernel (a macro, not a lambda: captured by reference, `pd` and `nw` went to scratch)
+#define V2X_STREAM8G_ISSUE_DMAS \
+                if (grp == 1) { \
+                    const int ahead = st + 2; \
+                    const int wslot = slot == 0 ? 2 : slot - 1; \
+                    if (ahead < S3) nw = issue_weights(ahead, wslot, wv, 4); \
+                    else if (has_next && ahead - S3 < S3) nw = issue_weights(ahead - S3, wslot, wv, 4); \
+                } else if (fill && kx < 2) { \
+                    const int npieces = hfn ? (PH0 * PW0 * 4 + 63) / 64 : PATCH8_PIECES; \
+_Pragma("unroll") \
+                    for (int t = 0; t < 5; ++t) { \
+                        const int tt = kx * 5 + t; \
+                        if (wv + 4 * tt >= npieces) break; \
+                        int d = pd[0]; \
+_Pragma("unroll") \
+                        for (int u = 1; u < 10; ++u) d = (tt == u) ? pd[u] : d; \
+                        if constexpr ((SDBG & 2) == 0) issue_piece(d, kcn, tt, (gc + 1) & 1); \
+                    } \
+                }
 //   WT (wave tiling): false -- a wave owns ALL BCO channels x 64 pixels (2 rows) of its group's 8x32 pixels: 24 weight + 8 pixel fragment
 //   reads per step; true -- a wave owns HALF the channels x 128 pixels (4 rows): 12 + 12 reads per step for the same 96 MFMAs (-25 % LDS
-//   reads; the step timeline, tools/stream8g_timeline.sh, showed the MFMA phase stretched 1.6x by LDS queueing: 165 KiB of LDS traffic
-//   per interval = 84 % of what the LDS moves in an ideal interval).  Same K order, bit-identical results.
+//   reads: -3.1...3.8 % per layer in the paired A/B).  Same K order, bit-identical results.
 template <int BCO, int EPI, bool WT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8g_kernel(const StreamArgs a) {
     constexpr int TH = 16, TW = 32;
@@ -957,23 +981,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int fjl = ln & 15, fql = ln >> 4;
                 // ---- L: group 1 streams the weights of step st+2 (wrapping into the next tile), group 0 the next chunk's patch
                 int nw = 0;   // weight DMAs this wave issues in this phase
-                if (grp == 1) {
-                    const int ahead = st + 2;
-                    const int wslot = slot == 0 ? 2 : slot - 1;   // (slot + 2) % 3
-                    if (ahead < S3) nw = issue_weights(ahead, wslot, wv, 4);
-                    else if (has_next && ahead - S3 < S3) nw = issue_weights(ahead - S3, wslot, wv, 4);
-                } else if (fill && kx < 2) {
-                    const int npieces = hfn ? (PH0 * PW0 * 4 + 63) / 64 : PATCH8_PIECES;   // the half-resolution patch is 3x smaller
-#pragma unroll
-                    for (int t = 0; t < 5; ++t) {
-                        const int tt = kx * 5 + t;
-                        if (wv + 4 * tt >= npieces) break;       // wave-uniform
-                        int d = pd[0];                          // select by the wave-uniform tt (a run-time index would go to scratch)
-#pragma unroll
-                        for (int u = 1; u < 10; ++u) d = (tt == u) ? pd[u] : d;
-                        if constexpr ((SDBG & 2) == 0) issue_piece(d, kcn, tt, (gc + 1) & 1);
-                    }
-                }
+                if constexpr (V2X_STREAM_LORDER_BUILD == 0) { V2X_STREAM8G_ISSUE_DMAS }
+                __builtin_amdgcn_sched_barrier(0);
                 // pixel fragments of the tap column: B[q * 2 + ch], q = r + ky = 0..3
                 bf16x8_t B[NB];
 #pragma unroll
@@ -999,6 +1008,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int i = 0; i < BT; ++i)
                         A[1][i] = *reinterpret_cast<const bf16x8_t *>(ws + (BT / HCO) * SLICE_BYTES + ((BT % HCO) + i) * 256);
+                }
+                if constexpr (V2X_STREAM_LORDER_BUILD == 1) {   // fragment reads first, DMA issue while they are in flight
+                    __builtin_amdgcn_sched_barrier(0);
+                    V2X_STREAM8G_ISSUE_DMAS
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): fragments in registers before the patch / ring may be overwritten
                 // drain: group 1 -- the weights issued one step ago (everything but this phase's own NWD DMAs; right after an epilogue
