@@ -39,11 +39,18 @@ def build_parser():
     ap.add_argument("--log", action="store_true")
     ap.add_argument("--nworker", default=0, type=int, help="DataLoader workers (parsed dataset)")
     ap.add_argument("--rsu", default=1, type=int, help="parsed dataset: 1 = agent0 (the RSU) takes part, 0 = vehicles only")
+    ap.add_argument("--engine", default="", choices=["", "torch", "hip", "hip-graph"],
+                    help="training graph: torch = PyTorch-ROCm ops (fp32, MIOpen); hip = bf16 NHWC graph on the hand-written kernels "
+                         "(V2X_TRAIN_HIP=1); hip-graph = the same with every step replayed as one hipGraph (V2X_TRAIN_GRAPH=1; FaFNet, and "
+                         "V2VNet while the agent table does not change).  Default: whatever the environment variables say")
     return ap
 
 
 def main(argv=None):
     args = build_parser().parse_args(argv)
+    if args.engine:
+        os.environ["V2X_TRAIN_HIP"] = "0" if args.engine == "torch" else "1"
+        os.environ["V2X_TRAIN_GRAPH"] = "1" if args.engine == "hip-graph" else "0"
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import CatFusion, DiscoNet, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
     from v2x_sim_amd.train.loop import init_for_training, make_optimizer, train_dataset, train_synthetic
