@@ -270,5 +270,20 @@ def test_wide_kernel_equals_256_pixel_kernel_bitwise(device, cfg, monkeypatch):
     monkeypatch.setenv("V2X_STREAM_WIDE", "0")
     ref = run()
     monkeypatch.delenv("V2X_STREAM_WIDE")
+    monkeypatch.setenv("V2X_WIDE3", "0")            # the 1-tap wide form (the 3-tap form walks K in another order: below)
     for _ in range(5):
         assert torch.equal(run(), ref)
+    monkeypatch.delenv("V2X_WIDE3")
+    # default for the plain epilogue: three taps per synchronisation (conv3x3_wide3_kernel), K order (chunk, kx, ky): the same products
+    # summed in another order -> at most one bf16 rounding apart, and bit-stable over launches
+    y3 = run()
+    name = ops.conv_kernel_name(pc, H, W)
+    three = not chain and cup + c >= 96
+    assert name == ("conv3x3_wide3_kernel<64>" if three else "conv3x3_wide_kernel<64, %d>" % (1 if chain else 0)), name
+    if not three:
+        assert torch.equal(y3, ref)
+    else:
+        assert torch.allclose(y3.float(), ref.float(), atol=2e-3, rtol=2 ** -7), float((y3.float() - ref.float()).abs().max())
+        assert float((y3 != ref).float().mean()) < 0.02
+    for _ in range(5):
+        assert torch.equal(run(), y3)

@@ -46,7 +46,7 @@ def main():
     g = torch.Generator().manual_seed(0)
     cases = [("conv6_1: (256 half-res + 128) -> 128 @64", 256, 128, 128, 64, 1, False), ("conv5_1: (512 half-res + 256) -> 256 @32", 512, 256, 256, 32, 1, False),
              ("conv3_2: 256 -> 256 @32", 256, 0, 256, 32, 0, False), ("conv6_2: 128 -> 128 @64", 128, 0, 128, 64, 0, False),
-             ("ConvGRU 512 -> 3x256 @32", 256, 256, 256, 32, 0, True), ("conv7_1: (128 half-res + 64) -> 64 @128", 128, 64, 64, 128, 1, False),
+             ("ConvGRU 512 -> 3x256 @32", 256, 256, 256, 32, 0, True), ("conv7_1: (128 half-res + 64) -> 64 @128", 128, 64, 64, 128, 1, False), ("conv7_2-like: 64 -> 64 @128 (streamed)", 64, 0, 64, 128, 0, False),
              ("halo conv8_2: 32 -> 32 @256", 32, 0, 32, 256, 0, "halo"), ("halo conv7_2: 64 -> 64 @128", 64, 0, 64, 128, 0, "halo"),
              ("halo conv8_1: (64 half-res + 32) -> 32 @256", 64, 32, 32, 256, 1, "halo"),
              ("s2 conv2_1: 64 -> 128 @128 -> 64", 64, 0, 128, 128, 0, "s2"), ("s2 conv3_1: 128 -> 256 @64 -> 32", 128, 0, 256, 64, 0, "s2")]

@@ -1363,6 +1363,198 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     stream_epilogue<BCO, TW, EPI, NF, EPI == SEPI_CHAIN>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain);
 }
 
+// ---- "wide3": the wide form with THREE taps per synchronisation (round 2) -------------------------------------------
+// The step of the kernel above is one tap: 32 MFMAs from 4 weight + 8 pixel fragment reads, one counted wait and one barrier.  Here a
+// step is one tap COLUMN kx of a chunk (the three taps ky = 0..2), as in conv3x3_stream8g_kernel: the 12 pixel fragments of the wave's
+// six patch rows serve all three taps (fragment (row r, tap ky) is row r + ky), so a step is 96 MFMAs from 12 + 12 fragment reads, ONE
+// counted wait and ONE barrier -- a third of the synchronisations and two thirds of the LDS reads per MFMA.  The weight ring holds
+// 3 steps of 3 slices (36 KiB); with the single-buffered 39-KiB patch that is 75 KiB: still two workgroups per CU.  K order is
+// (chunk, kx, ky) like stream8g: results agree with the other streamed kernels to one bf16 rounding, not bitwise.
+template <int BCO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_wide3_kernel(const StreamArgs a) {
+    constexpr int TH = 16, TW = 32, NF = 8, NB = 12;
+    constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
+    constexpr int TCO = BCO / 16;
+    constexpr int SLICE_BYTES = BCO * 64, STEP_BYTES = 3 * SLICE_BYTES;
+    constexpr int PPW = (WPATCH_PIECES + 3) / 4;   // patch pieces per wave (10)
+    static_assert(BCO == 64, "wide form: one 64-row channel tile (one weight piece per wave and tap)");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_ring = smem;                           // 3 x STEP_BYTES
+    char *s_patch = smem + 3 * STEP_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15, fq = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int co_tile = bid % a.n_co_tiles;
+    const int px_tile = bid / a.n_co_tiles;
+    const int txy = a.tiles_x * a.tiles_y;
+    const int n = px_tile / txy;
+    const int trem = px_tile - n * txy;
+    const int ty = trem / a.tiles_x;
+    const int tx = trem - ty * a.tiles_x;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    const int nc0 = a.C0 >> 5, nchunks = (a.C0 + a.C1) >> 5;
+    const int S3 = nchunks * 3;
+    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+
+    int pd[PPW];
+    auto build_pd = [&](bool hf) {
+        int lane_o = lane;   // opaque: see conv3x3_wide_kernel
+        asm volatile("" : "+v"(lane_o));
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            const int L = (wave + 4 * t) * 64 + lane_o;
+            const int pix = L >> 2, phys = L & 3;
+            int d;
+            if (!hf) {
+                const int pr = pix / PW, pc = pix - pr * PW;
+                const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+                const bool ok = pix < PH * PW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                d = ok ? ((((n * a.H + y) * a.W + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
+            } else {
+                const int Hs = a.H >> 1, Ws = a.W >> 1;
+                const int pr = pix / PW0, pc = pix - pr * PW0;
+                const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+                const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+                d = ok ? ((((n * Hs + y) * Ws + x) << 5) | ((phys ^ PSWZ(pc)) << 3)) : -1;
+            }
+            pd[t] = d;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    int frow[NF], ct[2][3];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) frow[f] = 4 * wave + (f >> 1);
+    auto build_ct = [&](bool hf) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = c * 16 + fj;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int pc = hf ? (((col + kx - 1) >> 1) + 1) : (col + kx);
+                ct[c][kx] = ((pc << 2) + (fq ^ PSWZ(pc))) * 16;
+            }
+        }
+    };
+
+    const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
+    auto issue_weights = [&](int st) {   // step st = (chunk st / 3, tap column st % 3): this wave's piece of each of the three tap slices
+        const int kc = st / 3, kx = st - kc * 3;
+        const int slot = st % 3;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+            glds16s(wsrc + (size_t)(kc * 9 + ky * 3 + kx) * (BCO * 32), s_ring + slot * STEP_BYTES + ky * SLICE_BYTES + wave * 1024);
+    };
+    auto issue_patch = [&](int kc, bool hf) {
+        const bool first = kc < nc0;
+        const uint16_t *src = first ? a.in0 : a.in1;
+        const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
+        const int npieces = hf ? (PH0 * PW0 * 4 + 63) / 64 : WPATCH_PIECES;
+#pragma unroll
+        for (int t = 0; t < PPW; ++t) {
+            if (wave + 4 * t >= npieces) break;              // wave-uniform
+            int d = pd[t];
+            asm volatile("" : "+v"(d));
+            const unsigned off = (unsigned)(d >> 5) * cs + (unsigned)((first ? kc : kc - nc0) * 32 + (d & 31));
+            glds16s(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + (wave + 4 * t) * 1024);
+        }
+    };
+
+    f32x4_t acc[TCO][NF];
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    issue_weights(0);   // S3 >= 6 (two chunks at least)
+    issue_weights(1);
+
+    int st = 0;
+    bool cur_half = false;
+    for (int kc = 0; kc < nchunks; ++kc) {
+        const bool half = (kc < nc0) && a.up0;
+        const int sh = half ? 1 : 0, row_bytes = (half ? PW0 : PW) * 64;
+        if (kc == 0 || half != cur_half) {   // wave-uniform
+            build_pd(half);
+            build_ct(half);
+            cur_half = half;
+        }
+        // ---- chunk boundary: everyone has left the previous chunk's patch -> refill, drain (also the weights in flight), meet
+        if (kc > 0) __builtin_amdgcn_s_barrier();
+        issue_patch(kc, half);
+        wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        int rowoff[NB / 2];   // patch rows 4*wave + q, q = r + ky = 0..5
+#pragma unroll
+        for (int q = 0; q < NB / 2; ++q) rowoff[q] = (((4 * wave + q - sh) >> sh) + sh) * row_bytes;
+#pragma unroll 1
+        for (int kx = 0; kx < 3; ++kx, ++st) {
+            if (kx > 0) {
+                // this step's three slices have landed (the step after it may be in flight); everyone is done with the slot of step st - 1
+                if (st + 1 < S3) wait_vmcnt<3>();
+                else wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+            }
+            if (st + 2 < S3) issue_weights(st + 2);
+            const char *ws = s_ring + (st % 3) * STEP_BYTES + (fq * BCO + fj) * 16;
+            bf16x8_t fb[NB], fa[2][TCO];
+            const int c0 = kx == 0 ? ct[0][0] : (kx == 1 ? ct[0][1] : ct[0][2]);
+            const int c1 = kx == 0 ? ct[1][0] : (kx == 1 ? ct[1][1] : ct[1][2]);
+#pragma unroll
+            for (int q = 0; q < NB / 2; ++q) {
+                fb[q * 2] = *reinterpret_cast<const bf16x8_t *>(s_patch + rowoff[q] + c0);
+                fb[q * 2 + 1] = *reinterpret_cast<const bf16x8_t *>(s_patch + rowoff[q] + c1);
+            }
+#pragma unroll
+            for (int i = 0; i < TCO; ++i) fa[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                auto mma = [&](int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = i0; i < i1; ++i)
+#pragma unroll
+                        for (int f = 0; f < NF; ++f)
+                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ky & 1][i], fb[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
+                };
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ky < 2) {
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i) fa[(ky + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(ws + (ky + 1) * SLICE_BYTES + i * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, TCO);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    stream_epilogue<BCO, TW, SEPI_BF16, NF, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr);
+}
+
+template <int BCO>
+static int launch_wide3(const StreamArgs &a, hipStream_t s) {
+    constexpr int smem = 3 * 3 * BCO * 64 + WPATCH_BYTES;   // 75 KiB: two workgroups per CU
+    static v2x_once_per_device attr_once;
+    auto kern = &conv3x3_wide3_kernel<BCO>;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_wide3_kernel");
+    return V2X_OK;
+}
+
 template <int BCO, int EPI>
 static int launch_wide(const StreamArgs &a, hipStream_t s) {
     constexpr int smem = RING * BCO * 64 + WPATCH_BYTES + (EPI == SEPI_CHAIN ? chain_lds_bytes<BCO>() : 0);   // 55 KiB (+8.5 chained): two workgroups per CU
@@ -1467,6 +1659,10 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
         if (!(e && e[0] == '0')) {
             a.tiles_y = d->H / 16;
             a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
+            // three taps per synchronisation for the plain epilogue and >= 3 chunks (paired A/B: conv7_1, 6 chunks, 507 -> 481 us per 160 maps;
+            // a 2-chunk 64 -> 64 layer 276 -> 280 us: the longer step's fill does not amortise); V2X_WIDE3=0 keeps the 1-tap form
+            const char *e3 = getenv("V2X_WIDE3");
+            if (!chain && ((d->C0 + d->C1) >> 5) >= 3 && !(e3 && e3[0] == '0')) return launch_wide3<64>(a, s);
             return chain ? launch_wide<64, SEPI_CHAIN>(a, s) : launch_wide<64, SEPI_BF16>(a, s);
         }
     }

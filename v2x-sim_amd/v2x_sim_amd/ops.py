@@ -57,6 +57,8 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         epi = 2 if pc.epilogue == V2X_EPI_GRU else (1 if pc.Cout2 else 0)
         if W % 32 == 0 and H % 16 == 0 and rows == 64 and pc.epilogue == V2X_EPI_BF16 and (pc.C0 + pc.C1) >= 64 \
                 and os.environ.get("V2X_STREAM_WIDE", "1") != "0":
+            if epi == 0 and (pc.C0 + pc.C1) >= 96 and os.environ.get("V2X_WIDE3", "1")[:1] != "0":
+                return "conv3x3_wide3_kernel<64>"          # 128 pixels per wave, three taps per synchronisation
             return "conv3x3_wide_kernel<64, %d>" % epi   # 128 pixels per wave (conv_stream.hip)
         if W % 32 == 0 and H % 16 == 0 and rows in (96, 128) \
                 and not os.environ.get("V2X_STREAM_WAVES", "").startswith("4"):
