@@ -47,6 +47,7 @@ def main():
     cases = [("conv6_1: (256 half-res + 128) -> 128 @64", 256, 128, 128, 64, 1, False), ("conv5_1: (512 half-res + 256) -> 256 @32", 512, 256, 256, 32, 1, False),
              ("conv3_2: 256 -> 256 @32", 256, 0, 256, 32, 0, False), ("conv6_2: 128 -> 128 @64", 128, 0, 128, 64, 0, False),
              ("ConvGRU 512 -> 3x256 @32", 256, 256, 256, 32, 0, True), ("conv7_1: (128 half-res + 64) -> 64 @128", 128, 64, 64, 128, 1, False), ("conv7_2-like: 64 -> 64 @128 (streamed)", 64, 0, 64, 128, 0, False),
+             ("conv2_2 -> conv3d_2 chain: 128 -> 128 -> 128 @64", 128, 0, 128, 64, 0, "chain"),
              ("halo conv8_2: 32 -> 32 @256", 32, 0, 32, 256, 0, "halo"), ("halo conv7_2: 64 -> 64 @128", 64, 0, 64, 128, 0, "halo"),
              ("halo conv8_1: (64 half-res + 32) -> 32 @256", 64, 32, 32, 256, 1, "halo"),
              ("s2 conv2_1: 64 -> 128 @128 -> 64", 64, 0, 128, 128, 0, "s2"), ("s2 conv3_1: 128 -> 256 @64 -> 32", 128, 0, 256, 64, 0, "s2")]
@@ -56,6 +57,10 @@ def main():
             w = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
             pc = packing.pack_conv_halo(name, w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, C0=c0 if c1 else c0 + c1, C1=c1, relu=True,
                                         device=dev)
+        elif gru == "chain":
+            w = torch.randn(cout, c0, 3, 3, generator=g) * 0.05
+            ch = (torch.randn(cout, cout, 1, 1, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, True)
+            pc = packing.pack_conv_stream(name, w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, C0=c0, relu=True, chain=ch, device=dev)
         elif gru == "s2":
             w = torch.randn(cout, c0, 3, 3, generator=g) * 0.05
             pc = packing.pack_conv_stream(name, w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, C0=c0, relu=True, stride=2, device=dev)
@@ -94,7 +99,8 @@ def main():
         d = t[:, 1] - t[:, 0]
         print("%-44s A %.1f us  B %.1f us  B-A %+.1f us (%+.2f %%, s.e. %.2f %%)  outputs %s" % (
             name, t[:, 0].mean(), t[:, 1].mean(), d.mean(), 100 * d.mean() / t[:, 0].mean(), 100 * d.std() / np.sqrt(reps) / t[:, 0].mean(),
-            "bit-identical" if same else "DIFFER"))
+            "bit-identical" if same else "DIFFER (max |d| %.3g of max |y| %.3g, %.2f %% of the entries)" % (
+                float((outs[0].float() - outs[1].float()).abs().max()), float(outs[0].float().abs().max()), 100 * float((outs[0] != outs[1]).float().mean()))))
 
 
 if __name__ == "__main__":

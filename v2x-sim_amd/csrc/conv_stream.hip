@@ -770,7 +770,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int STEP_BYTES = 3 * SLICE_BYTES;            // one tap column of a chunk
     constexpr int NWD = (3 * W_PIECES + 3) / 4;            // weight DMAs per wave of GROUP 1 and step (6 at 128 rows, 5 at 96)
     constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;   // output-store instructions per wave and tile
-    static_assert(EPI != SEPI_CHAIN, "the chained epilogue stays on conv3x3_stream8_kernel (its operands need the LDS)");
+    static_assert(EPI != SEPI_CHAIN, "the chained epilogue stays on conv3x3_stream8_kernel (its operands need the LDS; from L2: +5.3 %)");
     static_assert(TCO % 2 == 0 && PH * PW * 4 <= (PATCH8_PIECES - 1) * 64, "half taps; patch fits its buffer");
     constexpr int AT = WT ? HCO : TCO;                     // accumulator tiles of a wave: channel tiles x pixel fragments
     constexpr int NF = WT ? 8 : 4;
@@ -1647,6 +1647,8 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
             if (grouped && wt >= 1 && d->epilogue != V2X_EPI_GRU) return launch_stream8g<128, SEPI_BF16, true>(a, s);
             if (grouped && wt >= 2 && d->epilogue == V2X_EPI_GRU) return launch_stream8g<96, SEPI_GRU, true>(a, s);
             if (d->epilogue == V2X_EPI_GRU) return grouped ? launch_stream8g<96, SEPI_GRU>(a, s) : launch_stream8<96, SEPI_GRU>(a, s);
+            // (measured and rejected: the chained layer on the three-taps form with the second GEMM's weights read from L2 -- 410 -> 432 us, +5.3 %
+            // in the paired A/B: the epilogue's drain and L2 reads cost more than the 12-step layer gains from fewer barriers)
             if (chain) return launch_stream8<128, SEPI_CHAIN>(a, s);
             return grouped ? launch_stream8g<128, SEPI_BF16>(a, s) : launch_stream8<128, SEPI_BF16>(a, s);
         }
