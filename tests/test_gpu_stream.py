@@ -287,3 +287,43 @@ def test_wide_kernel_equals_256_pixel_kernel_bitwise(device, cfg, monkeypatch):
         assert float((y3 != ref).float().mean()) < 0.02
     for _ in range(5):
         assert torch.equal(run(), y3)
+
+
+@pytest.mark.parametrize("layer", ["conv5_1", "conv6_1", "conv7_1", "convgru", "conv2_1"])
+def test_full_size_properties_batch_equivariance_and_scaling(device, layer):
+    """Size-independent properties at the BENCH size (one half-batch = 320 maps; the oracle cannot follow there):
+    (a) the batch is a set -- permuting the maps permutes the outputs, bit for bit (the persistent kernels walk tiles of many maps per
+        workgroup: nothing may leak across maps or depend on a map's position in the launch);
+    (b) exact homogeneity under power-of-two scaling for the plain layers -- y(4 x) == 4 y(x) bitwise with shift = 0 (fp32 accumulation and
+        bf16 rounding commute with a power of two, ReLU is positively homogeneous), which pins every tap's weight to ITS pixel: a dropped or
+        doubled tap at some tile border would survive (a) but not the comparison with torch on the small cases above -- this ties the two."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(len(layer) * 7)
+    N = 320
+    if layer == "convgru":
+        w = torch.randn(768, 512, 3, 3, generator=g) * 0.02
+        pc = packing.pack_gru_stream("g", w, torch.randn(768, generator=g) * 0.1, torch.randn(768, generator=g) * 0.1, C0=256, C1=256, device=device)
+        xs = [torch.relu(torch.randn(N, 32, 32, 256, generator=g)).to(torch.bfloat16).to(device) for _ in range(2)]
+        plain = False
+    else:
+        c0, c1, cout, hw, up, stride = {"conv5_1": (512, 256, 256, 32, 1, 1), "conv6_1": (256, 128, 128, 64, 1, 1), "conv7_1": (128, 64, 64, 128, 1, 1),
+                                        "conv2_1": (64, 0, 128, 128, 0, 2)}[layer]
+        if hw == 128:
+            N = 160
+        w = torch.randn(cout, c0 + c1, 3, 3, generator=g) * (2.0 / ((c0 + c1) * 9)) ** 0.5
+        pc = packing.pack_conv_stream(layer, w, torch.rand(cout, generator=g) + 0.5, torch.zeros(cout), C0=c0 if c1 else c0 + c1, C1=c1, up0=up, relu=True,
+                                      stride=stride, device=device)
+        h0 = hw // 2 if up else hw
+        xs = [torch.relu(torch.randn(N, h0, h0, c0, generator=g)).to(torch.bfloat16).to(device)]
+        if c1:
+            xs.append(torch.relu(torch.randn(N, hw, hw, c1, generator=g)).to(torch.bfloat16).to(device))
+        plain = True
+    run = lambda t: ops.conv2d(pc, *t)
+    y = run(xs)
+    perm = torch.randperm(N, generator=g).to(device)
+    yp = run([t[perm].contiguous() for t in xs])
+    assert torch.equal(yp, y[perm]), "%s: outputs depend on the position of a map in the batch" % layer
+    if plain:
+        y4 = run([(t.float() * 4).to(torch.bfloat16) for t in xs])
+        assert torch.equal(y4.float(), y.float() * 4), "%s: y(4x) != 4 y(x)" % layer
+        assert float(y.float().abs().max()) > 0.1
