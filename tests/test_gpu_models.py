@@ -407,3 +407,39 @@ def test_sharded_when2com_equals_unsharded_bitwise(device):
     assert torch.equal(torch.cat([o["cls"] for o in outs]), ref["cls"])
     assert torch.equal(torch.cat([o["loc"] for o in outs]), ref["loc"])
     assert torch.equal(outs[0]["coef"], ref["coef"])
+
+
+def test_full_size_end_to_end_properties(device):
+    """The bench's half-batch (64 frames x 5 agents x 65 536 points -> logits) through size-independent properties, bit for bit:
+    (a) a sweep is a SET of points: shuffling every cloud's points changes nothing (occupancy and therefore logits);
+    (b) the frames of a batch are independent: permuting the frames (sweeps, poses, agent table together) permutes the logits.
+    Both involve every kernel of the path (voxeliser, pair kernel, all conv kernels, warp + ConvGRU, heads) at the size the
+    headline number is measured on."""
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+    from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
+    A, Bt, n = 5, 64, 65536
+    pm, _ = build(V2VNet, R.V2VNet, device)
+    sh = AgentShard(A, Bt, 0, 1)
+    rn = ShardedV2VNet(pm, sh)
+    nat = torch.full((Bt, A), A)
+    plan = sh.fusion_plan(nat, device)
+    g = torch.Generator().manual_seed(5)
+    pts = torch.from_numpy(synthetic_points(A * Bt, n, seed=123)).to(device)          # item = agent * Bt + frame
+    cnt = torch.full((A * Bt,), n, dtype=torch.int32, device=device)
+    trans = torch.from_numpy(synthetic_poses(Bt, A, seed=124)).to(device)
+    with torch.no_grad():
+        ref = rn.forward_points(pts, cnt, trans, plan)
+        cls_ref, loc_ref = ref["cls"].clone(), ref["loc"].clone()
+        del ref
+        # (a) shuffle the points inside every cloud (one permutation per cloud)
+        order = torch.argsort(torch.rand(A * Bt, n, generator=g), dim=1).to(device)
+        pts_s = torch.gather(pts, 1, order[:, :, None].expand(-1, -1, pts.shape[2]))
+        got = rn.forward_points(pts_s, cnt, trans, plan)
+        assert torch.equal(got["cls"], cls_ref) and torch.equal(got["loc"], loc_ref), "the logits depend on the order of the points in a sweep"
+        del got, pts_s, order
+        # (b) permute the frames
+        perm = torch.randperm(Bt, generator=g)
+        item = (torch.arange(A)[:, None] * Bt + perm[None, :]).reshape(-1).to(device)   # new item a * Bt + f' <- old item a * Bt + perm[f']
+        got = rn.forward_points(pts[item].contiguous(), cnt, trans[perm.to(device)].contiguous(), plan)
+        assert torch.equal(got["cls"], cls_ref[item]) and torch.equal(got["loc"], loc_ref[item]), "the logits of a frame depend on its position in the batch"
