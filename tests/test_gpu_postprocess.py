@@ -230,3 +230,53 @@ def test_rotated_nms_on_device_vs_oracle(device):
         got = index_r[i, :int(count_r[i])].cpu().numpy()
         assert np.array_equal(np.sort(got), np.sort([d["index"] for d in ref])), i
     assert int(count_r.sum()) > int(count_s.sum())
+
+
+@pytest.mark.parametrize("rotated", [False, True])
+def test_full_size_postprocess_properties(device, rotated):
+    """Row f-1 at the bench size (320 maps x 393 216 anchors; the python oracle needs minutes per map there) through properties:
+    (a) sortedness -- the kept detections of every map come out by descending score;
+    (b) idempotence -- running the post-processing again on ONLY the kept anchors (every other score pushed below the threshold) keeps
+        exactly the same anchors in the same order: survivors do not suppress each other;
+    (c) the batch is a set -- permuting the maps permutes the results bit for bit."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.utils import postprocess as P
+    cfg = Config("test")
+    anchors = P.build_anchor_map(cfg)
+    X, Y, A = anchors.shape[:3]
+    n_small = 8
+    cls_s, loc_s = _synthetic_logits(n_small, X, Y, A, n_obj=60, seed=11)
+    n = 320
+    rep = np.arange(n) % n_small
+    cls = torch.from_numpy(cls_s).to(device)[torch.from_numpy(rep).to(device)].contiguous()
+    loc = torch.from_numpy(loc_s).to(device)[torch.from_numpy(rep).to(device)].contiguous()
+    # make the 40 copies of a map differ: a per-map offset on the foreground logit (changes scores, keeps the objects)
+    off = torch.linspace(0.0, 0.5, n, device=device).view(n, 1)
+    cls[:, :, 1] += off
+    anc = torch.from_numpy(anchors.reshape(-1, 6)).to(device)
+    boxes, scores, index, count = ops.det_postprocess(cls, loc, anc, 0.7, 0.01, 4096, rotated=rotated)
+    cnt = count.cpu().numpy()
+    assert (cnt > 20).all() and (cnt < 4096).all()
+    sc = scores.cpu().numpy()
+    for i in range(n):
+        assert np.all(np.diff(sc[i, :cnt[i]]) <= 0), "map %d: kept scores not sorted" % i
+    # (b) only the survivors stay above the threshold
+    keep = torch.zeros((n, cls.shape[1]), dtype=torch.bool, device=device)
+    for i in range(n):
+        keep[i, index[i, :cnt[i]].long()] = True
+    cls2 = cls.clone()
+    cls2[:, :, 1] = torch.where(keep, cls[:, :, 1], torch.full_like(cls[:, :, 1], -20.0))
+    cls2[:, :, 0] = torch.where(keep, cls[:, :, 0], torch.full_like(cls[:, :, 0], 20.0))
+    b2, s2, i2, c2 = ops.det_postprocess(cls2, loc, anc, 0.7, 0.01, 4096, rotated=rotated)
+    assert torch.equal(c2, count)
+    for i in range(n):
+        assert torch.equal(i2[i, :cnt[i]], index[i, :cnt[i]]) and torch.equal(b2[i, :cnt[i]], boxes[i, :cnt[i]]), i
+    # (c) permutation of the maps
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(1)).to(device)
+    b3, s3, i3, c3 = ops.det_postprocess(cls[perm].contiguous(), loc[perm].contiguous(), anc, 0.7, 0.01, 4096, rotated=rotated)
+    assert torch.equal(c3, count[perm])
+    pc = perm.cpu().numpy()
+    for k in range(0, n, 7):
+        m = cnt[pc[k]]
+        assert torch.equal(i3[k, :m], index[pc[k], :m]) and torch.equal(s3[k, :m], scores[pc[k], :m])
