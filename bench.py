@@ -437,7 +437,7 @@ def main():
     else:
         kernels = None
 
-    latency = configs = None
+    latency = configs = training = None
     if rank == 0 and world == 1 and not args.no_extras and not force_dist:
         # free the step's graphs and buffers first: the extras build their own
         for h in halves:
@@ -454,6 +454,11 @@ def main():
             configs = bc.run_configs(64, 5, dev)
         except Exception as e:  # the headline record must not die with a side table
             configs = {"error": repr(e)}
+        try:
+            torch.cuda.empty_cache()
+            training = bc.run_training(dev)
+        except Exception as e:
+            training = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -475,7 +480,7 @@ def main():
                                    if world > 1 else "single GPU, no collective",
                        "exec_mode": exec_mode, "hip_graph": bool(mode)},
             "ranks_seen": ranks_seen, "exposed_exchange_ms_per_step": exposed_all,
-            "roofline": roofline, "cpu_baseline": cpu, "latency": latency, "configs": configs, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "latency": latency, "configs": configs, "training": training, "kernels": kernels,
         }
     if use_dist:
         dist.destroy_process_group()

@@ -140,3 +140,63 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def run_training(device, frames=2, agents=5, reps=5):
+    """Row f-3 in the bench line: one FaFNet / V2VNet training step (forward, loss, backward, Adam; `frames` x `agents` maps of synthetic scenes) on
+    (a) the fp32 PyTorch-ROCm graph (MIOpen), (b) the bf16 NHWC graph on the hand-written kernels (V2X_TRAIN_HIP=1), (c) FaFNet: the same replayed as
+    one hipGraph.  -> {model: {engine: ms per step}}"""
+    import os
+
+    import torch
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet, V2VNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.graph_step import GraphedTrainStep
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    cfg = Config("train")
+    data = synthetic_batch_on_device(cfg, frames, agents, seed=1, device=device)
+    saved = {k: os.environ.get(k) for k in ("V2X_TRAIN_HIP", "V2X_TRAIN_GRAPH")}
+
+    def timed(fn):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    out = {"maps_per_step": frames * agents}
+    try:
+        for name, cls, kw in (("FaFNet", FaFNet, dict(kd_flag=0, num_agent=agents)), ("V2VNet", V2VNet, dict(num_agent=agents))):
+            model = init_for_training(cls(cfg, **kw), seed=0).to(device).train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+
+            def step():
+                res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], frames)
+                loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+            rec = {}
+            for flag, label in (("0", "fp32 PyTorch-ROCm graph (MIOpen) ms"), ("1", "bf16 NHWC graph on the HIP kernels ms")):
+                os.environ["V2X_TRAIN_HIP"] = flag
+                rec[label] = timed(step)
+            if name == "FaFNet":
+                os.environ["V2X_TRAIN_HIP"] = "1"
+                opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=device), capturable=True)
+                g = GraphedTrainStep(model, opt_c, data, frames)
+                rec["the same as one replayed hipGraph ms"] = timed(lambda: g(data))
+                del g
+            out[name] = rec
+            del model, opt
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return out
