@@ -22,6 +22,12 @@
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
+typedef const __attribute__((address_space(3))) float lds_cf_t;     // LDS-resident float (explicit address space: a generic pointer would be a FLAT load)
+typedef const __attribute__((address_space(3))) f32x4_t lds_cf4_t;   // (the builtin vector type: HIP's float4 class cannot be read through an address-space pointer)
+__device__ __forceinline__ float4 lds_ld4(lds_cf_t *p) {
+    const f32x4_t v = *reinterpret_cast<lds_cf4_t *>(p);
+    return make_float4(v[0], v[1], v[2], v[3]);
+}
 
 __device__ __forceinline__ void glds16s(const void *g, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
@@ -86,6 +92,9 @@ extern "C" int v2x_debug_stream_timeline(unsigned *dst) {
 #ifndef V2X_STREAM_LPRIO_BUILD
 #define V2X_STREAM_LPRIO_BUILD 0
 #endif
+#ifndef V2X_STREAM_LSS_BUILD
+#define V2X_STREAM_LSS_BUILD 1
+#endif
 #ifndef V2X_STREAM_LORDER_BUILD
 #define V2X_STREAM_LORDER_BUILD 0
 #endif
@@ -131,9 +140,14 @@ __device__ __forceinline__ void stage_chain(const StreamArgs &a, char *cl) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // before the counted-DMA regime starts; read after many barriers
 }
 
+// lss != nullptr (plain and GRU epilogues): scale / shift (or the GRU's bias quadruples) of the rows this wave owns, staged in LDS by the
+// kernel -- lss[c] = scale, lss[lss_stride + c] = shift for local row c (GRU: float4 per local hidden channel).  vmcnt is in order: read
+// from global memory these few bytes can only be waited for together with every DMA the load phases have in flight, and in the one-workgroup-
+// per-CU ping-pong kernels nobody fills that gap (the other group is parked at the barrier).
 template <int BCO, int TW, int EPI, int NF = 4, bool CL = false>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&acc)[BCO / 16][NF], int co_tile, int n, int y0,
-                                                int x0, const int (&frow)[NF], int fj, int fq, const char *cl = nullptr) {
+                                                int x0, const int (&frow)[NF], int fj, int fq, const char *cl = nullptr,
+                                                lds_cf_t *lss = nullptr, int lss_stride = 0) {
     constexpr int TCO = BCO / 16;
     if constexpr (EPI == SEPI_GRU) {
         // rows are (r,z,n) triples of 16 hidden channels: tiles 3g, 3g+1, 3g+2  (packing.pack_gru_stream)
@@ -143,7 +157,8 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             if (hc >= a.Cout) continue;
             float4 bias[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bias[r] = reinterpret_cast<const float4 *>(a.scale)[hc + r];
+            for (int r = 0; r < 4; ++r)
+                bias[r] = lss ? lds_ld4(lss + (g * 16 + fq * 4 + r) * 4) : reinterpret_cast<const float4 *>(a.scale)[hc + r];
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 float h[4];
@@ -243,8 +258,8 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
         for (int i = 0; i < TCO; ++i) {
             const int co = co_tile * BCO + i * 16 + fq * 4;
             if (co >= a.Cout) continue;
-            const float4 sc = *reinterpret_cast<const float4 *>(a.scale + co);
-            const float4 sf = *reinterpret_cast<const float4 *>(a.shift + co);
+            const float4 sc = lss ? lds_ld4(lss + i * 16 + fq * 4) : *reinterpret_cast<const float4 *>(a.scale + co);
+            const float4 sf = lss ? lds_ld4(lss + lss_stride + i * 16 + fq * 4) : *reinterpret_cast<const float4 *>(a.shift + co);
 #pragma unroll
             for (int f = 0; f < NF; ++f) {
                 float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
@@ -920,7 +935,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // epilogue parameters of this workgroup's channel tile -> LDS (1 KiB behind the patches): see stream_epilogue
+    float *s_ss = reinterpret_cast<float *>(smem + 3 * STEP_BYTES + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0));
+    // (paired A/B: plain layers -0.7 ... -3.4 %, most on the 12-step layers; the ConvGRU +0.7 % -- its table stays in global memory)
+    if constexpr (V2X_STREAM_LSS_BUILD != 0 && EPI != SEPI_GRU) {
+        if constexpr (EPI == SEPI_GRU) {
+            constexpr int NH = BCO / 3;                    // hidden channels of the tile
+            for (int i = tid; i < NH * 4; i += 512) {
+                const int hc = co_tile * NH + (i >> 2);
+                s_ss[i] = hc < a.Cout ? a.scale[(size_t)hc * 4 + (i & 3)] : 0.f;
+            }
+        } else {
+            for (int i = tid; i < BCO; i += 512) {
+                const int co = co_tile * BCO + i;
+                s_ss[i] = co < a.Cout ? a.scale[co] : 0.f;
+                s_ss[BCO + i] = co < a.Cout ? a.shift[co] : 0.f;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();            // half-step offset
 
@@ -1127,8 +1160,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if constexpr (WT) stream_epilogue<BCO / 2, TW, EPI, 8, false>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr);
-        else stream_epilogue<BCO, TW, EPI, 4, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr);
+        constexpr bool LSS = V2X_STREAM_LSS_BUILD != 0 && EPI != SEPI_GRU;
+        // (the GRU's table is float4 per hidden channel: a channel half of the tile starts BCO / 6 channels = 4 * BCO / 6 floats in)
+        if constexpr (WT)
+            stream_epilogue<BCO / 2, TW, EPI, 8, false>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr,
+                                                        LSS ? (lds_cf_t *)s_ss + coh * (EPI == SEPI_GRU ? 4 * (BCO / 6) : BCO / 2) : (lds_cf_t *)nullptr, BCO);
+        else stream_epilogue<BCO, TW, EPI, 4, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, LSS ? (lds_cf_t *)s_ss : (lds_cf_t *)nullptr, BCO);
         if (!has_next) break;
         tile = next;
         n = nn;
@@ -1147,7 +1184,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 template <int BCO, int EPI, bool WT = false>
 static int launch_stream8g(const StreamArgs &a, hipStream_t s) {
-    constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0);   // 152 KiB at 128 rows, 134 KiB at 96
+    constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0) + 1024;   // 153 KiB at 128 rows, 135 KiB at 96 (+1 KiB: epilogue parameters)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static v2x_once_per_device attr_once;
     auto kern = &conv3x3_stream8g_kernel<BCO, EPI, WT>;
