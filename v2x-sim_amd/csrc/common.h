@@ -60,3 +60,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const v2x_f32x2_t v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, v2x_bf16x2_t));
 }
+
+// ReLU on two packed bf16: as 16-bit integers a negative bf16 (sign bit set) is a negative short, so max(x, 0) per half is ONE v_pk_max_i16
+// for two values; fmaxf on the fp32 values costs two instructions EACH (it canonicalises its operand first).  relu(round(v)) == round(relu(v)):
+// rounding is monotone and -0 maps to +0 either way.
+typedef short v2x_s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t v2x_relu_bf16x2(uint32_t x) {
+    const v2x_s16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(v2x_s16x2_t, x), (v2x_s16x2_t){0, 0});
+    return __builtin_bit_cast(uint32_t, r);
+}
+

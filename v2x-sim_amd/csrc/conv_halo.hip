@@ -389,15 +389,13 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                     const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
                     float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
                     float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
-                    if (a.relu) {
-                        v0 = fmaxf(v0, 0.f);
-                        v1 = fmaxf(v1, 0.f);
-                        v2 = fmaxf(v2, 0.f);
-                        v3 = fmaxf(v3, 0.f);
-                    }
                     uint2 o;
                     o.x = pack_bf16x2(v0, v1);
                     o.y = pack_bf16x2(v2, v3);
+                    if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
+                        o.x = v2x_relu_bf16x2(o.x);
+                        o.y = v2x_relu_bf16x2(o.y);
+                    }
                     uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) +
                                     ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co;
                     *reinterpret_cast<uint2 *>(dst) = o;
@@ -435,15 +433,17 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                         h[half * 4 + 2] = acc[i][f][2] * sc[i].z + sf[i].z;
                         h[half * 4 + 3] = acc[i][f][3] * sc[i].w + sf[i].w;
                     }
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) h[e] = fmaxf(h[e], 0.f);
-                    }
                     uint4 p;
                     p.x = pack_bf16x2(h[0], h[1]);
                     p.y = pack_bf16x2(h[2], h[3]);
                     p.z = pack_bf16x2(h[4], h[5]);
                     p.w = pack_bf16x2(h[6], h[7]);
+                    if (a.relu) {   // ReLU on the packed bf16 pairs
+                        p.x = v2x_relu_bf16x2(p.x);
+                        p.y = v2x_relu_bf16x2(p.y);
+                        p.z = v2x_relu_bf16x2(p.z);
+                        p.w = v2x_relu_bf16x2(p.w);
+                    }
                     hb[s] = __builtin_bit_cast(bf16x8_t, p);
                 }
                 const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
@@ -777,15 +777,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         h[hf * 4 + 2] = acc[i][f][2] * sc.z + sf.z;
                         h[hf * 4 + 3] = acc[i][f][3] * sc.w + sf.w;
                     }
-                    if (a.relu) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) h[e] = fmaxf(h[e], 0.f);
-                    }
                     uint4 p;
                     p.x = pack_bf16x2(h[0], h[1]);
                     p.y = pack_bf16x2(h[2], h[3]);
                     p.z = pack_bf16x2(h[4], h[5]);
                     p.w = pack_bf16x2(h[6], h[7]);
+                    if (a.relu) {   // ReLU on the packed bf16 pairs
+                        p.x = v2x_relu_bf16x2(p.x);
+                        p.y = v2x_relu_bf16x2(p.y);
+                        p.z = v2x_relu_bf16x2(p.z);
+                        p.w = v2x_relu_bf16x2(p.w);
+                    }
                     hb[ks] = __builtin_bit_cast(bf16x8_t, p);
                 }
                 const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
@@ -823,15 +825,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
                 float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
                 float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
-                if (a.relu) {
-                    v0 = fmaxf(v0, 0.f);
-                    v1 = fmaxf(v1, 0.f);
-                    v2 = fmaxf(v2, 0.f);
-                    v3 = fmaxf(v3, 0.f);
-                }
                 uint2 o;
                 o.x = pack_bf16x2(v0, v1);
                 o.y = pack_bf16x2(v2, v3);
+                if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
+                    o.x = v2x_relu_bf16x2(o.x);
+                    o.y = v2x_relu_bf16x2(o.y);
+                }
                 uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co;
                 *reinterpret_cast<uint2 *>(dst) = o;
             }

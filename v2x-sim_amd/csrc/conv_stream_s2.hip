@@ -218,15 +218,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         for (int f = 0; f < 2; ++f) {
             float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
             float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
-            if (a.relu) {
-                v0 = fmaxf(v0, 0.f);
-                v1 = fmaxf(v1, 0.f);
-                v2 = fmaxf(v2, 0.f);
-                v3 = fmaxf(v3, 0.f);
-            }
             uint2 o;
             o.x = pack_bf16x2(v0, v1);
             o.y = pack_bf16x2(v2, v3);
+            if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
+                o.x = v2x_relu_bf16x2(o.x);
+                o.y = v2x_relu_bf16x2(o.y);
+            }
             const size_t pix = (size_t)(n * Ho + y0 + (f ? frow1 : frow0)) * Wo + x0 + (TW == 32 ? f * 16 : 0) + fj;
             *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
         }
@@ -343,15 +341,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int f = 0; f < 2; ++f) {
                 float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
                 float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
-                if (a.relu) {
-                    v0 = fmaxf(v0, 0.f);
-                    v1 = fmaxf(v1, 0.f);
-                    v2 = fmaxf(v2, 0.f);
-                    v3 = fmaxf(v3, 0.f);
-                }
                 uint2 o;
                 o.x = pack_bf16x2(v0, v1);
                 o.y = pack_bf16x2(v2, v3);
+                if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
+                    o.x = v2x_relu_bf16x2(o.x);
+                    o.y = v2x_relu_bf16x2(o.y);
+                }
                 const size_t pix = (size_t)(n * Ho + y0 + wave) * Wo + x0 + f * 16 + fj;
                 *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
             }
