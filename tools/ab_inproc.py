@@ -50,10 +50,21 @@ def main():
              ("conv2_2 -> conv3d_2 chain: 128 -> 128 -> 128 @64", 128, 0, 128, 64, 0, "chain"),
              ("halo conv8_2: 32 -> 32 @256", 32, 0, 32, 256, 0, "halo"), ("halo conv7_2: 64 -> 64 @128", 64, 0, 64, 128, 0, "halo"),
              ("halo conv8_1: (64 half-res + 32) -> 32 @256", 64, 32, 32, 256, 1, "halo"),
+             ("halo heads: 32 -> 64 -> 12 | 36 fp32 @256", 32, 0, 64, 256, 0, "heads"),
              ("s2 conv2_1: 64 -> 128 @128 -> 64", 64, 0, 128, 128, 0, "s2"), ("s2 conv3_1: 128 -> 256 @64 -> 32", 128, 0, 256, 64, 0, "s2")]
     n = 320
     for name, c0, c1, cout, hw, up, gru in cases:
-        if gru == "halo":
+        split = 0
+        if gru == "heads":
+            from v2x_sim_amd._lib import V2X_EPI_F32
+            w = torch.randn(64, 32, 3, 3, generator=g) * 0.05
+            w2 = torch.zeros(48, 64, 1, 1)
+            w2[:12, :32] = torch.randn(12, 32, 1, 1, generator=g) * 0.1
+            w2[12:, 32:] = torch.randn(36, 32, 1, 1, generator=g) * 0.1
+            pc = packing.pack_conv_halo(name, w, torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1, relu=True,
+                                        chain=(w2, torch.ones(48), torch.randn(48, generator=g) * 0.1, False), epilogue=V2X_EPI_F32, device=dev)
+            split = 12
+        elif gru == "halo":
             w = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
             pc = packing.pack_conv_halo(name, w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, C0=c0 if c1 else c0 + c1, C1=c1, relu=True,
                                         device=dev)
@@ -82,7 +93,7 @@ def main():
         outs = []
         for v in (0, 1):
             use(v)
-            outs.append(ops.conv2d(pc, x0, x1).clone())
+            outs.append((lambda r: torch.cat([t.reshape(-1) for t in r]) if isinstance(r, tuple) else r.clone())(ops.conv2d(pc, x0, x1, split=split)))
         same = torch.equal(outs[0], outs[1])
         reps = 40
         t = np.zeros((reps, 2))
@@ -91,7 +102,7 @@ def main():
                 use(v)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                ops.conv2d(pc, x0, x1)
+                ops.conv2d(pc, x0, x1, split=split)
                 e1.record()
                 torch.cuda.synchronize()
                 if r >= 0:

@@ -69,4 +69,10 @@ __device__ __forceinline__ uint32_t v2x_relu_bf16x2(uint32_t x) {
     const v2x_s16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(v2x_s16x2_t, x), (v2x_s16x2_t){0, 0});
     return __builtin_bit_cast(uint32_t, r);
 }
+// The same with the floor in a register: floor = 0 -> ReLU, floor = 0x80008000 (two int16 minima) -> identity.  A kernel whose `relu` flag is a
+// run-time argument pays ONE instruction per pair either way instead of a max plus a select.
+__device__ __forceinline__ uint32_t v2x_relu_bf16x2_floor(uint32_t x, uint32_t floor_bits) {
+    const v2x_s16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(v2x_s16x2_t, x), __builtin_bit_cast(v2x_s16x2_t, floor_bits));
+    return __builtin_bit_cast(uint32_t, r);
+}
 

@@ -109,6 +109,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     static_assert(W_BYTES % 1024 == 0, "weights are moved 1 KiB per wave instruction");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t relu_floor = a.relu ? 0u : 0x80008000u;   // v2x_relu_bf16x2_floor: identity when the layer has no ReLU
     char *s_w = smem;
     char *s_patch = smem + W_BYTES;  // DB: two buffers of PATCH_BYTES, else one
     // Plain epilogue: scale/shift live in LDS.  vmcnt is in-order, so a GLOBAL load in the epilogue can only be waited for
@@ -392,10 +393,8 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                     uint2 o;
                     o.x = pack_bf16x2(v0, v1);
                     o.y = pack_bf16x2(v2, v3);
-                    if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
-                        o.x = v2x_relu_bf16x2(o.x);
-                        o.y = v2x_relu_bf16x2(o.y);
-                    }
+                    o.x = v2x_relu_bf16x2_floor(o.x, relu_floor);   // ReLU on the packed bf16 pairs; the floor is the identity when the layer has none
+                    o.y = v2x_relu_bf16x2_floor(o.y, relu_floor);
                     uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) +
                                     ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co;
                     *reinterpret_cast<uint2 *>(dst) = o;
@@ -438,12 +437,10 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                     p.y = pack_bf16x2(h[2], h[3]);
                     p.z = pack_bf16x2(h[4], h[5]);
                     p.w = pack_bf16x2(h[6], h[7]);
-                    if (a.relu) {   // ReLU on the packed bf16 pairs
-                        p.x = v2x_relu_bf16x2(p.x);
-                        p.y = v2x_relu_bf16x2(p.y);
-                        p.z = v2x_relu_bf16x2(p.z);
-                        p.w = v2x_relu_bf16x2(p.w);
-                    }
+                    p.x = v2x_relu_bf16x2_floor(p.x, relu_floor);
+                    p.y = v2x_relu_bf16x2_floor(p.y, relu_floor);
+                    p.z = v2x_relu_bf16x2_floor(p.z, relu_floor);
+                    p.w = v2x_relu_bf16x2_floor(p.w, relu_floor);
                     hb[s] = __builtin_bit_cast(bf16x8_t, p);
                 }
                 const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
@@ -535,6 +532,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int N_STORES = (COUT2 ? TCO2 : TCO) * 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t relu_floor = a.relu ? 0u : 0x80008000u;   // v2x_relu_bf16x2_floor: identity when the layer has no ReLU
     char *s_w = smem;
     char *s_patch = smem + W_BYTES;                       // [group][PATCH_BYTES]
     float *s_ss = reinterpret_cast<float *>(smem + W_BYTES + 2 * PATCH_BYTES);
@@ -782,12 +780,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     p.y = pack_bf16x2(h[2], h[3]);
                     p.z = pack_bf16x2(h[4], h[5]);
                     p.w = pack_bf16x2(h[6], h[7]);
-                    if (a.relu) {   // ReLU on the packed bf16 pairs
-                        p.x = v2x_relu_bf16x2(p.x);
-                        p.y = v2x_relu_bf16x2(p.y);
-                        p.z = v2x_relu_bf16x2(p.z);
-                        p.w = v2x_relu_bf16x2(p.w);
-                    }
+                    p.x = v2x_relu_bf16x2_floor(p.x, relu_floor);
+                    p.y = v2x_relu_bf16x2_floor(p.y, relu_floor);
+                    p.z = v2x_relu_bf16x2_floor(p.z, relu_floor);
+                    p.w = v2x_relu_bf16x2_floor(p.w, relu_floor);
                     hb[ks] = __builtin_bit_cast(bf16x8_t, p);
                 }
                 const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
@@ -828,10 +824,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 uint2 o;
                 o.x = pack_bf16x2(v0, v1);
                 o.y = pack_bf16x2(v2, v3);
-                if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
-                    o.x = v2x_relu_bf16x2(o.x);
-                    o.y = v2x_relu_bf16x2(o.y);
-                }
+                o.x = v2x_relu_bf16x2_floor(o.x, relu_floor);   // ReLU on the packed bf16 pairs; the floor is the identity when the layer has none
+                o.y = v2x_relu_bf16x2_floor(o.y, relu_floor);
                 uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co;
                 *reinterpret_cast<uint2 *>(dst) = o;
             }

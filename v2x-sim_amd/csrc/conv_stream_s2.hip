@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     static_assert(BCO == 64 || BCO == 128, "channel tiles of 64 or 128");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t relu_floor = a.relu ? 0u : 0x80008000u;   // v2x_relu_bf16x2_floor: identity when the layer has no ReLU
     char *s_ring = smem;
     char *s_patch = smem + S2_RING * SLICE_BYTES;
 
@@ -221,10 +222,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             uint2 o;
             o.x = pack_bf16x2(v0, v1);
             o.y = pack_bf16x2(v2, v3);
-            if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
-                o.x = v2x_relu_bf16x2(o.x);
-                o.y = v2x_relu_bf16x2(o.y);
-            }
+            o.x = v2x_relu_bf16x2_floor(o.x, relu_floor);   // ReLU on the packed bf16 pairs; the floor is the identity when the layer has none
+            o.y = v2x_relu_bf16x2_floor(o.y, relu_floor);
             const size_t pix = (size_t)(n * Ho + y0 + (f ? frow1 : frow0)) * Wo + x0 + (TW == 32 ? f * 16 : 0) + fj;
             *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
         }
@@ -245,6 +244,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     static_assert(BCO == 64, "one 64-row channel tile");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t relu_floor = a.relu ? 0u : 0x80008000u;   // v2x_relu_bf16x2_floor: identity when the layer has no ReLU
     char *s_w = smem;
     char *s_patch = smem + W_BYTES;
     // scale/shift in LDS: a global load between the stores of two channel tiles can only be waited for (in-order vmcnt)
@@ -344,10 +344,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 uint2 o;
                 o.x = pack_bf16x2(v0, v1);
                 o.y = pack_bf16x2(v2, v3);
-                if (a.relu) {   // ReLU on the packed bf16 pairs (common.h: one instruction per two values instead of two per value)
-                    o.x = v2x_relu_bf16x2(o.x);
-                    o.y = v2x_relu_bf16x2(o.y);
-                }
+                o.x = v2x_relu_bf16x2_floor(o.x, relu_floor);   // ReLU on the packed bf16 pairs; the floor is the identity when the layer has none
+                o.y = v2x_relu_bf16x2_floor(o.y, relu_floor);
                 const size_t pix = (size_t)(n * Ho + y0 + wave) * Wo + x0 + f * 16 + fj;
                 *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
             }
