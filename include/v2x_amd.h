@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 10
+#define V2X_AMD_ABI_VERSION 11
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -40,6 +40,16 @@ typedef void *v2x_stream_t; /* hipStream_t */
 
 int v2x_abi_version(void);
 const char *v2x_last_error(void);
+
+/* Kernel-selection switches.  The library picks, per layer shape, the kernel form that measured fastest; a few shapes have a second
+ * form that computes the same result (the bitwise-equality tests and the paired A/B tool compare them).  `name` is one of
+ *   STREAM_WAVES (8 | 4)  STREAM_G  STREAM_WT (0 | 1 | 2)  STREAM_M32  STREAM_PERSIST  STREAM_WIDE  WIDE3  HALO_PP  S2_RESIDENT
+ *   VOXELIZE_LDS  WARP_LDS                                   (0 | 1 unless noted; case-insensitive, an optional "V2X_" prefix is ignored)
+ * Each switch is initialised ONCE, at first use, from the environment variable V2X_<NAME> when that is set; afterwards only
+ * v2x_tuning_set changes it (process-wide, relaxed atomics: set it before the launches it should affect).  No upstream
+ * counterpart (the reference has one implementation per operator).  Unknown name -> V2X_EINVAL. */
+int v2x_tuning_set(const char *name, int value);
+int v2x_tuning_get(const char *name, int *value);
 
 /* ---------------------------------------------------------------- a1: voxel scatter
  * Replaces coperception/utils/data_util.py::voxelize_occupy (range filter,
@@ -199,14 +209,6 @@ int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
  * first->in_format = 1 (bit grid, in_zbits <= 16); H % 8 == 0, W % 32 == 0.  first->out is ignored; the result is
  * bit-identical to v2x_conv2d(first) followed by v2x_conv2d(second). */
 int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream);
-
-/* The decoder's last layer and the detection heads in one launch (conv_tail.hip): replaces Backbone.py::LidarDecoder's
- * conv8_2 + bn8_2 + relu followed by DetModelBase.py::ClassificationHead / SingleRegressionHead.  first: 3x3, stride 1, pad 1,
- * w_layout 1, 32 -> 32, bf16 epilogue, bf16 NHWC input; second: the fused heads descriptor v2x_conv2d takes (w_layout 1, 32 -> 64
- * hidden rows in chain order, Cout2 = 48, V2X_EPI_F32, optional split into two fp32 tensors).  H % 8 == 0, W % 32 == 0, an even
- * number of 8x32 tiles.  first->out is ignored -- the 32-channel map never reaches memory; the logits are bit-identical to
- * v2x_conv2d(first) followed by v2x_conv2d(second). */
-int v2x_conv2d_tail(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-3: backward of the 3x3 stride-1 convolutions
  * Upstream trains through torch.autograd (cuDNN / MIOpen kernels behind nn.Conv2d.backward, tools/det/train_codet.py).

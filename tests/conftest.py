@@ -43,3 +43,34 @@ def oracle_c_lib():
 def device():
     import torch
     return torch.device("cuda:0")
+
+
+class _Tune:
+    """tune("STREAM_G", 0) sets a kernel-selection / engine switch (v2x_sim_amd.tuning); tune.reset("STREAM_G") puts back the value it
+    had when the test started.  Everything touched is restored at teardown."""
+
+    def __init__(self):
+        self._orig = {}
+
+    def __call__(self, name, value):
+        from v2x_sim_amd import tuning
+        old = tuning.set(name, int(value))
+        self._orig.setdefault(name.upper(), old)
+
+    def reset(self, name):
+        from v2x_sim_amd import tuning
+        if name.upper() in self._orig:
+            tuning.set(name, self._orig[name.upper()])
+
+    def restore(self):
+        from v2x_sim_amd import tuning
+        for k, v in self._orig.items():
+            tuning.set(k, v)
+        self._orig.clear()
+
+
+@pytest.fixture
+def tune():
+    t = _Tune()
+    yield t
+    t.restore()

@@ -45,7 +45,6 @@ def _kernels(asm):
     ("conv_halo.hip", "_Z19conv3x3_halo_kernel", 3),
     ("conv_halo.hip", "_Z22conv3x3_halo_sb_kernel", 2),
     ("conv_halo.hip", "_Z22conv3x3_halo_pp_kernel", 3),
-    ("conv_tail.hip", "_Z19conv3x3_tail_kernel", 1),
     ("conv_halo_pair.hip", "_Z24conv3x3_pair_bits_kernel", 1),
     ("conv_igemm.hip", "_Z17conv_igemm_kernel", 9),
 ])

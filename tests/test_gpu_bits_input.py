@@ -58,7 +58,7 @@ def test_points_path_equals_dense_bev_path(device):
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 256), (2, 8, 32), (5, 40, 96), (1, 64, 32)])
-def test_conv_pair_equals_two_layers_bitwise(device, shape, monkeypatch):
+def test_conv_pair_equals_two_layers_bitwise(device, shape, tune):
     """conv_halo_pair.hip (conv_pre_1 -> conv_pre_2 in one launch, intermediate in LDS) against the two stand-alone
     bit-grid / bf16 halo launches: bit-identical, incl. single-tile maps (every halo pixel is zero padding), extents with
     many border tiles and dense / empty occupancy."""
@@ -80,5 +80,5 @@ def test_conv_pair_equals_two_layers_bitwise(device, shape, monkeypatch):
     fused = ops.conv2d_pair(stage[0].halo, stage[1].halo, bits, 13)
     ref = ops.conv2d(stage[1].halo, ops.conv2d(stage[0].halo, bits, zbits=13))
     assert torch.equal(fused, ref)
-    monkeypatch.setenv("V2X_CONV_PAIR", "0")
+    tune("CONV_PAIR", 0)
     assert not ops.pair_eligible(stage[0].halo, stage[1].halo, bits, 13)

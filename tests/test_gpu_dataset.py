@@ -249,19 +249,20 @@ def test_seg_drivers_on_a_parsed_dataset(device, tmp_path, capsys):
 
 
 @pytest.mark.parametrize("engine,com", [("hip", "v2v"), ("hip-graph", "lowerbound")])
-def test_train_driver_engine_flag(device, tmp_path, capsys, monkeypatch, engine, com):
+def test_train_driver_engine_flag(device, tmp_path, capsys, engine, com, tune):
     """tools/det/train_codet.py --engine hip | hip-graph: the driver trains on the hand-written kernels (bf16 NHWC graph; hip-graph = every
     step one hipGraph replay), the loss falls, and the checkpoint loads into the inference path."""
     import importlib.util
-    monkeypatch.setenv("V2X_TRAIN_HIP", "0")      # main() sets these; monkeypatch restores them afterwards
-    monkeypatch.setenv("V2X_TRAIN_GRAPH", "0")
+    tune("TRAIN_HIP", 0)      # main() sets these; the fixture restores them afterwards
+    tune("TRAIN_GRAPH", 0)
     tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "det")
     spec = importlib.util.spec_from_file_location("train_codet", os.path.join(tools, "train_codet.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     logdir = os.path.join(str(tmp_path), "log")
     mod.main(["--data", "synthetic", "--com", com, "--steps", "60", "--batch", "1", "--num_agent", "2", "--logpath", logdir, "--engine", engine, "--log"])
-    assert os.environ["V2X_TRAIN_HIP"] == "1" and os.environ["V2X_TRAIN_GRAPH"] == ("1" if engine == "hip-graph" else "0")
+    from v2x_sim_amd import tuning
+    assert tuning.get("TRAIN_HIP") == 1 and tuning.get("TRAIN_GRAPH") == (1 if engine == "hip-graph" else 0)
     out = capsys.readouterr().out
     print(out[-300:])
     ckpt = torch.load(os.path.join(logdir, "epoch_1.pth"), map_location="cpu")

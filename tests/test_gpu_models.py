@@ -68,24 +68,6 @@ def test_fafnet_lowerbound(device):
     assert got["cls"].shape == (2, 256 * 256 * 6, 2) and got["loc"].shape == (2, 256, 256, 6, 1, 6)
 
 
-def test_fused_tail_equals_unfused_models_bitwise(device, monkeypatch):
-    """DetModelBase.decode_heads: conv8_2 + heads as one launch (default) vs V2X_CONV_TAIL=0 (LidarDecoder.run +
-    get_cls_loc_result): the same bits for FaFNet and V2VNet end to end."""
-    from v2x_sim_amd.models.det import FaFNet, V2VNet
-    A, B = 5, 1
-    _, bev, T = make_inputs(A, B, n_pts=8000, seed=3)
-    nat = torch.full((B, A), A)
-    for P, O in ((FaFNet, R.FaFNet), (V2VNet, R.V2VNet)):
-        pm, _ = build(P, O, device)
-        outs = {}
-        for flag in ("0", "1"):
-            monkeypatch.setenv("V2X_CONV_TAIL", flag)
-            with torch.no_grad():
-                outs[flag] = pm(bev.to(device)) if P is FaFNet else pm(bev.to(device), T.to(device), nat, batch_size=B)
-        monkeypatch.delenv("V2X_CONV_TAIL")
-        assert torch.equal(outs["0"]["cls"], outs["1"]["cls"]) and torch.equal(outs["0"]["loc"], outs["1"]["loc"]), P.__name__
-
-
 def test_upperbound_full_size_points_to_logits(device):
     """BASELINE.json config 1 at its full size, end to end: 5 agents x 65 536 points, every ego grid = the union of all five
     sweeps moved into the ego frame (25 transform + scatter jobs, ONE launch) -> FaFNet on the HIP path.  The occupancy
@@ -123,7 +105,7 @@ def test_upperbound_full_size_points_to_logits(device):
             check(got["loc"], ref["loc"], tol, "upperbound loc emu=%s" % emu)
 
 
-@pytest.mark.parametrize("gnn_iter,source", [(1, "initial"), (2, "updated")])
+@pytest.mark.parametrize("gnn_iter,source", [(1, "initial"), (2, "updated"), (3, "initial"), (3, "updated")])
 def test_v2vnet(device, gnn_iter, source):
     from v2x_sim_amd.models.det import V2VNet
     A, B = 5, 1
@@ -138,6 +120,36 @@ def test_v2vnet(device, gnn_iter, source):
             ref = om(bev, T, nat, batch_size=B)
             check(got["cls"], ref["cls"], tol, "v2vnet cls emu=%s" % emu)
             check(got["loc"], ref["loc"], tol, "v2vnet loc emu=%s" % emu)
+
+
+@pytest.mark.parametrize("name,layer", [("V2VNet", 2), ("V2VNet", 4), ("MeanFusion", 2), ("MeanFusion", 4), ("MaxFusion", 2), ("CatFusion", 4)])
+def test_fusion_at_layer_2_and_4(device, name, layer):
+    """The drivers' --layer flag (SURVEY section 5 flag surface): fusion at the 128-channel 64x64 map (layer 2) and at the 512-channel
+    16x16 map (layer 4) instead of the default layer 3 -- V2VNet (ConvGRU of that width: layer_channel follows the layer) and the
+    FusionBase family, ragged batch, against both precisions of the oracle at the end-to-end tolerance of layer 3."""
+    from v2x_sim_amd.models import det
+    from v2x_sim_amd.models.det.base import LAYER_SHAPES
+    A, B = 5, 2
+    kw = dict(layer=layer)
+    if name == "V2VNet":
+        kw["layer_channel"] = LAYER_SHAPES[layer][0]
+    pm, om = build(getattr(det, name), getattr(R, name), device, seed=6 + layer, pkw=kw, okw=kw)
+    _, bev, T = make_inputs(A, B, n_pts=8000, seed=20 + layer)
+    nat = torch.tensor([[5] * A, [4] * A])
+    with torch.no_grad():
+        got = pm(bev.to(device), T.to(device), nat, batch_size=B)
+        for emu, tol in ((True, TOL_EMU), (False, TOL_FP32)):
+            om.emulate_bf16 = emu
+            ref = om(bev, T, nat, batch_size=B)
+            check(got["cls"], ref["cls"], tol, "%s layer %d cls emu=%s" % (name, layer, emu))
+            check(got["loc"], ref["loc"], tol, "%s layer %d loc emu=%s" % (name, layer, emu))
+    # the flag must matter: the oracle fusing at layer 3 with the same weights gives logits far outside the tolerance just met
+    if name in ("MeanFusion", "MaxFusion"):                      # (no layer-dependent parameters)
+        o3 = getattr(R, name)(layer=3).eval()
+        o3.load_state_dict(om.state_dict())
+        with torch.no_grad():
+            other = o3(bev, T, nat, batch_size=B)
+        assert float((other["cls"] - ref["cls"]).abs().max()) > 3 * TOL_FP32[0] * float(ref["cls"].abs().max())
 
 
 @pytest.mark.parametrize("name", ["SumFusion", "MeanFusion", "MaxFusion", "CatFusion", "DiscoNet"])

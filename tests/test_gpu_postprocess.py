@@ -203,6 +203,11 @@ def test_match_detections_and_map_on_device_vs_oracle(device):
                                            torch.from_numpy(cnt).to(device), gts, thr)
             ap_o, ngt, ndet = PR.eval_map(dets_o, gts_o, thr)
             assert abs(ap_d - ap_o) < 1e-9 and info["num_gt"] == ngt and info["num_det"] == ndet, (trial, thr, ap_d, ap_o)
+    # a negative count is the device post-processing's overflow signal: scoring such a map as "no detections" would be silent -> refused
+    bad = torch.from_numpy(cnt).to(device).clone()
+    bad[1] = -5
+    with pytest.raises(ValueError, match="overflowed"):
+        P.eval_map_device(torch.from_numpy(det).to(device), torch.from_numpy(sc).to(device), bad, gts, 0.5)
     # flags themselves on a hand case: two detections on one GT -> the better-scored one wins, the other is a false positive
     det = torch.tensor([[[0, 0, 2, 4, 0.0], [0.1, 0, 2, 4, 0.0], [9, 9, 2, 4, 0.0]]], device=device)
     gt = torch.tensor([[[0, 0, 2, 4, 0.0]]], device=device)

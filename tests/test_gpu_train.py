@@ -10,7 +10,8 @@
 2. A V2VNet trained for 600 steps on synthetic scenes (utils/synthetic_scene.py) has separated scores, so mAP stops being
    chaotic in the rounding noise (contrast tests/test_gpu_map.py): the HIP inference path (bf16 kernels + device-side
    NMS) and the fp32 CPU oracle (+ host NMS), loaded with the SAME trained weights, are compared on mAP@0.5 and mAP@0.7
-   over 100 held-out agent-frames (~1 030 ground-truth cars).  Target = BASELINE.json's +-0.2 points; measured 0.00-0.16.
+   over 320 held-out agent-frames (~3 400 ground-truth cars); the reference side is decoded, suppressed and scored by the
+   independent oracle/postprocess_ref.py, and BASELINE.json's +-0.2 points at IoU 0.5 are ASSERTED (round 3).
 PARITY UNPINNED w.r.t. the reference (no reference code or checkpoints in /root/reference); the oracle is build-owned.
 """
 import numpy as np
@@ -22,7 +23,8 @@ from oracle import coperception_ref as R
 pytestmark = pytest.mark.gpu
 
 TRAIN_STEPS = 600
-EVAL_FRAMES = 20
+EVAL_FRAMES = 16          # frames per evaluation chunk (x 5 agents)
+EVAL_CHUNKS = 4           # 4 x 16 x 5 = 320 held-out agent-frames, ~3 400 ground-truth cars
 
 
 def test_train_graph_loss_and_grads_match_oracle(device):
@@ -89,54 +91,67 @@ def test_loss_decreases(trained):
 
 
 def test_trained_detector_map_parity(trained, device):
+    """The mAP half of BASELINE.json's metric, north_star tolerance: |mAP@0.5(HIP path) - mAP@0.5(reference path)| <= 0.2 points, ASSERTED.
+    HIP side = the product end to end (bf16 kernels + device decode / NMS).  Reference side = the fp32 CPU oracle's logits through
+    oracle/postprocess_ref.py::detect, and BOTH detection sets are scored by oracle/postprocess_ref.py::eval_map -- no product code
+    decodes, suppresses or scores the reference side (round 2 used the product's own apply_nms_det / eval_map on both sides: a bug
+    there would have cancelled).  >= 3 000 ground-truth boxes, so one flipped borderline detection moves the AP by <= 0.035 points
+    and 0.2 is a meaningful bound rather than training luck."""
+    from oracle import postprocess_ref as PR
     from v2x_sim_amd.train.loop import synthetic_batch_on_device
     from v2x_sim_amd.utils import postprocess as P
     from v2x_sim_amd.utils.CoDetModule import FaFModule
     cfg, model, _ = trained
-    A, B = model.agent_num, EVAL_FRAMES
-    data = synthetic_batch_on_device(cfg, B, A, seed=424242, device=device, with_targets=False)
+    A = model.agent_num
     module = FaFModule(model, None, cfg, None, 0)
-    _, _, _, seq = module.predict_all(data, B, validation=False, num_agent=A)          # HIP engine (bf16 kernels) + device NMS
     om = R.V2VNet().eval()
     om.load_state_dict(model.state_dict())
-    with torch.no_grad():
-        ref = om(data["bev_seq"].cpu(), data["trans_matrices"].cpu(), data["num_agent"], batch_size=B)
-    det_hip, det_ref, gts = [], [], []
-    for k in range(A):
-        for b in range(B):
-            row = k * B + b
-            det_hip.append(seq[k][b])
-            det_ref.append(P.apply_nms_det(ref["loc"][row].numpy(), ref["cls"][row].numpy(), module.anchors,
-                                           module.score_thr, module.nms_thr))
-            gts.append(P.box_corners(data["gt_boxes"][k][b].astype(np.float64)))
-    n_gt = sum(g.shape[0] for g in gts)
+    anchors = np.asarray(module.anchors, dtype=np.float64).reshape(-1, 6)
+    det_hip, det_ref, gts, prod_hip, prod_gts = [], [], [], [], []
+    n_diff = n_pair = 0
+    worst_xy = 0.0
+    for chunk in range(EVAL_CHUNKS):
+        B = EVAL_FRAMES
+        data = synthetic_batch_on_device(cfg, B, A, seed=424242 + chunk, device=device, with_targets=False)
+        _, _, _, seq = module.predict_all(data, B, validation=False, num_agent=A)          # HIP engine (bf16 kernels) + device NMS
+        with torch.no_grad():
+            ref = om(data["bev_seq"].cpu(), data["trans_matrices"].cpu(), data["num_agent"], batch_size=B)
+        for k in range(A):
+            for b in range(B):
+                row = k * B + b
+                dh = seq[k][b]
+                dr = PR.detect(ref["cls"][row].numpy(), ref["loc"][row].numpy().reshape(-1, 6), anchors, module.score_thr, module.nms_thr)
+                det_hip.append([(float(s), PR.corners_of(tuple(float(v) for v in bx))) for s, bx in zip(dh["scores"], dh["boxes"])])
+                det_ref.append([(d["score"], d["corners"]) for d in dr])
+                gts.append([PR.corners_of(tuple(float(v) for v in g)) for g in data["gt_boxes"][k][b]])
+                prod_hip.append(dh)
+                prod_gts.append(P.box_corners(data["gt_boxes"][k][b].astype(np.float64)))
+                # detection-level agreement: same boxes, centimetres apart
+                n_diff += abs(len(dr) - dh["boxes"].shape[0])
+                for d in dr:
+                    if dh["boxes"].shape[0]:
+                        dist = np.hypot(dh["boxes"][:, 0] - d["box"][0], dh["boxes"][:, 1] - d["box"][1])
+                        if dist.min() < 1.0:
+                            worst_xy, n_pair = max(worst_xy, float(dist.min())), n_pair + 1
+    n_gt = sum(len(g) for g in gts)
+    assert n_gt >= 3000, n_gt
     out = {}
     for iou in (0.5, 0.7):
-        ap_ref, info = P.eval_map(det_ref, gts, iou)
-        ap_hip, info_h = P.eval_map(det_hip, gts, iou)
+        ap_ref, ngt_r, ndet_r = PR.eval_map(det_ref, gts, iou)
+        ap_hip, ngt_h, ndet_h = PR.eval_map(det_hip, gts, iou)
+        ap_prod, _ = P.eval_map(prod_hip, prod_gts, iou)                                    # the product's own scorer on its own detections
         out[iou] = (100 * ap_ref, 100 * ap_hip)
-        print("trained V2VNet, %d held-out agent-frames, %d gt boxes: mAP@%.1f  oracle-fp32 %.2f (%d det)  HIP %.2f (%d det)"
-              % (A * B, n_gt, iou, 100 * ap_ref, info["num_det"], 100 * ap_hip, info_h["num_det"]))
-    # detection-level agreement: same number of boxes per agent-frame (+-1) and, for boxes that pair up, centimetre agreement
-    worst_xy, n_pair, n_diff = 0.0, 0, 0
-    for dh, dr in zip(det_hip, det_ref):
-        n_diff += abs(dh["boxes"].shape[0] - dr["boxes"].shape[0])
-        for bx in dh["boxes"]:
-            if dr["boxes"].shape[0]:
-                d = np.hypot(dr["boxes"][:, 0] - bx[0], dr["boxes"][:, 1] - bx[1])
-                if d.min() < 1.0:
-                    worst_xy, n_pair = max(worst_xy, float(d.min())), n_pair + 1
+        print("trained V2VNet, %d held-out agent-frames, %d gt boxes: mAP@%.1f  oracle-fp32 %.3f (%d det)  HIP %.3f (%d det)  [product scorer on the HIP detections: %.3f]"
+              % (len(gts), n_gt, iou, 100 * ap_ref, ndet_r, 100 * ap_hip, ndet_h, 100 * ap_prod))
+        assert abs(ap_prod - ap_hip) < 1e-6, (iou, ap_prod, ap_hip)                         # product scorer == independent scorer
     print("detections: %d paired HIP/oracle boxes, worst centre distance %.3f m, %d unpaired" % (n_pair, worst_xy, n_diff))
     assert n_diff <= 0.02 * n_pair and worst_xy < 0.10      # measured 0.03-0.06 m across training runs (bf16 vs fp32 regression)
     assert out[0.5][0] > 30.0, "the detector did not train"
-    # north_star: mAP within +-0.2 of the reference.  One borderline detection (score within bf16 noise of the 0.7 threshold)
-    # is worth ~0.1 points here (100 / ~1 030 ground-truth boxes; 0.16 in the 621-box runs quoted below); measured over training runs (training on the GPU is not bit-reproducible):
-    # |dmAP| = 0.00, 0.16, 0.00 (0, 1, 0 of ~585 detections flipped).  The assertion allows three flipped detections so that
-    # the suite does not depend on the luck of a training run; the printed line is the evidence.
     for iou in (0.5, 0.7):
-        print("|dmAP@%.1f| = %.2f  (target 0.2: %s)" % (iou, abs(out[iou][0] - out[iou][1]),
-                                                        "met" if abs(out[iou][0] - out[iou][1]) <= 0.2 else "NOT met in this run"))
-        assert abs(out[iou][0] - out[iou][1]) <= 0.5, out
+        d = abs(out[iou][0] - out[iou][1])
+        print("|dmAP@%.1f| = %.3f points (north_star: 0.2; one flipped detection = %.3f)" % (iou, d, 100.0 / n_gt))
+    assert abs(out[0.5][0] - out[0.5][1]) <= 0.2, out           # BASELINE.json north_star: mAP@0.5 within +-0.2 of the reference
+    assert abs(out[0.7][0] - out[0.7][1]) <= 0.5, out           # (mAP@0.7 is not in the north_star: box-regression rounding moves IoUs across 0.7)
 
 
 def test_collaboration_helps(device):
@@ -257,7 +272,7 @@ def test_seg_train_then_test_drivers(device, tmp_path, capsys):
     assert agree > 0.995
 
 
-def test_training_on_the_hip_graph_reaches_the_same_detector(trained, device, monkeypatch):
+def test_training_on_the_hip_graph_reaches_the_same_detector(trained, device, tune):
     """Row f-3 end to end: the SAME training run (V2VNet, 600 Adam steps, same seeds, same synthetic scenes) on the bf16 NHWC HIP graph
     (V2X_TRAIN_HIP=1: conv forward / dgrad / wgrad and batch-statistics BN on libv2x_amd.so) instead of the fp32 MIOpen graph.  Both
     detectors are then served by the HIP inference engine on the same held-out scenes: the loss curve ends at the same level (+-25 %)
@@ -269,13 +284,13 @@ def test_training_on_the_hip_graph_reaches_the_same_detector(trained, device, mo
     from v2x_sim_amd.utils import postprocess as P
     from v2x_sim_amd.utils.CoDetModule import FaFModule
     cfg, ref_model, ref_hist = trained
-    monkeypatch.setenv("V2X_TRAIN_HIP", "1")
+    tune("TRAIN_HIP", 1)
     import time
     model = init_for_training(V2VNet(cfg), seed=0)
     t0 = time.time()
     hist = train_synthetic(model, cfg, TRAIN_STEPS, frames_per_step=2, lr=1e-3, seed=7, device=device, log=100)
     t_hip = time.time() - t0
-    monkeypatch.delenv("V2X_TRAIN_HIP")
+    tune.reset("TRAIN_HIP")
     last_ref, last_hip = np.mean([h[0] for h in ref_hist[-20:]]), np.mean([h[0] for h in hist[-20:]])
     print("final loss (mean of the last 20 steps): fp32 graph %.4f, HIP graph %.4f; %d steps on the HIP graph took %.1f s incl. scene generation"
           % (last_ref, last_hip, TRAIN_STEPS, t_hip))

@@ -78,7 +78,7 @@ def test_hip_conv_function_forward_dgrad_wgrad(device, N, H, W, Cin, Cout):
     assert not hip_conv.eligible(torch.zeros(64, 32, 3, 3), (2, 2), (1, 1), 256, 256)       # stride 2: MIOpen keeps it
 
 
-def test_training_step_on_hip_conv_kernels(device, monkeypatch):
+def test_training_step_on_hip_conv_kernels(device, tune):
     """V2X_TRAIN_HIP_CONV=1: one FaFNet training step with every eligible 3x3 layer (conv1_2 ... conv7_2: 13 layers) on the HIP
     forward / dgrad / wgrad kernels.  Loss within 1 % and every parameter gradient within 5 % (of the tensor's scale) of the
     all-MIOpen step -- bf16 activations and gradients through ~20 layers, batch-statistics BN in between."""
@@ -93,14 +93,14 @@ def test_training_step_on_hip_conv_kernels(device, monkeypatch):
     model.eval()   # running-statistics BN: batch statistics amplify ReLU flips chaotically (see test_gpu_train.py)
     grads, losses = {}, {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("V2X_TRAIN_HIP_CONV", flag)
+        tune("TRAIN_HIP_CONV", flag)
         model.zero_grad()
         res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
         loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
         loss.backward()
         losses[flag] = float(loss.detach())
         grads[flag] = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
-    monkeypatch.delenv("V2X_TRAIN_HIP_CONV")
+    tune.reset("TRAIN_HIP_CONV")
     print("loss MIOpen %.5f, HIP conv kernels %.5f" % (losses["0"], losses["1"]))
     assert abs(losses["1"] - losses["0"]) <= 1e-2 * abs(losses["0"])
     worst, worst_k = 0.0, ""
@@ -208,7 +208,7 @@ def test_hip_graph_conv_function_vs_autograd(device, N, H, W, Cin, Cout, stride,
     assert torch.allclose(conv_d.bias.grad.cpu(), conv_r.bias.grad, rtol=1e-4, atol=1e-3)
 
 
-def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
+def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch, tune):
     """V2X_TRAIN_HIP=1: a FaFNet training step (batch-statistics BN) on the bf16 NHWC HIP graph against the fp32 MIOpen graph: the
     loss within 2 %, the running statistics of every BN within 2 % of their scale, and parameter gradients that point the same way:
     cosine over all parameters together > 0.95 and no worse than 0.02 below a CONTROL -- the fp32 graph itself with its weights rounded to
@@ -225,7 +225,7 @@ def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
     data = synthetic_batch_on_device(cfg, 1, 2, seed=5, device=device)
     out = {}
     for flag in ("0", "1", "0r"):
-        monkeypatch.setenv("V2X_TRAIN_HIP", flag[0])
+        tune("TRAIN_HIP", int(flag[0]))
         model = copy.deepcopy(base)
         model.train()
         if flag == "0r":   # control: the fp32 graph with its weights rounded to bf16 -- the noise floor of this comparison
@@ -256,7 +256,7 @@ def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
     assert c_hip > 0.95 and c_hip >= c_ctl - 0.02 and abs(n1 - n0) <= 0.1 * n0
     finals = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+        tune("TRAIN_HIP", flag)
         model = copy.deepcopy(base)
         model.train()
         opt = torch.optim.SGD(model.parameters(), lr=2e-3, momentum=0.9)
@@ -269,13 +269,13 @@ def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch):
             opt.step()
             first = float(loss.detach()) if first is None else first
         finals[flag] = (first, float(loss.detach()))
-    monkeypatch.delenv("V2X_TRAIN_HIP")
+    tune.reset("TRAIN_HIP")
     print("30 SGD steps: fp32 graph %.4f -> %.4f, HIP graph %.4f -> %.4f" % (finals["0"] + finals["1"]))
     assert finals["0"][1] < 0.7 * finals["0"][0] and finals["1"][1] < 0.7 * finals["1"][0]
     assert abs(finals["1"][1] - finals["0"][1]) <= 0.15 * finals["0"][1]
 
 
-def test_hip_graph_v2vnet_step(device, monkeypatch):
+def test_hip_graph_v2vnet_step(device, tune):
     """V2VNet on the HIP training graph (encoder / decoder / heads on the kernels, warp + ConvGRU fusion on the fp32 graph in between):
     loss within 2 % of the fp32 graph's, every parameter that is in the graph (the ConvGRU's input weights included) receives a finite gradient,
     and FaFModule.step runs."""
@@ -291,7 +291,7 @@ def test_hip_graph_v2vnet_step(device, monkeypatch):
     data = synthetic_batch_on_device(cfg, 1, 2, seed=6, device=device)
     losses = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+        tune("TRAIN_HIP", flag)
         model = copy.deepcopy(base)
         model.train()
         res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 1)
@@ -310,7 +310,7 @@ def test_hip_graph_v2vnet_step(device, monkeypatch):
     first = module.step(data, 1, num_agent=2)[0]
     for _ in range(9):
         last = module.step(data, 1, num_agent=2)[0]
-    monkeypatch.delenv("V2X_TRAIN_HIP")
+    tune.reset("TRAIN_HIP")
     print("FaFModule.step on the HIP graph: loss %.4f -> %.4f in 10 steps" % (first, last))
     assert np.isfinite(last) and last < first
 
@@ -340,7 +340,7 @@ def test_hip_graph_conv1x1_vs_autograd(device, N, H, W, Cin, Cout, f32_out):
     assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-3)
 
 
-def test_graphed_training_step_equals_eager(device, monkeypatch):
+def test_graphed_training_step_equals_eager(device, tune):
     """train/graph_step.py: the whole HIP-graph training step (forward, loss, backward, optimizer) captured as one hipGraph.  Five replays
     on five different batches reproduce five eager steps from the same start: losses to 1e-6 and final parameters to 1e-6 of each
     tensor's scale (measured: identical digits -- a FaFNet step on the HIP graph has no atomics and no library-chosen algorithm in it,
@@ -351,7 +351,7 @@ def test_graphed_training_step_equals_eager(device, monkeypatch):
     from v2x_sim_amd.train import detection_loss, train_forward
     from v2x_sim_amd.train.graph_step import GraphedTrainStep
     from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
-    monkeypatch.setenv("V2X_TRAIN_HIP", "1")
+    tune("TRAIN_HIP", 1)
     cfg = Config("train")
     base = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=1).to(device)
     batches = [synthetic_batch_on_device(cfg, 1, 2, seed=10 + i, device=device) for i in range(5)]
@@ -396,14 +396,72 @@ def test_graphed_training_step_equals_eager(device, monkeypatch):
     print("graphed step (2 maps): %.2f ms" % ((time.time() - t0) / 20 * 1e3))
 
 
-def test_fafmodule_step_graphed_with_scheduler(device, monkeypatch):
+def test_graphed_step_keeps_optimizer_state_and_survives_epochs(device, tune):
+    """the captured step is built on an optimizer that ALREADY carries moments and step counters (a later epoch, the partial last
+    batch, --resume).  The constructor's warm-up steps must leave that state as they found it: 3 eager Adam steps + 3 graphed ones ==
+    6 eager ones (losses and parameters), and the run's loops -- which make a new FaFModule per call around the run's optimizer --
+    reuse the captured step instead of re-capturing (and re-warming) it every epoch."""
+    import copy
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.graph_step import GraphedTrainStep
+    from v2x_sim_amd.train.loop import init_for_training, make_optimizer, synthetic_batch_on_device, train_synthetic
+    tune("TRAIN_HIP", 1)
+    cfg = Config("train")
+    base = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=5).to(device)
+    batches = [synthetic_batch_on_device(cfg, 1, 2, seed=30 + i, device=device) for i in range(6)]
+
+    def eager_step(model, opt, d):
+        res = train_forward(model, d["bev_seq"], d["trans_matrices"], d["num_agent"], 1)
+        loss = detection_loss(res, d["labels"], d["reg_targets"], d["reg_loss_mask"])[0]
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return float(loss.detach())
+
+    ref = copy.deepcopy(base).train()
+    opt_r = torch.optim.Adam(ref.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True)
+    losses_r = [eager_step(ref, opt_r, d) for d in batches]
+    mixed = copy.deepcopy(base).train()
+    opt_m = torch.optim.Adam(mixed.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True)
+    losses_m = [eager_step(mixed, opt_m, d) for d in batches[:3]]
+    p0 = next(iter(opt_m.state))
+    before = {k: v.clone() for k, v in opt_m.state[p0].items() if torch.is_tensor(v)}
+    assert float(before["step"]) == 3 and float(before["exp_avg_sq"].abs().max()) > 0
+    step = GraphedTrainStep(mixed, opt_m, batches[3], 1)                 # warm-up runs 3 real steps, then must restore
+    for k, v in before.items():
+        assert torch.equal(opt_m.state[p0][k], v), "the warm-up changed the optimizer's %s" % k
+    losses_m += [float(step(d)[0]) for d in batches[3:]]
+    print("6 eager Adam steps  ", ["%.5f" % v for v in losses_r])
+    print("3 eager + 3 graphed ", ["%.5f" % v for v in losses_m])
+    assert np.allclose(losses_m, losses_r, rtol=2e-5)
+    assert float(opt_m.state[p0]["step"]) == 6
+    for (k, pe), (_, pg) in zip(ref.state_dict().items(), mixed.state_dict().items()):
+        if "num_batches_tracked" not in k:
+            assert float((pe.float() - pg.float()).abs().max()) <= 2e-5 * max(float(pe.float().abs().max()), 1e-3), k
+    # two "epochs" through the loop API: one optimizer, a new FaFModule per call, ONE captured step
+    tune("TRAIN_GRAPH", 1)
+    model = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=6).to(device)
+    opt, sched = make_optimizer(model, 1e-3, 8)
+    train_synthetic(model, cfg, 4, frames_per_step=1, seed=7, device=device, agents=2, opt=opt, sched=sched)
+    cache = opt.__dict__["_v2x_graphed_steps"]
+    assert len(cache) == 1
+    first = next(iter(cache.values()))
+    train_synthetic(model, cfg, 4, frames_per_step=1, seed=8, device=device, agents=2, opt=opt, sched=sched)
+    assert len(cache) == 1 and next(iter(cache.values())) is first
+    p1 = next(iter(opt.state))
+    assert float(opt.state[p1]["step"]) == 8                               # 8 real steps, no warm-up step counted, none lost
+
+
+def test_fafmodule_step_graphed_with_scheduler(device, tune):
     """V2X_TRAIN_HIP=1 V2X_TRAIN_GRAPH=1: FaFModule.step replays the captured step; make_optimizer's device-tensor learning rate is updated
     IN PLACE by the scheduler (the captured Adam reads the same tensor), and training on synthetic scenes reduces the loss."""
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import FaFNet
     from v2x_sim_amd.train.loop import init_for_training, make_optimizer, train_synthetic
-    monkeypatch.setenv("V2X_TRAIN_HIP", "1")
-    monkeypatch.setenv("V2X_TRAIN_GRAPH", "1")
+    tune("TRAIN_HIP", 1)
+    tune("TRAIN_GRAPH", 1)
     cfg = Config("train")
     model = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=2).to(device)
     opt, sched = make_optimizer(model, 1e-3, 40)
@@ -432,7 +490,7 @@ def test_fafmodule_step_graphed_with_scheduler(device, monkeypatch):
 
 
 @pytest.mark.parametrize("family", ["when2com", "max", "cat", "disco", "v2v_seg", "faf_seg"])
-def test_hip_graph_other_baselines_loss_parity(device, monkeypatch, family):
+def test_hip_graph_other_baselines_loss_parity(device, family, tune):
     """V2X_TRAIN_HIP=1 for the other detection baselines and the segmentation variants: encoder / decoder / heads on the kernels, their
     cross-agent fusion on the fp32 graph at the fusion layer.  One training-mode step: loss within 2 % of the all-fp32 graph's, finite
     gradients for the same set of parameters, and 15 Adam steps reduce the loss."""
@@ -465,7 +523,7 @@ def test_hip_graph_other_baselines_loss_parity(device, monkeypatch, family):
         return detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
     out = {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("V2X_TRAIN_HIP", flag)
+        tune("TRAIN_HIP", flag)
         model = copy.deepcopy(base).train()
         loss = loss_of(model)
         loss.backward()
@@ -475,7 +533,7 @@ def test_hip_graph_other_baselines_loss_parity(device, monkeypatch, family):
     print("%s: loss fp32 graph %.5f, HIP graph %.5f" % (family, out["0"][0], out["1"][0]))
     assert abs(out["1"][0] - out["0"][0]) <= 2e-2 * abs(out["0"][0])
     assert out["0"][1] == out["1"][1]
-    monkeypatch.setenv("V2X_TRAIN_HIP", "1")
+    tune("TRAIN_HIP", 1)
     model = copy.deepcopy(base).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     first = None
@@ -485,12 +543,12 @@ def test_hip_graph_other_baselines_loss_parity(device, monkeypatch, family):
         loss.backward()
         opt.step()
         first = float(loss.detach()) if first is None else first
-    monkeypatch.delenv("V2X_TRAIN_HIP")
+    tune.reset("TRAIN_HIP")
     print("%s: 15 Adam steps on the HIP graph %.4f -> %.4f" % (family, first, float(loss.detach())))
     assert float(loss.detach()) < first
 
 
-def test_graphed_v2vnet_step(device, monkeypatch):
+def test_graphed_v2vnet_step(device, tune):
     """The captured step for V2VNet (fixed agent table): the frame plan's index tensors come from the warm-up calls' cache, so the capture
     contains no host -> device copy.  Five replays track five eager steps (the fp32 fusion's index_add uses atomics: 1e-3, not bitwise),
     a batch with another agent table is refused, and FaFModule.step falls back to eager for it."""
@@ -500,7 +558,7 @@ def test_graphed_v2vnet_step(device, monkeypatch):
     from v2x_sim_amd.train import detection_loss, train_forward
     from v2x_sim_amd.train.graph_step import GraphedTrainStep
     from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
-    monkeypatch.setenv("V2X_TRAIN_HIP", "1")
+    tune("TRAIN_HIP", 1)
     cfg = Config("train")
     base = init_for_training(V2VNet(cfg, num_agent=3), seed=1).to(device)
     batches = [synthetic_batch_on_device(cfg, 1, 3, seed=20 + i, device=device) for i in range(5)]

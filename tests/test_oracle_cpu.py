@@ -252,3 +252,30 @@ def test_warp_pose_convention_of_synthetic_scenes():
                         plain += ok
     assert n >= 20 and hits == n, (n, hits)
     assert plain < n // 2          # the geometric matrix itself is NOT what the formula expects
+
+
+@pytest.mark.parametrize("with_state", [False, True])
+def test_convgru_cell_is_torch_grucell_per_pixel(with_state):
+    """Pins oracle/ASSUMPTIONS.md row 22 (gate order r, z, n; h' = n + z (h - n); b_hn inside the reset product) to torch's own code:
+    `convolutional_rnn.Conv2dGRUCell` is torch's GRUCell with the two linear maps replaced by convolutions, so with a 1x1 kernel every
+    pixel of the oracle's cell must BE torch.nn.GRUCell on that pixel's channel vector with the same parameters -- and with a 3x3 kernel
+    whose off-centre taps are zero as well."""
+    torch.manual_seed(11)
+    cin, hid = 24, 16
+    ref = torch.nn.GRUCell(cin, hid)
+    x = torch.randn(3, cin, 5, 7)
+    h0 = torch.randn(3, hid, 5, 7) if with_state else None
+    px = x.permute(0, 2, 3, 1).reshape(-1, cin)
+    ph = h0.permute(0, 2, 3, 1).reshape(-1, hid) if with_state else None
+    want = ref(px, ph).reshape(3, 5, 7, hid).permute(0, 3, 1, 2)
+    for k in (1, 3):
+        cell = R.Conv2dGRUCell(cin, hid, k)
+        with torch.no_grad():
+            for name in ("weight_ih", "weight_hh"):
+                w = torch.zeros_like(getattr(cell, name + "_l0"))
+                w[:, :, k // 2, k // 2] = getattr(ref, name)
+                getattr(cell, name + "_l0").copy_(w)
+            cell.bias_ih_l0.copy_(ref.bias_ih)
+            cell.bias_hh_l0.copy_(ref.bias_hh)
+            got = cell(x, h0)
+        assert torch.allclose(got, want, atol=1e-6, rtol=1e-6), float((got - want).abs().max())

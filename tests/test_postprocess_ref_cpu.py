@@ -118,3 +118,22 @@ def test_product_eval_map_equals_the_oracle():
     assert PR.eval_map([[]], [[PR.corners_of((0, 0, 1, 1, 0))]], 0.5)[0] == 0.0
     perfect = [[(0.9, PR.corners_of((0, 0, 2, 4, 0.1)))]]
     assert abs(PR.eval_map(perfect, [[PR.corners_of((0, 0, 2, 4, 0.1))]], 0.7)[0] - 1.0) < 1e-12
+
+
+def test_detect_prefilter_equals_full_scan():
+    """Full-size maps go through a vectorised pre-selection of the anchors near or above the threshold (the exact scalar test still
+    decides each): identical detections to the plain scan, including anchors sitting exactly on the threshold."""
+    import math
+    rng = np.random.default_rng(5)
+    M = 6000
+    cls = rng.normal(0, 1, (M, 2))
+    cls[:, 0] += 2.0                                   # most anchors are background
+    thr = 0.7
+    cls[17] = (0.0, math.log(thr / (1 - thr)))         # on the threshold
+    cls[18] = (0.0, math.log(thr / (1 - thr)) - 1e-9)  # a hair below
+    loc = rng.normal(0, 0.2, (M, 6))
+    anchors = np.concatenate([rng.uniform(-30, 30, (M, 2)), np.tile([[2.0, 4.0, 0.0, 1.0]], (M, 1))], 1)
+    fast = PR.detect(cls, loc, anchors, thr, 0.01)
+    slow = PR.detect(cls.tolist(), loc.tolist(), anchors.tolist(), thr, 0.01)
+    assert [d["index"] for d in fast] == [d["index"] for d in slow] and len(fast) > 20
+    assert all(a["score"] == b["score"] and a["box"] == b["box"] for a, b in zip(fast, slow))

@@ -1,5 +1,6 @@
 #!/bin/bash
-# usage: tools/ab_build.sh <file.hip stem> <macro> <v1> <v2> ...   -> rebuilds with -D<macro>=<v> and runs bench + layer profile for each
+# usage: tools/ab_build.sh <file.hip stem | all> <macro> <kernel-name filter, comma separated> <v1> <v2> ...
+#   -> rebuilds with -D<macro>=<v> and runs bench for each value, printing the per-launch time of the kernels whose name contains a filter term
 cd "$(dirname "$0")/.."
 STEM=$1; MACRO=$2; FILTER=$3; shift 3
 for rep in 1 2; do

@@ -27,20 +27,23 @@ def load_variant(path):
 
 def main():
     libs = [load_variant(sys.argv[1]), load_variant(sys.argv[2])]
-    # optional: per-variant environment, e.g.  A:V2X_STREAM_WT=1 B:V2X_STREAM_WT=2  (read by the dispatch at every call)
+    # optional: per-variant tuning switches, e.g.  A:STREAM_WT=1 B:STREAM_WT=2  (include/v2x_amd.h: v2x_tuning_set; set on the variant's OWN
+    # library handle at every switch, so the same .so may be passed twice)
     envs = [{}, {}]
     for a in sys.argv[3:]:
         v, kv = a.split(":", 1)
         k, val = kv.split("=", 1)
-        envs["AB".index(v)][k] = val
+        envs["AB".index(v)][k.upper().replace("V2X_", "")] = int(val)
+    defaults = {}
+    for k in set(envs[0]) | set(envs[1]):
+        out = C.c_int(0)
+        assert libs[0].v2x_tuning_get(k.encode(), C.byref(out)) == 0, k
+        defaults[k] = out.value
 
     def use(v):
         _lib._lib = libs[v]
-        for k in set(envs[0]) | set(envs[1]):
-            if k in envs[v]:
-                os.environ[k] = envs[v][k]
-            else:
-                os.environ.pop(k, None)
+        for k, d in defaults.items():
+            assert libs[v].v2x_tuning_set(k.encode(), envs[v].get(k, d)) == 0
     _lib.load()
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)

@@ -7,7 +7,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "v2x-sim_amd"))
-from v2x_sim_amd import ops, packing  # noqa: E402
+from v2x_sim_amd import ops, packing, tuning  # noqa: E402
 
 dev = torch.device("cuda:0")
 N = 160
@@ -54,9 +54,9 @@ for name, cup, c, cout, hw, gru in SHAPES:
             os.environ.pop("V2X_STREAM_WAVES", None)
             os.environ.pop("V2X_STREAM_PERSIST", None)
             if waves == "4":
-                os.environ["V2X_STREAM_WAVES"] = "4"
+                tuning.set("STREAM_WAVES", int("4"))
             elif waves == "8":
-                os.environ["V2X_STREAM_PERSIST"] = "0"
+                tuning.set("STREAM_PERSIST", int("0"))
             res.setdefault(waves, []).append(timed(fn))
     t4, t8, t8p = min(res["4"]), min(res["8"]), min(res["8p"])
     print("%-8s 4-wave %7.1f us (%6.0f TF/s)   8-wave %7.1f us (%6.0f TF/s)   8-wave persistent %7.1f us (%6.0f TF/s)  x%.3f" % (

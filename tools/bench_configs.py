@@ -156,7 +156,8 @@ def run_training(device, frames=2, agents=5, reps=5):
     from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
     cfg = Config("train")
     data = synthetic_batch_on_device(cfg, frames, agents, seed=1, device=device)
-    saved = {k: os.environ.get(k) for k in ("V2X_TRAIN_HIP", "V2X_TRAIN_GRAPH")}
+    from v2x_sim_amd import tuning
+    saved = {k: tuning.get(k) for k in ("TRAIN_HIP", "TRAIN_GRAPH")}
 
     def timed(fn):
         for _ in range(3):
@@ -183,10 +184,10 @@ def run_training(device, frames=2, agents=5, reps=5):
                 opt.step()
             rec = {}
             for flag, label in (("0", "fp32 PyTorch-ROCm graph (MIOpen) ms"), ("1", "bf16 NHWC graph on the HIP kernels ms")):
-                os.environ["V2X_TRAIN_HIP"] = flag
+                tuning.set("TRAIN_HIP", int(flag))
                 rec[label] = timed(step)
             if name == "FaFNet":
-                os.environ["V2X_TRAIN_HIP"] = "1"
+                tuning.set("TRAIN_HIP", int("1"))
                 opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=device), capturable=True)
                 g = GraphedTrainStep(model, opt_c, data, frames)
                 rec["the same as one replayed hipGraph ms"] = timed(lambda: g(data))
@@ -195,8 +196,5 @@ def run_training(device, frames=2, agents=5, reps=5):
             del model, opt
     finally:
         for k, v in saved.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+            tuning.set(k, v)
     return out

@@ -15,6 +15,7 @@ for _p in (ROOT, os.path.join(ROOT, "v2x-sim_amd")):
 
 import torch  # noqa: E402
 import torch.nn.functional as F  # noqa: E402
+from v2x_sim_amd import tuning  # noqa: E402
 
 
 def timed(fn, reps=10):
@@ -61,9 +62,9 @@ def main():
         res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 2)
         detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0].backward()
     for flag in ("0", "1"):
-        os.environ["V2X_TRAIN_HIP_CONV"] = flag
+        tuning.set("TRAIN_HIP_CONV", int(flag))
         print("FaFNet forward + backward, 10 maps, V2X_TRAIN_HIP_CONV=%s: %.1f ms" % (flag, timed(step, 5) / 1e3))
-    os.environ["V2X_TRAIN_HIP_CONV"] = "0"
+    tuning.set("TRAIN_HIP_CONV", int("0"))
     # the bf16 NHWC graph on the HIP kernels (train/hip_graph.py) against the fp32 MIOpen graph, optimizer step included
     # (the HIP graph re-packs every layer's weights on the GPU after each step -- that cost is inside the number)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
@@ -75,7 +76,7 @@ def main():
         loss.backward()
         opt.step()
     for flag in ("0", "1"):
-        os.environ["V2X_TRAIN_HIP"] = flag
+        tuning.set("TRAIN_HIP", int(flag))
         print("FaFNet training step (fwd + bwd + Adam), 10 maps, V2X_TRAIN_HIP=%s: %.1f ms" % (flag, timed(full_step, 5) / 1e3))
     # V2VNet (the fusion -- warp + ConvGRU -- between the HIP encoder and decoder)
     from v2x_sim_amd.models.det import V2VNet
@@ -89,9 +90,9 @@ def main():
         loss.backward()
         vopt.step()
     for flag in ("0", "1"):
-        os.environ["V2X_TRAIN_HIP"] = flag
+        tuning.set("TRAIN_HIP", int(flag))
         print("V2VNet training step (fwd + bwd + Adam), 10 maps, V2X_TRAIN_HIP=%s: %.1f ms" % (flag, timed(v_step, 5) / 1e3))
-    os.environ["V2X_TRAIN_HIP"] = "1"
+    tuning.set("TRAIN_HIP", int("1"))
     from v2x_sim_amd.train.graph_step import GraphedTrainStep
     opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True)
     gstep = GraphedTrainStep(model, opt_c, data, 2)

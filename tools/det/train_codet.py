@@ -49,8 +49,9 @@ def build_parser():
 def main(argv=None):
     args = build_parser().parse_args(argv)
     if args.engine:
-        os.environ["V2X_TRAIN_HIP"] = "0" if args.engine == "torch" else "1"
-        os.environ["V2X_TRAIN_GRAPH"] = "1" if args.engine == "hip-graph" else "0"
+        from v2x_sim_amd import tuning
+        tuning.set("TRAIN_HIP", int("0" if args.engine == "torch" else "1"))
+        tuning.set("TRAIN_GRAPH", int("1" if args.engine == "hip-graph" else "0"))
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import CatFusion, DiscoNet, FaFNet, MaxFusion, MeanFusion, SumFusion, V2VNet, When2com
     from v2x_sim_amd.train.loop import init_for_training, make_optimizer, train_dataset, train_synthetic

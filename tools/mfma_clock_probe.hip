@@ -74,6 +74,66 @@ __global__ __launch_bounds__(512) void mfma_block(float *out, int iters, uint32_
     if (sum == 12345.678f) out[threadIdx.x] = sum;
 }
 
+// The 32x32x16 form of the same block (round 3, conv3x3_stream8g_kernel<..., M32>): acc[mt][r] += A[mt] * B[r], NM x NR accumulators of 16
+// registers, the issue order of the kernel (fragment outer, pixel row inner).
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+template <int NM, int NR>
+__global__ __launch_bounds__(512) void mfma_block32(float *out, int iters, uint32_t seed) {
+    f32x16_t acc[NM][NR];
+    bf16x8_t A[NM], B[NR];
+    uint32_t r = seed * 2654435761u + threadIdx.x * 40503u + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+        uint4 u = make_uint4((r * (i + 3)) & 0x3fff3fffu, (r * (i + 5)) & 0x3fff3fffu, (r * (i + 7)) & 0x3fff3fffu, (r * (i + 11)) & 0x3fff3fffu);
+        if (!seed) u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        A[i] = __builtin_bit_cast(bf16x8_t, u);
+        asm volatile("" : "+v"(A[i]));
+#pragma unroll
+        for (int f = 0; f < NR; ++f) { acc[i][f] = (f32x16_t)((float)(i * NR + f)); asm volatile("" : "+v"(acc[i][f])); }
+    }
+#pragma unroll
+    for (int f = 0; f < NR; ++f) {
+        uint4 u = make_uint4((r * (f + 13)) & 0x3fff3fffu, (r * (f + 17)) & 0x3fff3fffu, (r * (f + 19)) & 0x3fff3fffu, (r * (f + 23)) & 0x3fff3fffu);
+        if (!seed) u = make_uint4(0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u);
+        B[f] = __builtin_bit_cast(bf16x8_t, u);
+        asm volatile("" : "+v"(B[f]));
+    }
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int f = 0; f < NR; ++f) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][f]) : "v"(A[i]), "v"(B[f]));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NM; ++i)
+#pragma unroll
+        for (int f = 0; f < NR; ++f) sum += acc[i][f][0] + acc[i][f][5] + acc[i][f][10] + acc[i][f][15];
+    if (sum == 12345.678f) out[threadIdx.x] = sum;
+}
+
+template <int NM, int NR>
+static void run_block32(float *out, hipEvent_t e0, hipEvent_t e1) {
+    const int iters = 10000;
+    for (int random = 0; random < 2; ++random)
+        for (int wps = 1; wps <= 2; ++wps) {
+            const int threads = 256 * wps, grid = 256;
+            float best = 1e30f;
+            for (int rep = 0; rep < 3; ++rep) {
+                (void)hipEventRecord(e0, 0);
+                hipLaunchKernelGGL((mfma_block32<NM, NR>), dim3(grid), dim3(threads), 0, 0, out, iters, random ? 99u + rep : 0u);
+                (void)hipEventRecord(e1, 0);
+                (void)hipEventSynchronize(e1);
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            const double n = (double)iters * NM * NR;
+            printf("32x32x16 block acc[%d][%d] += A[mt]*B[r], %s operands, %d wave(s)/SIMD: %7.1f TFLOP/s  (%.1f cycles per MFMA and SIMD at 2.4 GHz)\n", NM, NR,
+                   random ? "random  " : "constant", wps, (double)grid * (threads / 64) * n * 32768.0 / best / 1e9, best * 1e-3 * 2.4e9 / (n * wps));
+        }
+}
+
 template <int NA, int ORDER>
 static void run_block(float *out, hipEvent_t e0, hipEvent_t e1) {
     const int iters = 20000;
@@ -123,6 +183,8 @@ int main() {
     run_block<4, 1>(out, e0, e1);
     run_block<8, 0>(out, e0, e1);
     run_block<8, 1>(out, e0, e1);
+    run_block32<2, 4>(out, e0, e1);   // the 128-row layers' wave tile (2 row tiles x 4 pixel rows)
+    run_block32<3, 2>(out, e0, e1);   // the ConvGRU's (3 gates x 2 pixel rows)
     // sustained: the same kernel back to back for ~4 s (the power manager needs far longer than one 5-ms burst to settle)
     for (int random = 0; random < 2; ++random) {
         const int threads = 512, grid = 256;

@@ -12,11 +12,49 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
 
-template <int MODE, bool MF>
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// M32: the MFMA waves issue v_mfma_f32_32x32x16_bf16 (acc[2][4] of 16 registers: 8 MFMAs per iteration = the FLOPs of the 16 16x16x32 ones)
+template <int MODE, bool MF, bool M32 = false>
 __global__ __launch_bounds__(512) void probe(float *out, unsigned *times, const uint4 *src, int iters, int n2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (wave < 4) {
+    if (M32 && wave < 4) {
+        f32x16_t acc[2][4];
+        bf16x8_t A[2], B[4];
+        uint32_t r = threadIdx.x * 2654435761u + blockIdx.x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint4 u = make_uint4((r * (i + 3)) & 0x3fff3fffu, (r * (i + 5)) & 0x3fff3fffu, (r * (i + 7)) & 0x3fff3fffu, (r * (i + 11)) & 0x3fff3fffu);
+            if (i < 2) A[i] = __builtin_bit_cast(bf16x8_t, u);
+            u.x ^= 0x01010101u;
+            B[i] = __builtin_bit_cast(bf16x8_t, u);
+            asm volatile("" : "+v"(B[i]));
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            asm volatile("" : "+v"(A[i]));
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { acc[i][f] = (f32x16_t)((float)(i + f)); asm volatile("" : "+v"(acc[i][f])); }
+        }
+        __syncthreads();
+        if (!MF) return;
+        const unsigned t0 = (unsigned)__builtin_amdgcn_s_memrealtime();
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int f = 0; f < 4; ++f) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[i][f]) : "v"(A[i]), "v"(B[f]));
+        }
+        asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+        const unsigned t1 = (unsigned)__builtin_amdgcn_s_memrealtime();
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) sum += acc[i][f][0] + acc[i][f][7] + acc[i][f][15];
+        if (sum == 12345.678f) out[threadIdx.x] = sum;
+        if (lane == 0) times[blockIdx.x * 4 + wave] = t1 - t0;
+    } else if (wave < 4) {
         f32x4_t acc[4][4];
         bf16x8_t A[4], B[4];
         uint32_t r = threadIdx.x * 2654435761u + blockIdx.x;
@@ -50,6 +88,9 @@ __global__ __launch_bounds__(512) void probe(float *out, unsigned *times, const 
         if (lane == 0) times[blockIdx.x * 4 + wave] = t1 - t0;
     } else {
         __syncthreads();
+#ifdef COMP_PRIO
+        __builtin_amdgcn_s_setprio(COMP_PRIO);   // -DCOMP_PRIO=n: the companion at a raised priority (does its LDS-DMA get through beside 32x32x16 MFMAs then?)
+#endif
         uint32_t v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = lane + u;
@@ -91,7 +132,7 @@ __global__ __launch_bounds__(512) void probe(float *out, unsigned *times, const 
     }
 }
 
-template <int MODE>
+template <int MODE, bool M32 = false>
 static void run(const char *name, float *out, unsigned *d_times, const uint4 *src) {
     const int grid = 256;
     static unsigned h[2048];
@@ -99,19 +140,19 @@ static void run(const char *name, float *out, unsigned *d_times, const uint4 *sr
     // (a) MFMA waves long, companion short: how fast does the COMPANION progress beside MFMAs?  (b) companion alone.  (c) MFMA waves
     // short, companion long: how fast do the MFMAs go beside the companion?  (d) MFMA waves alone (MODE 0).
     const int co_iters = MODE == 5 ? 300 : 3000;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, true>), dim3(grid), dim3(512), 65536, 0, out, d_times, src, 40000, co_iters);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, true, M32>), dim3(grid), dim3(512), 65536, 0, out, d_times, src, 40000, co_iters);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h, d_times, sizeof(h), hipMemcpyDeviceToHost);
     for (int i = 0; i < 1024; ++i) co_ns[0] += h[1024 + i] * 10.0 / 1024;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, false>), dim3(grid), dim3(512), 65536, 0, out, d_times, src, 0, co_iters);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, false, M32>), dim3(grid), dim3(512), 65536, 0, out, d_times, src, 0, co_iters);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h, d_times, sizeof(h), hipMemcpyDeviceToHost);
     for (int i = 0; i < 1024; ++i) co_ns[1] += h[1024 + i] * 10.0 / 1024;
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, true>), dim3(grid), dim3(512), 65536, 0, out, d_times, src, 4000, co_iters * 40);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe<MODE, true, M32>), dim3(grid), dim3(512), 65536, 0, out, d_times, src, 4000, co_iters * 40);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h, d_times, sizeof(h), hipMemcpyDeviceToHost);
     for (int i = 0; i < 1024; ++i) mf_ns[0] += h[i] * 10.0 / 1024;
-    printf("%-52s: MFMA %.2f ns each beside it;  companion iteration %.0f ns beside MFMAs vs %.0f ns alone (%.2fx)\n", name, mf_ns[0] / (4000 * 16.0),
+    printf("%s %-52s: MFMA %.2f ns per 16x16x32-equivalent beside it;  companion iteration %.0f ns beside MFMAs vs %.0f ns alone (%.2fx)\n", M32 ? "[32x32x16]" : "[16x16x32]", name, mf_ns[0] / (4000 * 16.0),
            co_ns[0] / co_iters, co_ns[1] / co_iters, co_ns[0] / co_ns[1]);
 }
 
@@ -129,5 +170,10 @@ int main() {
     run<3>("companion: 4 dependent ds_read_b128", out, d_times, src);
     run<4>("companion: LDS-DMA (4 x 1 KiB, drained)", out, d_times, src);
     run<5>("companion: load-phase mix (200 VALU, 14 reads, 6 DMA)", out, d_times, src);
+    run<1, true>("companion: dense VALU (8 v_add per iteration)", out, d_times, src);
+    run<2, true>("companion: VALU ~25 % duty", out, d_times, src);
+    run<3, true>("companion: 4 dependent ds_read_b128", out, d_times, src);
+    run<4, true>("companion: LDS-DMA (4 x 1 KiB, drained)", out, d_times, src);
+    run<5, true>("companion: load-phase mix (200 VALU, 14 reads, 6 DMA)", out, d_times, src);
     return 0;
 }

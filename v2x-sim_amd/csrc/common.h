@@ -9,9 +9,29 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 // thread-local error text behind v2x_last_error()
 void v2x_set_error(const char *fmt, ...);
+
+// Kernel-selection switches (include/v2x_amd.h: v2x_tuning_set / v2x_tuning_get).  The DEFAULTS are the measured-fastest forms; the other
+// values exist for the bitwise-equality tests and the paired A/B runs.  Each is initialised ONCE from the environment variable V2X_<NAME>
+// at first use (api.hip) and changed afterwards only through v2x_tuning_set -- the dispatch never calls getenv.
+enum v2x_tune_id {
+    V2X_TUNE_STREAM_WAVES,    // 8 (default): 8-wave ping-pong streamed kernels where they apply; 4: the 4-wave kernel everywhere
+    V2X_TUNE_STREAM_G,        // 1: three taps per synchronisation (stream8g); 0: the 1-tap 8-wave kernel
+    V2X_TUNE_STREAM_WT,       // stream8g wave tiling: 0 all channels x 64 pixels per wave everywhere, 1 (default) half x 128 for the plain layers, 2 also for the ConvGRU
+    V2X_TUNE_STREAM_M32,      // 1: the 32x32x16-MFMA form of stream8g (only in libraries built with -DV2X_STREAM_M32_BUILD=1; measured slower)
+    V2X_TUNE_STREAM_PERSIST,  // 1: persistent stream8 grid; 0: one tile per workgroup
+    V2X_TUNE_STREAM_WIDE,     // 1: the wide 4-wave form for 64-row layers; 0: the 256-pixel kernel
+    V2X_TUNE_WIDE3,           // 1: three taps per synchronisation in the wide form (>= 3 chunks); 0: the 1-tap wide form
+    V2X_TUNE_HALO_PP,         // 1: 8-wave ping-pong halo kernel for conv8_1 / conv7_2; 0: the 4-wave kernel
+    V2X_TUNE_S2_RESIDENT,     // 1: resident-weights stride-2 kernel for conv1_1; 0: the streamed stride-2 kernel
+    V2X_TUNE_VOXELIZE_LDS,    // 1: LDS-binned voxeliser when the grid fits; 0: the global-atomic form
+    V2X_TUNE_WARP_LDS,        // 1: LDS-staged warp kernel; 0: the direct form
+    V2X_TUNE_COUNT
+};
+int v2x_tune(int id);
 
 #define V2X_REQUIRE(cond, ...)            \
     do {                                  \

@@ -970,20 +970,22 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
         return d->in_format == 1 ? launch_halo_sb<0, 32, 32, 0, 0, true>(a, s) : launch_halo_sb<0, 32, 32, 0, 0, false>(a, s);
     if (d->in_format == 1) return 1;  // bit-grid input exists for the 32 -> 32 first layer only
     if (C0 == 64 && C1 == 32 && d->Cout == 32 && co2 == 0 && e2 == 0 && a.n_tiles >= 2 && a.n_tiles % 2 == 0) {
-        // conv8_1: 8-wave ping-pong form (V2X_HALO_PP=0 keeps the 4-wave kernel: A/B runs and the bitwise-equality test)
-        const char *e = getenv("V2X_HALO_PP");
-        if (!(e && e[0] == '0')) return launch_halo_pp<64, 32, 32>(a, s);
+        // conv8_1: 8-wave ping-pong form (tuning switch HALO_PP = 0 keeps the 4-wave kernel: A/B runs and the bitwise-equality test)
+        if (v2x_tune(V2X_TUNE_HALO_PP) != 0) return launch_halo_pp<64, 32, 32>(a, s);
     }
     HALO_CASE(64, 32, 32, 0, 0)   // conv8_1: cat(up(x_7), x)
     if (C0 == 0 && C1 == 64 && d->Cout == 64 && co2 == 0 && e2 == 0 && a.n_tiles >= 2 && a.n_tiles % 2 == 0) {
         // conv7_2: resident 72-KiB weights + two single-buffered 43-KiB patches = 158.5 KiB, 8-wave ping-pong form
-        const char *e = getenv("V2X_HALO_PP");
-        if (!(e && e[0] == '0')) return launch_halo_pp<0, 64, 64>(a, s);
+        if (v2x_tune(V2X_TUNE_HALO_PP) != 0) return launch_halo_pp<0, 64, 64>(a, s);
     }
     HALO_CASE(0, 64, 64, 0, 0)    // conv7_2
     if (C0 == 0 && C1 == 64 && d->Cout == 64 && co2 == 64 && e2 == 1 && d->Cout2 == 64 && a.n_tiles >= 2 && a.n_tiles % 2 == 0 &&
         d->split == 0)
-        return launch_halo_pp<0, 64, 64, 64>(a, s);   // conv1_2 -> conv3d_1 chained (ping-pong form only)
+        return launch_halo_pp<0, 64, 64, 64>(a, s);   // conv1_2 -> conv3d_1 chained: ping-pong form
+    // ... and its 4-wave form for an ODD number of tiles (odd batch x odd tiles per map, e.g. a 24 x 32 map): the ping-pong kernel pairs
+    // tiles.  Same K order and epilogue -> the same bits (tests/test_gpu_stages.py::test_halo_chain_odd_tile_count), so the choice
+    // may depend on the batch without breaking the R-rank == 1-rank equality.
+    HALO_CASE(0, 64, 64, 64, 1)
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
 #undef HALO_CASE
     return 1;

@@ -339,8 +339,7 @@ extern "C" int v2x_voxelize_bits(const float *pts, const int32_t *n_pts, int n_c
     vp.Z = dims_xyz[2];
     // LDS-binned form: the cloud's grid as 16-bit words must fit one CU's LDS (and split into 16-B pieces)
     const size_t lds_bytes = (size_t)vp.X * vp.Y * 2;
-    const char *lds_env = getenv("V2X_VOXELIZE_LDS");   // read per call: tests toggle it to compare the two forms
-    const bool lds_off = lds_env && lds_env[0] == '0';
+    const bool lds_off = v2x_tune(V2X_TUNE_VOXELIZE_LDS) == 0;   // (tests switch it to compare the two forms)
     if (!lds_off && vp.Z <= 16 && lds_bytes <= 128 * 1024 && ((size_t)vp.X * vp.Y) % 8 == 0 && max_pts > 0 &&
         (reinterpret_cast<uintptr_t>(bits) & 15) == 0) {
         const bool vec4 = pt_stride == 4 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0;

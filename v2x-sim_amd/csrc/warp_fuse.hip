@@ -356,8 +356,7 @@ extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, 
     V2X_REQUIRE(mode == V2X_FUSE_WSUM || mode == V2X_FUSE_MEAN || mode == V2X_FUSE_MAX, "v2x_warp_fuse: bad mode");
     V2X_REQUIRE(n_out >= 0 && n_out <= 65535, "v2x_warp_fuse: n_out out of range");
     if (n_out == 0) return V2X_OK;
-    const char *lds_env = getenv("V2X_WARP_LDS");   // read per call: tests toggle it to compare the two forms
-    if (!(lds_env && lds_env[0] == '0') && H % WL_T == 0 && W % WL_T == 0 && C % WL_CW == 0) {
+    if (v2x_tune(V2X_TUNE_WARP_LDS) != 0 && H % WL_T == 0 && W % WL_T == 0 && C % WL_CW == 0) {
         hipLaunchKernelGGL(warp_fuse_lds_kernel, dim3((H / WL_T) * (W / WL_T), n_out, C / WL_CW), dim3(256), 0,
                            (hipStream_t)stream, feat, A, Bt, H, W, C, trans, items, coef, mode, out);
         V2X_CHECK_LAUNCH("warp_fuse_lds_kernel");

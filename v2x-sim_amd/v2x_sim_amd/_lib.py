@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU = 0, 1, 2
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 class ConvDesc(C.Structure):
@@ -42,6 +42,8 @@ class PackSpec(C.Structure):
 # name -> (restype, argtypes); every symbol include/v2x_amd.h declares
 SIGNATURES = {
     "v2x_abi_version": (C.c_int, []),
+    "v2x_tuning_set": (C.c_int, [C.c_char_p, C.c_int]),
+    "v2x_tuning_get": (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
     "v2x_last_error": (C.c_char_p, []),
     "v2x_voxelize_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int32),
@@ -68,7 +70,6 @@ SIGNATURES = {
     "v2x_conv_stream_tile_rows": (C.c_int, [C.c_int, C.c_int]),
     "v2x_conv2d": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "v2x_conv2d_pair": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
-    "v2x_conv2d_tail": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(ConvDesc), C.c_void_p]),
     "v2x_conv3x3_wgrad_splits": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "v2x_conv3x3_wgrad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
                                     C.c_void_p]),

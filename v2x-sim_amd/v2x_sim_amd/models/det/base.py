@@ -254,15 +254,8 @@ class DetModelBase(nn.Module):
         return ops.dense_to_nhwc(bevs[:, 0].to(torch.float32).contiguous(), INPUT_C_PAD)
 
     def decode_heads(self, pk, feats):
-        """Decoder + heads on the (possibly fused) pyramid `feats` -> {'loc', 'cls'}.  When the extent allows, conv8_2 and the
-        heads are ONE launch (conv_tail.hip: the decoder's 32-channel output map never reaches HBM); otherwise, or with
-        V2X_CONV_TAIL=0, LidarDecoder.run + get_cls_loc_result as before -- bit-identical either way."""
-        plan, heads = pk["dec"], pk["heads"]
-        y = LidarDecoder.run(plan, *feats, last=False)
-        if heads.split and ops.tail_eligible(plan[-1].halo, heads.halo, y):
-            cls, loc = ops.conv2d_tail(plan[-1].halo, heads.halo, y, heads.split)
-            return self._shape_cls_loc(cls, loc)
-        return self.get_cls_loc_result(ops.run_layer(plan[-1], y), heads)
+        """Decoder + heads on the (possibly fused) pyramid `feats` -> {'loc', 'cls'}."""
+        return self.get_cls_loc_result(LidarDecoder.run(pk["dec"], *feats), pk["heads"])
 
     def _shape_cls_loc(self, cls, loc):
         n = cls.shape[0]

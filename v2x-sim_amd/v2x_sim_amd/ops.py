@@ -5,11 +5,10 @@ happens inside libv2x_amd.so.  Every wrapper refuses non-device tensors -- there
 is deliberately no eager/CPU fallback.
 """
 import ctypes as C
-import os
 
 import torch
 
-from . import _lib
+from . import _lib, tuning
 from ._lib import ConvDesc, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_FUSE_MAX, V2X_FUSE_MEAN, V2X_FUSE_WSUM  # noqa: F401
 
 
@@ -45,7 +44,7 @@ _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 12
 def conv_kernel_name(pc, H=0, W=0, bits=False):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
     if pc.w_layout == 2 and pc.stride == 2:
-        if pc.Cout == 64 and pc.C0 == 32 and os.environ.get("V2X_S2_RESIDENT", "1") != "0":
+        if pc.Cout == 64 and pc.C0 == 32 and tuning.get("S2_RESIDENT") != 0:
             return "conv3x3_s2_resident_kernel<64>"
         rows = 128 if pc.Cout % 128 == 0 else 64
         if not (H % 8 == 0 and W % 64 == 0):
@@ -56,16 +55,18 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         th, tw = (8, 32) if W % 32 == 0 else (16, 16)
         epi = 2 if pc.epilogue == V2X_EPI_GRU else (1 if pc.Cout2 else 0)
         if W % 32 == 0 and H % 16 == 0 and rows == 64 and pc.epilogue == V2X_EPI_BF16 and (pc.C0 + pc.C1) >= 64 \
-                and os.environ.get("V2X_STREAM_WIDE", "1") != "0":
-            if epi == 0 and (pc.C0 + pc.C1) >= 96 and os.environ.get("V2X_WIDE3", "1")[:1] != "0":
+                and tuning.get("STREAM_WIDE") != 0:
+            if epi == 0 and (pc.C0 + pc.C1) >= 96 and tuning.get("WIDE3") != 0:
                 return "conv3x3_wide3_kernel<64>"          # 128 pixels per wave, three taps per synchronisation
             return "conv3x3_wide_kernel<64, %d>" % epi   # 128 pixels per wave (conv_stream.hip)
         if W % 32 == 0 and H % 16 == 0 and rows in (96, 128) \
-                and not os.environ.get("V2X_STREAM_WAVES", "").startswith("4"):
-            if epi != 1 and os.environ.get("V2X_STREAM_G", "1")[:1] != "0":
-                wt = int(os.environ.get("V2X_STREAM_WT", "1")[:1] or 1)   # wave tiling: half the channels x 128 pixels per wave
+                and tuning.get("STREAM_WAVES") != 4:
+            if epi != 1 and tuning.get("STREAM_G") != 0:
+                wt = tuning.get("STREAM_WT")   # wave tiling: half the channels x 128 pixels per wave
                 tiled = (wt >= 1 and epi == 0) or (wt >= 2 and epi == 2)
-                return "conv3x3_stream8g_kernel<%d, %d, %s>" % (rows, epi, "true" if tiled else "false")  # 8 waves, three taps per synchronisation
+                # 32x32x16 MFMA form: the wave-tiled plain layers and the (untiled) ConvGRU
+                m32 = tuning.get("STREAM_M32") != 0 and ((epi == 0 and tiled) or (epi == 2 and not tiled))
+                return "conv3x3_stream8g_kernel<%d, %d, %s, %s>" % (rows, epi, "true" if tiled else "false", "true" if m32 else "false")  # 8 waves, three taps per synchronisation
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
         return "conv3x3_stream_kernel<%d, %d, %d, %d>" % (rows, th, tw, epi)
     if pc.w_layout == 1:
@@ -75,8 +76,8 @@ def conv_kernel_name(pc, H=0, W=0, bits=False):
         if (c0, c1, pc.Cout, co2) == (0, 32, 32, 0):  # HBM-bound layers: single-buffer form (+ bit-grid input)
             return "conv3x3_halo_sb_kernel<0, 32, 32, 0, 0, %s>" % ("true" if bits else "false")
         if (c0, c1, pc.Cout, co2, e2) == (0, 64, 64, 64, 1):
-            return "conv3x3_halo_pp_kernel<0, 64, 64, 64>"   # conv1_2 -> conv3d_1 chained: ping-pong form only
-        if (c0, c1, pc.Cout, co2) in ((64, 32, 32, 0), (0, 64, 64, 0)) and os.environ.get("V2X_HALO_PP", "1")[:1] != "0":
+            return "conv3x3_halo_pp_kernel<0, 64, 64, 64>"   # conv1_2 -> conv3d_1 chained: ping-pong form (odd tile counts: the 4-wave form)
+        if (c0, c1, pc.Cout, co2) in ((64, 32, 32, 0), (0, 64, 64, 0)) and tuning.get("HALO_PP") != 0:
             return "conv3x3_halo_pp_kernel<%d, %d, %d, 0>" % (c0, c1, pc.Cout)   # conv8_1 / conv7_2: 8-wave ping-pong form
         return "conv3x3_halo_kernel<%d, %d, %d, %d, %d>" % (c0, c1, pc.Cout, co2, e2)
     rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
@@ -124,7 +125,7 @@ def voxelize_bits(points, n_pts, grid, out=None):
     X, Y, Z = grid.dims
     if out is None:
         out = torch.empty((n, X, Y), dtype=torch.int32, device=points.device)
-    lds = Z <= 16 and X * Y * 2 <= 128 * 1024 and (X * Y) % 8 == 0 and mp > 0 and os.environ.get("V2X_VOXELIZE_LDS", "1")[:1] != "0"
+    lds = Z <= 16 and X * Y * 2 <= 128 * 1024 and (X * Y) % 8 == 0 and mp > 0 and tuning.get("VOXELIZE_LDS") != 0
     prof = (_Prof("voxelize_lds_kernel", 0, points.numel() * 4 + out.numel() * 4) if lds else
             _Prof("voxelize_scatter_kernel", 0, points.numel() * 4 + 2 * out.numel() * 4))
     rc = lib.v2x_voxelize_bits(_dev(points, torch.float32, "points"), _dev(n_pts, torch.int32, "n_pts"), n, mp, st,
@@ -347,7 +348,7 @@ def pair_eligible(pa, pb, in0, zbits):
     ok = lambda pc: (pc is not None and pc.w_layout == 1 and pc.ksize == 3 and pc.stride == 1 and pc.C0 == 32 and not pc.C1  # noqa: E731
                      and pc.Cout == 32 and not pc.Cout2 and pc.epilogue == V2X_EPI_BF16)
     return (ok(pa) and ok(pb) and in0.dtype == torch.int32 and in0.dim() == 3 and 1 <= zbits <= 16
-            and in0.shape[1] % 8 == 0 and in0.shape[2] % 32 == 0 and os.environ.get("V2X_CONV_PAIR", "1")[:1] != "0")
+            and in0.shape[1] % 8 == 0 and in0.shape[2] % 32 == 0 and tuning.get("CONV_PAIR") != 0)
 
 
 def conv2d_pair(pa, pb, bits, zbits, out=None):
@@ -440,49 +441,6 @@ def bn_train_backward(x, dy, gamma, beta, mean, invstd, relu=True):
     return dx, dgamma, dbeta
 
 
-def tail_eligible(pa, pb, x):
-    """conv_tail.hip covers: halo-packed conv8_2 (32 -> 32, bf16) followed by the fused det heads (32 -> 64 chained to 48 fp32),
-    bf16 NHWC input with H % 8 == 0, W % 32 == 0 and an even number of 8x32 tiles.  OFF by default (V2X_CONV_TAIL=1 enables it):
-    bit-identical to the two launches and 2.7 GB per 320 maps lighter on HBM, but measured SLOWER (1.93-1.96 vs 1.67 ms same-box:
-    the fused kernel is bound by LDS reads and issue slots, not by HBM -- DESIGN.md section 9)."""
-    if pa is None or pb is None or os.environ.get("V2X_CONV_TAIL", "0")[:1] != "1":
-        return False
-    ok_a = (pa.w_layout == 1 and pa.ksize == 3 and pa.stride == 1 and pa.C0 == 32 and not pa.C1 and pa.Cout == 32 and not pa.Cout2
-            and pa.epilogue == V2X_EPI_BF16)
-    ok_b = (pb.w_layout == 1 and pb.ksize == 3 and pb.stride == 1 and pb.C0 == 32 and not pb.C1 and pb.Cout == 64 and pb.Cout2 == 48
-            and pb.epilogue == V2X_EPI_F32)
-    if not (ok_a and ok_b and x.dtype == torch.bfloat16 and x.dim() == 4):
-        return False
-    N, H, W, _ = x.shape
-    return H % 8 == 0 and W % 32 == 0 and (N * (H // 8) * (W // 32)) % 2 == 0 and N * H * W < (1 << 26)
-
-
-def conv2d_tail(pa, pb, x, split):
-    """heads(conv8_2(x)) in one launch, the 32-channel map stays in LDS.  x (N, H, W, 32) bf16 -> (cls (N, H, W, split),
-    loc (N, H, W, 48 - split)) fp32, bit-identical to the two v2x_conv2d launches."""
-    lib = _lib.load()
-    N, H, W, _ = x.shape
-    da, db = _pair_desc(pa, N, H, W), _pair_desc(pb, N, H, W)
-    da.in0 = _dev(x, torch.bfloat16, "x").value
-    out = torch.empty((N, H, W, split), dtype=torch.float32, device=x.device)
-    out2 = torch.empty((N, H, W, pb.Cout2 - split), dtype=torch.float32, device=x.device)
-    db.out, db.out_cstride, db.out_coff = out.data_ptr(), split, 0
-    db.out2, db.split, db.out2_cstride = out2.data_ptr(), split, out2.shape[3]
-    db.Cout2, db.relu2 = pb.Cout2, int(bool(pb.relu2))
-    db.weight2, db.scale2, db.shift2 = pb.weight2.data_ptr(), pb.scale2.data_ptr(), pb.shift2.data_ptr()
-    prof = None
-    if PROFILE is not None:
-        M = N * H * W
-        prof = _Prof("conv3x3_tail_kernel", 2.0 * M * (9 * 32 * 32 + 9 * 32 * 64 + 64 * 48),
-                     x.numel() * 2 + (out.numel() + out2.numel()) * 4 + (pa.weight.numel() + pb.weight.numel()) * 2, pa.name + "+" + pb.name)
-    rc = lib.v2x_conv2d_tail(C.byref(da), C.byref(db), _stream())
-    if prof is not None:
-        prof.done()
-    _lib.check(rc, "v2x_conv2d_tail(%s, %s)" % (pa.name, pb.name))
-    return out, out2
-
-
-# ------------------------------------------------------------------ a3
 def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
     """feat (A*Bt, H, W, C) bf16; trans (Bt, A, A, 4, 4) fp32; items (n_out, 2) int32; coef (n_out, A) fp32."""
     lib = _lib.load()
@@ -496,7 +454,7 @@ def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
         raise ValueError("coef must be (n_out, A)")
     if out is None:
         out = torch.empty((n_out, H, W, Cc), dtype=torch.bfloat16, device=feat.device)
-    lds = H % 8 == 0 and W % 8 == 0 and Cc % 128 == 0 and os.environ.get("V2X_WARP_LDS", "1")[:1] != "0"
+    lds = H % 8 == 0 and W % 8 == 0 and Cc % 128 == 0 and tuning.get("WARP_LDS") != 0
     prof = _Prof("warp_fuse_lds_kernel" if lds else "warp_fuse_kernel", 0, (n_out * (A - 1) + n_out) * H * W * Cc * 2)
     rc = lib.v2x_warp_fuse(_dev(feat, torch.bfloat16, "feat"), A, Bt, H, W, Cc, _dev(trans, torch.float32, "trans"),
                            _dev(items, torch.int32, "items"), n_out, _dev(coef, torch.float32, "coef"), mode,
@@ -615,7 +573,11 @@ class Layer:
         self.name = name or self.fallback[0].name
 
 
-def halo_eligible(H, W, w_layout=1):
+def halo_eligible(H, W, w_layout=1, cmax=0):
+    """cmax: the widest source's channel count -- the halo kernel's packed DMA tables hold a lane's element offset inside the patch rows
+    in 20 bits (conv_halo.hip: (10 W + 34) cmax < 2^20, i.e. W < 1 635 at 64 channels); wider maps take the layer's fallback."""
+    if w_layout == 1 and (10 * W + 34) * cmax >= (1 << 20):
+        return False
     if H % 8 == 0 and W % 32 == 0:
         return True
     return w_layout == 2 and H % 16 == 0 and W % 16 == 0  # the streamed kernel also has 16x16 tiles
@@ -636,9 +598,9 @@ def run_layer(layer, in0, in1=None, zbits=0):
     h = layer.halo
     if h is not None and h.stride == 2:
         # stride-2 streamed kernel: 4x32 output tiles, or 8x16 ones for narrow maps (conv4_1: 16x16 outputs)
-        if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and os.environ.get("V2X_S2_T16", "1")[:1] != "0"):
+        if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and tuning.get("S2_T16") != 0):
             return conv2d(h, in0, in1, split=layer.split)
-    elif h is not None and halo_eligible(H, W, h.w_layout):
+    elif h is not None and halo_eligible(H, W, h.w_layout, max(h.C0, h.C1 or 0)):
         use = True
         if h.w_layout == 2:
             # streamed kernel = one 256-pixel x <=128-channel tile per workgroup.  The choice looks at the map extent

@@ -9,11 +9,10 @@
   * ConvGRU (h0 = 0): W_ih rows regrouped as (r,z,n) triples of 16 hidden channels so one
     wave owns all three gates of its channels; biases packed float4 per hidden channel.
 """
-import os
 
 import torch
 
-from . import _lib
+from . import _lib, tuning
 from .ops import PackedConv, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU
 
 
@@ -234,7 +233,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
 CHAIN_STREAM = True   # conv1_2 -> conv3d_1 and conv2_2 -> conv3d_2: 1x1 chained in the streamed kernel's epilogue (False: separate launches for conv3d_2)
 STREAM_64 = True      # 64 -> 64 layers (conv7_2): streamed (wide 4-wave) kernel instead of the resident-weights halo kernel (471 vs 495 us)
-PP_64 = os.environ.get("V2X_PP_64", "1")[:1] != "0"   # 64 -> 64 layers (conv7_2): resident-weights 8-wave ping-pong halo kernel instead of the wide streamed one
+PP_64 = tuning.get("PP_64") != 0   # 64 -> 64 layers (conv7_2): resident-weights 8-wave ping-pong halo kernel instead of the wide streamed one
 STREAM_S2 = True      # stride-2 3x3 layers (conv1_1, conv2_1, conv3_1): patch-based stride-2 kernel instead of the gather kernel
 
 

@@ -116,11 +116,13 @@ def sparse_exchange(local, full, plan, rank, per_rank, group=None):
     the current stream wait, as with the all-gather); the own rows are copied on the current stream."""
     base = rank * per_rank
     full[base:base + per_rank].copy_(local)
+    # the plan speaks in ranks OF THE SHARD (0..R-1); P2POp's `peer` is a GLOBAL rank -- translate when the shard lives on a sub-group
+    peer = (lambda r: r) if group is None else (lambda r: dist.get_global_rank(group, r))
     ops_ = []
     for dst, lo, hi in plan["send"]:
-        ops_.append(dist.P2POp(dist.isend, _wire(local[lo - base:hi - base]), dst, group))
+        ops_.append(dist.P2POp(dist.isend, _wire(local[lo - base:hi - base]), peer(dst), group))
     for src, lo, hi in plan["recv"]:
-        ops_.append(dist.P2POp(dist.irecv, _wire(full[lo:hi]), src, group))
+        ops_.append(dist.P2POp(dist.irecv, _wire(full[lo:hi]), peer(src), group))
     return dist.batch_isend_irecv(ops_) if ops_ else []
 
 

@@ -14,10 +14,11 @@ reached through FaFModule.step() / train_forward().
 import torch
 import torch.nn.functional as F
 
+from .. import tuning
+
 
 def _hip_train():
-    import os
-    return os.environ.get("V2X_TRAIN_HIP_CONV", "0")[:1] == "1"
+    return tuning.get("TRAIN_HIP_CONV") == 1
 
 
 def _conv(x, conv):
@@ -244,8 +245,7 @@ def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch
     """bevs (A*B, 1, X, Y, Z) dense occupancy (the Dataset format) -> {'loc', 'cls'} with the shapes of the HIP path.
     Uses batch-statistics BN when model.training, running statistics otherwise.
     V2X_TRAIN_HIP=1: in train mode encoder, decoder and heads run as the bf16 NHWC graph on the hand-written kernels (train/hip_graph.py)."""
-    import os
-    if os.environ.get("V2X_TRAIN_HIP", "0")[:1] == "1" and model.training and bevs.is_cuda:
+    if tuning.get("TRAIN_HIP") == 1 and model.training and bevs.is_cuda:
         from . import hip_graph
         return hip_graph.train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size, inference)
     x = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)

@@ -33,6 +33,8 @@ class GraphedTrainStep:
         # side-effect-free warm-up: run real steps (allocator, lazy optimizer state, kernel attributes), then put parameters, buffers and
         # optimizer state back -- IN PLACE, the captured graph must see the very tensors the warm-up created
         snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
+        # the optimizer may already carry a run's moments and step counters (a later epoch, a partial last batch, --resume): keep them
+        opt_snap = {p: {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in optimizer.state.items()}
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -43,10 +45,15 @@ class GraphedTrainStep:
         with torch.no_grad():
             for k, v in model.state_dict().items():
                 v.copy_(snap[k])
-            for st in optimizer.state.values():
-                for v in st.values():
-                    if torch.is_tensor(v):
-                        v.zero_()
+            for p, st in optimizer.state.items():
+                before = opt_snap.get(p)
+                for k, v in st.items():
+                    if not torch.is_tensor(v):
+                        continue
+                    if before is not None and torch.is_tensor(before.get(k)):
+                        v.copy_(before[k])           # what the run had accumulated so far
+                    else:
+                        v.zero_()                    # state the warm-up itself created (a fresh optimizer)
         optimizer.zero_grad(set_to_none=True)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):

@@ -5,7 +5,7 @@ dense (A*B, 1, X, Y, Z) occupancy the reference Dataset yields; targets arrive s
 """
 import torch
 
-from .. import ops
+from .. import ops, tuning
 from ..utils import postprocess, synthetic_scene
 from ..utils.CoDetModule import FaFModule
 
@@ -53,8 +53,7 @@ def make_optimizer(model, lr, total_steps):
     """Adam + the step-wise MultiStepLR (x0.3 at 60 % and 85 % of `total_steps`) every loop here uses.  Drivers that
     train for several epochs create the pair ONCE over the whole run and hand it to the loops, so that Adam's moments and
     the decay schedule survive epoch boundaries (and checkpoints)."""
-    import os
-    if os.environ.get("V2X_TRAIN_GRAPH", "0")[:1] == "1" and next(model.parameters()).is_cuda:
+    if tuning.get("TRAIN_GRAPH") == 1 and next(model.parameters()).is_cuda:
         # hipGraph-captured steps (train/graph_step.py): step counter and learning rate live on the device; the scheduler updates the
         # lr tensor in place, so the captured optimizer step sees every decay
         dev = next(model.parameters()).device

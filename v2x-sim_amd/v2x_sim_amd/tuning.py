@@ -1,0 +1,57 @@
+"""Experiment / engine switches of the package, read from the environment ONCE (at import for the host-side ones, at first use inside
+libv2x_amd.so for the kernel-selection ones) and changed afterwards only through set() -- nothing on the hot path calls os.environ.
+
+Kernel-selection switches live in the library (include/v2x_amd.h: v2x_tuning_set / v2x_tuning_get; defaults = the measured-fastest forms):
+    STREAM_WAVES STREAM_G STREAM_WT STREAM_M32 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP S2_RESIDENT VOXELIZE_LDS WARP_LDS
+Host-side switches (this module):
+    S2_T16      1  stride-2 streamed kernel with 8x16 output tiles for narrow maps (conv4_1); 0: the gather kernel
+    CONV_PAIR   1  conv_pre_1 -> conv_pre_2 as one launch from the bit grid; 0: two launches
+    PP_64       1  pack the 64 -> 64 full-resolution layers for the ping-pong halo kernel (read when a model is packed)
+    TRAIN_HIP   0  training graph on the hand-written kernels (train/hip_graph.py) instead of the PyTorch-ROCm (MIOpen) graph
+    TRAIN_GRAPH 0  with TRAIN_HIP: the whole step as one replayed hipGraph
+    TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
+The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
+import ctypes as C
+import os
+
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 0, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0}
+LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STREAM_M32", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
+                    "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS")
+
+
+def _env_int(name, default):
+    v = os.environ.get("V2X_" + name, "")
+    try:
+        return int(v) if v != "" else default
+    except ValueError:
+        return default
+
+
+_host = {k: _env_int(k, d) for k, d in _HOST_DEFAULTS.items()}
+
+
+def _norm(name):
+    name = name.upper()
+    return name[4:] if name.startswith("V2X_") else name
+
+
+def get(name):
+    name = _norm(name)
+    if name in _host:
+        return _host[name]
+    from . import _lib
+    out = C.c_int(0)
+    _lib.check(_lib.load().v2x_tuning_get(name.encode(), C.byref(out)), "v2x_tuning_get(%s)" % name)
+    return out.value
+
+
+def set(name, value):  # noqa: A001 - mirrors the C entry's name
+    """-> the previous value."""
+    name = _norm(name)
+    old = get(name)
+    if name in _host:
+        _host[name] = int(value)
+    else:
+        from . import _lib
+        _lib.check(_lib.load().v2x_tuning_set(name.encode(), int(value)), "v2x_tuning_set(%s)" % name)
+    return old

@@ -38,13 +38,18 @@ class FaFModule(object):
         if not bev.is_cuda or next(self.model.parameters()).device != bev.device:
             raise RuntimeError("FaFModule.step trains on the MI355X: move the model and the batch to 'cuda'")
         self.model.train()
-        if self._graph_ok(data):
+        if self._graph_ok(data, batch_size):
             # V2X_TRAIN_HIP=1 V2X_TRAIN_GRAPH=1: the whole step as one hipGraph (train/graph_step.py), rebuilt when the batch shape changes
             from ..train.graph_step import GraphedTrainStep
-            key = tuple(tuple(data[k].shape) for k in ("bev_seq", "labels", "reg_targets", "reg_loss_mask")) + (batch_size,)
-            if self._graphed is None or self._graphed[0] != key:
-                self._graphed = (key, GraphedTrainStep(self.model, self.optimizer, data, batch_size))
-            loss, cls_loss, loc_loss = self._graphed[1](data)
+            # The captured steps live ON THE OPTIMIZER (one per batch shape), not on this module: the training loops build a new FaFModule
+            # per epoch around the run's one optimizer, and a step re-captured every epoch (or for the partial last batch and back) would
+            # pay its warm-up each time.  (The warm-up itself restores whatever optimizer state it finds: graph_step.py.)
+            key = self._graph_key(data, batch_size)
+            cache = self.optimizer.__dict__.setdefault("_v2x_graphed_steps", {})
+            if key not in cache:
+                cache[key] = GraphedTrainStep(self.model, self.optimizer, data, batch_size)
+            self._graphed = (key, cache[key])
+            loss, cls_loss, loc_loss = cache[key](data)
             return loss.item(), cls_loss.item(), loc_loss.item()
         result = train_forward(self.model, bev, data.get("trans_matrices"), data.get("num_agent"), batch_size)
         loss, cls_loss, loc_loss = detection_loss(result, data["labels"], data["reg_targets"], data["reg_loss_mask"])
@@ -53,14 +58,18 @@ class FaFModule(object):
         self.optimizer.step()
         return loss.item(), cls_loss.item(), loc_loss.item()
 
-    def _graph_ok(self, data):
-        import os
-        if os.environ.get("V2X_TRAIN_HIP", "0")[:1] != "1" or os.environ.get("V2X_TRAIN_GRAPH", "0")[:1] != "1":
+    def _graph_key(self, data, batch_size):
+        return (id(self.model),) + tuple(tuple(data[k].shape) for k in ("bev_seq", "labels", "reg_targets", "reg_loss_mask")) + (batch_size,)
+
+    def _graph_ok(self, data, batch_size):
+        from .. import tuning
+        if tuning.get("TRAIN_HIP") != 1 or tuning.get("TRAIN_GRAPH") != 1:
             return False
         if hasattr(self.model, "outc"):
             return False
         if hasattr(self.model, "convgru"):          # V2VNet: the frame plan is baked into the graph -- only for the agent table it was captured with
-            if self._graphed is not None and not torch.equal(data["num_agent"].cpu(), self._graphed[1].num_agent):
+            g = self.optimizer.__dict__.get("_v2x_graphed_steps", {}).get(self._graph_key(data, batch_size))
+            if g is not None and not torch.equal(data["num_agent"].cpu(), g.num_agent):
                 return False
         elif not hasattr(self.model, "stpn"):       # FaFNet has no per-batch host plan; the other baselines stay eager
             return False

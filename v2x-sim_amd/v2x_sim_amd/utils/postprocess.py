@@ -210,7 +210,13 @@ def eval_map_device(det_boxes, det_scores, det_count, gt_boxes_list, iou_thr=0.5
         gt[i, :g.shape[0]] = g
         gcount[i] = g.shape[0]
     dev = det_boxes.device
-    cnt = det_count.clamp(min=0).to(torch.int32).contiguous()
+    if bool((det_count < 0).any()):
+        # v2x_det_postprocess's overflow signal (more than `cap` candidates): clamping would score that map with ZERO detections while its
+        # ground truth still counts.  The caller re-runs such maps through the host path (FaFModule.postprocess does) before scoring.
+        bad = torch.nonzero(det_count < 0).flatten().tolist()
+        raise ValueError("eval_map_device: maps %s overflowed the device candidate capacity (count < 0); run them through "
+                         "apply_nms_det and pass their detections in, or raise the capacity" % bad[:8])
+    cnt = det_count.to(torch.int32).contiguous()
     tp = ops.match_detections(det_boxes.contiguous(), cnt, torch.from_numpy(gt).to(dev), torch.from_numpy(gcount).to(dev), iou_thr)
     cnt_h, tp_h, sc_h = cnt.cpu().numpy(), tp.cpu().numpy(), det_scores.cpu().numpy()
     scores = np.concatenate([sc_h[i, :cnt_h[i]] for i in range(n)]) if n else np.zeros(0)
