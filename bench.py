@@ -63,6 +63,10 @@ def parse(argv=None):
                          "2: the whole step as ONE hipGraph (N = 1 only, for comparison)")
     ap.add_argument("--transport", choices=("allgather", "needed"), default="allgather",
                     help="fusion-map exchange: RCCL all-gather (default) or grouped point-to-point of the needed rows only")
+    ap.add_argument("--layout", choices=("spread", "agent-per-gpu"), default="spread",
+                    help="spread (default): the agent-major (agent, frame) items in equal contiguous slices over ALL N ranks; "
+                         "agent-per-gpu: the north_star's literal layout -- rank a < 5 owns agent a's frames, ranks >= 5 idle "
+                         "(needs N >= 5; frames = frames_per_gpu * 5)")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency and other-config sub-records")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launcher, rendezvous (gloo), shard plan, collective, JSON relay")
     return ap.parse_args(argv)
@@ -136,6 +140,18 @@ def launch_ranks(args, argv):
     return rc
 
 
+def shard_layout(args, world, rank):
+    """-> (shard_world, shard_rank or None for an idle rank, process group of the shard or None = the default group).
+    `agent-per-gpu` runs the 5 agents on ranks 0..4 of the job (their own sub-group, created collectively by ALL ranks); the other
+    ranks only take part in the job-wide barriers and the max-over-ranks timing."""
+    if args.layout == "spread":
+        return world, rank, None
+    if world < AGENTS:
+        raise SystemExit("--layout agent-per-gpu needs --gpus >= %d (one GPU per agent)" % AGENTS)
+    group = dist.new_group(ranks=list(range(AGENTS))) if world > AGENTS else None
+    return AGENTS, (rank if rank < AGENTS else None), group
+
+
 def dry_run(args, world, rank):
     """CPU walk through everything around the kernels: rendezvous, agent-major partition, fusion plan, the exchange
     calls (gloo instead of RCCL), barrier + max-over-ranks timing, one JSON line from rank 0."""
@@ -144,26 +160,33 @@ def dry_run(args, world, rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    Bh = args.frames_per_gpu * world // 2
-    shard = AgentShard(AGENTS, Bh, rank, world)
+    sworld, srank, group = shard_layout(args, world, rank)
+    Bh = args.frames_per_gpu * sworld // 2
+    ok = torch.tensor([1])
+    t0 = time.perf_counter()
+    per_rank = AGENTS * Bh // sworld
+    if srank is not None:
+        shard = AgentShard(AGENTS, Bh, srank, sworld)
 
-    class _NoModel:
-        gnn_iter_num, neighbor_source, layer = 1, "initial", 3
-    runner = ShardedV2VNet(_NoModel(), shard, transport=args.transport)
-    plan = shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), "cpu")
-    local = torch.stack([torch.full((2, 2, 8), float(r)) for r in shard.rows])  # fp32: row ids beyond 256 stay exact
+        class _NoModel:
+            gnn_iter_num, neighbor_source, layer = 1, "initial", 3
+        runner = ShardedV2VNet(_NoModel(), shard, group=group, transport=args.transport)
+        plan = shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), "cpu")
+        local = torch.stack([torch.full((2, 2, 8), float(r)) for r in shard.rows])  # fp32: row ids beyond 256 stay exact
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        gathered, work = runner.start_exchange(local)
-        runner.wait(work)
+    if srank is not None:
+        for _ in range(args.steps):
+            gathered, work = runner.start_exchange(local)
+            runner.wait(work)
     if world > 1:
         dist.barrier()
     t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-    # every map an owned ego reads (all agents of its frame) must sit at its agent-major row
-    ok = torch.tensor([int(all(float(gathered[j * Bh + f, 0, 0, 0]) == j * Bh + f
-                               for _, f in plan["items"].tolist() for j in range(AGENTS)))])
+    if srank is not None:
+        # every map an owned ego reads (all agents of its frame) must sit at its agent-major row
+        ok = torch.tensor([int(all(float(gathered[j * Bh + f, 0, 0, 0]) == j * Bh + f
+                                   for _, f in plan["items"].tolist() for j in range(AGENTS)))])
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -171,8 +194,8 @@ def dry_run(args, world, rank):
     if rank == 0:
         print(json.dumps({"metric": "BEV frames/sec, V2VNet 5-agent detection (256x256 BEV)", "value": None, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": world,
-                          "exchange_ok": bool(int(ok)), "transport": args.transport,
-                          "items_per_rank": shard.per_rank, "elapsed_s": float(t)}), flush=True)
+                          "exchange_ok": bool(int(ok)), "transport": args.transport, "layout": args.layout, "active_ranks": sworld,
+                          "frames_per_step": 2 * Bh, "items_per_rank": per_rank, "elapsed_s": float(t)}), flush=True)
     return 0 if int(ok) else 1
 
 
@@ -249,7 +272,10 @@ def main():
     from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
     from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
 
-    Bt = args.frames_per_gpu * world            # frames per step, whole job
+    # layout of the (agent, frame) items over the ranks: all of them (spread) or one agent per rank on ranks 0..4 (agent-per-gpu)
+    sworld, srank, sgroup = shard_layout(args, world, rank) if use_dist else (1, 0, None)
+    active = srank is not None
+    Bt = args.frames_per_gpu * sworld           # frames per step, whole job (per-GPU work fixed: weak scaling)
     Bh = Bt // 2                                # frames per half-batch
     model = init_synthetic_weights(V2VNet(Config("test"), gnn_iter_times=args.gnn_iters, num_agent=AGENTS), seed=0)
     state = {k: v.clone() for k, v in model.state_dict().items()}
@@ -258,8 +284,8 @@ def main():
     # The step is two independent half-batches of Bh frames, each agent-sharded over all ranks.  Half A's exchange
     # is started asynchronously and flies under half B's encoder; half B's flies under half A's fusion/decoder/heads.
     # The decomposition is the same for every N (at N = 1 there is simply nothing to gather): weak scaling.
-    shard = AgentShard(AGENTS, Bh, rank, world)
-    runner = ShardedV2VNet(model, shard, transport=args.transport)
+    shard = AgentShard(AGENTS, Bh, srank if active else 0, sworld)      # (an idle rank builds rank 0's tables and never launches)
+    runner = ShardedV2VNet(model, shard, group=sgroup, transport=args.transport)
     if force_dist and world == 1:
         class _ForcedWorld1(ShardedV2VNet):     # take the world > 1 code path (async RCCL all-gather) on one rank
             def start_exchange(self, local, out=None, counts=None):
@@ -268,14 +294,15 @@ def main():
                 return out, dist.all_gather_into_tensor(out, local, async_op=True)
         runner = _ForcedWorld1(model, shard)
     halves = []
-    for h in range(2):
+    for h in range(2 if active else 0):
         # synthetic sweeps of this rank's (agent, frame) items of half h, resident in HBM
         pts = np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=1000 + 100000 * h + r) for r in shard.rows])
         halves.append({"points": torch.from_numpy(pts).to(dev),
                        "n_pts": torch.full((shard.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=dev),
                        "trans": torch.from_numpy(synthetic_poses(Bh, AGENTS, seed=99 + h)).to(dev),
                        "plan": shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), dev)})
-    model.packed(dev)
+    if active:
+        model.packed(dev)
     wait_events = []    # (start, end) HIP events around the stream-level wait for an exchange: the EXPOSED part of it
 
     def timed_wait(work):
@@ -302,13 +329,13 @@ def main():
         if use_dist:
             dist.barrier()
 
-    for _ in range(max(args.warmup, 1) if args.graph else args.warmup):
+    for _ in range((max(args.warmup, 1) if args.graph else args.warmup) if active else 0):
         out = step()
     torch.cuda.synchronize()
     barrier()               # every rank's warm-up collectives are finished before anybody starts capturing
     wait_events.clear()
 
-    mode = args.graph
+    mode = args.graph if active else -1
     if mode == 2 and use_dist:
         raise SystemExit("--graph 2 (whole step in one hipGraph) is for N = 1 without V2X_FORCE_DIST")
     if mode == 2:
@@ -329,7 +356,7 @@ def main():
             for h in halves:
                 h["xbuf"] = None
                 if use_dist:
-                    h["xbuf"] = torch.empty((world * shard.per_rank, 32, 32, 256), dtype=torch.bfloat16, device=dev)
+                    h["xbuf"] = torch.empty((sworld * shard.per_rank, 32, 32, 256), dtype=torch.bfloat16, device=dev)
             for h in halves:
                 h["g_enc"] = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(h["g_enc"], **cap):
@@ -351,9 +378,12 @@ def main():
             timed_wait(wb)
             b["g_dec"].replay()
         exec_mode = "4 hipGraph segments per step (encoder A, encoder B, fusion+decoder+heads A, B); exchange between them"
-    else:
+    elif mode == 0:
         run = step
         exec_mode = "eager launches"
+    else:
+        run = lambda: None      # noqa: E731 -- a rank without items (agent-per-gpu, rank >= 5): barriers and timing only
+        exec_mode = "idle rank"
     for _ in range(2):
         run()
     torch.cuda.synchronize()
@@ -385,7 +415,8 @@ def main():
     ranks_seen = dist.get_world_size() if use_dist else 1
 
     roofline = None
-    if not args.no_roofline:
+    kernels = None
+    if not args.no_roofline and active:
         # instrumented pass: HIP events around every launch, on the launch stream (eager, not the graph)
         ops.PROFILE = []
         n_inst = 3
@@ -434,8 +465,6 @@ def main():
         kernels = {k: {"us_per_step": v["ms"] * 1e3 / n_inst, "launches_per_step": v["launches"] // n_inst,
                        "tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "gbs": v["bytes"] / max(v["ms"], 1e-9) / 1e6}
                    for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
-    else:
-        kernels = None
 
     latency = configs = training = None
     if rank == 0 and world == 1 and not args.no_extras and not force_dist:
@@ -472,6 +501,7 @@ def main():
             "data": "synthetic (seeded 65536-pt sweeps per agent, random SE(2) poses, He-init weights)",
             "config": {"workload": "V2VNet 5-agent detection, points->logits (a1-a7), gnn_iter=%d" % args.gnn_iters,
                        "agents": AGENTS, "frames_per_step": Bt, "frames_per_gpu": args.frames_per_gpu,
+                       "layout": args.layout, "active_ranks": sworld,
                        "half_batches": 2,
                        "points_per_agent": POINTS_PER_SWEEP, "bev": [256, 256, 13],
                        "sharding": ("agent-major (agent,frame) items, contiguous slices; async RCCL %s of the fusion "

@@ -110,7 +110,16 @@ int v2x_indices_to_bits(const int32_t *idx, const int32_t *counts, int n, int ca
 enum {
     V2X_EPI_BF16 = 0, /* y = acc*scale[c] + shift[c], optional ReLU, bf16 NHWC out          */
     V2X_EPI_F32 = 1,  /* same, fp32 NHWC out (logits)                                        */
-    V2X_EPI_GRU = 2   /* rows are (r,z,n) gate triples; out = (1-z)*n, bf16; see DESIGN.md   */
+    V2X_EPI_GRU = 2,  /* rows are (r,z,n) gate triples; out = (1-z)*n, bf16; see DESIGN.md   */
+    V2X_EPI_DET = 3   /* detection heads with the score threshold fused in (halo kernel, chained layer only): instead of the
+                       * logits the launch emits the candidates of upstream postprocess.py::apply_nms_det's first step,
+                       * softmax(cls)[1] >= det_thr, ready for v2x_det_nms_candidates.  Shape: 3x3 32 -> 64 hidden (cls | reg,
+                       * chain order) chained with Cout2 = 64 rows in DET ORDER: packed row 16 t + 4 q + r, q < 3, belongs to
+                       * the anchors a0 = 2 q, a1 = 2 q + 1 of the pixel:  t = 0: cls[a0][0], cls[a0][1], cls[a1][0], cls[a1][1];
+                       * t = 1: loc[a0][0..3];  t = 2: loc[a0][4], loc[a0][5], loc[a1][0], loc[a1][1];  t = 3: loc[a1][2..5];
+                       * rows with q = 3 are zero (6 anchors x (2 + 6) = 48 real rows of 64).  out = keys uint64
+                       * [N][det_cap] (~score bits << 32 | anchor index << 12 | slot), out2 = codes fp32 [N][det_cap][6],
+                       * det_counts int32 [N] (ZEROED BY THE CALLER; the true count even when > det_cap).  H*W*6 < 2^20. */
 };
 
 typedef struct v2x_conv_desc {
@@ -148,6 +157,9 @@ typedef struct v2x_conv_desc {
     int32_t relu2;       /*   weight rows must be in the chain order ("weight layouts" below).     */
     int32_t in_format;   /* 0: in0 is bf16 NHWC.  1 (w_layout 1, C0 == 32, C1 == 0 only): in0 is the voxelizer's  */
     int32_t in_zbits;    /*    uint32 bit grid [N][H][W]; bit z < in_zbits = channel z, expanded on the fly.      */
+    int32_t *det_counts; /* V2X_EPI_DET only (else NULL / 0): candidate counters [N], score threshold, slots per map   */
+    float det_thr;
+    int32_t det_cap;     /*    <= 4096                                                                              */
 } v2x_conv_desc;
 
 /* ---------------------------------------------------------------- weight layouts and their packers (HOST side)
@@ -316,6 +328,14 @@ int v2x_det_postprocess_rotated(const float *cls, const float *loc, const float 
                                 float nms_thr, int cap, float *out_boxes, float *out_scores, int32_t *out_index,
                                 int32_t *out_count, unsigned long long *key_scratch, int32_t *count_scratch,
                                 v2x_stream_t stream);
+
+/* The second half of the two above for candidates that a V2X_EPI_DET launch of v2x_conv2d already selected (the logits never
+ * reach memory: apply_nms_det's softmax + threshold run in the heads' epilogue).  keys uint64 [n][cap], codes fp32 [n][cap][6],
+ * counts int32 [n] exactly as that launch wrote them; everything else as v2x_det_postprocess (rotated != 0: the rotated-box
+ * variant).  Same detections, bit for bit, as v2x_det_postprocess on the logits the heads would have written. */
+int v2x_det_nms_candidates(const unsigned long long *keys, const float *codes, const int32_t *counts, const float *anchors, int n,
+                           int M, int cap, float nms_thr, int rotated, float *out_boxes, float *out_scores, int32_t *out_index,
+                           int32_t *out_count, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-1: the metric (coperception/utils/mean_ap.py::eval_map)
  * Upstream intersects shapely polygons on the host; here the IoU of rotated boxes (x, y, w, h, yaw) is a convex clip in

@@ -19,15 +19,35 @@ def _run(*flags, env_extra=None):
                           capture_output=True, text=True, timeout=600)
 
 
-@pytest.mark.parametrize("transport", ["allgather", "needed"])
-def test_self_launch_two_ranks_gloo_dry_run(transport):
-    p = _run("--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--transport", transport)
+@pytest.mark.parametrize("gpus,transport", [(2, "allgather"), (2, "needed"), (4, "needed"), (8, "allgather"), (8, "needed")])
+def test_self_launch_gloo_dry_run(gpus, transport):
+    """2, 4 and 8 real ranks at the BENCH geometry (128 frames per GPU: two half-batches, 320 items per rank and half; at 8 ranks
+    5 x 512 items per half)."""
+    p = _run("--gpus", str(gpus), "--steps", "3", "--warmup", "1", "--dry-run", "--transport", transport)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     rec = json.loads(lines[-1])                      # the record is the LAST stdout line
     assert sum(ln.startswith('{"metric"') for ln in lines) == 1
-    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["dry_run"] and rec["exchange_ok"]
-    assert rec["items_per_rank"] == 5 * 64 and rec["transport"] == transport
+    assert rec["n_gpus"] == gpus and rec["ranks_seen"] == gpus and rec["dry_run"] and rec["exchange_ok"]
+    assert rec["items_per_rank"] == 5 * 64 and rec["transport"] == transport and rec["frames_per_step"] == 128 * gpus
+    assert rec["layout"] == "spread" and rec["active_ranks"] == gpus
+
+
+@pytest.mark.parametrize("gpus,transport", [(5, "allgather"), (8, "allgather"), (8, "needed")])
+def test_agent_per_gpu_layout_dry_run(gpus, transport):
+    """SURVEY 8(e) 'literal one-agent-per-GPU layout -- report both': --layout agent-per-gpu runs the five agents on ranks 0..4 (their
+    own sub-group at N = 8; ranks 5..7 idle through the barriers), 128 frames per active GPU."""
+    p = _run("--gpus", str(gpus), "--steps", "2", "--warmup", "1", "--dry-run", "--transport", transport, "--layout", "agent-per-gpu")
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+    assert rec["n_gpus"] == gpus and rec["ranks_seen"] == gpus and rec["exchange_ok"]
+    assert rec["layout"] == "agent-per-gpu" and rec["active_ranks"] == 5 and rec["frames_per_step"] == 128 * 5
+    assert rec["items_per_rank"] == 320                 # rank a owns agent a: 320 frames of it per half-batch
+
+
+def test_agent_per_gpu_needs_five_ranks():
+    p = _run("--gpus", "2", "--dry-run", "--layout", "agent-per-gpu")
+    assert p.returncode != 0 and "needs --gpus >= 5" in p.stderr
 
 
 def test_n1_dry_run_needs_no_launcher():

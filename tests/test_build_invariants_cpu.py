@@ -62,7 +62,10 @@ def test_conv_kernels_are_spill_free_and_use_lds_dma(tmp_path, src, kernel_prefi
         seg = re.search(r"\.private_segment_fixed_size:\s+(\d+)", md)
         assert seg and int(seg.group(1)) == 0, (n, seg and seg.group(1))
         vg = re.search(r"\.vgpr_count:\s+(\d+)", md)
-        assert vg and int(vg.group(1)) <= 256, (n, vg and vg.group(1))
+        # two waves per SIMD -> 256 registers; the chained 64 -> 64 -> 64 4-wave halo kernel (the odd-tile-count fallback of the ping-pong form)
+        # holds 158 KiB of LDS = one workgroup per CU = one wave per SIMD and may take a whole SIMD's 512
+        limit = 512 if n.startswith("_Z19conv3x3_halo_kernelILi0ELi64ELi64ELi64ELi1E") else 256
+        assert vg and int(vg.group(1)) <= limit, (n, vg and vg.group(1))
 
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")

@@ -80,18 +80,23 @@ def _worker(rank, world, port, A, Bt, q):
         dist.destroy_process_group()
 
 
-def test_all_gather_exchange_gloo_world2():
-    world, A, Bt = 2, 5, 2
+def _spawn(target, world, *args, timeout=240):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, A, Bt, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(world)]
+    res = [q.get(timeout=timeout) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+@pytest.mark.parametrize("world,Bt", [(2, 2), (4, 4), (8, 8)])
+def test_all_gather_exchange_gloo(world, Bt):
+    """world 2, 4 and 8 real gloo ranks (nothing above world 2 had run); 5 agents, Bt frames."""
+    _spawn(_worker, world, 5, Bt)
 
 
 def test_exchange_world1_is_identity():
@@ -213,15 +218,85 @@ def _sparse_worker(rank, world, port, A, Bt, q):
         dist.destroy_process_group()
 
 
-def test_sparse_transports_gloo_world2():
-    world, A, Bt = 2, 5, 4
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, A, Bt, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in range(world)]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+@pytest.mark.parametrize("world,Bt", [(2, 4), (4, 8), (8, 8)])
+def test_sparse_transports_gloo(world, Bt):
+    """'needed' (V2VNet) and 'sparse' (when2com) point-to-point transports on 2, 4 and 8 real gloo ranks."""
+    _spawn(_sparse_worker, world, 5, Bt)
+
+
+def test_bench_geometry_plans_world8():
+    """The driver's 8-GPU run: 128 frames per GPU = two half-batches of 512 frames -> 2 560 items per half, 320 per rank.  Host logic of
+    every rank at that size: the partition is agent-major and complete, each rank's slice lies inside ONE agent (so the 'needed' plan
+    fetches the 4 other agents' maps of its 320 frames: 1 280 rows instead of the all-gather's 2 240), and the plans pair up."""
+    from v2x_sim_amd.parallel import ShardedV2VNet
+    A, Bh, world = 5, 512, 8
+    class _M:
+        gnn_iter_num, neighbor_source = 1, "initial"
+    rows = []
+    for r in range(world):
+        sh = AgentShard(A, Bh, r, world)
+        assert sh.per_rank == 320 and len({a for a, _ in sh.items}) <= 2
+        rows += sh.rows
+        plan = sh.fusion_plan(torch.full((Bh, A), A), "cpu")
+        assert plan["n"] == 320 and plan["local_rows"] is None and plan["coef"].sum().item() == 320 * 4
+    assert rows == list(range(A * Bh))
+    rn = ShardedV2VNet(_M(), AgentShard(A, Bh, 0, world), transport="needed")
+    plans = rn.needed_plan()
+    needs = []
+    for r in range(world):
+        fr = {row % Bh for row in range(r * 320, (r + 1) * 320)}
+        needs.append([j * Bh + f for f in fr for j in range(A)])
+    _check_plans(plans, needs, 320)
+    assert max(p["rows"] for p in plans) <= 4 * 320 + 320 < 7 * 320
+    # the literal north_star layout: 5 ranks, one agent each -> every rank reads ALL other agents' maps: needed == all-gather
+    rn5 = ShardedV2VNet(_M(), AgentShard(A, Bh, 0, 5), transport="needed")
+    assert all(p["rows"] == 4 * Bh for p in rn5.needed_plan())
+    for r in range(5):
+        assert {a for a, _ in AgentShard(A, Bh, r, 5).items} == {r}
+
+
+def _subgroup_worker(rank, world, port, q):
+    """Shard on a SUB-GROUP whose members are not ranks 0..R-1 of the job (P2POp peers are GLOBAL ranks), and the
+    synchronous later-round exchange of the 'needed' transport (neighbor_source='updated')."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from v2x_sim_amd.parallel import ShardedV2VNet
+        members = [1, 3]
+        group = dist.new_group(ranks=members)          # collective over ALL ranks of the job
+        if rank in members:
+            A, Bt = 5, 4
+            srank = members.index(rank)
+            shard = AgentShard(A, Bt, srank, 2)
+            H, W, C = 2, 2, 8
+            mk = lambda rows, off: torch.stack([torch.full((H, W, C), float(r) + off) for r in rows]).to(torch.bfloat16)  # noqa: E731
+            class _M:
+                gnn_iter_num, neighbor_source = 2, "updated"
+            for transport in ("allgather", "needed"):
+                rn = ShardedV2VNet(_M(), shard, group=group, transport=transport)
+                for off in (0.0, 64.0):                # first round (start_exchange) and a later round (exchange_round)
+                    local = mk(shard.rows, off)
+                    if off == 0.0:
+                        full, work = rn.start_exchange(local)
+                        rn.wait(work)
+                    else:
+                        full = rn.exchange_round(local)
+                    need = set(shard.rows)
+                    if transport == "needed":
+                        need |= {r for _, lo, hi in rn.needed_plan()[srank]["recv"] for r in range(lo, hi)}
+                    else:
+                        need = set(range(A * Bt))
+                    for r in need:
+                        assert float(full[r, 0, 0, 0]) == float(r) + off, (transport, off, r, float(full[r, 0, 0, 0]))
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_on_a_subgroup_and_later_round_exchange_gloo_world4():
+    _spawn(_subgroup_worker, 4)

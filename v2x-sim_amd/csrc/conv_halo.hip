@@ -53,6 +53,10 @@ struct HaloArgs {
     void *out2;
     int out2_cstride;
     int tiles_x, tiles_y, n_tiles;
+    // EPI2 == 3 (fused detection heads): out = candidate keys [N][det_cap] u64, out2 = candidate box codes [N][det_cap][6] f32
+    int32_t *det_counts;  // [N], zeroed by the caller
+    float det_thr;
+    int det_cap;
 };
 
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
@@ -84,7 +88,11 @@ __device__ __forceinline__ int swz(int slot, int x) {
 
 constexpr int round64(int v) { return (v + 63) / 64 * 64; }
 
-// EPI2: 0 = none (plain epilogue, bf16 out), 1 = chained 1x1 with bf16 out, 2 = chained 1x1 with fp32 split out
+// EPI2: 0 = none (plain epilogue, bf16 out), 1 = chained 1x1 with bf16 out, 2 = chained 1x1 with fp32 split out,
+//       3 = detection heads: the chained 1x1's rows are in "det order" (include/v2x_amd.h, V2X_EPI_DET) so that lane (fj, fq < 3) holds
+//           the two class logits AND the six box codes of anchors 2 fq and 2 fq + 1 of its pixel; the foreground score is thresholded
+//           here and only the candidates (key = ~score | anchor | slot, six codes) leave the chip -- the 4 GB of fp32 logits per 320 maps
+//           that EPI2 = 2 writes and det_candidates_kernel reads back are never materialised
 // DB:   true  = two patch buffers, the next tile's patch streams in under this tile's MFMAs (MFMA-heavy variants);
 //       false = ONE patch buffer and a raw barrier after the output stores: the per-tile __syncthreads of the DB
 //               form drains vmcnt(0), i.e. also waits for the tile's own output stores, which serialises ~2 us of
@@ -445,6 +453,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 }
                 const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
                 const size_t pix = (size_t)(n * a.H + y) * a.W + x;
+                float4 dv[EPI2 == 3 ? TCO2 : 1];
 #pragma unroll
                 for (int i2 = 0; i2 < TCO2; ++i2) {
                     f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -452,6 +461,12 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                     for (int s = 0; s < COUT / 32; ++s)
                         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][s], hb[s], d, 0, 0, 0);
                     const int co = i2 * 16 + fq * 4;
+                    if constexpr (EPI2 == 3) {
+                        // same arithmetic as the logits path below (d * scale2 + shift2): bit-identical logits, kept in registers
+                        dv[i2] = make_float4(d[0] * s2v[i2].x + t2v[i2].x, d[1] * s2v[i2].y + t2v[i2].y,
+                                             d[2] * s2v[i2].z + t2v[i2].z, d[3] * s2v[i2].w + t2v[i2].w);
+                        continue;
+                    }
                     if (co >= a.cout2_real) continue;
                     const float4 s2 = s2v[i2], t2 = t2v[i2];
                     float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
@@ -474,6 +489,33 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                         *reinterpret_cast<uint2 *>(dst) = o;
                     }
                 }
+                if constexpr (EPI2 == 3) {
+                    static_assert(EPI2 != 3 || TCO2 == 4, "det order: 4 row tiles (2 class logits + 6 codes for each of a lane's 2 anchors)");
+                    if (fq < 3) {
+                        // det_candidates_kernel's formula, operation for operation: identical candidates and scores
+                        const float c0[2] = {dv[0].x, dv[0].z}, c1[2] = {dv[0].y, dv[0].w};
+                        const float code[2][6] = {{dv[1].x, dv[1].y, dv[1].z, dv[1].w, dv[2].x, dv[2].y},
+                                                  {dv[2].z, dv[2].w, dv[3].x, dv[3].y, dv[3].z, dv[3].w}};
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const float mx = fmaxf(c0[u], c1[u]);
+                            const float e0 = expf(c0[u] - mx), e1 = expf(c1[u] - mx);
+                            const float fg = e1 / (e0 + e1);
+                            if (fg >= a.det_thr) {
+                                const int pos = atomicAdd(&a.det_counts[n], 1);
+                                if (pos < a.det_cap) {
+                                    const unsigned m = (unsigned)((y * a.W + x) * 6 + 2 * fq + u);   // anchor index inside the map
+                                    reinterpret_cast<unsigned long long *>(a.out)[(size_t)n * a.det_cap + pos] =
+                                        ((unsigned long long)(~__float_as_uint(fg)) << 32) | (m << 12) | (unsigned)pos;
+                                    float *cd = reinterpret_cast<float *>(a.out2) + ((size_t)n * a.det_cap + pos) * 6;
+                                    *reinterpret_cast<float2 *>(cd) = make_float2(code[u][0], code[u][1]);
+                                    *reinterpret_cast<float2 *>(cd + 2) = make_float2(code[u][2], code[u][3]);
+                                    *reinterpret_cast<float2 *>(cd + 4) = make_float2(code[u][4], code[u][5]);
+                                }
+                            }
+                        }
+                    }
+                }
             }
         }
         if constexpr (DB) {
@@ -486,8 +528,10 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     }
 }
 
+// (the chained 64 -> 64 -> 64 instance -- the odd-tile-count fallback of the ping-pong kernel -- holds 158 KiB of LDS, one workgroup per
+// CU: it may use the registers of a whole SIMD, where 256 left it 48 bytes of scratch)
 template <int C0, int C1, int COUT, int COUT2, int EPI2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_kernel(const HaloArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((C0 == 0 && C1 == 64 && COUT2 == 64) ? 1 : 2, 2))) void conv3x3_halo_kernel(const HaloArgs a) {
     conv3x3_halo_body<C0, C1, COUT, COUT2, EPI2, true>(a);
 }
 
@@ -954,6 +998,9 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.split = d->split;
     a.out2 = d->out2;
     a.out2_cstride = d->out2_cstride;
+    a.det_counts = d->det_counts;
+    a.det_thr = d->det_thr;
+    a.det_cap = d->det_cap;
     {   // the packed DMA tables hold the lane's element offset inside the patch in 20 bits
         const int cmax = d->C1 ? (d->C0 > d->C1 ? d->C0 : d->C1) : d->C0;
         if ((long long)(PH * d->W + PW) * cmax >= (1 << 20)) return 1;
@@ -962,7 +1009,7 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.tiles_y = d->H / TH;
     a.n_tiles = d->N * a.tiles_x * a.tiles_y;
     const int co2 = d->Cout2 > 0 ? (d->Cout2 + 15) / 16 * 16 : 0;
-    const int e2 = d->Cout2 > 0 ? (d->epilogue == V2X_EPI_F32 ? 2 : 1) : 0;
+    const int e2 = d->Cout2 > 0 ? (d->epilogue == V2X_EPI_DET ? 3 : (d->epilogue == V2X_EPI_F32 ? 2 : 1)) : 0;
 #define HALO_CASE(c0, c1, co, c2, ep) \
     if (C0 == c0 && C1 == c1 && d->Cout == co && co2 == c2 && e2 == ep) return launch_halo<c0, c1, co, c2, ep>(a, s);
     // HBM-bound 32 -> 32 layers (conv_pre_1 (13 -> 32 padded), conv_pre_2, conv8_2): single-buffer form
@@ -987,6 +1034,12 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     // may depend on the batch without breaking the R-rank == 1-rank equality.
     HALO_CASE(0, 64, 64, 64, 1)
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
+    if (e2 == 3) {                // det heads with the score threshold in the epilogue: candidates instead of logits
+        if (!(C0 == 0 && C1 == 32 && d->Cout == 64 && d->Cout2 == 64 && d->det_counts && d->out && d->out2 && d->det_cap > 0 &&
+              d->det_cap <= 4096 && (long long)d->H * d->W * 6 < (1 << 20)))
+            return 1;
+        return launch_halo<0, 32, 64, 64, 3>(a, s);
+    }
 #undef HALO_CASE
     return 1;
 }

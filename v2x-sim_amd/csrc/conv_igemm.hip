@@ -340,7 +340,17 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
                     "v2x_conv2d(halo): two sources means in0 is the x2-upsampled one");
         V2X_REQUIRE((long long)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 32),
                     "v2x_conv2d(halo): tensor exceeds 32-bit element offsets");
-        V2X_REQUIRE(d->epilogue == V2X_EPI_BF16 || d->epilogue == V2X_EPI_F32, "v2x_conv2d(halo): bad epilogue");
+        V2X_REQUIRE(d->epilogue == V2X_EPI_BF16 || d->epilogue == V2X_EPI_F32 || d->epilogue == V2X_EPI_DET, "v2x_conv2d(halo): bad epilogue");
+        if (d->epilogue == V2X_EPI_DET) {   // detection heads with the threshold in the epilogue: candidates, not logits
+            V2X_REQUIRE(d->C0 == 32 && d->C1 == 0 && d->Cout == 64 && d->Cout2 == 64 && d->weight2 && d->scale2 && d->shift2 && d->in_format == 0,
+                        "v2x_conv2d(det heads): expects 32 -> 64 hidden chained with 64 rows in det order");
+            V2X_REQUIRE(d->out2 && d->det_counts && d->det_cap >= 64 && d->det_cap <= 4096 && (d->det_cap & (d->det_cap - 1)) == 0,
+                        "v2x_conv2d(det heads): needs keys (out), codes (out2), det_counts and a power-of-two det_cap in [64, 4096]");
+            V2X_REQUIRE((long long)d->H * d->W * 6 < (1ll << 20), "v2x_conv2d(det heads): H*W*6 must stay below 2^20 (anchor index and slot share a word)");
+            const int rcd = v2x_conv_halo_dispatch(d, (hipStream_t)stream);
+            V2X_REQUIRE(rcd != 1, "v2x_conv2d(det heads): no kernel for this shape");
+            return rcd;
+        }
         V2X_REQUIRE(d->in_format == 0 || (d->in_format == 1 && d->C0 == 32 && d->C1 == 0 && d->in_zbits >= 1 && d->in_zbits <= 32),
                     "v2x_conv2d(halo): bit-grid input needs C0 == 32, C1 == 0 and 1 <= in_zbits <= 32");
         if (d->Cout2 > 0) {

@@ -178,7 +178,10 @@ __global__ __launch_bounds__(256) void det_candidates_kernel(const float *__rest
     }
 }
 
-template <bool ROTATED>
+// SLOTTED (candidates from the fused detection heads, V2X_EPI_DET): the key's low word is (anchor index << 12 | slot) and `loc` holds the
+// six codes of each CANDIDATE at [map][slot] instead of every anchor's at [map][anchor] -- same order (score, then anchor index), same
+// decode, same suppression.
+template <bool ROTATED, bool SLOTTED = false>
 __global__ __launch_bounds__(256) void det_nms_kernel(const float *__restrict__ loc, const float *__restrict__ anchors,
                                                       int M, int cap, float nms_thr, const unsigned long long *__restrict__ keys,
                                                       const int32_t *__restrict__ counts, float *__restrict__ out_boxes,
@@ -222,8 +225,9 @@ __global__ __launch_bounds__(256) void det_nms_kernel(const float *__restrict__ 
     // order; compacted below)
     float *stage = out_boxes + (size_t)map * cap * 5;   // reused: kept boxes are written in place, front-compacted later
     for (int i = tid; i < cnt; i += 256) {
-        const unsigned m = (unsigned)(skey[i] & 0xffffffffu);
-        const float *l = loc + ((size_t)map * M + m) * 6;
+        const unsigned lowk = (unsigned)(skey[i] & 0xffffffffu);
+        const unsigned m = SLOTTED ? (lowk >> 12) : lowk;
+        const float *l = SLOTTED ? loc + ((size_t)map * cap + (lowk & 0xfffu)) * 6 : loc + ((size_t)map * M + m) * 6;
         const float *a = anchors + (size_t)m * 6;
         const float x = a[0] + l[0], y = a[1] + l[1];
         const float w = a[2] * expf(fminf(fmaxf(l[2], -4.0f), 4.0f));
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(256) void det_nms_kernel(const float *__restrict__ 
         if (k < nk) {
             for (int e = 0; e < 5; ++e) stage[(size_t)k * 5 + e] = v[e];
             out_scores[(size_t)map * cap + k] = __uint_as_float(~(unsigned)(key >> 32));
-            out_index[(size_t)map * cap + k] = (int)(key & 0xffffffffu);
+            out_index[(size_t)map * cap + k] = SLOTTED ? (int)((unsigned)(key & 0xffffffffu) >> 12) : (int)(key & 0xffffffffu);
         }
         __syncthreads();
     }
@@ -353,6 +357,30 @@ extern "C" int v2x_det_postprocess_rotated(const float *cls, const float *loc, c
                                            int32_t *count_scratch, v2x_stream_t stream) {
     return det_postprocess_impl(true, cls, loc, anchors, n, M, score_thr, nms_thr, cap, out_boxes, out_scores, out_index, out_count,
                                 key_scratch, count_scratch, stream);
+}
+
+extern "C" int v2x_det_nms_candidates(const unsigned long long *keys, const float *codes, const int32_t *counts, const float *anchors,
+                                      int n, int M, int cap, float nms_thr, int rotated, float *out_boxes, float *out_scores,
+                                      int32_t *out_index, int32_t *out_count, v2x_stream_t stream) {
+    V2X_REQUIRE(keys && codes && counts && anchors && out_boxes && out_scores && out_index && out_count, "v2x_det_nms_candidates: null pointer");
+    V2X_REQUIRE(n >= 0 && M > 0 && M < (1 << 20), "v2x_det_nms_candidates: M=%d must be below 2^20 (anchor index and slot share a 32-bit word)", M);
+    V2X_REQUIRE(cap >= 64 && cap <= DET_MAX_CAP && (cap & (cap - 1)) == 0, "v2x_det_nms_candidates: cap=%d must be a power of two in [64, %d]", cap, DET_MAX_CAP);
+    if (n == 0) return V2X_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int smem = cap * 28;
+    static v2x_once_per_device attr_once;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX_CAP * 28);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(det_nms_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, DET_MAX_CAP * 28);
+    }
+    if (rotated)
+        hipLaunchKernelGGL((det_nms_kernel<true, true>), dim3(n), dim3(256), smem, s, codes, anchors, M, cap, nms_thr, keys, counts, out_boxes,
+                           out_scores, out_index, out_count);
+    else
+        hipLaunchKernelGGL((det_nms_kernel<false, true>), dim3(n), dim3(256), smem, s, codes, anchors, M, cap, nms_thr, keys, counts, out_boxes,
+                           out_scores, out_index, out_count);
+    V2X_CHECK_LAUNCH("det_nms_kernel");
+    return V2X_OK;
 }
 
 extern "C" int v2x_rotated_iou(const float *boxes_a, int na, const float *boxes_b, int nb, float *iou, v2x_stream_t stream) {

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
-V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU = 0, 1, 2
+V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_EPI_DET = 0, 1, 2, 3
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
 ABI_VERSION = 11
 
@@ -30,6 +30,7 @@ class ConvDesc(C.Structure):
         ("w_layout", C.c_int32), ("Cout2", C.c_int32),
         ("weight2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("relu2", C.c_int32),
         ("in_format", C.c_int32), ("in_zbits", C.c_int32),
+        ("det_counts", C.c_void_p), ("det_thr", C.c_float), ("det_cap", C.c_int32),
     ]
 
 
@@ -88,6 +89,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_det_postprocess_rotated": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int,
                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_det_nms_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_rotated_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_match_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -245,7 +245,10 @@ class DetModelBase(nn.Module):
             halo = packing.pack_conv_halo("heads.fused", w1, torch.cat([s1, s2]), torch.cat([t1, t2]), relu=True,
                                           chain=(w2, torch.ones(ncls + nreg), b2, False), epilogue=V2X_EPI_F32,
                                           device=device)
-        return ops.Layer([hidden, final], halo, split=ncls, name="heads")
+        layer = ops.Layer([hidden, final], halo, split=ncls, name="heads")
+        # the same heads with the score threshold in the epilogue (detections without the logits round trip): DetModelBase.detections()
+        layer.det = packing.pack_heads_det("heads.det", c.conv1, c.bn1, c.conv2, bp[0], bp[1], bp[3], device=device) if halo is not None else None
+        return layer
 
     def _input_nhwc(self, bevs):
         """(N, 1, X, Y, Z) fp32 dense BEV (the reference Dataset format) -> (N, X, Y, c_pad) bf16."""
@@ -254,8 +257,30 @@ class DetModelBase(nn.Module):
         return ops.dense_to_nhwc(bevs[:, 0].to(torch.float32).contiguous(), INPUT_C_PAD)
 
     def decode_heads(self, pk, feats):
-        """Decoder + heads on the (possibly fused) pyramid `feats` -> {'loc', 'cls'}."""
-        return self.get_cls_loc_result(LidarDecoder.run(pk["dec"], *feats), pk["heads"])
+        """Decoder + heads on the (possibly fused) pyramid `feats` -> {'loc', 'cls'}; inside `with model.detections(thr, cap)` and when
+        the extent allows -> {'det': (keys, codes, counts)}: the candidates of apply_nms_det's threshold step straight from the heads'
+        epilogue (ops.conv2d_det), the logits never written."""
+        x = LidarDecoder.run(pk["dec"], *feats)
+        req = getattr(self, "_det_request", None)
+        det = getattr(pk["heads"], "det", None)
+        if (req is not None and det is not None and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0 and x.shape[1] * x.shape[2] * 6 < (1 << 20)
+                and (self.anchor_num_per_loc, self.category_num, self.box_code_size, self.out_seq_len) == (6, 2, 6, 1)):
+            return {"det": ops.conv2d_det(det, x, req[0], req[1])}
+        return self.get_cls_loc_result(x, pk["heads"])
+
+    def detections(self, score_thr, cap=4096):
+        """Context manager: forward() calls inside return candidates instead of logits (see decode_heads)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def _cm():
+            prev = getattr(self, "_det_request", None)
+            self._det_request = (float(score_thr), int(cap))
+            try:
+                yield self
+            finally:
+                self._det_request = prev
+        return _cm()
 
     def _shape_cls_loc(self, cls, loc):
         n = cls.shape[0]

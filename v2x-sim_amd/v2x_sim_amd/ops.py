@@ -519,6 +519,62 @@ def det_postprocess(cls, loc, anchors, score_thr=0.7, nms_thr=0.01, cap=4096, ro
     return boxes, scores, index, count
 
 
+def conv2d_det(pc, x, score_thr, cap=4096):
+    """The fused detection heads (packing.pack_heads_det; conv_halo.hip V2X_EPI_DET) on the decoder's output x (N, H, W, 32) bf16:
+    softmax(cls)[1] >= score_thr is evaluated in the epilogue, only the candidates leave the kernel.
+    -> keys (N, cap) int64, codes (N, cap, 6) fp32, counts (N,) int32 (the true count even when > cap) for det_nms_candidates."""
+    lib = _lib.load()
+    N, H, W, Cx = x.shape
+    if Cx != pc.C0 or pc.epilogue != _lib.V2X_EPI_DET:
+        raise ValueError("conv2d_det needs the det-heads packing and a %d-channel input" % pc.C0)
+    keys = torch.empty((N, cap), dtype=torch.int64, device=x.device)
+    codes = torch.empty((N, cap, 6), dtype=torch.float32, device=x.device)
+    counts = torch.zeros((N,), dtype=torch.int32, device=x.device)
+    d = ConvDesc()
+    d.in0, d.in1 = _dev(x, torch.bfloat16, "x").value, None
+    d.C0, d.C1, d.up0 = pc.C0, 0, 0
+    d.N, d.H, d.W = N, H, W
+    d.ksize, d.stride, d.pad = 3, 1, 1
+    d.Cout, d.w_rows, d.w_kpad = pc.Cout, pc.w_rows, pc.w_kpad
+    d.weight, d.scale, d.shift = pc.weight.data_ptr(), pc.scale.data_ptr(), pc.shift.data_ptr()
+    d.epilogue, d.relu = _lib.V2X_EPI_DET, int(bool(pc.relu))
+    d.out, d.out_cstride, d.out_coff = keys.data_ptr(), cap, 0
+    d.out2, d.split, d.out2_cstride = codes.data_ptr(), 0, 6
+    d.w_layout = 1
+    d.Cout2, d.relu2 = pc.Cout2, 0
+    d.weight2, d.scale2, d.shift2 = pc.weight2.data_ptr(), pc.scale2.data_ptr(), pc.shift2.data_ptr()
+    d.det_counts, d.det_thr, d.det_cap = counts.data_ptr(), float(score_thr), cap
+    prof = None
+    if PROFILE is not None:
+        M = N * H * W
+        prof = _Prof("conv3x3_halo_kernel<0, 32, 64, 64, 3>", 2.0 * M * (64 * 9 * 32 + 48 * 64), x.numel() * 2 + pc.weight.numel() * 2, pc.name)
+    rc = lib.v2x_conv2d(C.byref(d), _stream())
+    if prof is not None:
+        prof.done()
+    _lib.check(rc, "v2x_conv2d(%s, det)" % pc.name)
+    return keys, codes, counts
+
+
+def det_nms_candidates(keys, codes, counts, anchors, nms_thr=0.01, rotated=False):
+    """Second half of det_postprocess for the candidates conv2d_det selected: sort, 'faf' decode, greedy NMS.
+    -> (boxes (n, cap, 5), scores (n, cap), index (n, cap) int32, count (n,) int32), identical to det_postprocess on the logits."""
+    lib = _lib.load()
+    n, cap = keys.shape
+    anchors = anchors.reshape(-1, 6)
+    M = anchors.shape[0]
+    dev = keys.device
+    boxes = torch.empty((n, cap, 5), dtype=torch.float32, device=dev)
+    scores = torch.empty((n, cap), dtype=torch.float32, device=dev)
+    index = torch.empty((n, cap), dtype=torch.int32, device=dev)
+    count = torch.empty((n,), dtype=torch.int32, device=dev)
+    _lib.check(lib.v2x_det_nms_candidates(_dev(keys, torch.int64, "keys"), _dev(codes, torch.float32, "codes"), _dev(counts, torch.int32, "counts"),
+                                          _dev(anchors, torch.float32, "anchors"), n, M, cap, C.c_float(nms_thr), int(bool(rotated)),
+                                          _dev(boxes, torch.float32, "boxes"), _dev(scores, torch.float32, "scores"),
+                                          _dev(index, torch.int32, "index"), _dev(count, torch.int32, "count"), _stream()),
+               "v2x_det_nms_candidates")
+    return boxes, scores, index, count
+
+
 def rotated_iou(boxes_a, boxes_b):
     """boxes (na, 5), (nb, 5) fp32 (x, y, w, h, yaw) on the device -> (na, nb) fp32 IoU of the rotated rectangles."""
     lib = _lib.load()

@@ -13,6 +13,7 @@
 import torch
 
 from . import _lib, tuning
+from ._lib import V2X_EPI_DET
 from .ops import PackedConv, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU
 
 
@@ -128,6 +129,49 @@ def pack_heads(name, cls_conv1, cls_bn1, cls_conv2, reg_conv1, reg_bn1, reg_conv
     final = pack_conv(name + ".final", w2, torch.ones(ncls + nreg), b2, stride=1, pad=0, relu=False,
                       epilogue=V2X_EPI_F32, device=device)
     return hidden, final, ncls
+
+
+def det_row_order(n_anchor=6, n_cls=2, n_code=6):
+    """Row order of the chained 1x1 of the fused DETECTION heads (include/v2x_amd.h, V2X_EPI_DET): packed row 16 t + 4 q + r, q < 3,
+    belongs to anchors a0 = 2 q, a1 = 2 q + 1.  -> list of 64 entries: ("cls", anchor, class) | ("loc", anchor, code) | None (zero row)."""
+    if (n_anchor, n_cls, n_code) != (6, 2, 6):
+        raise ValueError("the fused detection heads cover 6 anchors x (2 class logits + 6 box codes)")
+    rows = [None] * 64
+    for q in range(3):
+        a0, a1 = 2 * q, 2 * q + 1
+        tiles = [[("cls", a0, 0), ("cls", a0, 1), ("cls", a1, 0), ("cls", a1, 1)],
+                 [("loc", a0, c) for c in range(4)],
+                 [("loc", a0, 4), ("loc", a0, 5), ("loc", a1, 0), ("loc", a1, 1)],
+                 [("loc", a1, c) for c in range(2, 6)]]
+        for t in range(4):
+            for r in range(4):
+                rows[16 * t + 4 * q + r] = tiles[t][r]
+    return rows
+
+
+def pack_heads_det(name, cls_conv1, cls_bn1, cls_conv2, reg_conv1, reg_bn1, reg_conv2, device="cuda"):
+    """The two det heads with the score threshold fused into the epilogue (conv_halo.hip, V2X_EPI_DET): the 3x3 hidden layer 32 -> 64
+    (cls | reg) chained with the block-diagonal 1x1 whose 48 rows are scattered into 64 in det order.  Same products and sums per logit
+    as pack_heads' fused fp32 layer -- only the row a logit is computed in changes."""
+    s1, t1 = fold_bn(cls_conv1.bias, cls_bn1, cls_conv1.out_channels)
+    s2, t2 = fold_bn(reg_conv1.bias, reg_bn1, reg_conv1.out_channels)
+    hc, hr = cls_conv1.out_channels, reg_conv1.out_channels
+    if (hc, hr, cls_conv2.out_channels, reg_conv2.out_channels) != (32, 32, 12, 36):
+        return None
+    w1 = torch.cat([cls_conv1.weight.detach().float().cpu(), reg_conv1.weight.detach().float().cpu()], 0)
+    wc, wr = cls_conv2.weight.detach().float().cpu().reshape(12, hc), reg_conv2.weight.detach().float().cpu().reshape(36, hr)
+    bc, br = cls_conv2.bias.detach().float().cpu(), reg_conv2.bias.detach().float().cpu()
+    w2, b2 = torch.zeros((64, hc + hr, 1, 1)), torch.zeros(64)
+    for rho, what in enumerate(det_row_order()):
+        if what is None:
+            continue
+        kind, a, c = what
+        if kind == "cls":
+            w2[rho, :hc, 0, 0], b2[rho] = wc[a * 2 + c], bc[a * 2 + c]
+        else:
+            w2[rho, hc:, 0, 0], b2[rho] = wr[a * 6 + c], br[a * 6 + c]
+    return pack_conv_halo(name, w1, torch.cat([s1, s2]), torch.cat([t1, t2]), relu=True, chain=(w2, torch.ones(64), b2, False),
+                          epilogue=V2X_EPI_DET, device=device)
 
 
 def pack_gru(name, weight_ih, bias_ih, bias_hh, *, C0, C1, device="cuda"):

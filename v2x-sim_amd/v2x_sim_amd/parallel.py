@@ -105,8 +105,8 @@ def plan_row_exchange(needs, per_rank):
 
 
 def _wire(t):
-    """gloo has no bf16: the CPU tests move the bits as int16 (RCCL sends bf16 natively)."""
-    return t.view(torch.int16) if (t.dtype == torch.bfloat16 and not t.is_cuda) else t
+    """gloo has no bf16 (and no int16 collectives): the CPU tests move the bits as uint8 (RCCL sends bf16 natively)."""
+    return t.view(torch.uint8) if (t.dtype == torch.bfloat16 and not t.is_cuda) else t
 
 
 def sparse_exchange(local, full, plan, rank, per_rank, group=None):
@@ -133,8 +133,6 @@ class ShardedV2VNet:
     def __init__(self, model, shard, exchange=None, group=None, transport="allgather"):
         if transport not in ("allgather", "needed"):
             raise ValueError("transport must be 'allgather' or 'needed'")
-        if transport == "needed" and model.gnn_iter_num > 1 and model.neighbor_source == "updated":
-            raise ValueError("transport='needed' serves the begin/finish exchange; GNN rounds on updated maps all-gather")
         self.model, self.shard, self.group, self.transport = model, shard, group, transport
         self._custom_exchange = exchange is not None
         self.exchange = exchange or (lambda t: exchange_features(t, shard.world, group))
@@ -160,6 +158,16 @@ class ShardedV2VNet:
     def encode(self, points, n_pts):
         """a1 + a2 for this rank's items (no collective: capturable in a hipGraph)."""
         return self.encode_points(points, n_pts, self.model.packed(points.device))
+
+    def exchange_round(self, cur):
+        """Synchronous exchange of a later GNN round's UPDATED maps (neighbor_source='updated'): the same transport and -- for
+        'needed' -- the same row plan as the first round (which rows a rank reads depends on the frames it owns, not on the round)."""
+        sh = self.shard
+        if sh.world == 1 or self._custom_exchange or self.transport == "allgather":
+            return self.exchange(cur)
+        gathered, work = self.start_exchange(cur)
+        self.wait(work)
+        return gathered
 
     def start_exchange(self, local, out=None, counts=None):
         """START the exchange of the fusion-layer maps without waiting for it -> (gathered, work).  `out` = optional
@@ -219,7 +227,7 @@ class ShardedV2VNet:
         if gathered0 is None:
             gathered0 = self.exchange(local)
         for it in range(m.gnn_iter_num):
-            src = gathered0 if (m.neighbor_source == "initial" or it == 0) else self.exchange(cur)
+            src = gathered0 if (m.neighbor_source == "initial" or it == 0) else self.exchange_round(cur)
             mean = ops.warp_fuse(src, sh.A, sh.Bt, trans, plan["items"], plan["coef"], V2X_FUSE_MEAN)
             rows = plan["local_rows"]
             ego = cur if rows is None else cur.index_select(0, rows)

@@ -23,6 +23,7 @@ class FaFModule(object):
         self.score_thr = 0.7
         self.nms_thr = 0.01
         self.device_postprocess = True    # False: upstream's host-side numpy path (utils/postprocess.apply_nms_det)
+        self.fused_detection = True       # with device_postprocess: score threshold in the heads' epilogue, logits never stored
         self.cap = 4096                   # candidate capacity per map of the device path
         self._anchors_dev = None
         self._graphed = None              # (batch-shape key, GraphedTrainStep) when V2X_TRAIN_GRAPH=1
@@ -78,11 +79,25 @@ class FaFModule(object):
     def postprocess(self, result):
         """Device-side score / threshold / decode / NMS (v2x_det_postprocess) for every map of `result` -> list of
         dict(boxes, corners, scores) like postprocess.apply_nms_det; maps with more than `cap` candidates fall back to the
-        host function (with random weights tens of thousands of anchors can pass the threshold)."""
+        host function (with random weights tens of thousands of anchors can pass the threshold).
+        result = {'det': ...} (the heads already thresholded, DetModelBase.detections): only sort + decode + NMS are left;
+        -> None if a map overflowed `cap` there (the caller re-runs the logits path: no logits exist to fall back on)."""
         from .. import ops
+        dev = (result["det"][0] if "det" in result else result["cls"]).device
+        if self._anchors_dev is None or self._anchors_dev.device != dev:
+            self._anchors_dev = torch.from_numpy(np.ascontiguousarray(self.anchors.reshape(-1, 6))).to(dev)
+        if "det" in result:
+            keys, codes, counts = result["det"]
+            boxes, scores, _, count = ops.det_nms_candidates(keys, codes, counts, self._anchors_dev, self.nms_thr)
+            count = count.cpu().numpy()
+            if (count < 0).any():
+                return None
+            kmax = int(max(1, count.max()))
+            boxes, scores = boxes[:, :kmax].cpu().numpy(), scores[:, :kmax].cpu().numpy()
+            return [{"boxes": boxes[i, :count[i]], "scores": scores[i, :count[i]],
+                     "corners": postprocess.box_corners(boxes[i, :count[i]]) if count[i] else np.zeros((0, 4, 2), np.float32)}
+                    for i in range(keys.shape[0])]
         cls, loc = result["cls"], result["loc"]
-        if self._anchors_dev is None or self._anchors_dev.device != cls.device:
-            self._anchors_dev = torch.from_numpy(np.ascontiguousarray(self.anchors.reshape(-1, 6))).to(cls.device)
         boxes, scores, _, count = ops.det_postprocess(cls.contiguous(), loc.contiguous(), self._anchors_dev, self.score_thr,
                                                       self.nms_thr, self.cap)
         count = count.cpu().numpy()
@@ -106,17 +121,29 @@ class FaFModule(object):
         that agent's BEV is empty (upstream skips such agents; the slot is kept so that callers pair detections with
         ground truth BY FRAME, never by list position).  when2com / who2com models run in `inference` mode."""
         bev_seq = data["bev_seq"]
-        with torch.no_grad():
-            if hasattr(self.model, "handshake"):
-                result = self.model(bev_seq, data["trans_matrices"], data["num_agent"], training=False, inference=inference,
-                                    batch_size=batch_size)
-            elif hasattr(self.model, "fuse"):
-                result = self.model(bev_seq, data["trans_matrices"], data["num_agent"], batch_size=batch_size)
-            else:
-                result = self.model(bev_seq)
+
+        def run():
+            with torch.no_grad():
+                if hasattr(self.model, "handshake"):
+                    return self.model(bev_seq, data["trans_matrices"], data["num_agent"], training=False, inference=inference,
+                                      batch_size=batch_size)
+                if hasattr(self.model, "fuse"):
+                    return self.model(bev_seq, data["trans_matrices"], data["num_agent"], batch_size=batch_size)
+                return self.model(bev_seq)
+        dets = None
+        if self.device_postprocess and self.fused_detection and hasattr(self.model, "detections"):
+            # detections without the logits round trip: the heads' epilogue thresholds the scores (DetModelBase.detections)
+            with self.model.detections(self.score_thr, self.cap):
+                result = run()
+            dets = self.postprocess(result) if "det" in result else None
+            if dets is None and "det" in result:
+                result = run()              # a map overflowed the candidate capacity: the logits path and its host fallback
+        else:
+            result = run()
         occupied = (bev_seq.reshape(bev_seq.shape[0], -1) != 0).any(dim=1).cpu().numpy()
         seq_results = [[] for _ in range(num_agent)]
-        dets = self.postprocess(result) if self.device_postprocess else None
+        if dets is None:
+            dets = self.postprocess(result) if self.device_postprocess else None
         if dets is None:
             cls = result["cls"].float().cpu().numpy()
             loc = result["loc"].float().cpu().numpy()
