@@ -285,3 +285,91 @@ def test_full_size_postprocess_properties(device, rotated):
     for k in range(0, n, 7):
         m = cnt[pc[k]]
         assert torch.equal(i3[k, :m], index[pc[k], :m]) and torch.equal(s3[k, :m], scores[pc[k], :m])
+
+
+# ------------------------------------------------------------------ detections without the logits round trip (V2X_EPI_DET)
+def _heads_model(device, seed=3, fg_bias=-2.5):
+    """FaFNet with synthetic weights whose foreground logit is biased down so that a few hundred anchors per map pass 0.7 (random
+    weights put ~half of the 393 216 anchors above it -- far beyond the candidate capacity)."""
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    m = init_synthetic_weights(FaFNet(Config("train")), seed=seed)
+    with torch.no_grad():
+        m.classification.conv2.bias[1::2] += fg_bias
+    return m.to(device)
+
+
+@pytest.mark.parametrize("N,H,W", [(3, 256, 256), (2, 64, 96), (5, 8, 32)])
+def test_fused_detection_heads_equal_logits_then_postprocess(device, N, H, W):
+    """The heads with the score threshold in the epilogue + v2x_det_nms_candidates against the heads' logits + v2x_det_postprocess:
+    the same candidates (counts), and bit for bit the same kept boxes, scores and anchor indices, stand-up and rotated NMS; the
+    candidate set is the oracle's (softmax(cls)[1] >= thr on the very logits the other launch wrote)."""
+    from oracle import postprocess_ref as PR
+    from v2x_sim_amd import ops
+    m = _heads_model(device)
+    pk = m.packed(device)
+    g = torch.Generator().manual_seed(N + H)
+    x = (torch.randn(N, H, W, 32, generator=g) * 0.7).relu().to(torch.bfloat16).to(device)
+    anchors = torch.randn(H * W * 6, 6, generator=g).to(device)
+    anchors[:, 2:4] = anchors[:, 2:4].abs() + 1.0
+    thr, cap = 0.7, 4096
+    cls, loc = ops.run_layer(pk["heads"], x)
+    cls, loc = cls.reshape(N, -1, 2), loc.reshape(N, -1, 6)
+    keys, codes, counts = ops.conv2d_det(pk["heads"].det, x, thr, cap)
+    # the candidate sets agree: with an NMS threshold of 1.0 nothing is suppressed, so v2x_det_postprocess's count IS its candidate count
+    assert torch.equal(ops.det_postprocess(cls, loc, anchors, thr, 1.0, cap)[3], counts)
+    if H * W <= 64 * 96:                                                  # ... and it is the oracle's (scalar fp64 softmax) up to threshold ties
+        n_ref = sum(1 for c in cls[0].cpu().tolist() if PR.fg_score(c[0], c[1]) >= thr)
+        assert abs(int(counts[0]) - n_ref) <= 1
+    assert 0 < int(counts.min()) and int(counts.max()) <= cap, counts.tolist()
+    for rotated in (False, True):
+        b0, s0, i0, c0 = ops.det_postprocess(cls, loc, anchors, thr, 0.05, cap, rotated=rotated)
+        b1, s1, i1, c1 = ops.det_nms_candidates(keys, codes, counts, anchors, 0.05, rotated=rotated)
+        assert torch.equal(c0, c1) and int(c0.min()) > 0
+        for i in range(N):
+            k = int(c0[i])
+            assert torch.equal(i0[i, :k], i1[i, :k]) and torch.equal(s0[i, :k], s1[i, :k]) and torch.equal(b0[i, :k], b1[i, :k]), (rotated, i)
+    # every candidate's six codes are the logits' codes of its anchor
+    i = 0
+    k = int(counts[i])
+    anchor = ((keys[i, :k] & 0xffffffff) >> 12).long()
+    slot = (keys[i, :k] & 0xfff).long()
+    assert torch.equal(codes[i][slot], loc[i][anchor]) and sorted(slot.tolist()) == list(range(k))
+    # overflow: more candidates than slots -> the true count is reported, the NMS entry signals -count like v2x_det_postprocess
+    keys2, codes2, counts2 = ops.conv2d_det(pk["heads"].det, x, 0.0, 64)
+    assert counts2.tolist() == [H * W * 6] * N
+    assert ops.det_nms_candidates(keys2, codes2, counts2, anchors, 0.05)[3].tolist() == [-H * W * 6] * N
+
+
+def test_predict_all_fused_detection_equals_logits_path(device):
+    """FaFModule.predict_all with the fused heads (default) and with the logits path: identical detections; a batch that overflows the
+    candidate capacity falls back to the logits path (and its host NMS) instead of losing maps."""
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.utils.CoDetModule import FaFModule
+    from v2x_sim_amd.utils.synthetic import synthetic_points
+    from oracle import voxelize_ref as VR
+    cfg = Config("train")
+    m = _heads_model(device, seed=5, fg_bias=0.0)
+    bev = torch.from_numpy(np.stack([VR.voxelize_occupy(p) for p in synthetic_points(2, 20000, seed=4)])[:, None]).to(device)
+    data = {"bev_seq": bev}
+    with torch.no_grad():                                       # calibrate the foreground bias: ~0.05 % of the anchors above 0.7
+        cls = m(bev)["cls"].float()
+        margin = (cls[..., 1] - cls[..., 0]).flatten()
+        q = torch.quantile(margin[torch.randperm(margin.numel(), device=margin.device)[:2000000]], 0.9995)
+        m.classification.conv2.bias[1::2] += float(np.log(0.7 / 0.3) - q)
+    mod = FaFModule(m, None, cfg, None, 0)
+    mod.nms_thr = 0.05
+    fused = mod.predict_all(data, 2, num_agent=1)[3][0]
+    assert "det" in mod.last_result and "cls" not in mod.last_result
+    mod.fused_detection = False
+    plain = mod.predict_all(data, 2, num_agent=1)[3][0]
+    assert "cls" in mod.last_result
+    assert sum(a["boxes"].shape[0] for a in fused) > 0
+    for a, b in zip(fused, plain):
+        assert np.array_equal(a["boxes"], b["boxes"]) and np.array_equal(a["scores"], b["scores"])
+    mod.fused_detection, mod.cap = True, 64                      # far too few slots: the call must still answer, from the logits
+    small = mod.predict_all(data, 2, num_agent=1)[3][0]
+    assert "cls" in mod.last_result
+    for a, b in zip(small, plain):
+        assert np.allclose(a["boxes"], b["boxes"], atol=1e-4) and a["boxes"].shape == b["boxes"].shape

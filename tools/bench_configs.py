@@ -105,6 +105,26 @@ def run_configs(frames=64, reps=5, dev=None):
     out["2+ device post-processing alone (score, threshold, decode, NMS; %d maps)" % (A * B)] = timed(
         lambda: ops.det_postprocess(res["cls"], res["loc"], anchors, thr, 0.01, 4096))
 
+    # points -> DETECTIONS: (a) the two stages above back to back, (b) the score threshold fused into the heads' epilogue
+    # (V2X_EPI_DET: candidates instead of 4 GB of fp32 logits per 320 maps) + sort / decode / NMS of the candidates
+    def two_stage():
+        r = r2.forward_points(pts, n_pts, trans, plan2)
+        return ops.det_postprocess(r["cls"], r["loc"], anchors, thr, 0.01, 4096)
+
+    def fused():
+        with v2v.detections(thr, 4096):
+            r = r2.forward_points(pts, n_pts, trans, plan2)
+        return ops.det_nms_candidates(*r["det"], anchors, 0.01)
+    t_two, t_fused = timed(two_stage), timed(fused)
+    with torch.no_grad():
+        da, db = two_stage(), fused()
+    same = bool(torch.equal(da[3], db[3])) and all(
+        bool(torch.equal(da[k][i, :int(da[3][i])], db[k][i, :int(db[3][i])])) for k in (0, 1, 2) for i in range(0, A * B, 37) if int(da[3][i]) >= 0)
+    p2d = {"frames": B, "score_thr_quantile": 0.999, "points_to_logits_then_postprocess_ms": t_two, "fused_heads_ms": t_fused,
+           "frames_per_s_two_stage": B / t_two * 1e3, "frames_per_s_fused": B / t_fused * 1e3, "gain": t_two / t_fused - 1.0,
+           "identical_detections": same}
+    out["2d V2VNet points -> detections, threshold fused into the heads (no logits round trip)"] = t_fused
+
     # -- config 3: when2com (inference 'activated') and who2com ('argmax_test')
     w2c = init_synthetic_weights(When2com(cfg), seed=0).to(dev)
     r3 = ShardedWhen2com(w2c, shard)
@@ -124,6 +144,7 @@ def run_configs(frames=64, reps=5, dev=None):
     out["4 V2VNet segmentation (8 classes, argmax + confusion matrix)"] = timed(seg_step)
 
     return {"frames_per_launch": B, "agents": A, "points_per_agent": 65536, "mode": "eager launches, points -> logits",
+            "points_to_detections": p2d,
             "configs": {k: {"ms_per_launch": v, "frames_per_s": B / v * 1e3} for k, v in out.items()}}
 
 

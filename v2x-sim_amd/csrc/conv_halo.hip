@@ -55,7 +55,7 @@ struct HaloArgs {
     int tiles_x, tiles_y, n_tiles;
     // EPI2 == 3 (fused detection heads): out = candidate keys [N][det_cap] u64, out2 = candidate box codes [N][det_cap][6] f32
     int32_t *det_counts;  // [N], zeroed by the caller
-    float det_thr;
+    float det_thr, det_margin;   // score threshold; logit(det_thr) - 1e-3 = the conservative pre-test on c1 - c0
     int det_cap;
 };
 
@@ -247,8 +247,15 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     };
 
     // chained 1x1: its weight fragments live in registers for the whole kernel
-    bf16x8_t w2f[TCO2 > 0 ? TCO2 : 1][COUT / 32];
-    if constexpr (COUT2 > 0) {
+    bf16x8_t w2f[(TCO2 > 0 && EPI2 != 3) ? TCO2 : 1][COUT / 32];
+    // detection heads: the block-diagonal 1x1 -- the class tile multiplies the cls hidden half (k-step 0) only, the three code tiles the
+    // reg hidden half (k-step 1) only; the other halves of the rows are zeros and are skipped (exact: they contribute +0)
+    bf16x8_t wdet[EPI2 == 3 ? 4 : 1];
+    if constexpr (EPI2 == 3) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            wdet[t] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(t * 16 + fj) * COUT + (t == 0 ? 0 : 32) + fq * 8);
+    } else if constexpr (COUT2 > 0) {
 #pragma unroll
         for (int i2 = 0; i2 < TCO2; ++i2)
 #pragma unroll
@@ -261,7 +268,8 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     bool first_tile = true;
     // output-store instructions a wave issues per tile (static: every channel tile is written; the det heads' 48 real
     // channels fill their 3 tiles exactly -- other padded widths fall back to the full drain)
-    constexpr int N_STORES = COUT2 == 0 ? TCO * 4 : ((COUT2 == 48 || COUT2 == 64) ? TCO2 * 4 : 0);
+    // (the detection heads store only their rare candidates: full drain, which then waits for nothing but the next patch)
+    constexpr int N_STORES = EPI2 == 3 ? 0 : (COUT2 == 0 ? TCO * 4 : ((COUT2 == 48 || COUT2 == 64) ? TCO2 * 4 : 0));
     if (DB && tile < a.n_tiles) load_patch(tile, 0);
 
     for (; tile < a.n_tiles; tile += gridDim.x) {
@@ -288,9 +296,12 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
         }
 
         const char *pb = s_patch + cur * PATCH_BYTES;
-        f32x4_t acc[TCO][4];
+        // detection heads (EPI2 == 3): the main loop computes only the CLASSIFICATION head's hidden rows (channel tiles 0, 1); the
+        // regression head's (tiles 2, 3) are computed in the epilogue, per 16-pixel fragment, only where a candidate may exist
+        constexpr int TCOM = (EPI2 == 3) ? 2 : TCO;
+        f32x4_t acc[TCOM][4];
 #pragma unroll
-        for (int i = 0; i < TCO; ++i)
+        for (int i = 0; i < TCOM; ++i)
 #pragma unroll
             for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -304,9 +315,9 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
         // are issued (hard scheduling fences keep that order), so the LDS latency runs under the matrix work even with
         // one wave per SIMD (conv8_1: 129 KiB of LDS -> 4 waves per CU).
         constexpr int KC0 = C0 / 32, KC1 = C1 / 32, KC = KC0 + KC1, NG = 3 * KC;
-        constexpr bool PIPE = (TCO == 2) && DB;   // the single-buffer form runs 4 workgroups per CU on a 128-VGPR budget
+        constexpr bool PIPE = (TCOM == 2) && DB;   // the single-buffer form runs 4 workgroups per CU on a 128-VGPR budget
         struct Frags {
-            bf16x8_t A[3][TCO];
+            bf16x8_t A[3][TCOM];
             bf16x8_t B[8];
         };
         Frags fr[PIPE ? 2 : 1];
@@ -317,7 +328,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 for (int ky = 0; ky < 3; ++ky) {
                     const int kslot = (ky * 3 + kx) * (SPP0 + SPP1) + kk * 4 + fq;
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i)
+                    for (int i = 0; i < TCOM; ++i)
                         F.A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
                 }
 #pragma unroll
@@ -335,7 +346,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 for (int ky = 0; ky < 3; ++ky) {
                     const int kslot = (ky * 3 + kx) * (SPP0 + SPP1) + SPP0 + kc * 4 + fq;
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i)
+                    for (int i = 0; i < TCOM; ++i)
                         F.A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + i * 16 + fj) * 16);
                 }
 #pragma unroll
@@ -354,7 +365,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int i = 0; i < TCO; ++i)
+                for (int i = 0; i < TCOM; ++i)
 #pragma unroll
                     for (int f = 0; f < 4; ++f) {
                         const int r = f >> 1, ch = f & 1;
@@ -387,7 +398,102 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
         const int rr = tile - n * txy;
         const int ty = rr / a.tiles_x;
         const int tx = rr - ty * a.tiles_x;
-        if constexpr (COUT2 == 0) {
+        if constexpr (EPI2 == 3) {
+            static_assert(EPI2 != 3 || (C0 == 0 && C1 == 32 && COUT == 64 && COUT2 == 64), "detection heads: 32 -> (32 | 32) -> det order");
+            auto hidden = [&](const f32x4_t &lo, const f32x4_t &hi, const float4 &s0, const float4 &t0, const float4 &s1, const float4 &t1) {
+                uint4 p;   // the arithmetic of the logits path's hidden layer, value for value
+                p.x = pack_bf16x2(lo[0] * s0.x + t0.x, lo[1] * s0.y + t0.y);
+                p.y = pack_bf16x2(lo[2] * s0.z + t0.z, lo[3] * s0.w + t0.w);
+                p.z = pack_bf16x2(hi[0] * s1.x + t1.x, hi[1] * s1.y + t1.y);
+                p.w = pack_bf16x2(hi[2] * s1.z + t1.z, hi[3] * s1.w + t1.w);
+                p.x = v2x_relu_bf16x2_floor(p.x, relu_floor);
+                p.y = v2x_relu_bf16x2_floor(p.y, relu_floor);
+                p.z = v2x_relu_bf16x2_floor(p.z, relu_floor);
+                p.w = v2x_relu_bf16x2_floor(p.w, relu_floor);
+                return __builtin_bit_cast(bf16x8_t, p);
+            };
+            // first-pass parameters: hidden scale / shift of tiles 0, 1 (channels 8 fq .. 8 fq + 7) and the class tile of the 1x1
+            const float4 det_sc0 = *reinterpret_cast<const float4 *>(a.scale + 8 * fq), det_sf0 = *reinterpret_cast<const float4 *>(a.shift + 8 * fq);
+            const float4 det_sc1 = *reinterpret_cast<const float4 *>(a.scale + 8 * fq + 4), det_sf1 = *reinterpret_cast<const float4 *>(a.shift + 8 * fq + 4);
+            const float4 det_s2 = *reinterpret_cast<const float4 *>(a.scale2 + fq * 4), det_t2 = *reinterpret_cast<const float4 *>(a.shift2 + fq * 4);
+            // ---- first pass, all four fragments at once (independent chains): class logits of the lane's two anchors and the conservative
+            // pre-test on the logit margin (score >= thr <=> c1 - c0 >= logit(thr); det_margin = that minus 1e-3).  The exact softmax formula
+            // below decides, but only fragments that can hold a candidate pay for it and for the regression half.
+            float4 cl[4];
+            unsigned long long any_f[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const bf16x8_t hb0 = hidden(acc[0][f], acc[1][f], det_sc0, det_sf0, det_sc1, det_sf1);
+                const f32x4_t d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdet[0], hb0, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                cl[f] = make_float4(d[0] * det_s2.x + det_t2.x, d[1] * det_s2.y + det_t2.y, d[2] * det_s2.z + det_t2.z, d[3] * det_s2.w + det_t2.w);
+                const bool maybe = fq < 3 && ((cl[f].y - cl[f].x >= a.det_margin) || (cl[f].w - cl[f].z >= a.det_margin));
+                any_f[f] = __builtin_amdgcn_ballot_w64(maybe);
+            }
+            if ((any_f[0] | any_f[1] | any_f[2] | any_f[3]) != 0) {     // wave-uniform; false for almost every wave of a trained detector
+                // ---- second pass, per fragment with a possible candidate: the regression head's hidden rows (tiles 2, 3) from the patch still
+                // in LDS, in the main loop's K order (kx, then ky), then the six codes of each anchor.  Its parameters are loaded here
+                // (rare path): hidden scale / shift of tile i -> channels kappa = 32 (i >> 1) + 8 fq + 4 (i & 1) (chain order).
+                const float4 sc2 = *reinterpret_cast<const float4 *>(a.scale + 32 + 8 * fq), sf2 = *reinterpret_cast<const float4 *>(a.shift + 32 + 8 * fq);
+                const float4 sc3 = *reinterpret_cast<const float4 *>(a.scale + 36 + 8 * fq), sf3 = *reinterpret_cast<const float4 *>(a.shift + 36 + 8 * fq);
+                float4 s2v[3], t2v[3];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    s2v[t] = *reinterpret_cast<const float4 *>(a.scale2 + (t + 1) * 16 + fq * 4);
+                    t2v[t] = *reinterpret_cast<const float4 *>(a.shift2 + (t + 1) * 16 + fq * 4);
+                }
+#pragma unroll   // (four copies of the rare path: a run-time fragment index would put cl / any_f into scratch)
+                for (int f = 0; f < 4; ++f) {
+                    const float4 c = cl[f];
+                    if (any_f[f] == 0) continue;
+                    const int r = f >> 1, ch = f & 1;
+                    f32x4_t g2 = (f32x4_t){0.f, 0.f, 0.f, 0.f}, g3 = g2;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int ky = 0; ky < 3; ++ky) {
+                            const int kslot = (ky * 3 + kx) * SPP1 + fq;
+                            const int pr = 2 * wave + r + ky, pc = ch * 16 + fj + kx;
+                            const bf16x8_t Bf = *reinterpret_cast<const bf16x8_t *>(pb + NS0 * 16 + ((pr * PW + pc) * SPP1 + swz<SPP1>(fq, pc)) * 16);
+                            const bf16x8_t A2 = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + 32 + fj) * 16);
+                            const bf16x8_t A3 = *reinterpret_cast<const bf16x8_t *>(s_w + (kslot * COUT + 48 + fj) * 16);
+                            g2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, Bf, g2, 0, 0, 0);
+                            g3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A3, Bf, g3, 0, 0, 0);
+                        }
+                    const bf16x8_t hb1 = hidden(g2, g3, sc2, sf2, sc3, sf3);
+                    float4 cd[3];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const f32x4_t e = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wdet[t + 1], hb1, (f32x4_t){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                        cd[t] = make_float4(e[0] * s2v[t].x + t2v[t].x, e[1] * s2v[t].y + t2v[t].y, e[2] * s2v[t].z + t2v[t].z, e[3] * s2v[t].w + t2v[t].w);
+                    }
+                    if (fq < 3) {
+                        const int y = ty * TH + 2 * wave + r, x = tx * TW + ch * 16 + fj;
+                        const float c0[2] = {c.x, c.z}, c1[2] = {c.y, c.w};
+                        const float code[2][6] = {{cd[0].x, cd[0].y, cd[0].z, cd[0].w, cd[1].x, cd[1].y},
+                                                  {cd[1].z, cd[1].w, cd[2].x, cd[2].y, cd[2].z, cd[2].w}};
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            // det_candidates_kernel's formula, operation for operation: identical candidates and scores
+                            const float mx = fmaxf(c0[u], c1[u]);
+                            const float e0 = expf(c0[u] - mx), e1 = expf(c1[u] - mx);
+                            const float fg = e1 / (e0 + e1);
+                            if (fg >= a.det_thr) {
+                                const int pos = atomicAdd(&a.det_counts[n], 1);
+                                if (pos < a.det_cap) {
+                                    const unsigned m = (unsigned)((y * a.W + x) * 6 + 2 * fq + u);   // anchor index inside the map
+                                    reinterpret_cast<unsigned long long *>(a.out)[(size_t)n * a.det_cap + pos] =
+                                        ((unsigned long long)(~__float_as_uint(fg)) << 32) | (m << 12) | (unsigned)pos;
+                                    float *co = reinterpret_cast<float *>(a.out2) + ((size_t)n * a.det_cap + pos) * 6;
+                                    *reinterpret_cast<float2 *>(co) = make_float2(code[u][0], code[u][1]);
+                                    *reinterpret_cast<float2 *>(co + 2) = make_float2(code[u][2], code[u][3]);
+                                    *reinterpret_cast<float2 *>(co + 4) = make_float2(code[u][4], code[u][5]);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else if constexpr (COUT2 == 0) {
 #pragma unroll
             for (int i = 0; i < TCO; ++i) {
                 const int co = i * 16 + fq * 4;
@@ -453,7 +559,6 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 }
                 const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
                 const size_t pix = (size_t)(n * a.H + y) * a.W + x;
-                float4 dv[EPI2 == 3 ? TCO2 : 1];
 #pragma unroll
                 for (int i2 = 0; i2 < TCO2; ++i2) {
                     f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -461,12 +566,6 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                     for (int s = 0; s < COUT / 32; ++s)
                         d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][s], hb[s], d, 0, 0, 0);
                     const int co = i2 * 16 + fq * 4;
-                    if constexpr (EPI2 == 3) {
-                        // same arithmetic as the logits path below (d * scale2 + shift2): bit-identical logits, kept in registers
-                        dv[i2] = make_float4(d[0] * s2v[i2].x + t2v[i2].x, d[1] * s2v[i2].y + t2v[i2].y,
-                                             d[2] * s2v[i2].z + t2v[i2].z, d[3] * s2v[i2].w + t2v[i2].w);
-                        continue;
-                    }
                     if (co >= a.cout2_real) continue;
                     const float4 s2 = s2v[i2], t2 = t2v[i2];
                     float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
@@ -487,33 +586,6 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                         o.y = pack_bf16x2(v2, v3);
                         uint16_t *dst = reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co;
                         *reinterpret_cast<uint2 *>(dst) = o;
-                    }
-                }
-                if constexpr (EPI2 == 3) {
-                    static_assert(EPI2 != 3 || TCO2 == 4, "det order: 4 row tiles (2 class logits + 6 codes for each of a lane's 2 anchors)");
-                    if (fq < 3) {
-                        // det_candidates_kernel's formula, operation for operation: identical candidates and scores
-                        const float c0[2] = {dv[0].x, dv[0].z}, c1[2] = {dv[0].y, dv[0].w};
-                        const float code[2][6] = {{dv[1].x, dv[1].y, dv[1].z, dv[1].w, dv[2].x, dv[2].y},
-                                                  {dv[2].z, dv[2].w, dv[3].x, dv[3].y, dv[3].z, dv[3].w}};
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const float mx = fmaxf(c0[u], c1[u]);
-                            const float e0 = expf(c0[u] - mx), e1 = expf(c1[u] - mx);
-                            const float fg = e1 / (e0 + e1);
-                            if (fg >= a.det_thr) {
-                                const int pos = atomicAdd(&a.det_counts[n], 1);
-                                if (pos < a.det_cap) {
-                                    const unsigned m = (unsigned)((y * a.W + x) * 6 + 2 * fq + u);   // anchor index inside the map
-                                    reinterpret_cast<unsigned long long *>(a.out)[(size_t)n * a.det_cap + pos] =
-                                        ((unsigned long long)(~__float_as_uint(fg)) << 32) | (m << 12) | (unsigned)pos;
-                                    float *cd = reinterpret_cast<float *>(a.out2) + ((size_t)n * a.det_cap + pos) * 6;
-                                    *reinterpret_cast<float2 *>(cd) = make_float2(code[u][0], code[u][1]);
-                                    *reinterpret_cast<float2 *>(cd + 2) = make_float2(code[u][2], code[u][3]);
-                                    *reinterpret_cast<float2 *>(cd + 4) = make_float2(code[u][4], code[u][5]);
-                                }
-                            }
-                        }
                     }
                 }
             }
@@ -1000,6 +1072,10 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.out2_cstride = d->out2_cstride;
     a.det_counts = d->det_counts;
     a.det_thr = d->det_thr;
+    {
+        const double t = d->det_thr;
+        a.det_margin = (t > 0.0 && t < 1.0) ? (float)(log(t / (1.0 - t)) - 1e-3) : (t <= 0.0 ? -3.0e38f : 80.0f);   // thr <= 0: every anchor; >= 1: practically none
+    }
     a.det_cap = d->det_cap;
     {   // the packed DMA tables hold the lane's element offset inside the patch in 20 bits
         const int cmax = d->C1 ? (d->C0 > d->C1 ? d->C0 : d->C1) : d->C0;

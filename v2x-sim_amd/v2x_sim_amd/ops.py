@@ -622,10 +622,11 @@ class Layer:
     conv_halo.hip (3x3 stride 1, H % 8 == 0, W % 32 == 0); `fallback` is the list of gather-kernel
     convs computing the same thing for any other extent.  `split` > 0: two output tensors."""
 
-    __slots__ = ("halo", "fallback", "split", "name")
+    __slots__ = ("halo", "fallback", "split", "name", "det")
 
     def __init__(self, fallback, halo=None, split=0, name=None):
         self.fallback, self.halo, self.split = list(fallback), halo, split
+        self.det = None      # det heads only: the packing with the score threshold in the epilogue (packing.pack_heads_det)
         self.name = name or self.fallback[0].name
 
 
