@@ -199,9 +199,21 @@ def dry_run(args, world, rank):
     return 0 if int(ok) else 1
 
 
-def measure_latency(model, dev, frames_list=(1, 8, 32), reps=30):
+def measure_latency(model, dev, frames_list=(1, 8, 32), reps=30, small_batch=True):
     """Latency mode (SURVEY.md 8d batch sizes): ONE hipGraph replay of points -> logits for `frames` collaborative frames,
-    host-synchronised per replay, median over `reps`."""
+    host-synchronised per replay, median over `reps`.  small_batch: with the tuning switch SMALL_BATCH = 1 (split-K for the streamed layers
+    whose launch has fewer tiles than CUs; v2x_sim_amd/ops.py::small_batch_splitk) -- what a caller serving single frames turns on."""
+    from v2x_sim_amd import tuning
+    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+    from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
+    prev = tuning.set("SMALL_BATCH", 1 if small_batch else 0)
+    try:
+        return _measure_latency(model, dev, frames_list, reps, small_batch)
+    finally:
+        tuning.set("SMALL_BATCH", prev)
+
+
+def _measure_latency(model, dev, frames_list, reps, small_batch):
     from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
     from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
     out = {}
@@ -232,7 +244,8 @@ def measure_latency(model, dev, frames_list=(1, 8, 32), reps=30):
         out["b%d_ms" % frames] = ts[len(ts) // 2]
         out["b%d_frames_per_s" % frames] = frames / ts[len(ts) // 2] * 1e3
         del g, res
-    out["mode"] = "one hipGraph replay of points->logits per batch, host-synchronised, median of %d" % reps
+    out["mode"] = "one hipGraph replay of points->logits per batch, host-synchronised, median of %d; %s" % (
+        reps, "SMALL_BATCH = 1 (split-K for launches with fewer tiles than CUs)" if small_batch else "default kernel dispatch (the throughput step's)")
     return out
 
 
@@ -475,6 +488,7 @@ def main():
         out = run = None
         torch.cuda.empty_cache()
         latency = measure_latency(model, dev)
+        latency["default_dispatch"] = measure_latency(model, dev, small_batch=False)
         try:
             import importlib.util
             spec = importlib.util.spec_from_file_location("bench_configs", os.path.join(ROOT, "tools", "bench_configs.py"))

@@ -125,7 +125,7 @@ def test_voxelize_lds_form_equals_atomic_form(device, tune):
             buf[i, :c.shape[0], :4] = c
         pts = torch.from_numpy(buf).to(device)
         grid = ops.VoxelGrid()
-        tune("VOXELIZE_LDS", 1)
+        tune("VOXELIZE_LDS", 2)      # 2 = the LDS-binned form at any cloud count (1 = default: the global-atomic form below 49 clouds)
         lds = ops.voxelize_bits(pts, cnt, grid).clone()
         tune("VOXELIZE_LDS", 0)
         atm = ops.voxelize_bits(pts, cnt, grid).clone()
@@ -646,7 +646,7 @@ def test_voxelize_counts_beyond_capacity_and_bad_jobs(device, tune):
     over = torch.tensor([4096 + 5000, 4096, 1 << 30], dtype=torch.int32, device=device)   # counts beyond the capacity
     exact = torch.full((3,), 4096, dtype=torch.int32, device=device)
     ref = ops.voxelize_bits(pts, exact, grid).clone()
-    for form in ("1", "0"):
+    for form in ("2", "0"):
         tune("VOXELIZE_LDS", form)
         assert torch.equal(ops.voxelize_bits(pts, over, grid), ref), "form %s read past the cloud" % form
     tune.reset("VOXELIZE_LDS")

@@ -329,3 +329,65 @@ def test_full_size_properties_batch_equivariance_and_scaling(device, layer):
         y4 = run([(t.float() * 4).to(torch.bfloat16) for t in xs])
         assert torch.equal(y4.float(), y.float() * 4), "%s: y(4x) != 4 y(x)" % layer
         assert float(y.float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("cfg", [
+    # (C_up, C, Cout, N, H, W, gru, splitk)
+    (512, 256, 256, 5, 32, 32, False, 6),    # conv5_1 at ONE collaborative frame: 24 chunks in 6 ranges, half-resolution source first
+    (0, 256, 256, 5, 32, 32, False, 4),      # conv3_2 / conv5_2: 8 chunks
+    (0, 512, 512, 5, 16, 16, False, 8),      # conv4_2: 16x16 tiles
+    (256, 128, 128, 5, 64, 64, False, 3),    # conv6_1
+    (0, 128, 128, 2, 16, 32, False, 3),      # 4 chunks in 3 ranges (2, 2) -> refused (an empty range): falls to 2
+    (256, 256, 256, 5, 32, 32, True, 2),     # ConvGRU: gate epilogue in the reduce kernel
+    (256, 256, 256, 3, 32, 32, True, 5),     # 16 chunks in 5 ranges of 4, 4, 4, 4 (the last one would be empty): refused -> 4
+    (128, 64, 64, 5, 128, 128, False, 2),    # conv7_1: 64-row tiles
+])
+def test_small_batch_splitk(device, cfg, tune):
+    """Latency mode: the chunk range of a streamed layer divided over `splitk` workgroups per tile + splitk_reduce_kernel (fixed-order sum,
+    epilogue).  Against torch fp32 on the same bf16 operands (one bf16 ulp), against the default kernel (fp32 summation order: one bf16
+    rounding on few entries), bit-stable over launches; a split with an empty range is refused by the library."""
+    from v2x_sim_amd import ops, packing
+    cup, c, cout, N, H, W, gru, splitk = cfg
+    g = torch.Generator().manual_seed(sum(cfg[:6]) + splitk)
+    x = bf16r(torch.randn(N, c, H, W, generator=g))
+    if gru:
+        x0 = bf16r(torch.randn(N, cup, H, W, generator=g))
+        cell = R.Conv2dGRUCell(cup + c, cout, 3)
+        with torch.no_grad():
+            for p in cell.parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            ref = cell(torch.cat((x0, x), 1), None, emulate=True)
+        pc = packing.pack_gru_stream("g", cell.weight_ih_l0, cell.bias_ih_l0, cell.bias_hh_l0, C0=cup, C1=c, device=device)
+        a0, a1 = nhwc(x0, device), nhwc(x, device)
+        tol = dict(atol=2 ** -7, rtol=2 ** -7)
+    else:
+        w = torch.randn(cout, cup + c, 3, 3, generator=g) * (2.0 / ((cup + c) * 9)) ** 0.5
+        scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+        pc = packing.pack_conv_stream("t", w, scale, shift, C0=cup if cup else c, C1=c if cup else 0, up0=1 if cup else 0, device=device)
+        if cup:
+            xu = bf16r(torch.randn(N, cup, H // 2, W // 2, generator=g))
+            xin = torch.cat((F.interpolate(xu, scale_factor=(2, 2)), x), 1)
+            a0, a1 = nhwc(xu, device), nhwc(x, device)
+        else:
+            xin, a0, a1 = x, nhwc(x, device), None
+        ref = F.relu(F.conv2d(xin, bf16r(w), None, 1, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+        tol = dict(atol=2e-3, rtol=2 ** -7)
+    base = ops.conv2d(pc, a0, a1)
+    chunks = (cup + c) // 32
+    if -(-chunks // splitk) * (splitk - 1) >= chunks:
+        with pytest.raises(Exception, match="not tileable|v2x_conv2d"):
+            ops.conv2d(pc, a0, a1, splitk=splitk)
+        splitk -= 1
+    y = ops.conv2d(pc, a0, a1, splitk=splitk)
+    assert torch.allclose(back(y), ref, **tol), float((back(y) - ref).abs().max())
+    assert torch.allclose(y.float(), base.float(), **tol) and float((y != base).float().mean()) < 0.03
+    for _ in range(4):
+        assert torch.equal(ops.conv2d(pc, a0, a1, splitk=splitk), y)
+    # the switch: off -> run_layer launches the default kernel; on -> small_batch_splitk picks a split that fills the chip
+    assert ops.small_batch_splitk(pc, N, H, W) == 0
+    tune("SMALL_BATCH", 1)
+    s_auto = ops.small_batch_splitk(pc, N, H, W)
+    tiles = N * (H * W // 256) * (pc.w_rows // ops._lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue))
+    assert s_auto == 0 or (2 <= s_auto <= chunks // 2 and tiles < 200 and tiles * s_auto <= 520), (s_auto, tiles, chunks)
+    if s_auto:
+        assert torch.allclose(back(ops.conv2d(pc, a0, a1, splitk=s_auto)), ref, **tol)

@@ -47,6 +47,11 @@ struct StreamArgs {
     const uint16_t *w2;   // bf16 [64][64] row-major, K in the chain (kappa) order of conv_halo.hip
     const float *scale2, *shift2;
     int relu2;
+    // split-K (small batches, conv3x3_stream_kernel<..., SPLITK = true>): blockIdx.y walks `ksplit` contiguous ranges of the 32-channel
+    // chunks and stores its raw fp32 sums to ws[split][pixel][w_rows]; splitk_reduce_kernel adds them in split order and applies the epilogue
+    int ksplit;
+    float *ws;
+    int w_rows;
 };
 
 constexpr int PATCH_PIECES = 24;             // wave instructions (1 KiB each) per patch buffer
@@ -363,7 +368,7 @@ __device__ __forceinline__ void stream_epilogue32(const StreamArgs &a, f32x16_t 
     }
 }
 
-template <int BCO, int TH, int TW, int EPI>
+template <int BCO, int TH, int TW, int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream_kernel(const StreamArgs a) {
     constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
     constexpr int TCO = BCO / 16;
@@ -400,8 +405,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int y0 = ty * TH, x0 = tx * TW;
 
     const int nc0 = a.C0 >> 5, nchunks = (a.C0 + a.C1) >> 5;
-    const int S = nchunks * 9;
-    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    // the chunk range of this workgroup: all of them, or (SPLITK) the blockIdx.y-th of a.ksplit contiguous ranges (the host makes sure
+    // that none is empty); steps and ring slots are counted from the range's first step
+    int kc_lo = 0, kc_hi = nchunks;
+    if constexpr (SPLITK) {
+        const int per = (nchunks + a.ksplit - 1) / a.ksplit;
+        kc_lo = blockIdx.y * per;
+        kc_hi = kc_lo + per < nchunks ? kc_lo + per : nchunks;
+    }
+    const int S = (kc_hi - kc_lo) * 9;
+    const uint16_t *wbase = a.w + ((size_t)co_tile * nchunks + kc_lo) * 9 * (BCO * 32);
     // zero page for out-of-image patch pixels and count-keeping dummy DMAs: the packer appends 64 B of zeros
     const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
 
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- prologue: whole patch of chunk 0 (6 pieces per wave), weight slices of steps 0..2 --------
 #pragma unroll
-    for (int t = 0; t < 6; ++t) issue_patch_piece(0, t, 0);
+    for (int t = 0; t < 6; ++t) issue_patch_piece(kc_lo, t, 0);
     issue_weights(0);  // S = 9 * chunks >= 9, so steps 1 and 2 always exist
     issue_weights(1);
     issue_weights(2);
@@ -478,8 +491,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
     int s = 0;
-    for (int kc = 0; kc < nchunks; ++kc) {
-        const char *pb = s_patch + (kc & 1) * PATCH_BYTES;
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
+        const char *pb = s_patch + ((kc - kc_lo) & 1) * PATCH_BYTES;
         const bool half = (kc < nc0) && a.up0;
         const int sh = half ? 1 : 0, row_bytes = (half ? PW0 : PW) * 64;  // wave-uniform
 #pragma unroll 1  // ky stays rolled (full unrolling hoists per-tap offsets into ~70 registers and spills; scratch
@@ -503,7 +516,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // 3. keep the pipe full: weight slice of step s+3, one piece of the next chunk's patch
                 if (s + 3 < S) {
                     issue_weights(s + 3);
-                    if (tap < 6 && kc + 1 < nchunks) issue_patch_piece(kc + 1, tap, (kc + 1) & 1);
+                    if (tap < 6 && kc + 1 < kc_hi) issue_patch_piece(kc + 1, tap, (kc + 1 - kc_lo) & 1);
                     else issue_dummy();
                 }
                 // 4. MFMAs of (chunk kc, tap)
@@ -532,7 +545,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
 
-    stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+    if constexpr (SPLITK) {
+        // raw fp32 partial sums of this chunk range: ws[split][pixel][w_rows], the lane's 4 consecutive rows as one 16-byte store
+        const size_t npix = (size_t)a.N * a.H * a.W;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+                *reinterpret_cast<f32x4_t *>(a.ws + ((size_t)blockIdx.y * npix + pix) * a.w_rows + co_tile * BCO + i * 16 + fq * 4) = acc[i][f];
+            }
+    } else {
+        stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+    }
+}
+
+// Second half of a split-K launch: out = epilogue(sum over the splits, in split order -- deterministic) of ws[split][pixel][w_rows].
+// Plain layers: a thread owns 4 consecutive channels of a pixel (scale / shift / ReLU, bf16).  ConvGRU: a thread owns 4 hidden channels
+// hc..hc+3, whose gate rows sit at tile * 96 + group * 48 + {0, 16, 32} + c of the packed (r, z, n)-triple order (hc = 32 tile + 16 group + c).
+template <bool GRU>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ ws, int ksplit, long long npix, int w_rows, int Cout,
+                                                            const float *__restrict__ scale, const float *__restrict__ shift, int relu,
+                                                            uint16_t *__restrict__ out, int out_cstride, int out_coff) {
+    const int quads = Cout / 4;
+    const long long total = npix * quads;
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long pix = t / quads;
+        const int c = (int)(t - pix * quads) * 4;
+        if constexpr (GRU) {
+            const int row = (c >> 5) * 96 + ((c >> 4) & 1) * 48 + (c & 15);
+            f32x4_t g[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) g[q] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < ksplit; ++sp)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) g[q] += *reinterpret_cast<const f32x4_t *>(ws + ((size_t)sp * npix + pix) * w_rows + row + 16 * q);
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float4 b = reinterpret_cast<const float4 *>(scale)[c + r];   // (b_ir + b_hr, b_iz + b_hz, b_in, b_hn)
+                const float rg = 1.0f / (1.0f + __expf(-(g[0][r] + b.x)));
+                const float zg = 1.0f / (1.0f + __expf(-(g[1][r] + b.y)));
+                const float ng = tanhf(g[2][r] + b.z + rg * b.w);
+                h[r] = ng + zg * (0.0f - ng);
+            }
+            uint2 o;
+            o.x = pack_bf16x2(h[0], h[1]);
+            o.y = pack_bf16x2(h[2], h[3]);
+            *reinterpret_cast<uint2 *>(out + pix * out_cstride + out_coff + c) = o;
+        } else {
+            f32x4_t v = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            for (int sp = 0; sp < ksplit; ++sp) v += *reinterpret_cast<const f32x4_t *>(ws + ((size_t)sp * npix + pix) * w_rows + c);
+            const float4 sc = *reinterpret_cast<const float4 *>(scale + c), sf = *reinterpret_cast<const float4 *>(shift + c);
+            uint2 o;
+            o.x = pack_bf16x2(v[0] * sc.x + sf.x, v[1] * sc.y + sf.y);
+            o.y = pack_bf16x2(v[2] * sc.z + sf.z, v[3] * sc.w + sf.w);
+            if (relu) {
+                o.x = v2x_relu_bf16x2(o.x);
+                o.y = v2x_relu_bf16x2(o.y);
+            }
+            *reinterpret_cast<uint2 *>(out + pix * out_cstride + out_coff + c) = o;
+        }
+    }
 }
 
 // ---- 8-wave "ping-pong" form --------------------------------------------------------------------------
@@ -1792,6 +1866,30 @@ static int launch_stream(const StreamArgs &a, hipStream_t s) {
     return V2X_OK;
 }
 
+// split-K pair of launches (small batches: a.ksplit chunk ranges per tile so that few tiles still fill the chip)
+template <int BCO, int TH, int TW, int EPI>
+static int launch_stream_splitk(const StreamArgs &a, hipStream_t s) {
+    constexpr int smem = RING * BCO * 64 + 2 * PATCH_BYTES;
+    static v2x_once_per_device attr_once;
+    auto kern = &conv3x3_stream_kernel<BCO, TH, TW, SEPI_BF16, true>;   // (the epilogue is the reduce kernel's)
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles, a.ksplit), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_stream_kernel(split-K)");
+    const long long npix = (long long)a.N * a.H * a.W;
+    const long long threads = npix * (a.Cout / 4);
+    int grid = (int)((threads + 255) / 256 < 4096 ? (threads + 255) / 256 : 4096);
+    if (EPI == SEPI_GRU)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(grid), dim3(256), 0, s, a.ws, a.ksplit, npix, a.w_rows, a.Cout, a.scale, a.shift, a.relu,
+                           reinterpret_cast<uint16_t *>(a.out), a.out_cstride, a.out_coff);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(grid), dim3(256), 0, s, a.ws, a.ksplit, npix, a.w_rows, a.Cout, a.scale, a.shift, a.relu,
+                           reinterpret_cast<uint16_t *>(a.out), a.out_cstride, a.out_coff);
+    V2X_CHECK_LAUNCH("splitk_reduce_kernel");
+    return V2X_OK;
+}
+
 // rows per channel tile the stream kernel uses for (Cout, epilogue); 0 = unsupported
 extern "C" int v2x_conv_stream_tile_rows(int Cout, int epilogue) {
     if (epilogue == V2X_EPI_GRU) return (Cout % 32 == 0) ? 96 : 0;
@@ -1832,7 +1930,20 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.scale2 = d->scale2;
     a.shift2 = d->shift2;
     a.relu2 = d->relu2;
+    a.ksplit = d->splitk;
+    a.ws = d->splitk_ws;
+    a.w_rows = d->w_rows;
     const bool chain = d->Cout2 > 0;
+    if (d->splitk > 1) {
+        // small-batch form: the 4-wave kernel with the chunk range divided over blockIdx.y + the reduce kernel.  Plain and GRU epilogues,
+        // every split at least one chunk; sums are added in split order (results differ from the unsplit kernels in fp32 summation order)
+        const int nchunks = (d->C0 + d->C1) >> 5;
+        const int per = (nchunks + d->splitk - 1) / d->splitk;
+        if (chain || !d->splitk_ws || d->splitk > nchunks || per * (d->splitk - 1) >= nchunks || (rows != 128 && rows != 96 && rows != 64)) return 1;
+        if (d->epilogue == V2X_EPI_GRU) return t16 ? launch_stream_splitk<96, 16, 16, SEPI_GRU>(a, s) : launch_stream_splitk<96, 8, 32, SEPI_GRU>(a, s);
+        if (rows == 128) return t16 ? launch_stream_splitk<128, 16, 16, SEPI_BF16>(a, s) : launch_stream_splitk<128, 8, 32, SEPI_BF16>(a, s);
+        return t16 ? launch_stream_splitk<64, 16, 16, SEPI_BF16>(a, s) : launch_stream_splitk<64, 8, 32, SEPI_BF16>(a, s);
+    }
     if (chain) {  // chained 1x1: 64 -> 64 -> 64 (conv1_2 -> conv3d_1) and 128 -> 128 -> 128 (conv2_2 -> conv3d_2)
         if ((d->Cout != 64 && d->Cout != 128) || d->Cout2 != d->Cout || d->w_rows != d->Cout || d->epilogue != V2X_EPI_BF16 ||
             !d->weight2 || !d->scale2 || !d->shift2)

@@ -31,6 +31,7 @@ class ConvDesc(C.Structure):
         ("weight2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("relu2", C.c_int32),
         ("in_format", C.c_int32), ("in_zbits", C.c_int32),
         ("det_counts", C.c_void_p), ("det_thr", C.c_float), ("det_cap", C.c_int32),
+        ("splitk", C.c_int32), ("splitk_ws", C.c_void_p),
     ]
 
 

@@ -125,7 +125,8 @@ def voxelize_bits(points, n_pts, grid, out=None):
     X, Y, Z = grid.dims
     if out is None:
         out = torch.empty((n, X, Y), dtype=torch.int32, device=points.device)
-    lds = Z <= 16 and X * Y * 2 <= 128 * 1024 and (X * Y) % 8 == 0 and mp > 0 and tuning.get("VOXELIZE_LDS") != 0
+    vl = tuning.get("VOXELIZE_LDS")
+    lds = Z <= 16 and X * Y * 2 <= 128 * 1024 and (X * Y) % 8 == 0 and mp > 0 and vl != 0 and (vl == 2 or n > 48)
     prof = (_Prof("voxelize_lds_kernel", 0, points.numel() * 4 + out.numel() * 4) if lds else
             _Prof("voxelize_scatter_kernel", 0, points.numel() * 4 + 2 * out.numel() * 4))
     rc = lib.v2x_voxelize_bits(_dev(points, torch.float32, "points"), _dev(n_pts, torch.int32, "n_pts"), n, mp, st,
@@ -234,10 +235,11 @@ def conv_out_hw(pc, H, W):
     return Ho, Wo
 
 
-def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0):
+def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
     """in0 (N, H>>up0, W>>up0, C0) bf16 NHWC [, in1 (N, H, W, C1)] -> out (N, Ho, Wo, Cout) NHWC.
 
-    split > 0: returns (out[..., :split], out2[..., Cout-split]) as two contiguous tensors."""
+    split > 0: returns (out[..., :split], out2[..., Cout-split]) as two contiguous tensors.
+    splitk > 1 (streamed stride-1 layers without a chained 1x1): the small-batch form, see small_batch_splitk()."""
     lib = _lib.load()
     # the gather kernel does its row arithmetic in 24 bits (N*H*W < 2^24): larger batches go through in slices of whole
     # maps (contiguous NHWC views, same stream) -- the only kernel with that limit, and only 256x256 inputs reach it
@@ -315,6 +317,10 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0):
     if pc.Cout2:
         d.Cout2, d.relu2 = pc.Cout2, int(bool(pc.relu2))
         d.weight2, d.scale2, d.shift2 = pc.weight2.data_ptr(), pc.scale2.data_ptr(), pc.shift2.data_ptr()
+    ws = None
+    if splitk > 1:
+        ws = torch.empty((splitk, N * Ho * Wo, pc.w_rows), dtype=torch.float32, device=in0.device)
+        d.splitk, d.splitk_ws = splitk, ws.data_ptr()
     prof = None
     if PROFILE is not None:
         rows_logical = 3 * pc.Cout if pc.epilogue == V2X_EPI_GRU else pc.Cout
@@ -323,7 +329,9 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0):
         nbytes = in0.numel() * (4 if from_bits else 2) + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
-        prof = _Prof(conv_kernel_name(pc, H, W, from_bits), flops, nbytes, pc.name)
+        prof = _Prof(conv_kernel_name(pc, H, W, from_bits) if splitk <= 1 else
+                     "conv3x3_stream_kernel<%d, split-K %d> + splitk_reduce" % (lib.v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue), splitk),
+                     flops, nbytes, pc.name)
     rc = lib.v2x_conv2d(C.byref(d), _stream())
     if prof is not None:
         prof.done()
@@ -630,6 +638,34 @@ class Layer:
         self.name = name or self.fallback[0].name
 
 
+def small_batch_splitk(pc, N, H, W):
+    """Latency mode (tuning switch SMALL_BATCH = 1, off by default): how many chunk ranges a streamed stride-1 layer is split into so
+    that a launch has about one workgroup per CU.  One collaborative frame is 5 maps: a 32x32 layer with 256 output channels is then 40
+    tiles of 256 pixels x 128 channels on 256 CUs, each walking all its chunks (conv5_1: 216 steps) -- 117 us for 18 GFLOP.  With the
+    chunks divided over `splitk` workgroups per tile (partial sums added by splitk_reduce_kernel in range order) the same layer runs on
+    ~240.  The switch is EXPLICIT, never derived from the batch inside a model: the split changes the fp32 summation order (one bf16
+    rounding of the output), and kernel selection that followed the item count would break the R-rank == 1-rank bitwise equality."""
+    if pc.w_layout != 2 or pc.stride != 1 or tuning.get("SMALL_BATCH") == 0:
+        return 0
+    rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
+    if rows not in (64, 96, 128):
+        return 0
+    t16 = W % 32 != 0
+    if (t16 and (W % 16 or H % 16)) or (not t16 and H % 8):
+        return 0
+    tiles = N * (H * W // 256) * (pc.w_rows // rows)       # workgroups of the 4-wave form (256-pixel tiles)
+    chunks = (pc.C0 + pc.C1) // 32
+    # Measured (one frame = 5 maps / eight = 40, tools/layer_profile.py): a split pays when the unsplit launch has fewer than ~200 tiles
+    # AND every range keeps >= 2 chunks (conv6_2, 4 chunks: 4 ranges of one 35 us vs 32 unsplit); the 4-wave kernel WITHOUT a split is slower
+    # than the 8-wave forms even at 160 workgroups (conv5_1 at 40 maps: 163 vs 137 us), so there is no "more, smaller tiles" mode.
+    if pc.Cout2 or tiles >= 200 or chunks < 4:
+        return 0
+    want = min(chunks // 2, -(-320 // tiles))
+    while want > 1 and -(-chunks // want) * (want - 1) >= chunks:     # no empty range
+        want -= 1
+    return want if want > 1 else 0
+
+
 def halo_eligible(H, W, w_layout=1, cmax=0):
     """cmax: the widest source's channel count -- the halo kernel's packed DMA tables hold a lane's element offset inside the patch rows
     in 20 bits (conv_halo.hip: (10 W + 34) cmax < 2^20, i.e. W < 1 635 at 64 channels); wider maps take the layer's fallback."""
@@ -666,7 +702,7 @@ def run_layer(layer, in0, in1=None, zbits=0):
             # per map, enough to fill 256 CUs from ~13 frames x 5 agents on; below 16x16 the gather kernel is used.
             use = H * W >= 256
         if use:
-            return conv2d(h, in0, in1, split=layer.split)
+            return conv2d(h, in0, in1, split=layer.split, splitk=small_batch_splitk(h, in0.shape[0], H, W))
     y = conv2d(layer.fallback[0], in0, in1, split=layer.split if len(layer.fallback) == 1 else 0)
     for i, pc in enumerate(layer.fallback[1:], 1):
         y = conv2d(pc, y, split=layer.split if i == len(layer.fallback) - 1 else 0)

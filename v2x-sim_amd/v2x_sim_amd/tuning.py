@@ -7,6 +7,8 @@ Host-side switches (this module):
     S2_T16      1  stride-2 streamed kernel with 8x16 output tiles for narrow maps (conv4_1); 0: the gather kernel
     CONV_PAIR   1  conv_pre_1 -> conv_pre_2 as one launch from the bit grid; 0: two launches
     PP_64       1  pack the 64 -> 64 full-resolution layers for the ping-pong halo kernel (read when a model is packed)
+    SMALL_BATCH 0  latency mode: split-K for the streamed layers when a launch has fewer tiles than CUs (ops.small_batch_splitk; results
+                   differ from the default kernels by fp32 summation order), global-atomic voxeliser for fewer than 64 clouds (bit-identical)
     TRAIN_HIP   0  training graph on the hand-written kernels (train/hip_graph.py) instead of the PyTorch-ROCm (MIOpen) graph
     TRAIN_GRAPH 0  with TRAIN_HIP: the whole step as one replayed hipGraph
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
@@ -14,7 +16,7 @@ The tests use the `tune` fixture (tests/conftest.py), which restores every value
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 0, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 0, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 0}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STREAM_M32", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS")
 
