@@ -44,7 +44,10 @@ PEAK_MFMA_TFLOPS = 2500.0
 AGENTS = 5
 POINTS_PER_SWEEP = 65536
 # committed PMC traffic summaries, newest first (tools/profile_round.sh -> tools/pmc_traffic.py)
-TRAFFIC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+# algorithmic FLOPs of one 5-agent frame, points -> logits: encoder + decoder + heads, + one ConvGRU pass per GNN round
+# (h0 = 0: W_hh is never multiplied and not counted)
+GFLOP_PER_FRAME_BASE, GFLOP_PER_GNN_ROUND = 155.8, 36.2
 
 
 def parse(argv=None):
@@ -523,6 +526,7 @@ def main():
                                     % ("all-gather" if args.transport == "allgather" else "grouped send/recv of the needed rows"))
                                    if world > 1 else "single GPU, no collective",
                        "exec_mode": exec_mode, "hip_graph": bool(mode)},
+            "whole_step_frac": (GFLOP_PER_FRAME_BASE + GFLOP_PER_GNN_ROUND * args.gnn_iters) * 1e9 * fps / world / (PEAK_MFMA_TFLOPS * 1e12),
             "ranks_seen": ranks_seen, "exposed_exchange_ms_per_step": exposed_all,
             "roofline": roofline, "cpu_baseline": cpu, "latency": latency, "configs": configs, "training": training, "kernels": kernels,
         }

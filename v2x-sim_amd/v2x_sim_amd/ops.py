@@ -324,7 +324,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
     prof = None
     if PROFILE is not None:
         rows_logical = 3 * pc.Cout if pc.epilogue == V2X_EPI_GRU else pc.Cout
-        k_logical = pc.ksize * pc.ksize * (pc.C0 + pc.C1)
+        k_logical = pc.ksize * pc.ksize * (zbits if from_bits else pc.C0 + pc.C1)   # bit-grid input: zbits real channels, the rest padding
         M = N * Ho * Wo
         nbytes = in0.numel() * (4 if from_bits else 2) + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
@@ -373,7 +373,8 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
     prof = None
     if PROFILE is not None:
         M = N * H * W
-        prof = _Prof("conv3x3_pair_bits_kernel", 2.0 * M * 9 * (pa.Cout * pa.C0 + pb.Cout * pb.C0),
+        # algorithmic FLOPs: the first layer has `zbits` (13) real input channels -- the 32 of the packed layout are zero padding
+        prof = _Prof("conv3x3_pair_bits_kernel", 2.0 * M * 9 * (pa.Cout * zbits + pb.Cout * pb.C0),
                      bits.numel() * 4 + out.numel() * 2 + (pa.weight.numel() + pb.weight.numel()) * 2, pa.name + "+" + pb.name)
     rc = lib.v2x_conv2d_pair(C.byref(da), C.byref(db), _stream())
     if prof is not None:
