@@ -1,0 +1,19 @@
+#!/bin/bash
+# per-kernel time of one training step (all launches: this library's and PyTorch's elementwise / reduction / Adam kernels)
+cd "$(dirname "$0")/.."
+O=gpurun_out/train_prof
+mkdir -p $O
+export TMPDIR=/tmp
+for m in faf v2v; do
+  rocprofv3 --kernel-trace --stats -d $O/$m -o t --output-format csv -- python3 tools/train_step_run.py $m > $O/$m.log 2>&1
+  python3 - $(find $O/$m -name "*kernel_stats.csv") > $O/${m}_kernels.txt <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+print("total kernel time per step: %.2f ms (8 steps traced)" % (tot / 8e6))
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
+    print("%8.1f us/step  x%-5.1f %5.1f %%  %s" % (float(r["TotalDurationNs"]) / 8e3, int(r["Calls"]) / 8.0, 100 * float(r["TotalDurationNs"]) / tot, r["Name"][:150]))
+PY
+  rm -rf $O/$m
+done
+head -50 $O/faf_kernels.txt
