@@ -204,6 +204,12 @@ typedef struct v2x_pack_spec {
 size_t v2x_pack_conv_size(const v2x_pack_spec *spec, int32_t *w_rows, int32_t *w_kpad);
 /* w_oihw: HOST fp32 [rows][Cin][k][k]; dst: HOST buffer of v2x_pack_conv_size bytes. */
 int v2x_pack_conv(const v2x_pack_spec *spec, const float *w_oihw, uint16_t *dst);
+/* The same packing as v2x_pack_conv ON THE DEVICE, one launch (training re-packs every layer after every optimizer step): w_oihw_dev
+ * fp32 DEVICE [rows][Cin][k][k], dst_dev DEVICE buffer of v2x_pack_conv_size bytes, bit-identical to the host packer's output.
+ * transform = 1: `spec` describes the DATA-GRADIENT layer of a convolution (spec->Cout = its Cin, spec->Cin = its Cout) and the weights
+ * W'[o][c][ky][kx] = W[c][o][2-ky][2-kx] are read from the convolution's own tensor W [spec->Cin][spec->Cout][k][k].  Plain layers only
+ * (no V2X_EPI_GRU regrouping, chain = 0). */
+int v2x_pack_conv_device(const v2x_pack_spec *spec, const float *w_oihw_dev, int transform, uint16_t *dst_dev, v2x_stream_t stream);
 /* Chained 1x1: w2 HOST fp32 [Cout2][Cout] -> dst_w bf16 [ceil16(Cout2)][Cout]; scale2 / shift2 (NULL = ones / zeros)
  * -> fp32 [ceil16(Cout2)], zero beyond Cout2. */
 int v2x_pack_chain_1x1(int Cout2, int Cout, const float *w2, const float *scale2, const float *shift2, uint16_t *dst_w,
@@ -241,6 +247,9 @@ int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x
 int v2x_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout);
 int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, int H, int W, int Cin, int Cout, float *workspace,
                       int n_split, v2x_stream_t stream);
+/* The fixed-order sum of the partials, written in the parameter's own layout: dw_oihw fp32 [Cout][cin_out][3][3] =
+ * sum_s workspace[s][co][ky][kx][ci] for ci < cin_out <= Cin (cin_out < Cin: the layer's input was stored zero-padded). */
+int v2x_conv3x3_wgrad_reduce(const float *workspace, int n_split, int Cout, int Cin, int cin_out, float *dw_oihw, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-3: batch-statistics BatchNorm + ReLU on bf16 NHWC maps
  * Replaces nn.BatchNorm2d / nn.BatchNorm3d in TRAIN mode followed by F.relu as Backbone.py applies them after every convolution
@@ -309,6 +318,12 @@ int v2x_seg_argmax_confusion(const float *logits, const uint8_t *label, int n, i
  * w_k = exp(s_k) / sum_j exp(s_j) per pixel, out = sum_k w_k * map_k. */
 int v2x_pixel_weighted_fuse(const float *scores, int score_stride, const float *valid, const uint16_t *maps, int n_items,
                             int A, int H, int W, int C, uint16_t *out, v2x_stream_t stream);
+
+/* Per-channel sum of a bf16 [M][C] map -> fp32 [C]: the bias gradient of a convolution (db = dy summed over batch and pixels;
+ * upstream: autograd's sum inside nn.Conv2d.backward).  Fixed summation order (bit-reproducible).  C as for the BN entries;
+ * workspace: v2x_channel_sum_workspace_size(M, C) bytes (0 = unsupported shape). */
+long long v2x_channel_sum_workspace_size(long long M, int C);
+int v2x_channel_sum_bf16(const uint16_t *x, long long M, int C, float *out, float *workspace, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-1: detection post-processing
  * Replaces coperception/utils/postprocess.py::apply_nms_det per (agent, frame) map: foreground softmax score, score

@@ -583,3 +583,46 @@ def test_graphed_v2vnet_step(device, tune):
     other["num_agent"][0, :] = 2
     with pytest.raises(ValueError):
         step(other)
+
+
+@pytest.mark.parametrize("cout,cin,stride,cin_pad", [(32, 13, 1, 32), (32, 32, 1, None), (64, 64, 1, None), (128, 64, 2, None), (128, 384, 1, None),
+                                                      (32, 96, 1, None), (512, 256, 2, None), (64, 32, 2, None)])
+def test_pack_conv_device_equals_torch_packing(device, cout, cin, stride, cin_pad):
+    """v2x_pack_conv_device (one launch per layer, row f-3) against the torch-op packing of packing.layer_conv_bn it replaces in the training
+    graph: the same bytes, for the forward layer and for the data-gradient layer (flipped, transposed weights), in every layout the backbone's
+    layers take (halo, streamed stride 1 / 2, gather)."""
+    import types
+    from v2x_sim_amd import packing
+    g = torch.Generator().manual_seed(cout + cin)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.1).to(device)
+    b = torch.randn(cout, generator=g).to(device)
+
+    def ref_layer(weight, bias, s, cp):
+        conv = types.SimpleNamespace(weight=weight, bias=bias, kernel_size=(3, 3), stride=(s, s), padding=(1, 1), out_channels=weight.shape[0])
+        with packing.on_device(device):
+            return packing.layer_conv_bn("ref", conv, None, device=device, relu=False, cin_pad=cp)
+    for dgrad in (False, True):
+        if dgrad and cin_pad:
+            continue                               # (the first layer needs no data gradient)
+        got = packing.pack_conv_device("t", w, b, stride=stride, cin_pad=cin_pad, dgrad=dgrad)
+        ref = ref_layer(w.flip(2, 3).transpose(0, 1).contiguous(), None, 1, None) if dgrad else ref_layer(w, b, stride, cin_pad)
+        gp = got.halo if got.halo is not None else got.fallback[0]
+        rp = ref.halo if got.halo is not None else ref.fallback[0]
+        assert rp is not None and (gp.w_layout or 0) == (rp.w_layout or 0), (dgrad, gp.w_layout, None if rp is None else rp.w_layout)
+        assert gp.w_rows == rp.w_rows and gp.w_kpad == rp.w_kpad and (gp.C0, gp.C1, gp.Cout, gp.stride) == (rp.C0, rp.C1, rp.Cout, rp.stride)
+        assert torch.equal(gp.weight.view(torch.int16).flatten(), rp.weight.view(torch.int16).flatten()), dgrad
+        assert torch.equal(gp.scale, rp.scale) and torch.equal(gp.shift, rp.shift)
+
+
+@pytest.mark.parametrize("shape", [(10, 256, 256, 32), (3, 64, 64, 128), (2, 16, 16, 512), (1, 8, 32, 64), (5, 7, 3, 256)])
+def test_channel_sum_vs_torch(device, shape):
+    """v2x_channel_sum_bf16 (the convolutions' bias gradient): against torch's fp64 sum of the same bf16 values (fp32-accumulation error
+    only), and bit-reproducible."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(shape, generator=g) + 0.3).to(torch.bfloat16).to(device)
+    got = ops.channel_sum(x)
+    ref = x.double().reshape(-1, shape[-1]).sum(0)
+    scale = float(x.double().abs().reshape(-1, shape[-1]).sum(0).max())
+    assert float((got.double() - ref).abs().max()) <= 2e-6 * scale, float((got.double() - ref).abs().max())
+    assert torch.equal(ops.channel_sum(x), got)

@@ -142,6 +142,53 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
             }
 }
 
+// dW[co][ci][ky][kx] (the parameter's own OIHW layout, ci < cin_out) = sum over the n_split partials ws[s][co][tap][ci], in slot order
+// (deterministic).  Replaces the caller's `ws.sum(0).permute(0, 3, 1, 2).contiguous()[:, :cin]` (a reduction and a permuting copy per layer).
+// A block = 32 output elements (ci fastest: coalesced reads of the partials) x 8 slices of the split range: a thread adds its slice's
+// partials in slot order, the 8 slice sums of an element are added in slice order -- a fixed tree, so the result does not depend on the
+// launch geometry (the small layers have up to 512 partials per element: one thread per element walked them as 512 dependent loads).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ ws, int n_split, int Cout, int Cin, int cin_out,
+                                                           float *__restrict__ dw) {
+    __shared__ float part[8][32];
+    const long long total = (long long)Cout * 9 * cin_out;
+    const size_t slab = (size_t)Cout * 9 * Cin;
+    const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int per = (n_split + 7) / 8;
+    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+        const long long t = base + e;
+        float s = 0.0f;
+        long long ct = 0;
+        int ci = 0;
+        if (t < total) {
+            ci = (int)(t % cin_out);
+            ct = t / cin_out;                       // co * 9 + tap
+            const int k1 = (q + 1) * per < n_split ? (q + 1) * per : n_split;
+            for (int k = q * per; k < k1; ++k) s += ws[(size_t)k * slab + (size_t)ct * Cin + ci];
+        }
+        part[q][e] = s;
+        __syncthreads();
+        if (q == 0 && t < total) {
+            float v = part[0][e];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) v += part[j][e];
+            const int tap = (int)(ct % 9);
+            const int co = (int)(ct / 9);
+            dw[((size_t)co * cin_out + ci) * 9 + tap] = v;
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int v2x_conv3x3_wgrad_reduce(const float *workspace, int n_split, int Cout, int Cin, int cin_out, float *dw_oihw, v2x_stream_t stream) {
+    V2X_REQUIRE(workspace && dw_oihw && n_split >= 1 && Cout > 0 && Cin > 0 && cin_out > 0 && cin_out <= Cin, "v2x_conv3x3_wgrad_reduce: bad arguments");
+    const long long total = (long long)Cout * 9 * cin_out;
+    const long long blocks = (total + 31) / 32;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, workspace, n_split, Cout, Cin,
+                       cin_out, dw_oihw);
+    V2X_CHECK_LAUNCH("wgrad_reduce_kernel");
+    return V2X_OK;
+}
+
 extern "C" int v2x_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
     // number of workspace slots the library would use: enough blocks for two rounds of the 256 CUs, at most one block per pixel tile
     if (N <= 0 || H <= 0 || W <= 0 || H % WG_TH || W % WG_TW || Cin <= 0 || Cin % WG_CI || Cout <= 0 || Cout % 32) return 0;

@@ -129,6 +129,88 @@ extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16
     return V2X_OK;
 }
 
+// ---- the same packing ON THE DEVICE (row f-3: training re-packs every layer after every optimizer step) ------------------------
+// One launch per layer: a thread builds one 16-byte group (8 consecutive k of one packed row) of the destination straight from the fp32
+// OIHW parameter -- the torch-op form of this (permute, pad, reshape, cast, scatter into a zeroed buffer) was ~10 small kernels per
+// layer and packing: 336 fills and 181 copies per FaFNet training step.  transform = 1 builds the DATA-GRADIENT layer of a convolution:
+// `spec` then describes that layer (Cout = the convolution's Cin, Cin = its Cout) and W'[o][c][ky][kx] = W[c][o][2-ky][2-kx] is read
+// from the convolution's own weight tensor.  Plain layers only (no GRU row regrouping, no chain order).
+struct DevPackGeom {
+    int rows_src, cin, cin_p, taps, K, w_kpad, tile, cout, layout, transform;
+    long long groups, data_groups;   // 16-byte groups of the destination; of them real rows (layout 2: the rest is the zero page)
+};
+
+__global__ __launch_bounds__(256) void pack_conv_device_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, const DevPackGeom g) {
+    for (long long grp = (long long)blockIdx.x * 256 + threadIdx.x; grp < g.groups; grp += (long long)gridDim.x * 256) {
+        int row = -1, k0 = 0;
+        if (g.layout == 0) {
+            const int per = g.w_kpad / 8;
+            row = (int)(grp / per);
+            k0 = (int)(grp - (long long)row * per) * 8;
+            if (row >= g.rows_src || k0 >= g.K) row = -1;
+        } else if (g.layout == 1) {
+            const int s = (int)(grp / g.cout);
+            row = (int)(grp - (long long)s * g.cout);
+            k0 = 8 * s;
+        } else if (grp < g.data_groups) {
+            long long o = grp;
+            const int r = (int)(o % g.tile);
+            o /= g.tile;
+            const int slot = (int)(o & 3);
+            o >>= 2;
+            const int tap = (int)(o % 9);
+            o /= 9;
+            const int n_chunks = g.cin_p / 32;
+            const int ch = (int)(o % n_chunks);
+            const int t = (int)(o / n_chunks);
+            row = t * g.tile + r;
+            k0 = tap * g.cin_p + ch * 32 + slot * 8;
+        }
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (row >= 0) {
+            const int tap = k0 / g.cin_p, c0 = k0 - tap * g.cin_p;   // cin_p % 8 == 0: the 8 k of a group share their tap
+            float f[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c = c0 + j;
+                float x = 0.0f;
+                if (c < g.cin)
+                    x = g.transform ? w[((size_t)c * g.rows_src + row) * g.taps + (g.taps - 1 - tap)] : w[((size_t)row * g.cin + c) * g.taps + tap];
+                f[j] = x;
+            }
+            v = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+        }
+        *reinterpret_cast<uint4 *>(dst + grp * 8) = v;
+    }
+}
+
+extern "C" int v2x_pack_conv_device(const v2x_pack_spec *p, const float *w_oihw_dev, int transform, uint16_t *dst_dev, v2x_stream_t stream) {
+    PackGeom g;
+    const int rc = pack_geometry(p, &g);
+    if (rc != V2X_OK) return rc;
+    V2X_REQUIRE(w_oihw_dev && dst_dev, "v2x_pack_conv_device: null pointer");
+    V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain, "v2x_pack_conv_device: plain layers only (no GRU regrouping, no chain order)");
+    V2X_REQUIRE(transform == 0 || transform == 1, "v2x_pack_conv_device: transform must be 0 or 1");
+    V2X_REQUIRE(g.elems % 8 == 0, "v2x_pack_conv_device: internal: destination not a whole number of 16-byte groups");
+    DevPackGeom d;
+    d.rows_src = g.rows_src;
+    d.cin = p->Cin;
+    d.cin_p = g.cin_p;
+    d.taps = p->ksize * p->ksize;
+    d.K = g.K;
+    d.w_kpad = g.w_kpad;
+    d.tile = g.tile;
+    d.cout = p->Cout;
+    d.layout = p->w_layout;
+    d.transform = transform;
+    d.groups = (long long)(g.elems / 8);
+    d.data_groups = p->w_layout == 2 ? (long long)g.rows_src * g.K / 8 : d.groups;
+    const long long blocks = (d.groups + 255) / 256;
+    hipLaunchKernelGGL(pack_conv_device_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, dst_dev, d);
+    V2X_CHECK_LAUNCH("pack_conv_device_kernel");
+    return V2X_OK;
+}
+
 extern "C" int v2x_pack_chain_1x1(int Cout2, int Cout, const float *w2, const float *scale2, const float *shift2,
                                   uint16_t *dst_w, float *dst_scale, float *dst_shift) {
     V2X_REQUIRE(Cout2 > 0 && Cout > 0 && w2 && dst_w, "v2x_pack_chain_1x1: bad arguments");

@@ -63,6 +63,10 @@ SIGNATURES = {
     "v2x_indices_to_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.c_void_p, C.c_void_p]),
     "v2x_pack_conv_size": (C.c_size_t, [C.POINTER(PackSpec), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "v2x_pack_conv_device": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_channel_sum_workspace_size": (C.c_longlong, [C.c_longlong, C.c_int]),
+    "v2x_channel_sum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_conv3x3_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_pack_conv": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_void_p]),
     "v2x_pack_chain_1x1": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_pack_gru_bias": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),

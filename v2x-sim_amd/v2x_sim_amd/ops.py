@@ -383,9 +383,10 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
     return out
 
 
-def conv3x3_wgrad(x, dy):
-    """Weight gradient of a 3x3 stride-1 pad-1 conv.  x (N, H, W, Cin), dy (N, H, W, Cout) bf16 NHWC -> dW (Cout, Cin, 3, 3) fp32
-    (the parameter's own layout).  MFMA kernel contracting over pixels + a fixed-order sum of the per-block partials."""
+def conv3x3_wgrad(x, dy, cin_out=None):
+    """Weight gradient of a 3x3 stride-1 pad-1 conv.  x (N, H, W, Cin), dy (N, H, W, Cout) bf16 NHWC -> dW (Cout, cin_out or Cin, 3, 3) fp32
+    (the parameter's own layout; cin_out < Cin: the input was stored zero-padded).  MFMA kernel contracting over pixels + a fixed-order
+    sum of the per-block partials written straight in OIHW order (v2x_conv3x3_wgrad_reduce)."""
     lib = _lib.load()
     N, H, W, Cin = x.shape
     Cout = dy.shape[3]
@@ -400,7 +401,26 @@ def conv3x3_wgrad(x, dy):
                                _dev(ws, torch.float32, "workspace"), ns, _stream())
     prof.done()
     _lib.check(rc, "v2x_conv3x3_wgrad")
-    return ws.sum(0).permute(0, 3, 1, 2).contiguous()
+    cin_out = Cin if cin_out is None else cin_out
+    dw = torch.empty((Cout, cin_out, 3, 3), dtype=torch.float32, device=x.device)
+    _lib.check(lib.v2x_conv3x3_wgrad_reduce(_dev(ws, torch.float32, "workspace"), ns, Cout, Cin, cin_out, _dev(dw, torch.float32, "dw"), _stream()),
+               "v2x_conv3x3_wgrad_reduce")
+    return dw
+
+
+def channel_sum(x):
+    """x (..., C) bf16 NHWC -> (C,) fp32 = the sum over every other axis, in a fixed order (the bias gradient of a convolution)."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    nbytes = lib.v2x_channel_sum_workspace_size(M, Cc)
+    if nbytes == 0:
+        return x.float().reshape(M, Cc).sum(0)          # channel counts the kernel does not tile (C / 8 must divide 256)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.v2x_channel_sum_bf16(_dev(x, torch.bfloat16, "x"), M, Cc, _dev(out, torch.float32, "out"), _dev(ws, torch.float32, "workspace"),
+                                        _stream()), "v2x_channel_sum_bf16")
+    return out
 
 
 def bn_train_forward(x, gamma, beta, running_mean, running_var, eps, momentum, relu=True):

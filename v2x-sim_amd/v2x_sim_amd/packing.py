@@ -131,6 +131,71 @@ def pack_heads(name, cls_conv1, cls_bn1, cls_conv2, reg_conv1, reg_bn1, reg_conv
     return hidden, final, ncls
 
 
+_CONSTS = {}
+
+
+def _const(n, value, device, n_real=None):
+    key = (n, value, str(device), n_real)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = torch.full((n,), value, dtype=torch.float32, device=device)
+        if n_real is not None and n_real < n:
+            t[n_real:] = 0.0
+        _CONSTS[key] = t
+    return t
+
+
+def train_layout(cin_p, cout, stride):
+    """Which packed layout the training graph's single-source 3x3 layers take (the rule of layer_conv_bn): 1 = halo kernel, 2 = streamed
+    kernels (stride 1 and 2), 0 = gather kernel."""
+    if stride == 1 and (cin_p, cout) in ((32, 32), (64, 64)):
+        return 1
+    if stride == 1 and cin_p >= (64 if STREAM_64 else 128) and cin_p % 32 == 0 and cout % 64 == 0 and STREAM_KERNEL:
+        return 2
+    if stride == 2 and cin_p % 32 == 0 and cout % 64 == 0 and STREAM_KERNEL:
+        return 2
+    return 0
+
+
+def pack_conv_device(name, weight, bias, *, stride=1, cin_pad=None, dgrad=False):
+    """One-launch device packing of a plain 3x3 layer for the training graph (v2x_pack_conv_device): weight = the fp32 parameter ON THE
+    DEVICE, [Cout, Cin, 3, 3].  dgrad: the layer that computes the convolution's data gradient (stride-1 convolution of dy with the flipped,
+    transposed weights, no bias).  -> ops.Layer carrying exactly ONE packing (the kernel family train_layout picks; the gather packing
+    as the layer's `fallback`, the others as its `halo`), scale = 1, shift = bias."""
+    import ctypes as C
+    from ._lib import PackSpec
+    from .ops import Layer
+    lib = _lib.load()
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous():
+        w = w.float().contiguous()
+    co_w, ci_w = w.shape[0], w.shape[1]
+    cout, cin = (ci_w, co_w) if dgrad else (co_w, ci_w)
+    cin_p = cin if cin_pad is None else cin_pad
+    layout = train_layout(cin_p, cout, 1 if dgrad else stride)
+    spec = PackSpec(Cout=cout, Cin=cin, ksize=3, cin_pad=cin_p, w_layout=layout, epilogue=V2X_EPI_BF16, chain=0)
+    rows, kpad = C.c_int32(0), C.c_int32(0)
+    nbytes = lib.v2x_pack_conv_size(C.byref(spec), C.byref(rows), C.byref(kpad))
+    if nbytes == 0:
+        raise ValueError("pack_conv_device(%s): %s" % (name, lib.v2x_last_error().decode()))
+    buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.v2x_pack_conv_device(C.byref(spec), C.c_void_p(w.data_ptr()), 1 if dgrad else 0, C.c_void_p(buf.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "v2x_pack_conv_device(%s)" % name)
+    n_par = rows.value
+    scale = _const(n_par, 1.0, w.device, cout)        # shared read-only vectors: no fill per packing (ones for the real rows, zeros for the padding)
+    if bias is not None and not dgrad:
+        if n_par == cout and bias.dtype == torch.float32:
+            shift = bias.detach()                      # the parameter itself (the packing lives until its next update)
+        else:
+            shift = torch.zeros((n_par,), dtype=torch.float32, device=w.device)
+            shift[:cout] = bias.detach().float()
+    else:
+        shift = _const(n_par, 0.0, w.device)
+    pc = PackedConv(name=name, weight=buf, scale=scale, shift=shift, C0=cin_p, C1=0, Cout=cout, ksize=3, stride=1 if dgrad else stride, pad=1,
+                    up0=0, epilogue=V2X_EPI_BF16, relu=False, w_rows=n_par, w_kpad=kpad.value, w_layout=layout or None, Cout2=0)
+    return Layer([pc], None, name=name) if layout == 0 else Layer([], pc, name=name)
+
+
 def det_row_order(n_anchor=6, n_cls=2, n_code=6):
     """Row order of the chained 1x1 of the fused DETECTION heads (include/v2x_amd.h, V2X_EPI_DET): packed row 16 t + 4 q + r, q < 3,
     belongs to anchors a0 = 2 q, a1 = 2 q + 1.  -> list of 64 entries: ("cls", anchor, class) | ("loc", anchor, code) | None (zero row)."""

@@ -50,13 +50,8 @@ def _layer(kind, weight, bias, stride, cin_pad):
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]
-    with packing.on_device(weight.device):
-        if kind == "fwd":
-            layer = packing.layer_conv_bn("train.fwd", _conv_like(weight, bias, stride), None, device=weight.device, relu=False,
-                                          cin_pad=cin_pad)
-        else:   # data gradient: stride-1 convolution with the flipped, transposed weights (no bias)
-            wt = weight.detach().flip(2, 3).transpose(0, 1).contiguous()
-            layer = packing.layer_conv_bn("train.dgrad", _conv_like(wt, None, 1), None, device=weight.device, relu=False)
+    # one device launch per packing (v2x_pack_conv_device); the data gradient = a stride-1 convolution with the flipped, transposed weights
+    layer = packing.pack_conv_device("train." + kind, weight, bias, stride=stride, cin_pad=cin_pad, dgrad=kind == "dgrad")
     if len(_CACHE) > 512:
         _CACHE.clear()
     _CACHE[key] = (ver, layer, weakref.ref(weight))
@@ -96,9 +91,9 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.run_layer(_layer("dgrad", weight, None, 1, None), dyz)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv3x3_wgrad(x, dyz)[:, :weight.shape[1]]
+            dw = ops.conv3x3_wgrad(x, dyz, cin_out=weight.shape[1])
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = dy.float().sum((0, 1, 2))
+            db = ops.channel_sum(dy)
         return dx, dw, db, None
 
 
