@@ -207,7 +207,7 @@ def run_training(device, frames=2, agents=5, reps=5):
             for flag, label in (("0", "fp32 PyTorch-ROCm graph (MIOpen) ms"), ("1", "bf16 NHWC graph on the HIP kernels ms")):
                 tuning.set("TRAIN_HIP", int(flag))
                 rec[label] = timed(step)
-            if name == "FaFNet":
+            if True:    # both: V2VNet's step is captured for the fixed agent table of `data` (train/graph_step.py)
                 tuning.set("TRAIN_HIP", int("1"))
                 opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=device), capturable=True)
                 g = GraphedTrainStep(model, opt_c, data, frames)

@@ -96,9 +96,10 @@ def warp_batch(feat, T):
     return F.grid_sample(y, g2, mode="bilinear", padding_mode="zeros", align_corners=False)
 
 
-def _gru_step(g, x):
-    """convolutional_rnn.Conv2dGRU cell with hidden=None (h0 = 0): gh = b_hh exactly, h = n + z*(0 - n)."""
-    gi = F.conv2d(x, g.weight_ih_l0, g.bias_ih_l0, 1, g.kernel_size // 2)
+def _gru_step(g, x, conv=None):
+    """convolutional_rnn.Conv2dGRU cell with hidden=None (h0 = 0): gh = b_hh exactly, h = n + z*(0 - n).
+    conv: optional replacement of the input convolution (train/hip_graph.py runs it on the hand-written kernels)."""
+    gi = F.conv2d(x, g.weight_ih_l0, g.bias_ih_l0, 1, g.kernel_size // 2) if conv is None else conv(x, g.weight_ih_l0, g.bias_ih_l0)
     i_r, i_z, i_n = gi.chunk(3, 1)
     h_r, h_z, h_n = g.bias_hh_l0.view(1, -1, 1, 1).chunk(3, 1)
     r = torch.sigmoid(i_r + h_r)
@@ -107,8 +108,8 @@ def _gru_step(g, x):
     return n - zg * n
 
 
-def v2v_fuse(model, feat, trans, num_agent_tensor, B):
-    """feat (A*B, C, H, W) agent-major -> updated maps (same shape)."""
+def v2v_fuse(model, feat, trans, num_agent_tensor, B, gru_conv=None):
+    """feat (A*B, C, H, W) agent-major -> updated maps (same shape).  gru_conv: see _gru_step."""
     A = model.agent_num
     counts, items, rows = model.frame_plan(num_agent_tensor, B, A)
     if min(counts) < 2:
@@ -133,7 +134,7 @@ def v2v_fuse(model, feat, trans, num_agent_tensor, B):
         base = feat if model.neighbor_source == "initial" else cur
         warped = warp_batch(base.index_select(0, src), Tp)
         mean = torch.zeros((len(items),) + tuple(feat.shape[1:]), device=dev, dtype=feat.dtype).index_add_(0, dst, warped) / cnt
-        h = _gru_step(model.convgru, torch.cat([cur.index_select(0, rows_t), mean], 1))
+        h = _gru_step(model.convgru, torch.cat([cur.index_select(0, rows_t), mean], 1), gru_conv)
         cur = cur.index_copy(0, rows_t, h)
     return cur
 

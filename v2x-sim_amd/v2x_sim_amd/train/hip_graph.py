@@ -248,6 +248,17 @@ def heads(model, x):
             "loc": loc.reshape(-1, loc.size(1), loc.size(2), model.anchor_num_per_loc, model.out_seq_len, model.box_code_size)}
 
 
+def _gru_conv_hip(x, weight, bias):
+    """The ConvGRU's input convolution (2C -> 3C, 3x3: 5.4 GMAC per map -- the heaviest layer of a V2VNet step) forward, data gradient and
+    weight gradient on the hand-written kernels: fp32 NCHW in / out for the fp32 fusion graph around it (warp, gate arithmetic), bf16 NHWC
+    inside like every other layer of this graph.  Falls back to F.conv2d where the map does not tile."""
+    N, Cc, H, W = x.shape
+    if not hip_eligible(weight, 1, H, W) or Cc % 32:
+        return F.conv2d(x, weight, bias, 1, 1)
+    y = _Conv3x3.apply(x.permute(0, 2, 3, 1).to(BF16).contiguous(), weight, bias, 1)
+    return y.permute(0, 3, 1, 2).float()
+
+
 def _fused_on_fp32_graph(fuse, model, feat, *args):
     """The cross-agent fusion runs on the fp32 NCHW graph (train/graph.py): convert the fusion-layer maps, fuse, convert back."""
     out = fuse(model, feat.permute(0, 3, 1, 2).float(), *args)
@@ -272,15 +283,15 @@ def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch
             y = decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x))
         else:
             feats = encoder(model.u_encoder, x)
-            feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size)
+            feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size, _gru_conv_hip)
             y = decoder(model.decoder, *feats)
         return conv1x1(y, model.outc.conv.weight, model.outc.conv.bias, f32_out=True)
     if hasattr(model, "stpn"):                      # FaFNet: lowerbound / upperbound
         return heads(model, decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x)))
     feats = encoder(model.u_encoder, x)
     res_extra = {}
-    if hasattr(model, "convgru"):                   # V2VNet
-        feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size)
+    if hasattr(model, "convgru"):                   # V2VNet: warp + gate arithmetic on the fp32 graph, the GRU's convolution on the kernels
+        feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size, _gru_conv_hip)
     elif hasattr(model, "query_key_net"):           # when2com / who2com: its key / query tower reads the input on the fp32 graph
         x32 = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)
         fused, prob, coef = _fused_on_fp32_graph(lambda m, f: graph.when2com_fuse(m, x32, f, T, num_agent_tensor, batch_size, model.training, inference),
