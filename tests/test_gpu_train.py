@@ -27,13 +27,14 @@ EVAL_FRAMES = 16          # frames per evaluation chunk (x 5 agents)
 EVAL_CHUNKS = 4           # 4 x 16 x 5 = 320 held-out agent-frames, ~3 400 ground-truth cars
 
 
-def test_train_graph_loss_and_grads_match_oracle(device):
+def test_train_graph_loss_and_grads_match_oracle(device, tune):
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import V2VNet
     from v2x_sim_amd.train import detection_loss, train_forward
     from v2x_sim_amd.train.loop import synthetic_batch_on_device
     from v2x_sim_amd.utils.synthetic import init_synthetic_weights
     A = 2
+    tune("TRAIN_HIP", 0)      # the fp32 graph of train/graph.py is what has the oracle's arithmetic (the default, bf16 HIP graph: test_gpu_train_kernels.py)
     cfg = Config("train")
     # random biases / BN statistics: with zero biases every empty BEV region sits EXACTLY on the ReLU kink
     # (pre-activation 0.0), where the subgradient is a convention and 1e-9 of kernel noise flips it
@@ -77,9 +78,14 @@ def trained(device):
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import V2VNet
     from v2x_sim_amd.train.loop import init_for_training, train_synthetic
+    from v2x_sim_amd import tuning
     cfg = Config("train")
     model = init_for_training(V2VNet(cfg), seed=0)
-    hist = train_synthetic(model, cfg, TRAIN_STEPS, frames_per_step=2, lr=1e-3, seed=7, device=device, log=50)
+    prev = tuning.set("TRAIN_HIP", 0)         # THIS detector is trained on the fp32 graph (upstream's precision); the HIP-graph twin is trained below
+    try:
+        hist = train_synthetic(model, cfg, TRAIN_STEPS, frames_per_step=2, lr=1e-3, seed=7, device=device, log=50)
+    finally:
+        tuning.set("TRAIN_HIP", prev)
     return cfg, model, hist
 
 

@@ -9,14 +9,15 @@ Host-side switches (this module):
     PP_64       1  pack the 64 -> 64 full-resolution layers for the ping-pong halo kernel (read when a model is packed)
     SMALL_BATCH 0  latency mode: split-K for the streamed layers when a launch has fewer tiles than CUs (ops.small_batch_splitk; results
                    differ from the default kernels by fp32 summation order), global-atomic voxeliser for fewer than 64 clouds (bit-identical)
-    TRAIN_HIP   0  training graph on the hand-written kernels (train/hip_graph.py) instead of the PyTorch-ROCm (MIOpen) graph
+    TRAIN_HIP   1  training graph on the hand-written kernels (train/hip_graph.py: bf16 NHWC activations, fp32 master weights); 0: the fp32
+                   PyTorch-ROCm (MIOpen) graph of train/graph.py -- upstream's precision, 5x slower
     TRAIN_GRAPH 0  with TRAIN_HIP: the whole step as one replayed hipGraph
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
 The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 0, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 0}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 0}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STREAM_M32", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS")
 
