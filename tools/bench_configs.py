@@ -195,7 +195,7 @@ def run_training(device, frames=2, agents=5, reps=5):
     try:
         for name, cls, kw in (("FaFNet", FaFNet, dict(kd_flag=0, num_agent=agents)), ("V2VNet", V2VNet, dict(num_agent=agents))):
             model = init_for_training(cls(cfg, **kw), seed=0).to(device).train()
-            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
 
             def step():
                 res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], frames)
@@ -209,7 +209,7 @@ def run_training(device, frames=2, agents=5, reps=5):
                 rec[label] = timed(step)
             if True:    # both: V2VNet's step is captured for the fixed agent table of `data` (train/graph_step.py)
                 tuning.set("TRAIN_HIP", int("1"))
-                opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=device), capturable=True)
+                opt_c = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=device), capturable=True, fused=True)
                 g = GraphedTrainStep(model, opt_c, data, frames)
                 rec["the same as one replayed hipGraph ms"] = timed(lambda: g(data))
                 del g

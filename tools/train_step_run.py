@@ -20,7 +20,7 @@ cfg = Config("train")
 v2v = len(sys.argv) > 1 and sys.argv[1] == "v2v"
 model = init_for_training(V2VNet(cfg, num_agent=5) if v2v else FaFNet(cfg, kd_flag=0, num_agent=5), seed=0).to(dev).train()
 data = synthetic_batch_on_device(cfg, 2, 5, seed=1, device=dev)
-opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True)
+opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True, fused=True)
 tuning.set("TRAIN_HIP", 1)
 for it in range(8):
     res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 2)

@@ -57,9 +57,11 @@ def make_optimizer(model, lr, total_steps):
         # hipGraph-captured steps (train/graph_step.py): step counter and learning rate live on the device; the scheduler updates the
         # lr tensor in place, so the captured optimizer step sees every decay
         dev = next(model.parameters()).device
-        opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(float(lr), device=dev), capturable=True)
+        opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(float(lr), device=dev), capturable=True, fused=True)
     else:
-        opt = torch.optim.Adam(model.parameters(), lr=lr)
+        # fused: ONE multi-tensor kernel per step on the device (the default per-parameter form issues two tiny elementwise launches per
+        # parameter: 184 of them = 0.47 ms of a 10-map FaFNet step)
+        opt = torch.optim.Adam(model.parameters(), lr=lr, fused=next(model.parameters()).is_cuda)
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(total_steps * 0.6), int(total_steps * 0.85)], gamma=0.3)
     return opt, sched
 
