@@ -626,3 +626,20 @@ def test_channel_sum_vs_torch(device, shape):
     scale = float(x.double().abs().reshape(-1, shape[-1]).sum(0).max())
     assert float((got.double() - ref).abs().max()) <= 2e-6 * scale, float((got.double() - ref).abs().max())
     assert torch.equal(ops.channel_sum(x), got)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (1, 8, 32, 32, 32), (3, 24, 32, 96, 32), (2, 32, 32, 256, 128), (10, 128, 128, 64, 64)])
+def test_wgrad_transpose_read_form_equals_first_form_bitwise(device, N, H, W, Cin, Cout, tune):
+    """conv3x3_wgrad_tr_kernel (LDS-DMA tiles in their natural layout + ds_read_b64_tr_b16 fragments; default) against the first form (VALU
+    transposes into LDS): the same products summed in the same order -> bit-identical partials and gradients; borders, ragged tile shares,
+    both channel-tile forms (Cout % 64 == 0 and == 32)."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(N + H + Cin + Cout)
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(device)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(torch.bfloat16).to(device)
+    new = ops.conv3x3_wgrad(x, dy)
+    tune("WGRAD_TR", 0)
+    old = ops.conv3x3_wgrad(x, dy)
+    tune.reset("WGRAD_TR")
+    assert torch.equal(new, old), float((new - old).abs().max())
+    assert torch.equal(ops.conv3x3_wgrad(x, dy), new)

@@ -142,6 +142,147 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const WgradArgs a) {
             }
 }
 
+// ---- second form (round 3): natural-layout tiles by LDS-DMA, fragments by the gfx950 TRANSPOSE READ -------------------------------------
+// The kernel above spends as long transposing its operands into LDS (eight ds_write_b16 per 16 loaded bytes, three tap-shifted copies of
+// the input patch: ~190 LDS stores per thread and tile, synchronous global loads in front of them) as on its MFMAs, with 94 KiB of LDS = one
+// workgroup per CU and nothing to overlap with.  Here the dY tile [256 px][CO] and the input patch [10 x 34 px][32 ci] land in LDS in their
+// NATURAL channel-contiguous layout by LDS-DMA (no VALU, no shifted copies: a tap shift is a pixel offset), and every MFMA operand -- 8
+// consecutive PIXELS of one channel per lane -- is two ds_read_b64_tr_b16: within a 16-lane group lane i points at the 4 channels
+// 4 (i & 3) .. of pixel p0 + (i >> 2) and receives channel i of the pixels p0 .. p0 + 3 (tools/tr_read_probe.hip).  53 KiB of LDS: THREE
+// workgroups per CU cover each other's DMA waits.  Bank spread (a 32-lane half of the read = pixels p0 .. p0 + 3 and p0 + 8 .. p0 + 11 must
+// touch 64 distinct banks): the 32-byte channel groups of a pixel are XOR-ed with pixel-column bits on the DMA's SOURCE side -- dY: group ^
+// (bit 1 | bit 3 << 1 of the column), patch: half ^ bit 3 of the patch column.  Same sums in the same order as the first form: bit-identical.
+typedef __attribute__((ext_vector_type(4))) short wg_s16x4_t;
+typedef const __attribute__((address_space(1))) void *wg_gptr_t;
+typedef __attribute__((address_space(3))) void *wg_lptr_t;
+__device__ __attribute__((aligned(64))) const uint32_t g_wgrad_zero_page[16] = {0};
+constexpr int WT_X_PIX = (WG_TH + 2) * (WG_TW + 2);                 // 340 patch pixels
+constexpr int WT_X_BYTES = ((WT_X_PIX * 64 + 1023) / 1024) * 1024;   // 22 KiB (whole 1-KiB DMA pieces)
+
+__device__ __forceinline__ bf16x8_t wg_tr_frag(const char *lds, int off_lo, int off_hi) {
+    const wg_s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4_t *)(lds + off_lo));
+    const wg_s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) wg_s16x4_t *)(lds + off_hi));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv3x3_wgrad_tr_kernel(const WgradArgs a) {
+    constexpr int RT = CO == 64 ? WG_TH : WG_TH / 2;
+    constexpr int DY_BYTES = WG_PX * CO * 2;             // 32 KiB (CO = 64) / 16 KiB
+    constexpr int DY_PIECES = DY_BYTES / 1024;           // LDS-DMA wave instructions for the dY tile
+    constexpr int X_PIECES = WT_X_BYTES / 1024;          // 22
+    constexpr int CPP = CO / 8;                          // 16-byte chunks per dY pixel
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_dy = smem;
+    char *s_x = smem + DY_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fj = lane & 15, fq = lane >> 4;
+    const int wco = CO == 64 ? wave : (wave & 1);
+    const int row0 = CO == 64 ? 0 : (wave >> 1) * RT;
+    const int n_ci_t = a.Cin / WG_CI;
+    const int blk = blockIdx.x;
+    const int split = blk % a.n_split;
+    const int cc = blk / a.n_split;
+    const int ci_t = cc % n_ci_t, co_t = cc / n_ci_t;
+    const int txy = a.tiles_x * a.tiles_y;
+
+    // per-lane read offsets (tile-invariant).  Lane (i = fj, k-slot fq), half h: pixel column 8 fq + 4 h + (i >> 2), channels 4 (i & 3) ..
+    int dy_off[2], x_off[3][2];          // dY: [h];  patch: [kx][h], for ci sub-tile 0 (sub-tile 1 = the other 32-byte half: ^ 32)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = 8 * fq + 4 * h + (fj >> 2);
+        // 128-byte pixels (CO = 64): rows p and p + 2 share their banks -> 2 swizzle bits (column bits 1 and 3); 64-byte pixels: bit 3 only
+        const int sw = CO == 64 ? (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : ((col >> 3) & 1);
+        dy_off[h] = col * (CO * 2) + ((wco ^ sw) * 32) + (fj & 3) * 8;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int pc = col + kx;
+            x_off[kx][h] = pc * 64 + (((pc >> 3) & 1) * 32) + (fj & 3) * 8;
+        }
+    }
+
+    f32x4_t acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    for (int tile = split; tile < a.n_tiles; tile += a.n_split) {
+        const int n = tile / txy;
+        const int r0 = tile - n * txy;
+        const int ty = r0 / a.tiles_x;
+        const int y0 = ty * WG_TH, x0 = (r0 - ty * a.tiles_x) * WG_TW;
+        __syncthreads();   // everyone is done reading the previous tile
+        // ---- dY tile: LDS slot L (16 B) = pixel L / CPP, physical chunk L % CPP; logical chunk = physical ^ (swizzle << 1)
+#pragma unroll
+        for (int t = 0; t < DY_PIECES / 4; ++t) {
+            const int piece = wave + 4 * t;
+            const int L = piece * 64 + lane;
+            const int px = L / CPP, ch = L - px * CPP;
+            const int col = px & 31;
+            const int sw = CO == 64 ? (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : ((col >> 3) & 1);
+            const int lch = ch ^ (sw << 1);
+            const uint16_t *src = a.dy + ((size_t)(n * a.H + y0 + (px >> 5)) * a.W + x0 + col) * a.Cout + co_t * CO + lch * 8;
+            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(s_dy + piece * 1024), 16, 0, 0);
+        }
+        // ---- input patch: slot L = patch pixel L / 4, physical chunk L % 4; logical chunk = physical ^ (bit 3 of the patch column << 1)
+#pragma unroll
+        for (int t = 0; t < (X_PIECES + 3) / 4; ++t) {
+            const int piece = wave + 4 * t;
+            if (piece >= X_PIECES) break;     // wave-uniform
+            const int L = piece * 64 + lane;
+            const int p = L >> 2, ch = L & 3;
+            const int pr = p / (WG_TW + 2), pc = p - pr * (WG_TW + 2);
+            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
+            const bool ok = p < WT_X_PIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+            const int lch = ch ^ (((pc >> 3) & 1) << 1);
+            const void *src = ok ? (const void *)(a.x + ((size_t)(n * a.H + y) * a.W + x) * a.Cin + ci_t * WG_CI + lch * 8) : (const void *)g_wgrad_zero_page;
+            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(s_x + piece * 1024), 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        // ---- MFMAs: patch row row0 + pr serves (r, ky) with r + ky = pr, r = output row relative to row0
+        bf16x8_t A[3];
+#pragma unroll
+        for (int pr = 0; pr < RT + 2; ++pr) {
+            if (pr < RT) A[pr % 3] = wg_tr_frag(s_dy + (row0 + pr) * (WG_TW * CO * 2), dy_off[0], dy_off[1]);
+            bf16x8_t B[3][2];
+            const char *xrow = s_x + (row0 + pr) * ((WG_TW + 2) * 64);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) B[kx][j] = wg_tr_frag(xrow, x_off[kx][0] ^ (j * 32), x_off[kx][1] ^ (j * 32));
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int r = pr - ky;
+                if (r < 0 || r >= RT) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ky * 3 + kx][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r % 3], B[kx][j], acc[ky * 3 + kx][j], 0, 0, 0);
+            }
+        }
+    }
+    const int slot = CO == 64 ? split : 2 * split + (wave >> 1);
+    float *dst = a.ws + (size_t)slot * a.Cout * 9 * a.Cin;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co_t * CO + wco * 16 + fq * 4 + e;
+                const int ci = ci_t * WG_CI + j * 16 + fj;
+                dst[((size_t)co * 9 + t) * a.Cin + ci] = acc[t][j][e];
+            }
+}
+
 // dW[co][ci][ky][kx] (the parameter's own OIHW layout, ci < cin_out) = sum over the n_split partials ws[s][co][tap][ci], in slot order
 // (deterministic).  Replaces the caller's `ws.sum(0).permute(0, 3, 1, 2).contiguous()[:, :cin]` (a reduction and a permuting copy per layer).
 // A block = 32 output elements (ci fastest: coalesced reads of the partials) x 8 slices of the split range: a thread adds its slice's
@@ -234,6 +375,19 @@ extern "C" int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
     }
     const int grid = (Cout / (rows32 ? 32 : WG_CO)) * (Cin / WG_CI) * a.n_split;
+    if (v2x_tune(V2X_TUNE_WGRAD_TR) != 0) {   // the transpose-read form (default); 0: the first form (A/B, bitwise-equality test)
+        static v2x_once_per_device tr_once;
+        if (v2x_first_use_on_device(tr_once)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_tr_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_PX * 64 * 2 + WT_X_BYTES);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_tr_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_PX * 32 * 2 + WT_X_BYTES);
+        }
+        if (rows32)
+            hipLaunchKernelGGL(conv3x3_wgrad_tr_kernel<32>, dim3(grid), dim3(256), WG_PX * 32 * 2 + WT_X_BYTES, (hipStream_t)stream, a);
+        else
+            hipLaunchKernelGGL(conv3x3_wgrad_tr_kernel<64>, dim3(grid), dim3(256), WG_PX * 64 * 2 + WT_X_BYTES, (hipStream_t)stream, a);
+        V2X_CHECK_LAUNCH("conv3x3_wgrad_tr_kernel");
+        return V2X_OK;
+    }
     if (rows32)
         hipLaunchKernelGGL(conv3x3_wgrad_kernel<32>, dim3(grid), dim3(256), WG_SMEM, (hipStream_t)stream, a);
     else
