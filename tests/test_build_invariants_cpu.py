@@ -39,6 +39,7 @@ def _kernels(asm):
     ("conv_stream.hip", "_Z22conv3x3_stream8_kernel", 3),
     ("conv_stream.hip", "_Z23conv3x3_stream8g_kernel", 2),
     ("conv_stream_s2.hip", "_Z24conv3x3_s2_stream_kernel", 2),
+    ("conv_stream_s2.hip", "_Z18conv3x3_s2g_kernel", 2),
     ("conv_stream.hip", "_Z19conv3x3_wide_kernel", 2),
     ("conv_stream.hip", "_Z20conv3x3_wide3_kernel", 1),
     ("conv_stream_s2.hip", "_Z26conv3x3_s2_resident_kernel", 1),

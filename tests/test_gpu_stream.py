@@ -248,6 +248,44 @@ def test_stride2_stream_conv_vs_torch_and_gather(device, cfg):
 
 
 @pytest.mark.parametrize("cfg", [
+    # (C, Cout, N, H, W): output maps tile by 8 x 32, or by 16 x 16
+    (64, 128, 2, 32, 128),     # conv2_1 class: two chunks, 8 x 32 tiles, 2 x 2 tiles per map
+    (128, 256, 3, 16, 64),     # conv3_1 class: two channel tiles, one tile per map (every border is padding)
+    (256, 512, 2, 32, 32),     # conv4_1: 16 x 16 outputs -> the 16 x 16 tile form, four channel tiles, 8 chunks
+    (96, 128, 5, 64, 96),      # three chunks, 16 x 16 tiles, 2 x 3 tiles per map
+    (64, 128, 40, 48, 64),     # persistent walk: more tiles than workgroups (3 x 1 tiles x 40 maps on <= 256 CUs needs > 256: see N)
+])
+def test_stride2_three_tap_kernel_vs_torch_and_one_tap(device, cfg, tune):
+    """conv3x3_s2g_kernel (8 waves, three taps per synchronisation, parity-split patch refilled in place) vs torch fp32 on the same bf16
+    operands and vs the 1-tap stride-2 kernel: K order (chunk, kx in {0, 2, 1}, ky) differs, so one bf16 rounding, not bits.  S2_G = 2
+    forces the form for launches that would not fill the chip; repeated launches are bit-stable."""
+    from v2x_sim_amd import ops, packing
+    C, Cout, N, H, W = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    if N == 40:
+        N = 2 * torch.cuda.get_device_properties(0).multi_processor_count // 3 + 7     # > 2 tiles per workgroup, ragged tail
+    x = bf16r(torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    ref = F.relu(F.conv2d(x, bf16r(w), None, 2, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = packing.pack_conv_stream("s2", w, scale, shift, C0=C, stride=2, device=device)
+    xd = nhwc(x, device)
+    tune("S2_G", 2)
+    assert ops.conv_kernel_name(pc, H, W, False, N).startswith("conv3x3_s2g_kernel")
+    got = ops.conv2d(pc, xd)
+    for _ in range(3):
+        assert torch.equal(ops.conv2d(pc, xd), got)
+    tune("S2_G", 0)
+    assert ops.conv_kernel_name(pc, H, W, False, N).startswith("conv3x3_s2_stream_kernel")
+    one = ops.conv2d(pc, xd)
+    got, one = back(got), back(one)
+    assert got.shape == ref.shape == (N, Cout, H // 2, W // 2)
+    assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
+    assert torch.allclose(got, one, atol=2e-3, rtol=2 ** -7)
+    assert float((got != one).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("cfg", [
     # (C_up, C, N, H, W, chain)
     (128, 64, 2, 32, 64, False),   # conv7_1 class: half-resolution source + skip
     (0, 64, 3, 16, 32, False),     # conv7_2 class (one 16x32 tile per map)

@@ -137,3 +137,18 @@ def test_voxelize_wrapper_validates_the_count_vector():
     with pytest.raises(ValueError, match="one count per cloud"):
         ops.voxelize_fused_bits(pts, torch.zeros(4, dtype=torch.int32), torch.zeros((1, 3, 4)), torch.zeros(1, dtype=torch.int32),
                                 torch.zeros(1, dtype=torch.int32), 1, grid)
+
+
+def test_param_version_sees_fused_optimizer_steps():
+    """A fused optimizer step leaves Tensor._version alone; packing.watch_optimizer's post-step hook is what the packed-weight caches see."""
+    import torch
+    from v2x_sim_amd import packing
+    p = torch.nn.Parameter(torch.randn(4, 4))
+    for fused in (False, True):
+        opt = packing.watch_optimizer(torch.optim.Adam([p], lr=1e-3, fused=fused))
+        assert packing.watch_optimizer(opt) is opt          # idempotent: one hook
+        p.grad = torch.ones_like(p)
+        v0 = packing.param_version(p)
+        opt.step()
+        v1 = packing.param_version(p)
+        assert v1 != v0 and v1[1] == v0[1] + 1, (fused, v0, v1)

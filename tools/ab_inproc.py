@@ -30,7 +30,11 @@ def main():
     # optional: per-variant tuning switches, e.g.  A:STREAM_WT=1 B:STREAM_WT=2  (include/v2x_amd.h: v2x_tuning_set; set on the variant's OWN
     # library handle at every switch, so the same .so may be passed twice)
     envs = [{}, {}]
+    only = None
     for a in sys.argv[3:]:
+        if a.startswith("only="):       # only=s2 : run the cases whose name contains the text
+            only = a[5:]
+            continue
         v, kv = a.split(":", 1)
         k, val = kv.split("=", 1)
         envs["AB".index(v)][k.upper().replace("V2X_", "")] = int(val)
@@ -54,7 +58,10 @@ def main():
              ("halo conv8_2: 32 -> 32 @256", 32, 0, 32, 256, 0, "halo"), ("halo conv7_2: 64 -> 64 @128", 64, 0, 64, 128, 0, "halo"),
              ("halo conv8_1: (64 half-res + 32) -> 32 @256", 64, 32, 32, 256, 1, "halo"),
              ("halo heads: 32 -> 64 -> 12 | 36 fp32 @256", 32, 0, 64, 256, 0, "heads"),
-             ("s2 conv2_1: 64 -> 128 @128 -> 64", 64, 0, 128, 128, 0, "s2"), ("s2 conv3_1: 128 -> 256 @64 -> 32", 128, 0, 256, 64, 0, "s2")]
+             ("s2 conv2_1: 64 -> 128 @128 -> 64", 64, 0, 128, 128, 0, "s2"), ("s2 conv3_1: 128 -> 256 @64 -> 32", 128, 0, 256, 64, 0, "s2"),
+             ("s2 conv4_1: 256 -> 512 @32 -> 16", 256, 0, 512, 32, 0, "s2")]
+    if only:
+        cases = [c for c in cases if only in c[0]]
     n = 320
     for name, c0, c1, cout, hw, up, gru in cases:
         split = 0

@@ -18,7 +18,21 @@
 #ifndef V2X_S2_PSWZ_BUILD
 #define V2X_S2_PSWZ_BUILD 1   // patch swizzle (entry >> 1) & 3; 2 = (entry >> 2) & 3 (conv_stream.hip PSWZ): measured no different here (297 vs 299 us)
 #endif
+#ifndef V2X_S2G_DBG_BUILD
+#define V2X_S2G_DBG_BUILD 0   // phase probe of conv3x3_s2g_kernel (tools/s2g_phase_probe.sh; results are garbage): 1 no weight DMAs, 2 no patch DMAs, 4 no pixel-fragment reads, 8 no MFMAs, 16 no weight-fragment reads, 32 no counted waits
+#endif
 #include <cstdlib>
+
+int v2x_num_cus();   // conv_stream.hip
+#if (V2X_S2G_DBG_BUILD & 64)
+// timestamp build (tools/s2g_timeline.sh): lane 0 of wave 0 of each group of workgroup 0 stamps the shader clock at 6 points of each of its
+// first S2G_T_STEPS steps: 0 top of the load phase, 1 DMAs issued, 2 fragments read + waits done, 3 first barrier passed, 4 MFMAs done, 5 end-of-phase wait done
+constexpr int S2G_T_STEPS = 96;
+__device__ unsigned v2x_s2g_timeline[2 * S2G_T_STEPS * 8];
+extern "C" int v2x_debug_s2g_timeline(unsigned *dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2x_s2g_timeline), sizeof(unsigned) * 2 * S2G_T_STEPS * 8);
+}
+#endif
 
 typedef const __attribute__((address_space(1))) void *gptr_t;
 typedef __attribute__((address_space(3))) void *lptr_t;
@@ -353,6 +367,403 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- 8-wave ping-pong form with THREE taps per synchronisation ("s2g") ---------------------------------------------------------------
+// The streamed kernel above synchronises once per tap (16 MFMAs per wave between barriers) and DRAINS at every chunk boundary: its
+// single patch buffer is refilled with nothing but the other workgroup of the CU to cover the HBM latency (wave-wait 46 % of the
+// cycles, 0.27-0.36 of the MFMA peak at 320 maps, profiles/r02_pmc_sq_h.csv).  Here, as in conv3x3_stream8g_kernel (conv_stream.hip):
+//   * 8 waves in two groups half a step apart -- a group's load phase (pixel fragment reads) runs under the other group's MFMA phase;
+//     the workgroup owns 128 channels x 256 output pixels (8 x 32 or 16 x 16), a wave 64 channels x 64 pixels;
+//   * a step is a tap COLUMN of a 32-channel chunk (ky = 0..2 of one kx): 48 MFMAs per wave per synchronisation, the wave's pixel
+//     fragments shared between the tap rows (output row r, tap row ky -> patch row 2r + ky: 5 / 9 distinct rows per wave);
+//   * the patch is split by column PARITY into two LDS regions that are refilled separately, and a chunk walks kx = 0, 2, 1: the
+//     EVEN region serves kx = 0 (entry c) and kx = 2 (entry c + 1) and BOTH sets of fragments are read in the first load phase of
+//     the chunk (the wave has 64 accumulator registers, so 20 fragments fit), after which the region is free: the next chunk's even
+//     columns are DMA'd during step 1 and have until step 0 of the next chunk to land; the ODD region serves kx = 1 (step 2) and is
+//     refilled during step 0 of its own chunk.  One patch buffer (70 KiB) therefore behaves like a double buffer and nothing drains
+//     at a chunk boundary.
+//   * a stride-2 tile moves FOUR times the bytes of a stride-1 tile per MFMA (47 KiB of LDS-DMA per step and workgroup: 750 cycles of the
+//     CU's 64 B/clk vector-memory path against 1 536 cycles of MFMAs).  Issued in the load phases (the first forms of this kernel: 9
+//     DMAs ~ 1 000 cycles, tools/s2g_timeline.py) that path is the critical one; here every DMA is issued INSIDE an MFMA phase, one
+//     after each block of four MFMAs, so the path is busy evenly and a load phase is fragment reads only.
+//   * division of labour: GROUP 0 fills the patch (odd region of chunk kc in M0(s0), even region of chunk kc+1 in M0(s1): 8-9 pieces per
+//     wave), GROUP 1 streams the weights (the 24 pieces of step g+2 in M1(g), 6 per wave, 3-step ring).  Waits are counted and sit at the
+//     END of the MFMA phases: group 0 waits for the odd region at the end of M0(s1) and for the even region at the end of M0(s2); group
+//     1 waits at the end of M1(g) for what it issued in M1(g-1).  Only tap row 0 of a step is read in a LOAD phase (the MFMA phase starts
+//     without an exposed LDS latency): its pieces are the first two of a wave's six and are waited for at the end of L1(g) (vmcnt(4)).
+// Hazards (interval 2s = L0(s) | M1(s-1), 2s+1 = M0(s) | L1(s); steps s0, s1, s2 of chunk kc are global steps 3kc..3kc+2):
+//   even region: last read L1(s0) @6kc+1; rewritten in M0(s1) @6kc+3, landed by the end of M0(s2) @6kc+5, read L0(s0') @6kc+6.
+//   odd region: last read L1(s2) @6kc-1; rewritten in M0(s0) @6kc+1, landed by the end of M0(s1) @6kc+3, read L0(s2) @6kc+4.
+//   ring slot t%3: last read M1(t-3) @2t-4; rewritten in M1(t-2) @2t-2; tap row 0 landed by the end of L1(t-1) @2t-1, read L0(t) @2t; the
+//     rest landed by the end of M1(t-1) @2t, read from M0(t) @2t+1.
+// K order is (chunk, kx in {0, 2, 1}, ky): the fp32 sums differ from the 1-tap kernel in their last bits (one bf16 rounding of the output).
+template <int TH, int TW>
+struct S2GGeom {
+    static constexpr int PR = 2 * TH + 1;                        // patch rows
+    static constexpr int NE = TW + 1, NO = TW;                   // even / odd patch columns
+    static constexpr int E_SLOTS = PR * NE * 4, O_SLOTS = PR * NO * 4;
+    static constexpr int E_PIECES = (E_SLOTS + 63) / 64, O_PIECES = (O_SLOTS + 63) / 64;
+    static constexpr int RW = TH / 4;                            // output rows of a wave
+    static constexpr int NCF = TW / 16;                          // 16-pixel column fragments of a wave
+    static constexpr int NBR = 2 * RW + 1;                       // distinct patch rows of a wave
+    static constexpr int NB = NBR * NCF;                         // pixel fragments per tap column
+    static constexpr int NPW = 9;                                // patch pieces per wave of group 0 and region, at most = DMA slots of an MFMA phase
+    static_assert(TH * TW == 256 && RW * NCF == 4, "256 output pixels, 4 fragments per wave");
+    static_assert((E_PIECES + 3) / 4 <= NPW && (O_PIECES + 3) / 4 <= NPW, "pieces per wave");
+};
+
+template <int TH, int TW>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_s2g_kernel(const S2Args a) {
+    using G = S2GGeom<TH, TW>;
+    constexpr int BCO = 128;
+    constexpr int SLICE_BYTES = BCO * 64, STEP_BYTES = 3 * SLICE_BYTES;
+    constexpr int N_ST = 16;                               // output stores per wave and tile
+    constexpr int NWD = 6;                                 // weight DMAs per wave of group 1 and step
+    constexpr int DBG = V2X_S2G_DBG_BUILD;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *s_ring = smem;                                   // 3 x STEP_BYTES
+    char *s_E = smem + 3 * STEP_BYTES;
+    char *s_O = s_E + G::E_PIECES * 1024;
+    float *s_ss = reinterpret_cast<float *>(s_O + G::O_PIECES * 1024);   // [BCO scale | BCO shift]
+    const uint32_t relu_floor = a.relu ? 0u : 0x80008000u;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wv = wave & 3;
+    const int coh = wv & 1, ph = wv >> 1;
+    const int R0 = grp * (TH / 2) + ph * G::RW;            // the wave's first output row of the tile
+
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int n_tiles = a.n_px_tiles * a.n_co_tiles;
+    const int co_tile = bid % a.n_co_tiles;
+    const int txy = a.tiles_x * a.tiles_y;
+    const int nchunks = a.C >> 5;
+    const int S3 = nchunks * 3;
+    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
+
+    auto tile_coords = [&](int t, int &n, int &y0, int &x0) {
+        const int px_tile = t / a.n_co_tiles;
+        n = px_tile / txy;
+        const int trem = px_tile - n * txy;
+        const int ty = trem / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (trem - ty * a.tiles_x) * TW;
+    };
+    // lane id from volatile asm: what is derived from it is not hoisted out of the loops and kept in registers across the MFMA phases
+    auto fresh_lane = [&]() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    // tile-independent part of the DMA source descriptor of piece p of a patch region: (patch row << 16) | (patch column << 4) | logical
+    // 16-B slot, -1 behind the region
+    auto desc_const = [&](bool odd, int p, int lane) -> int {
+        const int L = p * 64 + lane;
+        const int RS = (odd ? G::NO : G::NE) * 4;
+        const int r = L / RS, q = L - r * RS;
+        const int ent = q >> 2, phys = q & 3;
+        return r < G::PR ? ((r << 16) | ((2 * ent + (odd ? 1 : 0)) << 4) | (phys ^ ((ent >> 1) & 3))) : -1;
+    };
+    // ... completed for a tile: (input pixel index << 5) | (logical slot * 8 elements), -1 = zero page
+    auto desc_tile = [&](int pk, int n, int y0, int x0) -> int {
+        const int y = 2 * y0 - 1 + (pk >> 16), x = 2 * x0 - 1 + ((pk >> 4) & 0xfff);
+        const bool ok = pk >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        return ok ? ((((n * a.H + y) * a.W + x) << 5) | ((pk & 15) << 3)) : -1;
+    };
+    auto issue_piece = [&](int d, int kc, char *dst) {
+        if constexpr ((DBG & 2) != 0) return;
+        const unsigned off = (unsigned)(d >> 5) * (unsigned)a.C + (unsigned)(kc * 32 + (d & 31));
+        glds16q(d >= 0 ? (const void *)(a.in + off) : zero_page, dst);
+    };
+    // piece p = wv + 4u of step t (chunk t / 3, tap column j = t % 3 -> kx = 0, 2, 1); piece p = (tap row p / 8, piece p % 8 of its slice):
+    // a wave's first two pieces (u = 0, 1) are tap row 0
+    auto issue_weight = [&](int t, int slot, int u, int lw) {
+        if constexpr ((DBG & 1) != 0) return;
+        const int kc = t / 3, j = t - kc * 3;
+        const int kx = j == 0 ? 0 : (j == 1 ? 2 : 1);
+        const int p = wv + 4 * u;
+        const int ky = p >> 3, pis = p & 7;
+        glds16q(wbase + (size_t)(kc * 9 + ky * 3 + kx) * (BCO * 32) + pis * 512 + lw * 8, s_ring + slot * STEP_BYTES + ky * SLICE_BYTES + pis * 1024);
+    };
+    // s_waitcnt vmcnt(K) for the wave-uniform run-time K in {0, 4, 6, 8, 9} (+ N_ST)
+    auto wait_keep = [&](int k, bool plus_stores) {
+        if constexpr ((DBG & 32) != 0) return;
+#define S2G_WAIT_CASE(K) case K: if (plus_stores) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K + N_ST) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(K) : "memory"); break;
+        switch (k) {
+            S2G_WAIT_CASE(4) S2G_WAIT_CASE(6) S2G_WAIT_CASE(8) S2G_WAIT_CASE(9)
+            default: S2G_WAIT_CASE(0)
+        }
+#undef S2G_WAIT_CASE
+    };
+
+    int tile = bid;
+    int n, y0, x0;
+    tile_coords(tile, n, y0, x0);
+    // group 0: this wave's pieces of the two regions, piece = wv + 4t
+    // (the odd region's rows are 128 / 64 slots: its constant part is shifts and masks, recomputed where needed; the even region's rows of
+    // 132 / 68 slots need a division, kept in registers)
+    int pkE[G::NPW], pdE[G::NPW], pdO[G::NPW];
+    {
+        const int l0 = fresh_lane();
+#pragma unroll
+        for (int t = 0; t < G::NPW; ++t) {
+            pkE[t] = desc_const(false, wv + 4 * t, l0);
+            pdE[t] = desc_tile(pkE[t], n, y0, x0);
+            pdO[t] = desc_tile(desc_const(true, wv + 4 * t, l0), n, y0, x0);
+        }
+    }
+    if (grp == 0) {
+        // prologue: even region of chunk 0
+#pragma unroll
+        for (int t = 0; t < G::NPW; ++t)
+            if (wv + 4 * t < G::E_PIECES) issue_piece(pdE[t], 0, s_E + (wv + 4 * t) * 1024);
+    } else {
+        // prologue: weights of steps 0 and 1
+        const int lw = fresh_lane();
+#pragma unroll
+        for (int u = 0; u < NWD; ++u) {
+            issue_weight(0, 0, u, lw);
+            issue_weight(1, 1, u, lw);
+        }
+    }
+    for (int i = tid; i < BCO; i += 512) {
+        s_ss[i] = a.scale[co_tile * BCO + i];
+        s_ss[BCO + i] = a.shift[co_tile * BCO + i];
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();            // half-step offset
+
+#if (V2X_S2G_DBG_BUILD & 64)
+    unsigned *s_tl = reinterpret_cast<unsigned *>(s_ss + 2 * BCO);
+    int tl_n = 0;
+#define S2G_STAMP(pt) do { if (blockIdx.x == 0 && wv == 0 && tl_n < S2G_T_STEPS) { const unsigned t_ = (unsigned)__builtin_readcyclecounter(); if (fresh_lane() == 0) s_tl[(grp * S2G_T_STEPS + tl_n) * 8 + (pt)] = t_; } } while (0)
+#else
+#define S2G_STAMP(pt) do { } while (0)
+#endif
+    bool relaxed = false;   // group 1, first step after an epilogue: what its two waits are for is OLDER than the tile's output stores, which may stay in flight
+    for (;;) {
+        const int next = tile + nwg;
+        const bool has_next = next < n_tiles;
+        int nn = 0, ny0 = 0, nx0 = 0;
+        if (has_next) tile_coords(next, nn, ny0, nx0);
+
+        f32x4_t acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+        for (int kc = 0; kc < nchunks; ++kc) {
+            const bool last_chunk = kc + 1 == nchunks;
+            const bool fill_e = !last_chunk || has_next;
+            const int kcn = last_chunk ? 0 : kc + 1;
+            bf16x8_t Bq[2][G::NB];                         // [0]: kx = 0 (step 0), then kx = 1 (step 2); [1]: kx = 2 (step 1)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                S2G_STAMP(0);
+                const int ln = fresh_lane();
+                const int fjl = ln & 15, fql = ln >> 4;
+                // DMAs of this phase.  Group 1: the weights of step g+2; group 0: the odd region of this chunk (step 0), the even region of the next (step 1)
+                int wt = kc * 3 + j + 2;
+                bool w_ok = true;
+                if (wt >= S3) {
+                    wt -= S3;
+                    w_ok = has_next;
+                }
+                const int nd = grp ? (w_ok ? NWD : 0)
+                                   : (j == 0 ? (G::O_PIECES - wv + 3) / 4 : ((j == 1 && fill_e) ? (G::E_PIECES - wv + 3) / 4 : 0));   // DMAs of this wave in this phase
+                __builtin_amdgcn_sched_barrier(0);
+                S2G_STAMP(1);
+                // ---- L: pixel fragments.  Fragment (patch row q of the wave, column fragment ch) at Bq[.][q * NCF + ch]
+                if constexpr ((DBG & 4) != 0) {
+                    if (j == 0) {
+#pragma unroll
+                        for (int q = 0; q < G::NB; ++q) Bq[0][q] = Bq[1][q] = __builtin_bit_cast(bf16x8_t, make_uint4(ln, q, kc, j));
+                    }
+                } else if (j == 0) {
+#pragma unroll
+                    for (int ch = 0; ch < G::NCF; ++ch) {
+                        const int i0 = ch * 16 + fjl, i2 = i0 + 1;
+                        const int c0 = (i0 * 4 + (fql ^ ((i0 >> 1) & 3))) * 16, c2 = (i2 * 4 + (fql ^ ((i2 >> 1) & 3))) * 16;
+#pragma unroll
+                        for (int q = 0; q < G::NBR; ++q) {
+                            const char *prow = s_E + (2 * R0 + q) * (G::NE * 64);
+                            Bq[0][q * G::NCF + ch] = *reinterpret_cast<const bf16x8_t *>(prow + c0);
+                            Bq[1][q * G::NCF + ch] = *reinterpret_cast<const bf16x8_t *>(prow + c2);
+                        }
+                    }
+                } else if (j == 2) {
+#pragma unroll
+                    for (int ch = 0; ch < G::NCF; ++ch) {
+                        const int i1 = ch * 16 + fjl;
+                        const int c1 = (i1 * 4 + (fql ^ ((i1 >> 1) & 3))) * 16;
+#pragma unroll
+                        for (int q = 0; q < G::NBR; ++q)
+                            Bq[0][q * G::NCF + ch] = *reinterpret_cast<const bf16x8_t *>(s_O + (2 * R0 + q) * (G::NO * 64) + c1);
+                    }
+                }
+                const char *ws = s_ring + j * STEP_BYTES + (fql * BCO + fjl) * 16 + coh * 1024;
+                bf16x8_t A[2][4];
+                // tap row 0 of this step: complete and visible from interval 2g+1 on (group 1 waited for it at the end of M1(g-1)) -- group 1 reads
+                // it here, in its load phase L1(g) @2g+1; group 0 (L0(g) @2g) at the top of its MFMA phase
+                auto read_a0 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr ((DBG & 16) == 0) A[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+                        else A[0][i] = A[1][i] = __builtin_bit_cast(bf16x8_t, make_uint4(ln, i, kc, j));
+                    }
+                };
+                if (grp == 1) read_a0();
+                __builtin_amdgcn_sched_barrier(0);
+                // the DMAs after the fragment reads (nothing issued in a phase is written where that phase reads): the reads land under the DMA issue
+                if (grp == 1) {
+                    if (w_ok) {
+#pragma unroll
+                        for (int u = 0; u < NWD; ++u) issue_weight(wt, (j + 2) % 3, u, ln);
+                    }
+                } else if (j == 0) {
+#pragma unroll
+                    for (int t = 0; t < G::NPW; ++t)
+                        if (wv + 4 * t < G::O_PIECES) issue_piece(pdO[t], kc, s_O + (wv + 4 * t) * 1024);
+                } else if (j == 1 && fill_e) {
+#pragma unroll
+                    for (int t = 0; t < G::NPW; ++t)
+                        if (wv + 4 * t < G::E_PIECES) issue_piece(pdE[t], kcn, s_E + (wv + 4 * t) * 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // group 0, while the fragments are in flight: complete the patch descriptors that change with the tile -- the odd region's in the
+                // last load phase of the previous tile (or the first of the kernel), the even region's (which the last chunk fills for the NEXT tile)
+                // in the first load phase of the last chunk
+                if (grp == 0) {
+                    if (j == 2 && last_chunk && has_next) {
+#pragma unroll
+                        for (int t = 0; t < G::NPW; ++t) pdO[t] = desc_tile(desc_const(true, wv + 4 * t, ln), nn, ny0, nx0);
+                    }
+                    if (j == 0 && last_chunk && has_next) {
+#pragma unroll
+                        for (int t = 0; t < G::NPW; ++t) pdE[t] = desc_tile(pkE[t], nn, ny0, nx0);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): fragments in registers before the regions may be overwritten
+                S2G_STAMP(2);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                S2G_STAMP(3);
+                // ---- M: three taps of 16 MFMAs; the next tap's weight fragments are read after the first four MFMAs of a tap
+                if (grp == 0) read_a0();
+                auto &B = Bq[j == 1 ? 1 : 0];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    auto mma = [&](int i0, int i1) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int i = i0; i < i1; ++i)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) {
+                                if constexpr ((DBG & 8) == 0)
+                                    acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky & 1][i], B[(2 * (f / G::NCF) + ky) * G::NCF + (f % G::NCF)], acc[i][f], 0, 0, 0);
+                                else if (f == 0)
+                                    acc[i][0] += __builtin_bit_cast(f32x4_t, A[ky & 1][i]) + __builtin_bit_cast(f32x4_t, B[(2 * (f / G::NCF) + ky) * G::NCF]);
+                            }
+                    };
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(0, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (ky < 2 && (DBG & 16) == 0) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) A[(ky + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(ws + (ky + 1) * SLICE_BYTES + i * 256);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(1, 4);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                S2G_STAMP(4);
+                // end of the MFMA phase: group 1 -- everything but this phase's own DMAs (the weights of the next step are complete); group 0 --
+                // the odd region (issued in M(s0)) after step 1, the next even region (issued in M(s1)) after step 2
+                if (grp == 1) {
+                    wait_keep(nd, relaxed);
+                    relaxed = false;
+                } else if (j == 1) {
+                    wait_keep(nd, false);
+                } else if (j == 2 && (DBG & 32) == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                S2G_STAMP(5);
+#if (V2X_S2G_DBG_BUILD & 64)
+                ++tl_n;
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue: BN / ReLU, bf16, 8-byte NHWC stores (16 per wave)
+        {
+            const int le = fresh_lane();
+            const int fje = le & 15, fqe = le >> 4;
+            const int Ho = a.H >> 1, Wo = a.W >> 1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int cl = coh * 64 + i * 16 + fqe * 4;
+                const int co = co_tile * BCO + cl;
+                const float4 sc = *reinterpret_cast<const float4 *>(s_ss + cl);
+                const float4 sf = *reinterpret_cast<const float4 *>(s_ss + BCO + cl);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    float v0 = acc[i][f][0] * sc.x + sf.x, v1 = acc[i][f][1] * sc.y + sf.y;
+                    float v2 = acc[i][f][2] * sc.z + sf.z, v3 = acc[i][f][3] * sc.w + sf.w;
+                    uint2 o;
+                    o.x = v2x_relu_bf16x2_floor(pack_bf16x2(v0, v1), relu_floor);
+                    o.y = v2x_relu_bf16x2_floor(pack_bf16x2(v2, v3), relu_floor);
+                    const size_t pix = (size_t)(n * Ho + y0 + R0 + f / G::NCF) * Wo + x0 + (f % G::NCF) * 16 + fje;
+                    *reinterpret_cast<uint2 *>(a.out + pix * a.out_cstride + a.out_coff + co) = o;
+                }
+            }
+        }
+        if (!has_next) break;
+        tile = next;
+        n = nn;
+        y0 = ny0;
+        x0 = nx0;
+        relaxed = true;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the offset barrier of group 1
+#if (V2X_S2G_DBG_BUILD & 64)
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 2 * S2G_T_STEPS * 8; i += 512) v2x_s2g_timeline[i] = s_tl[i];
+#endif
+#undef S2G_STAMP
+}
+
+template <int TH, int TW>
+static int launch_s2g(const S2Args &a, hipStream_t s) {
+    using G = S2GGeom<TH, TW>;
+    constexpr int smem = 3 * 3 * 128 * 64 + (G::E_PIECES + G::O_PIECES) * 1024 + 2 * 128 * 4 + ((V2X_S2G_DBG_BUILD & 64) ? 2 * 96 * 8 * 4 : 0);   // 72 + 70 + 1 KiB
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static v2x_once_per_device attr_once;
+    auto kern = &conv3x3_s2g_kernel<TH, TW>;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    const int n_tiles = a.n_px_tiles * a.n_co_tiles;
+    int grid = n_tiles;
+    const int g = v2x_num_cus() / a.n_co_tiles * a.n_co_tiles;   // persistent: a workgroup's tiles share one channel tile
+    if (g > 0 && g < n_tiles) grid = g;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_s2g_kernel");
+    return V2X_OK;
+}
+
 static int launch_s2_resident(const S2Args &a, hipStream_t s) {
     constexpr int smem = 9 * 64 * 64 + S2_PATCH_BYTES + 512;   // 36 + 37 KiB + scale/shift
     static v2x_once_per_device attr_once;
@@ -406,6 +817,21 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.tiles_y = (d->H / 2) / (t32 ? S2_TH : 8);
     a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
     a.n_co_tiles = d->Cout / rows;
+    // 8-wave three-tap form: 128-row tiles, >= 2 chunks, 256-pixel output tiles (8 x 32, or 16 x 16 for the 16 x 16 maps), and enough
+    // tiles to fill the chip (one workgroup per CU; small launches keep the 128-pixel kernel: twice the workgroups)
+    if (rows == 128 && d->C0 >= 64 && v2x_tune(V2X_TUNE_S2_G) != 0 && (long long)d->N * d->H * d->W < (1ll << 26)) {
+        const int Ho = d->H / 2, Wo = d->W / 2;
+        const bool g32 = Ho % 8 == 0 && Wo % 32 == 0, g16 = !g32 && Ho % 16 == 0 && Wo % 16 == 0;
+        const long long tiles = (long long)d->N * (Ho * Wo / 256) * (d->Cout / 128);
+        if ((g32 || g16) && (tiles >= 2 * v2x_num_cus() || v2x_tune(V2X_TUNE_S2_G) == 2)) {
+            S2Args b = a;
+            b.tiles_x = Wo / (g32 ? 32 : 16);
+            b.tiles_y = Ho / (g32 ? 8 : 16);
+            b.n_px_tiles = d->N * b.tiles_x * b.tiles_y;
+            b.n_co_tiles = d->Cout / 128;
+            return g32 ? launch_s2g<8, 32>(b, s) : launch_s2g<16, 16>(b, s);
+        }
+    }
     if (t16) return rows == 128 ? launch_s2<128, 8, 16>(a, s) : launch_s2<64, 8, 16>(a, s);
     if (rows == 64 && a.n_co_tiles == 1 && d->C0 == 32) {   // one chunk, one channel tile: resident weights (conv1_1)
         if (v2x_tune(V2X_TUNE_S2_RESIDENT) != 0) return launch_s2_resident(a, s);

@@ -214,7 +214,8 @@ class DetModelBase(nn.Module):
         if torch.device(device).type != "cuda":
             raise RuntimeError("v2x_sim_amd models run on the MI355X only: move the model to 'cuda' "
                                "(no CPU fallback exists in the product path)")
-        key = (str(device), sum(t._version for t in self.parameters()) + sum(t._version for t in self.buffers()))
+        key = (str(device), sum(t._version + getattr(t, "_v2x_epoch", 0) for t in self.parameters())
+               + sum(t._version + getattr(t, "_v2x_epoch", 0) for t in self.buffers()))   # _v2x_epoch: packing.watch_optimizer (fused optimizers do not bump _version)
         if self._packed is None or self._packed_key != key:
             with torch.no_grad():
                 self._packed = self._pack(device)

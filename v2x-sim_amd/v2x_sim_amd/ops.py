@@ -41,12 +41,20 @@ class _Prof:
 _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 128: (128, 128, 2, 2), 96: (96, 128, 2, 2)}
 
 
-def conv_kernel_name(pc, H=0, W=0, bits=False):
+def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
     if pc.w_layout == 2 and pc.stride == 2:
         if pc.Cout == 64 and pc.C0 == 32 and tuning.get("S2_RESIDENT") != 0:
             return "conv3x3_s2_resident_kernel<64>"
         rows = 128 if pc.Cout % 128 == 0 else 64
+        s2g = tuning.get("S2_G")
+        if rows == 128 and pc.C0 >= 64 and s2g != 0:       # conv_stream_s2.hip: v2x_conv_stream_s2_dispatch
+            Ho, Wo = H // 2, W // 2
+            g32 = Ho % 8 == 0 and Wo % 32 == 0
+            g16 = not g32 and Ho % 16 == 0 and Wo % 16 == 0
+            tiles = N * (Ho * Wo // 256) * (pc.Cout // 128)
+            if (g32 or g16) and (s2g == 2 or tiles >= 2 * torch.cuda.get_device_properties(0).multi_processor_count):
+                return "conv3x3_s2g_kernel<%s>" % ("8, 32" if g32 else "16, 16")
         if not (H % 8 == 0 and W % 64 == 0):
             return "conv3x3_s2_stream_kernel<%d, 8, 16>" % rows    # 16 x 16 outputs (conv4_1)
         return "conv3x3_s2_stream_kernel<%d, 4, 32>" % rows
@@ -329,7 +337,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
         nbytes = in0.numel() * (4 if from_bits else 2) + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
-        prof = _Prof(conv_kernel_name(pc, H, W, from_bits) if splitk <= 1 else
+        prof = _Prof(conv_kernel_name(pc, H, W, from_bits, N) if splitk <= 1 else
                      "conv3x3_stream_kernel<%d, split-K %d> + splitk_reduce" % (lib.v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue), splitk),
                      flops, nbytes, pc.name)
     rc = lib.v2x_conv2d(C.byref(d), _stream())

@@ -17,6 +17,34 @@ from ._lib import V2X_EPI_DET
 from .ops import PackedConv, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU
 
 
+
+# ---- "has this parameter changed?" for the packed-weight caches ---------------------------------------------------------------------------
+# Tensor._version counts in-place writes made through autograd-visible ops, and that is what the caches keyed on.  FUSED optimizers
+# (torch.optim.Adam(fused=True): one multi-tensor kernel) and hipGraph replays update the parameters WITHOUT bumping it: a cache keyed on
+# _version alone keeps serving the packed weights of step 0 and nothing learns.  watch_optimizer() registers a post-step hook that stamps
+# every parameter the optimizer owns; param_version() is what the caches compare.
+def param_version(t):
+    return (t._version, getattr(t, "_v2x_epoch", 0))
+
+
+def note_params_changed(params):
+    for q in params:
+        q._v2x_epoch = getattr(q, "_v2x_epoch", 0) + 1
+
+
+def watch_optimizer(opt):
+    """Idempotent: after every opt.step() the packed-weight caches see the optimizer's parameters as changed."""
+    if opt is None or opt.__dict__.get("_v2x_watched") or not hasattr(opt, "register_step_post_hook"):
+        return opt
+
+    def _hook(o, *_a, **_k):
+        for g in o.param_groups:
+            note_params_changed(g["params"])
+    opt.register_step_post_hook(_hook)
+    opt.__dict__["_v2x_watched"] = True
+    return opt
+
+
 def _ceil_to(x, m):
     return (x + m - 1) // m * m
 

@@ -46,7 +46,7 @@ _PACK_CACHE = {}
 def _packed(kind, weight, bias, device):
     """Packed forward / dgrad weights of a parameter, re-packed only when the parameter changed (optimizer step)."""
     key = (kind, id(weight), str(device))   # the parameter OBJECT (weak reference checked on a hit): a data_ptr can be reused
-    ver = (weight._version, None if bias is None else bias._version)
+    ver = (packing.param_version(weight), None if bias is None else packing.param_version(bias))
     hit = _PACK_CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]

@@ -46,7 +46,7 @@ def _conv_like(weight, bias, stride):
 def _layer(kind, weight, bias, stride, cin_pad):
     # keyed on the parameter OBJECT (weak reference checked on a hit): a data_ptr can be reused by another model's tensor
     key = (kind, id(weight), stride, cin_pad)
-    ver = (weight._version, None if bias is None else bias._version)
+    ver = (packing.param_version(weight), None if bias is None else packing.param_version(bias))
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]
@@ -145,7 +145,7 @@ def cbr(x, conv, bn):
 
 def _layer_1x1(kind, weight, bias, f32_out, cout_pad):
     key = (kind, id(weight), f32_out, cout_pad)
-    ver = (weight._version, None if bias is None else bias._version)
+    ver = (packing.param_version(weight), None if bias is None else packing.param_version(bias))
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]

@@ -5,7 +5,7 @@ dense (A*B, 1, X, Y, Z) occupancy the reference Dataset yields; targets arrive s
 """
 import torch
 
-from .. import ops, tuning
+from .. import ops, packing, tuning
 from ..utils import postprocess, synthetic_scene
 from ..utils.CoDetModule import FaFModule
 
@@ -62,6 +62,7 @@ def make_optimizer(model, lr, total_steps):
         # fused: ONE multi-tensor kernel per step on the device (the default per-parameter form issues two tiny elementwise launches per
         # parameter: 184 of them = 0.47 ms of a 10-map FaFNet step)
         opt = torch.optim.Adam(model.parameters(), lr=lr, fused=next(model.parameters()).is_cuda)
+    packing.watch_optimizer(opt)     # a fused step does not bump the parameters' version counters: the packed-weight caches need the hook
     sched = torch.optim.lr_scheduler.MultiStepLR(opt, milestones=[int(total_steps * 0.6), int(total_steps * 0.85)], gamma=0.3)
     return opt, sched
 

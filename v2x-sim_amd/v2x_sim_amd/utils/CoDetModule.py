@@ -19,6 +19,8 @@ class FaFModule(object):
         self.model = model
         self.config = config
         self.optimizer = optimizer
+        from .. import packing
+        packing.watch_optimizer(optimizer)   # fused optimizers update the parameters without bumping their version counters
         self.anchors = postprocess.build_anchor_map(config)
         self.score_thr = 0.7
         self.nms_thr = 0.01

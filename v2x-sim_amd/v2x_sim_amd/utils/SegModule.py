@@ -11,6 +11,8 @@ class SegModule(object):
         if kd_flag:
             raise NotImplementedError("knowledge distillation is out of scope (DESIGN.md section 8)")
         self.model, self.config, self.optimizer = model, config, optimizer
+        from .. import packing
+        packing.watch_optimizer(optimizer)   # fused optimizers update the parameters without bumping their version counters
 
     def step(self, data, num_agent=5, batch_size=1):
         """data: 'bev_seq' (A*B, 1, X, Y, Z), 'labels' (A*B, X, Y) uint8/int64, 'trans_matrices', 'num_agent' -> loss (float)."""
