@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 11
+#define V2X_AMD_ABI_VERSION 12
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -324,6 +324,16 @@ int v2x_pixel_weighted_fuse(const float *scores, int score_stride, const float *
  * workspace: v2x_channel_sum_workspace_size(M, C) bytes (0 = unsupported shape). */
 long long v2x_channel_sum_workspace_size(long long M, int C);
 int v2x_channel_sum_bf16(const uint16_t *x, long long M, int C, float *out, float *workspace, v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- f-3: the cross-agent warp of the TRAINING graph, forward and data gradient
+ * Replaces F.affine_grid + F.grid_sample(mode="bilinear", padding_mode="zeros", align_corners=False) of
+ * coperception/models/det/base/IntermediateModelBase.py::feature_transformation (applied twice there: rotation, then translation) and its
+ * autograd backward.  in / out fp32 [P][C][H][W] (the fusion stage of the training graph is fp32 NCHW), theta fp32 [P][2][3] (the matrices
+ * F.affine_grid takes).  v2x_warp_affine_bwd_f32 is the exact transpose of v2x_warp_affine_f32 with respect to `in` (theta carries no
+ * gradient: poses are data), computed as a gather in a fixed order -- bit-reproducible, unlike the atomic scatter of
+ * grid_sampler_2d_backward.  Agreement with torch: fp32 rounding of the coordinate arithmetic (tests/test_gpu_train_kernels.py). */
+int v2x_warp_affine_f32(const float *in, const float *theta, int P, int C, int H, int W, float *out, v2x_stream_t stream);
+int v2x_warp_affine_bwd_f32(const float *dout, const float *theta, int P, int C, int H, int W, float *din, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-1: detection post-processing
  * Replaces coperception/utils/postprocess.py::apply_nms_det per (agent, frame) map: foreground softmax score, score

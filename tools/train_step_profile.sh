@@ -11,9 +11,11 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 print("total kernel time per step: %.2f ms (8 steps traced)" % (tot / 8e6))
+lib = [r for r in rows if any(t in r["Name"].lower() for t in ("miopen", "cijk", "naive_conv", "igemm_fwd", "igemm_bwd", "igemm_wrw", "gridwise"))]
+print("vendor-library convolution / GEMM kernels in the step: %s" % (", ".join(sorted(set(r["Name"][:60] for r in lib))) or "none"))
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
     print("%8.1f us/step  x%-5.1f %5.1f %%  %s" % (float(r["TotalDurationNs"]) / 8e3, int(r["Calls"]) / 8.0, 100 * float(r["TotalDurationNs"]) / tot, r["Name"][:150]))
 PY
   rm -rf $O/$m
 done
-head -50 $O/faf_kernels.txt
+head -50 $O/faf_kernels.txt; head -50 $O/v2v_kernels.txt

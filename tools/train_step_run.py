@@ -9,7 +9,7 @@ for _p in (ROOT, os.path.join(ROOT, "v2x-sim_amd")):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 import torch  # noqa: E402
-from v2x_sim_amd import tuning  # noqa: E402
+from v2x_sim_amd import packing, tuning  # noqa: E402
 from v2x_sim_amd.configs import Config  # noqa: E402
 from v2x_sim_amd.models.det import FaFNet, V2VNet  # noqa: E402
 from v2x_sim_amd.train import detection_loss, train_forward  # noqa: E402
@@ -20,7 +20,7 @@ cfg = Config("train")
 v2v = len(sys.argv) > 1 and sys.argv[1] == "v2v"
 model = init_for_training(V2VNet(cfg, num_agent=5) if v2v else FaFNet(cfg, kd_flag=0, num_agent=5), seed=0).to(dev).train()
 data = synthetic_batch_on_device(cfg, 2, 5, seed=1, device=dev)
-opt = torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True, fused=True)
+opt = packing.watch_optimizer(torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True, fused=True))   # the hook the training loops install: a fused step must invalidate the packed-weight caches
 tuning.set("TRAIN_HIP", 1)
 for it in range(8):
     res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 2)

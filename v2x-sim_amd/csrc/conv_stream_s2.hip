@@ -818,12 +818,13 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
     a.n_co_tiles = d->Cout / rows;
     // 8-wave three-tap form: 128-row tiles, >= 2 chunks, 256-pixel output tiles (8 x 32, or 16 x 16 for the 16 x 16 maps), and enough
-    // tiles to fill the chip (one workgroup per CU; small launches keep the 128-pixel kernel: twice the workgroups)
+    // tiles for four rounds of the persistent grid (one workgroup per CU: at 2.5 tiles per workgroup -- conv2_1 at 8 frames -- the
+    // 128-pixel kernel with twice the workgroups is 20 % faster)
     if (rows == 128 && d->C0 >= 64 && v2x_tune(V2X_TUNE_S2_G) != 0 && (long long)d->N * d->H * d->W < (1ll << 26)) {
         const int Ho = d->H / 2, Wo = d->W / 2;
         const bool g32 = Ho % 8 == 0 && Wo % 32 == 0, g16 = !g32 && Ho % 16 == 0 && Wo % 16 == 0;
         const long long tiles = (long long)d->N * (Ho * Wo / 256) * (d->Cout / 128);
-        if ((g32 || g16) && (tiles >= 2 * v2x_num_cus() || v2x_tune(V2X_TUNE_S2_G) == 2)) {
+        if ((g32 || g16) && (tiles >= 4 * v2x_num_cus() || v2x_tune(V2X_TUNE_S2_G) == 2)) {
             S2Args b = a;
             b.tiles_x = Wo / (g32 ? 32 : 16);
             b.tiles_y = Ho / (g32 ? 8 : 16);

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_EPI_DET = 0, 1, 2, 3
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ConvDesc(C.Structure):
@@ -66,6 +66,8 @@ SIGNATURES = {
     "v2x_pack_conv_device": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_channel_sum_workspace_size": (C.c_longlong, [C.c_longlong, C.c_int]),
     "v2x_channel_sum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_warp_affine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_warp_affine_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_conv3x3_wgrad_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_pack_conv": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_void_p]),
     "v2x_pack_chain_1x1": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

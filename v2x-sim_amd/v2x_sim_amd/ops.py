@@ -53,7 +53,7 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
             g32 = Ho % 8 == 0 and Wo % 32 == 0
             g16 = not g32 and Ho % 16 == 0 and Wo % 16 == 0
             tiles = N * (Ho * Wo // 256) * (pc.Cout // 128)
-            if (g32 or g16) and (s2g == 2 or tiles >= 2 * torch.cuda.get_device_properties(0).multi_processor_count):
+            if (g32 or g16) and (s2g == 2 or tiles >= 4 * torch.cuda.get_device_properties(0).multi_processor_count):
                 return "conv3x3_s2g_kernel<%s>" % ("8, 32" if g32 else "16, 16")
         if not (H % 8 == 0 and W % 64 == 0):
             return "conv3x3_s2_stream_kernel<%d, 8, 16>" % rows    # 16 x 16 outputs (conv4_1)
@@ -428,6 +428,22 @@ def channel_sum(x):
     out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
     _lib.check(lib.v2x_channel_sum_bf16(_dev(x, torch.bfloat16, "x"), M, Cc, _dev(out, torch.float32, "out"), _dev(ws, torch.float32, "workspace"),
                                         _stream()), "v2x_channel_sum_bf16")
+    return out
+
+
+def warp_affine(x, theta, backward=False):
+    """F.grid_sample(x, F.affine_grid(theta, x.shape, align_corners=False), "bilinear", "zeros", align_corners=False) on the HIP kernel
+    (warp_train.hip), or -- backward=True -- its exact transpose applied to an output gradient x (deterministic gather).
+    x (P, C, H, W) fp32 contiguous, theta (P, 2, 3) fp32 on the same device -> (P, C, H, W) fp32."""
+    lib = _lib.load()
+    P, Cc, H, W = x.shape
+    if theta.shape != (P, 2, 3):
+        raise ValueError("warp_affine: theta must be (%d, 2, 3), got %s" % (P, tuple(theta.shape)))
+    theta = theta.contiguous()
+    out = torch.empty_like(x)
+    fn = lib.v2x_warp_affine_bwd_f32 if backward else lib.v2x_warp_affine_f32
+    _lib.check(fn(_dev(x, torch.float32, "x"), _dev(theta, torch.float32, "theta"), P, Cc, H, W, _dev(out, torch.float32, "out"), _stream()),
+               "v2x_warp_affine_bwd_f32" if backward else "v2x_warp_affine_f32")
     return out
 
 

@@ -82,6 +82,11 @@ def heads(model, x):
                             model.box_code_size)}
 
 
+# train/hip_graph.py sets this while it runs a fusion stage: (feat, theta) -> resampled maps on the hand-written kernels (forward AND data
+# gradient; the PyTorch backward of grid_sample is an atomic scatter -- 17 % of a V2VNet training step, and not bit-reproducible)
+_affine_sample_override = None
+
+
 def warp_batch(feat, T):
     """feat (P, C, H, W); T (P, 4, 4) pose of the source w.r.t. the ego -> maps in the ego frame
     (upstream feature_transformation: rotate about the map centre, then translate by (4*T03/128, -4*T13/128))."""
@@ -90,6 +95,8 @@ def warp_batch(feat, T):
     o = torch.ones(P, device=feat.device, dtype=feat.dtype)
     rot = torch.stack([torch.stack([T[:, 0, 0], T[:, 0, 1], z], 1), torch.stack([T[:, 1, 0], T[:, 1, 1], z], 1)], 1)
     tr = torch.stack([torch.stack([o, z, 4 * T[:, 0, 3] / 128], 1), torch.stack([z, o, -4 * T[:, 1, 3] / 128], 1)], 1)
+    if _affine_sample_override is not None and feat.is_cuda and feat.dtype == torch.float32:
+        return _affine_sample_override(_affine_sample_override(feat, rot), tr)
     g1 = F.affine_grid(rot, feat.shape, align_corners=False)
     g2 = F.affine_grid(tr, feat.shape, align_corners=False)
     y = F.grid_sample(feat, g1, mode="bilinear", padding_mode="zeros", align_corners=False)

@@ -28,7 +28,7 @@ import weakref
 import torch
 import torch.nn.functional as F
 
-from .. import ops, packing
+from .. import ops, packing, tuning
 
 BF16 = torch.bfloat16
 
@@ -259,9 +259,32 @@ def _gru_conv_hip(x, weight, bias):
     return y.permute(0, 3, 1, 2).float()
 
 
+class _AffineSample(torch.autograd.Function):
+    """grid_sample(x, affine_grid(theta)) (bilinear, zeros, align_corners=False) of fp32 NCHW maps: forward on v2x_warp_affine_f32, the data
+    gradient on its exact transpose v2x_warp_affine_bwd_f32 (a deterministic gather).  theta carries no gradient (poses are data)."""
+
+    @staticmethod
+    def forward(ctx, x, theta):
+        theta = theta.detach().to(torch.float32).contiguous()
+        ctx.save_for_backward(theta)
+        return ops.warp_affine(x.contiguous(), theta)
+
+    @staticmethod
+    def backward(ctx, dy):
+        theta, = ctx.saved_tensors
+        return ops.warp_affine(dy.contiguous(), theta, backward=True), None
+
+
 def _fused_on_fp32_graph(fuse, model, feat, *args):
-    """The cross-agent fusion runs on the fp32 NCHW graph (train/graph.py): convert the fusion-layer maps, fuse, convert back."""
-    out = fuse(model, feat.permute(0, 3, 1, 2).float(), *args)
+    """The cross-agent fusion runs on the fp32 NCHW graph (train/graph.py): convert the fusion-layer maps, fuse, convert back.  The warp
+    inside it (graph.warp_batch) runs on the hand-written kernels, forward and backward (WARP_HIP=0: F.grid_sample and its atomic backward)."""
+    from . import graph
+    prev = graph._affine_sample_override
+    graph._affine_sample_override = _AffineSample.apply if tuning.get("WARP_HIP") != 0 else None
+    try:
+        out = fuse(model, feat.permute(0, 3, 1, 2).float(), *args)
+    finally:
+        graph._affine_sample_override = prev
     extra = ()
     if isinstance(out, tuple):
         out, extra = out[0], out[1:]
