@@ -269,6 +269,13 @@ int v2x_bn_train_forward(const uint16_t *x, long long M, int C, const float *gam
 int v2x_bn_train_backward(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
                           const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma, float *dbeta,
                           float *workspace, v2x_stream_t stream);
+/* The same, and dx_sum[c] = the sum over the M pixels of dx as stored (bf16-rounded), fp32 [C]: the bias gradient of the convolution whose
+ * output x is (autograd's reduction in nn.Conv2d.backward), accumulated by the kernel that writes dx instead of a second pass over it.
+ * sum_workspace: v2x_bn_dxsum_workspace_size(M, C) bytes.  Fixed summation order. */
+long long v2x_bn_dxsum_workspace_size(long long M, int C);
+int v2x_bn_train_backward_dxsum(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
+                                const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma, float *dbeta,
+                                float *dx_sum, float *workspace, float *sum_workspace, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- a3 (+ the sum of a4/a5): warp + fuse
  * Replaces DetModelBase.py::feature_transformation (affine_grid + grid_sample twice,

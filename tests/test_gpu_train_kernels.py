@@ -761,3 +761,59 @@ def test_v2vnet_hip_graph_warp_on_kernels_matches_grid_sample_path(device, tune)
     assert l1 == l1b and all(torch.equal(g1[n], g1b[n]) for n in g1)
     print("HIP graph, warp on the kernels vs grid_sample: loss %.6f vs %.6f, gradient difference %.2e of the norm" % (l1, l0, rel(g1, g0)))
     assert set(g1) == set(g0) and abs(l1 - l0) <= 2e-3 * max(1.0, abs(l0)) and rel(g1, g0) < 0.25
+
+
+@pytest.mark.parametrize("M,C,relu", [(2 * 64 * 64, 32, True), (3 * 32 * 32, 128, True), (10 * 16 * 16, 512, False), (777, 64, True)])
+def test_bn_backward_accumulates_the_conv_bias_gradient(device, M, C, relu):
+    """v2x_bn_train_backward_dxsum: the same dx, dgamma, dbeta as v2x_bn_train_backward, bit for bit, plus the per-channel sum of dx AS STORED
+    (what ops.channel_sum(dx) -- the bias gradient of the convolution in front of the BN -- would reduce in a second pass); fixed order."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g).to(torch.bfloat16).to(device)
+    dy = torch.randn(M, C, generator=g).to(torch.bfloat16).to(device)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(device), (torch.randn(C, generator=g) * 0.3).to(device)
+    _, mean, invstd = ops.bn_train_forward(x, gamma, beta, None, None, 1e-5, 0.1, relu)
+    dx0, dg0, db0 = ops.bn_train_backward(x, dy, gamma, beta, mean, invstd, relu)
+    dx1, dg1, db1, dsum = ops.bn_train_backward(x, dy, gamma, beta, mean, invstd, relu, dx_sum=True)
+    assert torch.equal(dx0, dx1) and torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    ref = dx1.double().sum(0)
+    tol = 1e-6 * float(dx1.double().abs().sum(0).max()) + 1e-7
+    assert float((dsum.double() - ref).abs().max()) <= tol, (float((dsum.double() - ref).abs().max()), tol)
+    assert torch.allclose(dsum, ops.channel_sum(dx1), atol=tol, rtol=0)
+    for _ in range(3):
+        assert torch.equal(ops.bn_train_backward(x, dy, gamma, beta, mean, invstd, relu, dx_sum=True)[3], dsum)
+
+
+def test_conv_bias_gradients_come_from_the_bn_backward_kernel(device, tune, monkeypatch):
+    """In the HIP training graph every conv + BN pair takes its bias gradient from the BN backward kernel's accumulated sums (attached to the
+    gradient tensor, hip_graph._attached_channel_sum) instead of a second pass over dx: on a FaFNet step ops.channel_sum is left with the
+    layers whose gradient reaches them another way (the width-padded 16-pixel layer), and the bias gradients equal the reduced ones."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.train import detection_loss, hip_graph, train_forward
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    tune("TRAIN_HIP", 1)
+    cfg = Config("train", binary=True, only_det=True)
+    model = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=4).to(device).train()
+    data = synthetic_batch_on_device(cfg, 1, 2, seed=6, device=device)
+    calls = []
+    real = ops.channel_sum
+    monkeypatch.setattr(ops, "channel_sum", lambda t: (calls.append(tuple(t.shape)), real(t))[1])
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        res = train_forward(model, data["bev_seq"], None, None, 1)
+        detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0].backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if n.endswith("bias") and p.grad is not None}
+    g1 = step()
+    n_attached = len(calls)
+    monkeypatch.setattr(hip_graph, "_attached_channel_sum", lambda dy: None)     # every layer reduces its own gradient
+    calls.clear()
+    g0 = step()
+    print("ops.channel_sum calls per FaFNet step: %d with the BN kernel's sums, %d without" % (n_attached, len(calls)))
+    assert n_attached <= 2 < len(calls) - 10
+    for n in g0:
+        scale = float(g0[n].abs().max())
+        # (a bias in front of a batch-statistics BN has a zero true gradient: both values are cancelling sums of ~1e5 terms, equal up to summation order)
+        assert torch.allclose(g1[n], g0[n], atol=1e-3 * max(scale, 1e-3), rtol=1e-4), (n, float((g1[n] - g0[n]).abs().max()), scale)

@@ -115,9 +115,21 @@ __device__ __forceinline__ void bn_sum_partials(const BnArgs &a, int c, double &
     __shared__ double rs[BN_THREADS], rq[BN_THREADS];
     const int t = threadIdx.x;
     double s = 0.0, q = 0.0;
-    for (int b = t; b < a.n_blocks; b += BN_THREADS) {
-        s += (double)a.partial[((size_t)b * 2) * a.C + c];
-        q += (double)a.partial[((size_t)b * 2 + 1) * a.C + c];
+    // all of the thread's (at most 8) loads first, then the additions in the same order as a plain loop: one memory latency instead of eight
+    // (these finish kernels are pure latency: 6.5 us per launch, 44 launches per training step, before this)
+    constexpr int NP = BN_MAX_BLOCKS / BN_THREADS;
+    float vs[NP], vq[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int b = t + k * BN_THREADS;
+        const bool ok = b < a.n_blocks;
+        vs[k] = ok ? a.partial[((size_t)b * 2) * a.C + c] : 0.f;
+        vq[k] = ok ? a.partial[((size_t)b * 2 + 1) * a.C + c] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        s += (double)vs[k];
+        q += (double)vq[k];
     }
     rs[t] = s;
     rq[t] = q;
@@ -184,10 +196,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const BnArgs a) {
     }
 }
 
+// SUM: also the per-channel sum of the dx values AS STORED (bf16-rounded) -- the bias gradient of the convolution that produced x
+// (db = sum over pixels of dx; upstream: autograd's reduction in nn.Conv2d.backward), one partial per workgroup and channel in
+// a.partial[blockIdx.x][C] (the finish kernel of the channel sum adds them in workgroup order): saves the separate read of dx
+template <bool SUM>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnArgs a) {
+    __shared__ float red[SUM ? BN_THREADS : 1][9];
     const int t = threadIdx.x;
     const int g = t % a.G;
-    float mu[8], is[8], ga[8], be[8], k0[8], k1[8];
+    float mu[8], is[8], ga[8], be[8], k0[8], k1[8], acc[8];
     const float inv_m = 1.f / (float)a.M;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -198,6 +215,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnArgs a
         be[i] = a.beta[c];
         k0[i] = a.dbeta[c] * inv_m;
         k1[i] = a.dgamma[c] * inv_m;
+        acc[i] = 0.f;
     }
     const long long total = a.M * a.G;
     const uint4 *xv = reinterpret_cast<const uint4 *>(a.x);
@@ -214,8 +232,60 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const BnArgs a
             const float gr = (a.relu && !(y > 0.f)) ? 0.f : d[i];
             x[i] = ga[i] * is[i] * (gr - k0[i] - xh * k1[i]);
         }
-        ov[v] = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+        const uint4 o = make_uint4(pack_bf16x2(x[0], x[1]), pack_bf16x2(x[2], x[3]), pack_bf16x2(x[4], x[5]), pack_bf16x2(x[6], x[7]));
+        ov[v] = o;
+        if (SUM) {
+            float r[8];
+            unpack8(o, r);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += r[i];
+        }
     }
+    if (SUM) {
+        // (the grid stride is a multiple of BN_THREADS and BN_THREADS % G == 0: a thread keeps its channel group.)  Lanes l, l + G, l + 2G, ...
+        // of a wave share a group: butterfly over those offsets, then the (at most four) waves' results of a group through LDS, in wave order.
+        for (int off = a.G; off < 64; off <<= 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += __shfl_xor(acc[i], off);
+        }
+        const int lane = t & 63, gw = a.G < 64 ? a.G : 64;      // lanes 0 .. gw-1 of a wave hold its sums
+        if (lane < gw) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[t][i] = acc[i];
+        }
+        __syncthreads();
+        if (t < a.G) {
+            float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            for (int w = 0; w < BN_THREADS / 64; ++w) {
+                const int l = ((t - w * 64) % a.G + a.G) % a.G;                // the lane of wave w whose group is t
+                if (l < gw) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) sum[i] += red[w * 64 + l][i];
+                }
+            }
+            // channel-major partials [C][gridDim.x]: the finish kernel reads a channel's partials as one contiguous run
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a.partial[(size_t)(t * 8 + i) * gridDim.x + blockIdx.x] = sum[i];
+        }
+    }
+}
+
+// one wave per channel over the channel-major partials of bn_bwd_apply_kernel<true>: lane l adds entries l, l + 64, ... (fp64), fixed butterfly
+__global__ __launch_bounds__(256) void bn_dxsum_finish_kernel(const float *__restrict__ part, int nblk, int C, float *__restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    const float *p = part + (size_t)c * nblk;
+    double s = 0.0;
+    for (int b0 = lane; b0 < nblk; b0 += 64 * 8) {        // eight loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (b0 + 64 * k < nblk) ? p[b0 + 64 * k] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)v[k];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[c] = (float)s;
 }
 
 static int bn_plan(long long M, int C, BnArgs &a) {
@@ -272,9 +342,11 @@ extern "C" int v2x_bn_train_forward(const uint16_t *x, long long M, int C, const
     return V2X_OK;
 }
 
-extern "C" int v2x_bn_train_backward(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
-                                     const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma,
-                                     float *dbeta, float *workspace, v2x_stream_t stream) {
+constexpr int BN_DXSUM_MAX_BLOCKS = 2048;
+
+static int bn_train_backward_impl(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
+                                  const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma,
+                                  float *dbeta, float *workspace, float *dx_sum, float *sum_workspace, v2x_stream_t stream) {
     V2X_REQUIRE(x && dy && gamma && beta && save_mean && save_invstd && dx && dgamma && dbeta && workspace, "v2x_bn_train_backward: null pointer");
     V2X_REQUIRE(bn_shape_ok(M, C), "v2x_bn_train_backward: needs M > 0 and C in {8, 16, 32, ..., 2048} (C / 8 divides 256), got M=%lld C=%d", M, C);
     BnArgs a = {};
@@ -295,10 +367,37 @@ extern "C" int v2x_bn_train_backward(const uint16_t *x, const uint16_t *dy, long
     hipLaunchKernelGGL(bn_finish_grads_kernel, dim3(C), dim3(BN_THREADS), 0, s, a);
     const long long total = M * a.G;
     long long blocks = (total + BN_THREADS - 1) / BN_THREADS;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, a);
+    if (dx_sum) {
+        if (blocks > BN_DXSUM_MAX_BLOCKS) blocks = BN_DXSUM_MAX_BLOCKS;
+        a.partial = sum_workspace;                 // the statistics' partials (workspace) are consumed by the finish kernel above
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, a);
+        hipLaunchKernelGGL(bn_dxsum_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, s, sum_workspace, (int)blocks, C, dx_sum);
+    } else {
+        if (blocks > 8192) blocks = 8192;
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3((unsigned)blocks), dim3(BN_THREADS), 0, s, a);
+    }
     V2X_CHECK_LAUNCH("bn_train_backward");
     return V2X_OK;
+}
+
+extern "C" int v2x_bn_train_backward(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
+                                     const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma,
+                                     float *dbeta, float *workspace, v2x_stream_t stream) {
+    return bn_train_backward_impl(x, dy, M, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, workspace, nullptr, nullptr, stream);
+}
+
+extern "C" long long v2x_bn_dxsum_workspace_size(long long M, int C) {
+    if (!bn_shape_ok(M, C)) return 0;
+    long long blocks = (M * (C / 8) + BN_THREADS - 1) / BN_THREADS;
+    if (blocks > BN_DXSUM_MAX_BLOCKS) blocks = BN_DXSUM_MAX_BLOCKS;
+    return blocks * C * (long long)sizeof(float);
+}
+
+extern "C" int v2x_bn_train_backward_dxsum(const uint16_t *x, const uint16_t *dy, long long M, int C, const float *gamma, const float *beta,
+                                           const float *save_mean, const float *save_invstd, int relu, uint16_t *dx, float *dgamma,
+                                           float *dbeta, float *dx_sum, float *workspace, float *sum_workspace, v2x_stream_t stream) {
+    V2X_REQUIRE(dx_sum && sum_workspace, "v2x_bn_train_backward_dxsum: null pointer");
+    return bn_train_backward_impl(x, dy, M, C, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta, workspace, dx_sum, sum_workspace, stream);
 }
 
 
@@ -346,7 +445,13 @@ __global__ __launch_bounds__(256) void channel_sum_finish_kernel(const float *__
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0;
-    for (int b = lane; b < nblk; b += 64) s += (double)part[(size_t)b * C + c];
+    for (int b0 = lane; b0 < nblk; b0 += 64 * 8) {        // eight loads in flight, added in index order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = (b0 + 64 * k < nblk) ? part[(size_t)(b0 + 64 * k) * C + c] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += (double)v[k];
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
     if (lane == 0) out[c] = (float)s;

@@ -471,8 +471,9 @@ def bn_train_forward(x, gamma, beta, running_mean, running_var, eps, momentum, r
     return y, mean, invstd
 
 
-def bn_train_backward(x, dy, gamma, beta, mean, invstd, relu=True):
-    """Backward of bn_train_forward: -> (dx bf16 like x, dgamma (C,), dbeta (C,)) fp32."""
+def bn_train_backward(x, dy, gamma, beta, mean, invstd, relu=True, dx_sum=False):
+    """Backward of bn_train_forward: -> (dx bf16 like x, dgamma (C,), dbeta (C,)) fp32; dx_sum=True: also the per-channel sum of dx as stored
+    (fp32 (C,): the bias gradient of the convolution that produced x), accumulated by the kernel that writes dx."""
     lib = _lib.load()
     C = x.shape[-1]
     M = x.numel() // C
@@ -484,14 +485,19 @@ def bn_train_backward(x, dy, gamma, beta, mean, invstd, relu=True):
     dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
     prof = _Prof("bn_train_backward", 0.0, x.numel() * 2 * 5)
-    rc = lib.v2x_bn_train_backward(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"), M, C, _dev(gamma, torch.float32, "gamma"),
-                                   _dev(beta, torch.float32, "beta"), _dev(mean, torch.float32, "save_mean"),
-                                   _dev(invstd, torch.float32, "save_invstd"), 1 if relu else 0, _dev(dx, torch.bfloat16, "dx"),
-                                   _dev(dgamma, torch.float32, "dgamma"), _dev(dbeta, torch.float32, "dbeta"),
-                                   _dev(ws, torch.float32, "workspace"), _stream())
+    args = [_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"), M, C, _dev(gamma, torch.float32, "gamma"),
+            _dev(beta, torch.float32, "beta"), _dev(mean, torch.float32, "save_mean"), _dev(invstd, torch.float32, "save_invstd"),
+            1 if relu else 0, _dev(dx, torch.bfloat16, "dx"), _dev(dgamma, torch.float32, "dgamma"), _dev(dbeta, torch.float32, "dbeta")]
+    if dx_sum:
+        ws2 = torch.empty(lib.v2x_bn_dxsum_workspace_size(M, C) // 4, dtype=torch.float32, device=x.device)
+        dsum = torch.empty(C, dtype=torch.float32, device=x.device)
+        rc = lib.v2x_bn_train_backward_dxsum(*args, _dev(dsum, torch.float32, "dx_sum"), _dev(ws, torch.float32, "workspace"),
+                                             _dev(ws2, torch.float32, "sum_workspace"), _stream())
+    else:
+        rc = lib.v2x_bn_train_backward(*args, _dev(ws, torch.float32, "workspace"), _stream())
     prof.done()
     _lib.check(rc, "v2x_bn_train_backward")
-    return dx, dgamma, dbeta
+    return (dx, dgamma, dbeta, dsum) if dx_sum else (dx, dgamma, dbeta)
 
 
 def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):

@@ -85,7 +85,7 @@ class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy_in, dy = dy, dy.contiguous()
         dyz = _zero_insert(dy) if ctx.stride == 2 else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
@@ -93,8 +93,20 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = ops.conv3x3_wgrad(x, dyz, cin_out=weight.shape[1])
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.channel_sum(dy)
+            db = _attached_channel_sum(dy_in)
+            if db is None:
+                db = ops.channel_sum(dy)
         return dx, dw, db, None
+
+
+def _attached_channel_sum(dy):
+    """The per-channel sum the BN backward kernel accumulated while it wrote this gradient (_BnRelu.backward attaches it to the tensor it
+    returns; autograd hands that same tensor object to the producing convolution's backward when the convolution's output has one
+    consumer).  None when the gradient did not come from there, or was modified since: the caller then reduces it itself."""
+    tag = getattr(dy, "_v2x_chsum", None)
+    if tag is None or tag[0] != dy._version or tag[1].shape[0] != dy.shape[-1]:
+        return None
+    return tag[1]
 
 
 class _BnRelu(torch.autograd.Function):
@@ -108,7 +120,8 @@ class _BnRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
-        dx, dgamma, dbeta = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu)
+        dx, dgamma, dbeta, dsum = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu, dx_sum=True)
+        dx._v2x_chsum = (dx._version, dsum)      # the bias gradient of the convolution in front of this BN (_attached_channel_sum)
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
@@ -183,7 +196,11 @@ class _Conv1x1(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         cout = weight.shape[0]
         cp = (cout + 31) // 32 * 32
-        db = dy.float().sum((0, 1, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        db = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _attached_channel_sum(dy)
+            if db is None:
+                db = dy.float().sum((0, 1, 2))
         dyp = F.pad(dy, (0, cp - cout)).to(BF16).contiguous() if (cp != cout or dy.dtype != BF16) else dy.contiguous()
         dx = dw = None
         if ctx.needs_input_grad[0]:
