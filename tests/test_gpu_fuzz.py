@@ -55,6 +55,15 @@ def _cases():
         H, W = 8 * rnd.randint(1, 5), 64 * rnd.randint(1, 2)
         N = rnd.choice([1, 2, 3, 7])
         cases.append(("s2", 0, c, cout, N, H, W))
+    for _ in range(8):       # stride 2, 8-wave three-tap form (forced: S2_G = 2): 128-row tiles, >= 2 chunks, outputs tile by 8 x 32 or 16 x 16
+        c = rnd.choice([64, 96, 128, 256])
+        cout = rnd.choice([128, 256])
+        if rnd.random() < 0.5:
+            H, W = 16 * rnd.randint(1, 3), 64 * rnd.randint(1, 2)      # 8 x 32 output tiles
+        else:
+            H, W = 32 * rnd.randint(1, 2), 32 * rnd.choice([1, 3])      # 16 x 16 output tiles
+        N = rnd.choice([1, 2, 5, 70, 133])                              # 70, 133: the persistent grid wraps (unevenly)
+        cases.append(("s2g", 0, c, cout, N, H, W))
     for _ in range(10):      # halo family: the instantiations that exist
         key = rnd.choice([(0, 32, 32), (64, 32, 32), (0, 64, 64)])
         H, W = 8 * rnd.randint(1, 5), 32 * rnd.randint(1, 3)
@@ -64,15 +73,17 @@ def _cases():
 
 
 @pytest.mark.parametrize("case", _cases(), ids=lambda c: "-".join(str(v) for v in c))
-def test_conv_kernels_random_shapes(device, case):
+def test_conv_kernels_random_shapes(device, case, tune):
     from v2x_sim_amd import ops, packing
     kind, cup, c, cout, N, H, W = case
+    if kind == "s2g":
+        tune("S2_G", 2)
     g = torch.Generator().manual_seed(sum(case[1:]) * 7919 + len(case[0]))
     x = bf16r(torch.randn(N, c, H, W, generator=g))
     x_up = bf16r(torch.randn(N, cup, H // 2, W // 2, generator=g)) if cup else None
     w = torch.randn(cout, cup + c, 3, 3, generator=g) * (2.0 / ((cup + c) * 9)) ** 0.5
     scale, shift = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
-    stride = 2 if kind == "s2" else 1
+    stride = 2 if kind in ("s2", "s2g") else 1
     xin = torch.cat((F.interpolate(x_up, scale_factor=(2, 2)), x), 1) if cup else x
     ref = F.relu(F.conv2d(xin, bf16r(w), None, stride, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
     if kind == "halo":
@@ -81,6 +92,8 @@ def test_conv_kernels_random_shapes(device, case):
         pc = packing.pack_conv_stream("t", w, scale, shift, C0=cup if cup else c, C1=c if cup else 0, up0=1 if cup else 0,
                                       stride=stride, device=device)
     run = (lambda: ops.conv2d(pc, nhwc(x_up, device), nhwc(x, device))) if cup else (lambda: ops.conv2d(pc, nhwc(x, device)))
+    if kind == "s2g":
+        assert ops.conv_kernel_name(pc, H, W, False, N).startswith("conv3x3_s2g_kernel"), case
     y = run()
     got = back(y)
     assert got.shape == ref.shape
