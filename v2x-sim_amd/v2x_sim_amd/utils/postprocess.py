@@ -99,6 +99,12 @@ def apply_nms_det(loc, cls, anchors, score_thr=0.7, nms_thr=0.01, max_out=None):
     if sel.size == 0:
         return {"boxes": np.zeros((0, 5), np.float32), "corners": np.zeros((0, 4, 2), np.float32),
                 "scores": np.zeros((0,), np.float32)}
+    if sel.size > 20000:
+        # upstream's greedy NMS is O(kept x candidates): a detector that fires on a large part of the map (an untrained or diverged model)
+        # keeps this host path busy for minutes per map -- say so instead of looking hung
+        import warnings
+        warnings.warn("apply_nms_det: %d of %d anchors pass the score threshold %.2f; the host NMS will take a long time "
+                      "(is the model trained?)" % (sel.size, score.size, score_thr), RuntimeWarning, stacklevel=2)
     boxes = decode_boxes(loc[sel], anchors[sel])
     corners = box_corners(boxes)
     keep = nms_standup(standup(corners), score[sel], nms_thr, max_out)
