@@ -429,3 +429,20 @@ def test_small_batch_splitk(device, cfg, tune):
     assert s_auto == 0 or (2 <= s_auto <= chunks // 2 and tiles < 200 and tiles * s_auto <= 520), (s_auto, tiles, chunks)
     if s_auto:
         assert torch.allclose(back(ops.conv2d(pc, a0, a1, splitk=s_auto)), ref, **tol)
+
+
+def test_gru_xcd_walk_is_a_pure_reordering(device, tune):
+    """GRU_XCD_WALK only permutes which workgroup computes which (pixel tile, channel tile) of the ConvGRU's persistent grid (8 x 4 tiles per XCD
+    and round instead of 4 x 8: -16 % fabric reads): identical bits, also when the tile count is not a multiple of the grid."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(11)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    for N in (ncu // 16 + 3, 2 * ncu // 16 + 1):          # 2 pixel tiles x 8 channel tiles per map: more tiles than workgroups, ragged tail
+        w = torch.randn(768, 512, 3, 3, generator=g) * 0.02
+        pc = packing.pack_gru_stream("gru", w, torch.randn(768, generator=g) * 0.1, torch.randn(768, generator=g) * 0.1, C0=256, C1=256, device=device)
+        x0 = torch.randn(N, 32, 32, 256, generator=g).to(torch.bfloat16).to(device)
+        x1 = torch.randn(N, 32, 32, 256, generator=g).to(torch.bfloat16).to(device)
+        tune("GRU_XCD_WALK", 0)
+        ref = ops.conv2d(pc, x0, x1)
+        tune("GRU_XCD_WALK", 1)
+        assert torch.equal(ops.conv2d(pc, x0, x1), ref)

@@ -52,6 +52,7 @@ struct StreamArgs {
     int ksplit;
     float *ws;
     int w_rows;
+    int xcd_walk;   // stream8g, 8 channel tiles on 256 workgroups: 1 = an XCD walks 8 pixel tiles x 4 channel tiles per round instead of 4 x 8 (tuning switch GRU_XCD_WALK; the ConvGRU)
 };
 
 constexpr int PATCH_PIECES = 24;             // wave instructions (1 KiB each) per patch buffer
@@ -992,6 +993,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+        if (a.xcd_walk != 0 && a.n_co_tiles == 8 && r == 0 && q == 32) {
+            // an XCD's 32 workgroups of a round: 8 pixel tiles x 4 channel tiles (5.0 MB of patches + 3.5 MB of weights through its 4-MiB L2)
+            // instead of 4 x 8 (2.5 + 7.1 MB); the two XCDs of a pair share the 8 pixel tiles.  Measured on the ConvGRU: FETCH_SIZE 1.47 -> 1.24 GB
+            // per 320 maps, time -0.1 +- 0.1 %, bit-identical (tools/gru_xcd_walk_probe.sh)
+            const int x = bid >> 5, i = bid & 31;
+            bid = (((x >> 1) * 8 + (i >> 2)) << 3) + (x & 1) * 4 + (i & 3);
+        }
         if constexpr (V2X_STREAM_XCDCO_BUILD != 0) {
             // EXPERIMENT: one channel tile per XCD (its weights stay in that XCD's L2) instead of all channel tiles on every XCD
             const int nco = a.n_co_tiles;
@@ -1933,6 +1941,7 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.ksplit = d->splitk;
     a.ws = d->splitk_ws;
     a.w_rows = d->w_rows;
+    a.xcd_walk = (d->epilogue == V2X_EPI_GRU) ? v2x_tune(V2X_TUNE_GRU_XCD_WALK) : 0;
     const bool chain = d->Cout2 > 0;
     if (d->splitk > 1) {
         // small-batch form: the 4-wave kernel with the chunk range divided over blockIdx.y + the reduce kernel.  Plain and GRU epilogues,
