@@ -45,6 +45,33 @@ def _voxel_gpu(pts_list, dev, grid=None):
     return bits, grid
 
 
+@pytest.mark.parametrize("voxel", [(0.25, 0.25, 0.4), (0.3, 0.5, 0.5), (0.4, 0.125, 0.25), (1.0, 0.7, 2.0)])
+def test_voxelize_power_of_two_voxels_take_the_exact_reciprocal(device, voxel, tune):
+    """Per axis the quotient fp64(p) / fp64(voxel) is formed by the exact reciprocal when the voxel size is a power of two (one multiply instead of an
+    IEEE division) and by the division otherwise: both are the correctly rounded quotient, so every mix of axes is bit-exact against the oracle's
+    numpy fp64 division -- LDS form and global-atomic form, points on and next to voxel boundaries included."""
+    from v2x_sim_amd import ops
+    ext = ((-16.0, 16.0), (-16.0, 16.0), (-3.0, 2.0))
+    grid = ops.VoxelGrid(voxel_size=voxel, area_extents=ext)
+    rng = np.random.default_rng(int(sum(voxel) * 1000))
+    pts = np.zeros((3, 20000, 4), np.float32)
+    pts[..., :2] = rng.uniform(-17, 17, (3, 20000, 2))
+    pts[..., 2] = rng.uniform(-3.5, 2.5, (3, 20000))
+    # exact multiples of the voxel size and their float32 neighbours: the floor must fall on the same side as numpy's
+    k = rng.integers(-40, 40, (3, 4000, 3)).astype(np.float64) * np.asarray(voxel)
+    edge = k.astype(np.float32)
+    pts[:, :4000, :3] = edge
+    pts[:, 4000:8000, :3] = np.nextafter(edge, np.float32(np.inf))
+    pts[:, 8000:12000, :3] = np.nextafter(edge, np.float32(-np.inf))
+    for mode in (2, 0):                                     # the LDS form at any cloud count, the global-atomic form
+        tune("VOXELIZE_LDS", mode)
+        bits, _ = _voxel_gpu([p for p in pts], device, grid)
+        got = ops.bits_to_dense(bits, grid.dims[2]).cpu().numpy()
+        for i in range(3):
+            ref = VR.voxelize_occupy(pts[i], np.asarray(voxel), np.asarray(ext))
+            assert got[i].shape == ref.shape and np.array_equal(got[i], ref), (voxel, mode, i)
+
+
 @pytest.mark.parametrize("sizes", [(65536, 65536, 65536, 65536, 65536), (4096, 0, 17, 300), (2048,)])
 def test_voxelize_bit_exact(device, sizes):
     from v2x_sim_amd import ops

@@ -17,8 +17,22 @@
 
 struct VoxParams {
     double lo[3], hi[3], vs[3], mn[3];
+    double inv[3];   // 1 / vs where vs is a power of two (exact)
+    int pow2[3];
     int X, Y, Z;
 };
+
+// fp64(p) / fp64(voxel) of the spec.  An IEEE division costs ~40 instructions per coordinate (three of them were half of the LDS kernel's time);
+// when the voxel size is a power of two (0.25 m in x and y by default) the product with its EXACT reciprocal is the same correctly rounded
+// number -- bit-identical, one instruction.  The choice is per axis and uniform over the launch.
+__device__ __forceinline__ double vox_quot(double p, const VoxParams &vp, int k) { return vp.pow2[k] ? p * vp.inv[k] : p / vp.vs[k]; }
+
+static void vox_reciprocal(VoxParams &vp, int a) {
+    int e = 0;
+    const double m = frexp(vp.vs[a], &e);
+    vp.pow2[a] = (m == 0.5 && e > -1000 && e < 1000) ? 1 : 0;     // a power of two whose reciprocal is a normal number
+    vp.inv[a] = vp.pow2[a] ? 1.0 / vp.vs[a] : 0.0;
+}
 
 __global__ __launch_bounds__(256) void voxelize_scatter_kernel(const float *__restrict__ pts,
                                                                const int32_t *__restrict__ n_pts, int max_pts,
@@ -35,9 +49,9 @@ __global__ __launch_bounds__(256) void voxelize_scatter_kernel(const float *__re
         const bool keep = (vp.lo[0] < x) && (x < vp.hi[0]) && (vp.lo[1] < y) && (y < vp.hi[1]) &&
                           (vp.lo[2] < z) && (z < vp.hi[2]);
         if (!keep) continue;
-        const int ix = (int)(floor(x / vp.vs[0]) - vp.mn[0]);
-        const int iy = (int)(floor(y / vp.vs[1]) - vp.mn[1]);
-        const int iz = (int)(floor(z / vp.vs[2]) - vp.mn[2]);
+        const int ix = (int)(floor(vox_quot(x, vp, 0)) - vp.mn[0]);
+        const int iy = (int)(floor(vox_quot(y, vp, 1)) - vp.mn[1]);
+        const int iz = (int)(floor(vox_quot(z, vp, 2)) - vp.mn[2]);
         // extents that are not voxel multiples could produce an edge index == dim; the
         // reference would raise IndexError there, we drop the point instead of corrupting memory.
         if ((unsigned)ix >= (unsigned)vp.X || (unsigned)iy >= (unsigned)vp.Y || (unsigned)iz >= (unsigned)vp.Z)
@@ -60,9 +74,9 @@ __device__ __forceinline__ void vox_lds_point(bool valid, double x, double y, do
     const bool keep = valid && (vp.lo[0] < x) && (x < vp.hi[0]) && (vp.lo[1] < y) && (y < vp.hi[1]) &&
                       (vp.lo[2] < z) && (z < vp.hi[2]);
     if (!keep) return;
-    const int ix = (int)(floor(x / vp.vs[0]) - vp.mn[0]);
-    const int iy = (int)(floor(y / vp.vs[1]) - vp.mn[1]);
-    const int iz = (int)(floor(z / vp.vs[2]) - vp.mn[2]);
+    const int ix = (int)(floor(vox_quot(x, vp, 0)) - vp.mn[0]);
+    const int iy = (int)(floor(vox_quot(y, vp, 1)) - vp.mn[1]);
+    const int iz = (int)(floor(vox_quot(z, vp, 2)) - vp.mn[2]);
     if ((unsigned)ix >= (unsigned)vp.X || (unsigned)iy >= (unsigned)vp.Y || (unsigned)iz >= (unsigned)vp.Z) return;
     const int pix = ix * vp.Y + iy;
     atomicOr(&sgrid[pix >> 1], (1u << iz) << ((pix & 1) * 16));
@@ -160,9 +174,9 @@ __global__ __launch_bounds__(256) void voxelize_fused_scatter_kernel(const float
         const bool keep = (vp.lo[0] < x) && (x < vp.hi[0]) && (vp.lo[1] < y) && (y < vp.hi[1]) &&
                           (vp.lo[2] < z) && (z < vp.hi[2]);
         if (!keep) continue;
-        const int ix = (int)(floor(x / vp.vs[0]) - vp.mn[0]);
-        const int iy = (int)(floor(y / vp.vs[1]) - vp.mn[1]);
-        const int iz = (int)(floor(z / vp.vs[2]) - vp.mn[2]);
+        const int ix = (int)(floor(vox_quot(x, vp, 0)) - vp.mn[0]);
+        const int iy = (int)(floor(vox_quot(y, vp, 1)) - vp.mn[1]);
+        const int iz = (int)(floor(vox_quot(z, vp, 2)) - vp.mn[2]);
         if ((unsigned)ix >= (unsigned)vp.X || (unsigned)iy >= (unsigned)vp.Y || (unsigned)iz >= (unsigned)vp.Z)
             continue;
         atomicOr(&grid[(size_t)ix * vp.Y + iy], 1u << iz);
@@ -332,6 +346,7 @@ extern "C" int v2x_voxelize_bits(const float *pts, const int32_t *n_pts, int n_c
         vp.hi[a] = extents[2 * a + 1];
         vp.vs[a] = voxel[a];
         V2X_REQUIRE(voxel[a] > 0.0, "v2x_voxelize_bits: voxel size must be > 0");
+        vox_reciprocal(vp, a);
         vp.mn[a] = floor(extents[2 * a] / voxel[a]);
     }
     vp.X = dims_xyz[0];
@@ -459,6 +474,7 @@ extern "C" int v2x_voxelize_fused_bits(const float *pts, const int32_t *n_pts, i
         vp.hi[a] = extents[2 * a + 1];
         vp.vs[a] = voxel[a];
         V2X_REQUIRE(voxel[a] > 0.0, "v2x_voxelize_fused_bits: voxel size must be > 0");
+        vox_reciprocal(vp, a);
         vp.mn[a] = floor(extents[2 * a] / voxel[a]);
     }
     vp.X = dims_xyz[0];
