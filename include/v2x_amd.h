@@ -342,6 +342,14 @@ int v2x_channel_sum_bf16(const uint16_t *x, long long M, int C, float *out, floa
 int v2x_warp_affine_f32(const float *in, const float *theta, int P, int C, int H, int W, float *out, v2x_stream_t stream);
 int v2x_warp_affine_bwd_f32(const float *dout, const float *theta, int P, int C, int H, int W, float *din, v2x_stream_t stream);
 
+/* f-3: the decoder's up + concat of the TRAINING graph and its backward (the inference kernels fold it into their loaders: v2x_conv_desc.up0).
+ * Replaces torch.cat((F.interpolate(x, scale_factor=(2, 2)), skip), dim=1) of Backbone.py::LidarDecoder and its autograd backward.
+ * lo bf16 [N][H][W][C0] (H, W = the LOW-resolution extent), skip bf16 [N][2H][2W][C1] -> out bf16 [N][2H][2W][C0 + C1] (lo's channels first).
+ * Backward: dcat bf16 [N][2H][2W][C0 + C1] -> d_lo [N][H][W][C0] = the 2x2 sums (fp32, row-major order, rounded once), d_skip [N][2H][2W][C1].
+ * C0, C1 multiples of 8. */
+int v2x_upcat_bf16(const uint16_t *lo, const uint16_t *skip, int N, int H, int W, int C0, int C1, uint16_t *out, v2x_stream_t stream);
+int v2x_upcat_bwd_bf16(const uint16_t *dcat, int N, int H, int W, int C0, int C1, uint16_t *d_lo, uint16_t *d_skip, v2x_stream_t stream);
+
 /* ---------------------------------------------------------------- f-1: detection post-processing
  * Replaces coperception/utils/postprocess.py::apply_nms_det per (agent, frame) map: foreground softmax score, score
  * threshold, 'faf' anchor decode (x, y, w, h, yaw) and greedy NMS on the axis-aligned stand-up boxes, in

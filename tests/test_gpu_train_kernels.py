@@ -817,3 +817,28 @@ def test_conv_bias_gradients_come_from_the_bn_backward_kernel(device, tune, monk
         scale = float(g0[n].abs().max())
         # (a bias in front of a batch-statistics BN has a zero true gradient: both values are cancelling sums of ~1e5 terms, equal up to summation order)
         assert torch.allclose(g1[n], g0[n], atol=1e-3 * max(scale, 1e-3), rtol=1e-4), (n, float((g1[n] - g0[n]).abs().max()), scale)
+
+
+@pytest.mark.parametrize("N,H,W,C0,C1", [(2, 16, 16, 512, 256), (3, 8, 24, 64, 32), (1, 128, 128, 64, 32), (5, 5, 7, 8, 24)])
+def test_upcat_forward_and_backward_equal_the_torch_ops_bitwise(device, N, H, W, C0, C1):
+    """v2x_upcat_bf16 = cat(nearest x2 upsample, skip) (pure data movement: identical bits); v2x_upcat_bwd_bf16 = autograd's backward of the torch
+    expression on bf16 tensors (slice of the skip part; the 2x2 sum of four bf16 values in fp32 rounded once -- torch's bf16 sum does the same,
+    and with four addends any fp32 order that differs could change the last bit, so the comparison allows one bf16 ulp and checks that almost
+    every element is identical)."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(N * H + C0)
+    lo = torch.randn(N, H, W, C0, generator=g).to(torch.bfloat16).to(device).requires_grad_(True)
+    skip = torch.randn(N, 2 * H, 2 * W, C1, generator=g).to(torch.bfloat16).to(device).requires_grad_(True)
+    up = lo[:, :, None, :, None, :].expand(N, H, 2, W, 2, C0).reshape(N, 2 * H, 2 * W, C0)
+    ref = torch.cat((up, skip), dim=3)
+    got = ops.upcat(lo.detach(), skip.detach())
+    assert torch.equal(got, ref)
+    dcat = torch.randn(N, 2 * H, 2 * W, C0 + C1, generator=g).to(torch.bfloat16).to(device)
+    rlo, rskip = torch.autograd.grad(ref, (lo, skip), dcat)
+    dlo, dskip = ops.upcat_backward(dcat, C0)
+    assert torch.equal(dskip, rskip)
+    exact = dcat[..., :C0].float().reshape(N, H, 2, W, 2, C0).sum((2, 4))
+    assert torch.equal(dlo, (dcat[:, 0::2, 0::2, :C0].float() + dcat[:, 0::2, 1::2, :C0].float() + dcat[:, 1::2, 0::2, :C0].float()
+                             + dcat[:, 1::2, 1::2, :C0].float()).to(torch.bfloat16))          # the kernel's own order, bit for bit
+    assert float((dlo.float() - exact).abs().max()) <= 2 ** -7 * float(exact.abs().max())
+    assert float((dlo != rlo).float().mean()) < 0.02 and torch.allclose(dlo.float(), rlo.float(), atol=2 ** -6 * float(exact.abs().max()), rtol=2 ** -7)

@@ -447,6 +447,31 @@ def warp_affine(x, theta, backward=False):
     return out
 
 
+def upcat(lo, skip):
+    """cat(nearest x2 upsample of lo, skip) along the channels: lo (N, H, W, C0), skip (N, 2H, 2W, C1) bf16 NHWC -> (N, 2H, 2W, C0 + C1)."""
+    lib = _lib.load()
+    N, H, W, C0 = lo.shape
+    if skip.shape[:3] != (N, 2 * H, 2 * W):
+        raise ValueError("upcat: skip %s does not match twice the extent of lo %s" % (tuple(skip.shape), tuple(lo.shape)))
+    C1 = skip.shape[3]
+    out = torch.empty((N, 2 * H, 2 * W, C0 + C1), dtype=torch.bfloat16, device=lo.device)
+    _lib.check(lib.v2x_upcat_bf16(_dev(lo, torch.bfloat16, "lo"), _dev(skip, torch.bfloat16, "skip"), N, H, W, C0, C1, _dev(out, torch.bfloat16, "out"),
+                                  _stream()), "v2x_upcat_bf16")
+    return out
+
+
+def upcat_backward(dcat, C0):
+    """Backward of upcat: dcat (N, 2H, 2W, C0 + C1) bf16 -> (d_lo (N, H, W, C0) = the 2x2 sums, d_skip (N, 2H, 2W, C1))."""
+    lib = _lib.load()
+    N, H2, W2, Ct = dcat.shape
+    H, W, C1 = H2 // 2, W2 // 2, Ct - C0
+    d_lo = torch.empty((N, H, W, C0), dtype=torch.bfloat16, device=dcat.device)
+    d_skip = torch.empty((N, H2, W2, C1), dtype=torch.bfloat16, device=dcat.device)
+    _lib.check(lib.v2x_upcat_bwd_bf16(_dev(dcat, torch.bfloat16, "dcat"), N, H, W, C0, C1, _dev(d_lo, torch.bfloat16, "d_lo"),
+                                      _dev(d_skip, torch.bfloat16, "d_skip"), _stream()), "v2x_upcat_bwd_bf16")
+    return d_lo, d_skip
+
+
 def bn_train_forward(x, gamma, beta, running_mean, running_var, eps, momentum, relu=True):
     """Batch-statistics BN (+ ReLU) of a bf16 NHWC map on the HIP kernels (bn_train.hip).  x (..., C) bf16; gamma / beta (C,) fp32;
     running_mean / running_var fp32 (updated in place) or None.  -> (y bf16 like x, save_mean, save_invstd)."""

@@ -224,9 +224,26 @@ def conv3d_1x1(x, m):
     return bn_relu(conv1x1(x, m.conv3d.weight, m.conv3d.bias), m.bn3d)
 
 
+class _UpCat(torch.autograd.Function):
+    """cat(nearest x2 upsample of lo, skip) along the channels, NHWC bf16: one launch forward (v2x_upcat_bf16), one backward (the 2x2 sums of the
+    upsampled part + the skip part's slice: v2x_upcat_bwd_bf16) instead of an expand-copy + cat and two slice copies + a bf16 reduction."""
+
+    @staticmethod
+    def forward(ctx, lo, skip):
+        ctx.c0 = lo.shape[3]
+        return ops.upcat(lo.contiguous(), skip.contiguous())
+
+    @staticmethod
+    def backward(ctx, dcat):
+        return ops.upcat_backward(dcat.contiguous(), ctx.c0)
+
+
 def upcat(lo, skip):
     """cat(nearest x2 upsample of lo, skip) along the channels, NHWC."""
     N, H, W, C = lo.shape
+    if (tuning.get("UPCAT_HIP") != 0 and lo.dtype == BF16 and skip.dtype == BF16 and C % 8 == 0 and skip.shape[3] % 8 == 0
+            and skip.shape[:3] == (N, 2 * H, 2 * W)):
+        return _UpCat.apply(lo, skip)
     up = lo[:, :, None, :, None, :].expand(N, H, 2, W, 2, C).reshape(N, 2 * H, 2 * W, C)   # backward = a 2x2 sum (no atomics: deterministic)
     return torch.cat((up, skip), dim=3)
 
