@@ -842,3 +842,28 @@ def test_upcat_forward_and_backward_equal_the_torch_ops_bitwise(device, N, H, W,
                              + dcat[:, 1::2, 1::2, :C0].float()).to(torch.bfloat16))          # the kernel's own order, bit for bit
     assert float((dlo.float() - exact).abs().max()) <= 2 ** -7 * float(exact.abs().max())
     assert float((dlo != rlo).float().mean()) < 0.02 and torch.allclose(dlo.float(), rlo.float(), atol=2 ** -6 * float(exact.abs().max()), rtol=2 ** -7)
+
+
+@pytest.mark.parametrize("cout,cin,f32_out", [(64, 64, False), (128, 128, False), (12, 32, True), (36, 32, True), (8, 64, True)])
+def test_pack_conv1x1_device_equals_torch_packing(device, cout, cin, f32_out):
+    """packing.pack_conv1x1_device (one launch) against the torch-op packing the training graph used for its 1x1 layers: the same bytes and
+    PackedConv fields, forward layer and data-gradient layer (transposed weights, the gradient's channels padded to a multiple of 32)."""
+    from v2x_sim_amd import packing
+    from v2x_sim_amd._lib import V2X_EPI_BF16, V2X_EPI_F32
+    g = torch.Generator().manual_seed(cout * 7 + cin)
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).to(device)
+    b = torch.randn(cout, generator=g).to(device)
+    cp = (cout + 31) // 32 * 32
+    w2 = w.reshape(cout, cin)
+    with packing.on_device(device):
+        sc, sh = packing.fold_bn(b, None, cout)
+        ref_f = packing.pack_conv("r", w2[:, :, None, None], sc, sh, stride=1, pad=0, relu=False, epilogue=V2X_EPI_F32 if f32_out else V2X_EPI_BF16, device=device)
+        sc, sh = packing.fold_bn(None, None, cin)
+        ref_d = packing.pack_conv("r", F.pad(w2.t(), (0, cp - cout))[:, :, None, None], sc, sh, stride=1, pad=0, relu=False, epilogue=V2X_EPI_BF16, device=device)
+    got_f = packing.pack_conv1x1_device("t", w, b, f32_out=f32_out)
+    got_d = packing.pack_conv1x1_device("t", w, None, dgrad=True, cout_pad=cp)
+    for got, ref in ((got_f, ref_f), (got_d, ref_d)):
+        assert (got.C0, got.C1, got.Cout, got.ksize, got.stride, got.pad, got.epilogue, got.relu, got.w_rows, got.w_kpad) == \
+               (ref.C0, ref.C1, ref.Cout, ref.ksize, ref.stride, ref.pad, ref.epilogue, ref.relu, ref.w_rows, ref.w_kpad)
+        assert torch.equal(got.weight.view(torch.int16).flatten(), ref.weight.view(torch.int16).flatten())
+        assert torch.equal(got.scale, ref.scale) and torch.equal(got.shift, ref.shift)

@@ -224,6 +224,46 @@ def pack_conv_device(name, weight, bias, *, stride=1, cin_pad=None, dgrad=False)
     return Layer([pc], None, name=name) if layout == 0 else Layer([], pc, name=name)
 
 
+def pack_conv1x1_device(name, weight, bias, *, dgrad=False, cout_pad=0, f32_out=False):
+    """One-launch device packing of a 1x1 layer for the training graph (v2x_pack_conv_device, gather layout): weight = the fp32 parameter ON THE
+    DEVICE, [Cout, Cin, 1, 1] (or [Cout, Cin]).  dgrad: the layer dx = dy . W (the transposed weights; dy's channels zero-padded to cout_pad, no
+    bias, bf16 output).  -> PackedConv with scale = 1, shift = bias -- the bytes of the torch-op packing it replaces (pad / transpose / cast /
+    scatter into a zeroed buffer: ~8 small launches per packing, 8 packings per training step)."""
+    import ctypes as C
+    from ._lib import PackSpec
+    from ._lib import V2X_EPI_F32
+    lib = _lib.load()
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous():
+        w = w.float().contiguous()
+    co_w, ci_w = w.shape[0], w.shape[1]
+    if dgrad:
+        cout, cin, cin_p = ci_w, co_w, max(cout_pad, co_w)
+    else:
+        cout, cin, cin_p = co_w, ci_w, ci_w
+    epi = V2X_EPI_F32 if (f32_out and not dgrad) else V2X_EPI_BF16
+    spec = PackSpec(Cout=cout, Cin=cin, ksize=1, cin_pad=cin_p, w_layout=0, epilogue=epi, chain=0)
+    rows, kpad = C.c_int32(0), C.c_int32(0)
+    nbytes = lib.v2x_pack_conv_size(C.byref(spec), C.byref(rows), C.byref(kpad))
+    if nbytes == 0:
+        raise ValueError("pack_conv1x1_device(%s): %s" % (name, lib.v2x_last_error().decode()))
+    buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.v2x_pack_conv_device(C.byref(spec), C.c_void_p(w.data_ptr()), 1 if dgrad else 0, C.c_void_p(buf.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "v2x_pack_conv_device(%s)" % name)
+    n_par = rows.value
+    scale = _const(n_par, 1.0, w.device, cout)
+    if bias is not None and not dgrad:
+        if n_par == cout and bias.dtype == torch.float32:
+            shift = bias.detach()
+        else:
+            shift = torch.zeros((n_par,), dtype=torch.float32, device=w.device)
+            shift[:cout] = bias.detach().float()
+    else:
+        shift = _const(n_par, 0.0, w.device)
+    return PackedConv(name=name, weight=buf.view(n_par, kpad.value), scale=scale, shift=shift, C0=cin_p, C1=0, Cout=cout, ksize=1, stride=1, pad=0,
+                      up0=0, epilogue=epi, relu=False, w_rows=n_par, w_kpad=kpad.value)
+
+
 def det_row_order(n_anchor=6, n_cls=2, n_code=6):
     """Row order of the chained 1x1 of the fused DETECTION heads (include/v2x_amd.h, V2X_EPI_DET): packed row 16 t + 4 q + r, q < 3,
     belongs to anchors a0 = 2 q, a1 = 2 q + 1.  -> list of 64 entries: ("cls", anchor, class) | ("loc", anchor, code) | None (zero row)."""

@@ -162,19 +162,9 @@ def _layer_1x1(kind, weight, bias, f32_out, cout_pad):
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]
-    from .._lib import V2X_EPI_BF16, V2X_EPI_F32
-    cout, cin = weight.shape[0], weight.shape[1]
-    w2 = weight.detach().reshape(cout, cin)
-    with packing.on_device(weight.device):
-        if kind == "fwd":
-            scale, shift = packing.fold_bn(bias, None, cout)
-            pc = packing.pack_conv("train.fwd1x1", w2[:, :, None, None], scale, shift, stride=1, pad=0, relu=False,
-                                   epilogue=V2X_EPI_F32 if f32_out else V2X_EPI_BF16, device=weight.device)
-        else:   # dx = dy . W: a 1x1 layer with the transposed weights, the gradient's channels zero-padded to cout_pad
-            wt = F.pad(w2.t(), (0, cout_pad - cout))                                    # [Cin][cout_pad]
-            scale, shift = packing.fold_bn(None, None, cin)
-            pc = packing.pack_conv("train.dgrad1x1", wt[:, :, None, None], scale, shift, stride=1, pad=0, relu=False,
-                                   epilogue=V2X_EPI_BF16, device=weight.device)
+    # one device launch per packing (v2x_pack_conv_device, gather layout); dgrad: dx = dy . W, the gradient's channels zero-padded to cout_pad
+    pc = packing.pack_conv1x1_device("train." + kind + "1x1", weight, bias if kind == "fwd" else None, dgrad=kind != "fwd", cout_pad=cout_pad,
+                                     f32_out=f32_out)
     _CACHE[key] = (ver, pc, weakref.ref(weight))
     return pc
 
