@@ -139,6 +139,16 @@ def conv3x3(x, conv):
     return y.permute(0, 2, 3, 1).to(BF16).contiguous()
 
 
+_PENDING_COUNTERS = []
+_DEFER_COUNTERS = [False]      # set by train_forward for the duration of a forward pass
+
+
+def _flush_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
+
+
 def bn_relu(x, bn, relu=True):
     """nn.BatchNorm2d / nn.BatchNorm3d in train mode (+ ReLU) on a bf16 NHWC map."""
     if not bn.training:
@@ -146,7 +156,10 @@ def bn_relu(x, bn, relu=True):
     rm = bn.running_mean if bn.track_running_stats else None
     rv = bn.running_var if bn.track_running_stats else None
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if _DEFER_COUNTERS[0]:
+            _PENDING_COUNTERS.append(bn.num_batches_tracked)  # train_forward bumps them all in ONE launch (22 tiny `+= 1` kernels per step otherwise)
+        else:
+            bn.num_batches_tracked += 1
     if bn.momentum is None:
         raise NotImplementedError("cumulative-average BatchNorm (momentum=None)")
     return _BnRelu.apply(x.contiguous(), bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, relu)
@@ -316,6 +329,17 @@ def _fused_on_fp32_graph(fuse, model, feat, *args):
 
 
 def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
+    """See _train_forward; the BatchNorm layers' num_batches_tracked counters are bumped together, in one launch, when the forward is complete."""
+    prev, _DEFER_COUNTERS[0] = _DEFER_COUNTERS[0], True
+    try:
+        return _train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size, inference)
+    finally:
+        _DEFER_COUNTERS[0] = prev
+        if not prev:
+            _flush_counters()
+
+
+def _train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
     """bevs (A*B, 1, X, Y, Z) on the MI355X -> {'loc', 'cls'} fp32 (segmentation variants: NHWC fp32 logits), shapes as
     train/graph.py::train_forward.  Every detection / segmentation baseline: encoder, decoder and heads on the kernels; the cross-agent
     fusion (V2VNet's warp + ConvGRU, when2com's handshake, sum / mean / max / cat / DiscoNet) on the fp32 graph at the fusion layer.
