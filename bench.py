@@ -15,7 +15,9 @@ all-gathers are asynchronous and hidden under the other half's compute.
 
 Execution mode is the SAME for every N (`exec_mode` in the record): the step's four collective-free segments
 (encoder A, encoder B, fusion+decoder+heads A, ... B) are replayed from hipGraphs and the exchange runs between them
-(at N = 1 there is nothing to exchange), so the 1 -> 8 curve compares equals.
+(at N = 1 there is nothing to exchange), so the 1 -> 8 curve compares equals.  The two half-batches run on two streams
+(own graph memory pools) and are joined at the end of the step: one half's kernels fill the tails and the HBM-bound
+phases of the other (+2.3...3.0 % at N = 1 against `--graph 4`, the one-stream order).
 
 Prints ONE JSON line (rank 0).  `roofline` is computed from HIP events recorded live around every
 kernel launch of an instrumented pass on the launch stream; `cpu_baseline` times the CPU oracle
@@ -62,8 +64,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--graph", type=int, default=1,
-                    help="1: four hipGraph segments with the exchange between them (every N); 0: eager launches; "
-                         "2: the whole step as ONE hipGraph (N = 1 only, for comparison)")
+                    help="1: four hipGraph segments with the exchange between them, the two half-batches on two streams (every N); "
+                         "4: the same on one stream; 0: eager launches; 2: the whole step as ONE hipGraph (N = 1 only, for comparison)")
     ap.add_argument("--transport", choices=("allgather", "needed"), default="allgather",
                     help="fusion-map exchange: RCCL all-gather (default) or grouped point-to-point of the needed rows only")
     ap.add_argument("--layout", choices=("spread", "agent-per-gpu"), default="spread",
@@ -360,40 +362,53 @@ def main():
             out = step()
         run = g.replay
         exec_mode = "one hipGraph per step"
-    elif mode == 1:
-        # four collective-free segments, each a hipGraph on a shared pool (replayed in capture order); the exchange
-        # (RCCL, eager) runs between them on static buffers
+    elif mode in (1, 4):
+        # four collective-free segments (encoder A, encoder B, fusion + decoder + heads A, B), each a hipGraph; the exchange (RCCL, eager) runs
+        # between them on static buffers.  mode 1 (default): the two half-batches on TWO STREAMS -- kernels of one half fill the tails and the
+        # HBM-bound phases (heads, conv8_2, conv1_1) of the other: +2.3...3.0 % at N = 1 against the one-stream order (mode 4), same box;
+        # four quarter-batches on four streams: -1.4 %.  The halves of a step are joined before the next step starts.
         # capture_error_mode="thread_local": RCCL's watchdog thread polls the events of earlier collectives while this
         # thread captures -- under the default global mode that query is "operation not permitted when stream is
         # capturing" and takes the process down (seen with V2X_FORCE_DIST=1 on one GPU)
-        pool = torch.cuda.graph_pool_handle()
-        cap = dict(pool=pool, capture_error_mode="thread_local")
+        two = mode == 1
+        shared_pool = torch.cuda.graph_pool_handle()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else [torch.cuda.current_stream()] * 2
         with torch.no_grad():
-            for h in halves:
+            for h, st in zip(halves, streams):
                 h["xbuf"] = None
+                h["stream"] = st
+                # concurrent halves must not share intermediate buffers: one memory pool per half (one-stream order: one pool, replayed in capture order)
+                h["cap"] = dict(pool=torch.cuda.graph_pool_handle() if two else shared_pool, capture_error_mode="thread_local")
                 if use_dist:
                     h["xbuf"] = torch.empty((sworld * shard.per_rank, 32, 32, 256), dtype=torch.bfloat16, device=dev)
             for h in halves:
                 h["g_enc"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(h["g_enc"], **cap):
+                with torch.cuda.graph(h["g_enc"], **h["cap"]):
                     h["feats"] = runner.encode(h["points"], h["n_pts"])
             for h in halves:
                 h["g_dec"] = torch.cuda.CUDAGraph()
                 gathered = h["xbuf"] if use_dist else h["feats"][L]
-                with torch.cuda.graph(h["g_dec"], **cap):
+                with torch.cuda.graph(h["g_dec"], **h["cap"]):
                     h["out"] = runner.decode(h["feats"], gathered, h["trans"], h["plan"])
 
         def run():
-            a, b = halves
-            a["g_enc"].replay()
-            _, wa = runner.start_exchange(a["feats"][L], out=a["xbuf"]) if use_dist else (None, None)
-            b["g_enc"].replay()
-            _, wb = runner.start_exchange(b["feats"][L], out=b["xbuf"]) if use_dist else (None, None)
-            timed_wait(wa)
-            a["g_dec"].replay()
-            timed_wait(wb)
-            b["g_dec"].replay()
-        exec_mode = "4 hipGraph segments per step (encoder A, encoder B, fusion+decoder+heads A, B); exchange between them"
+            cur = torch.cuda.current_stream()
+            works = []
+            for h in halves:                    # encoder A, exchange A (async), encoder B, exchange B: the same host order on every rank
+                if two:
+                    h["stream"].wait_stream(cur)
+                with torch.cuda.stream(h["stream"]):
+                    h["g_enc"].replay()
+                    works.append(runner.start_exchange(h["feats"][L], out=h["xbuf"])[1] if use_dist else None)
+            for h, w in zip(halves, works):
+                with torch.cuda.stream(h["stream"]):
+                    timed_wait(w)
+                    h["g_dec"].replay()
+            if two:
+                for h in halves:
+                    cur.wait_stream(h["stream"])
+        exec_mode = ("4 hipGraph segments per step (encoder A, encoder B, fusion+decoder+heads A, B); exchange between them; "
+                     + ("the two half-batches on two streams, joined at the end of the step" if two else "one stream"))
     elif mode == 0:
         run = step
         exec_mode = "eager launches"
