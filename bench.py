@@ -543,6 +543,8 @@ def main():
                        "exec_mode": exec_mode, "hip_graph": bool(mode)},
             "whole_step_frac": (GFLOP_PER_FRAME_BASE + GFLOP_PER_GNN_ROUND * args.gnn_iters) * 1e9 * fps / world / (PEAK_MFMA_TFLOPS * 1e12),
             "ranks_seen": ranks_seen, "exposed_exchange_ms_per_step": exposed_all,
+            "exposed_exchange_note": "HIP-event time a half-batch's stream waits for its exchange; with the two half-batches on two streams the GPU runs "
+                                     "the other half's kernels during that wait (one-stream order: --graph 4)",
             "roofline": roofline, "cpu_baseline": cpu, "latency": latency, "configs": configs, "training": training, "kernels": kernels,
         }
     if use_dist:
