@@ -298,6 +298,13 @@ enum { V2X_FUSE_WSUM = 0, V2X_FUSE_MEAN = 1, V2X_FUSE_MAX = 2 };
 int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
                   const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
                   v2x_stream_t stream);
+/* The same launch with its workgroups ordered by FRAME: order int32 [order_len] = the output-map index of (frame slot, ego) in slots of
+ * order_stride entries (-1 = none), order_len >= n_out.  The workgroups of XCD x (linear id % 8) compute the slots x, x + 8, ...: the
+ * output maps of a frame read the same A source maps, which then cross the fabric once per frame instead of once per ego.  Same arithmetic,
+ * identical bits; only the LDS-staged form (H, W multiples of 8, C of 128) uses the table, the direct form ignores it. */
+int v2x_warp_fuse_ordered(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans, const int32_t *items, int n_out,
+                          const float *coef, int mode, uint16_t *out, const int32_t *order, int order_stride, int order_len,
+                          v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- a5: attention handshake
  * Replaces When2com.py::MIMOGeneralDotProductAttention (query projection, key.query

@@ -434,6 +434,42 @@ def test_warp_fuse_lds_form_bitwise_and_oracle(device, mode, tune):
     assert torch.allclose(got, bf16r(ref), atol=4e-3, rtol=2 ** -7), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("ragged", [False, True])
+def test_warp_fuse_frame_ordered_launch_is_bit_identical(device, ragged, tune):
+    """WARP_XCD: v2x_warp_fuse_ordered computes the output maps of one frame on one XCD (a permutation of which workgroup computes which tile):
+    identical bits to the plain grid, with every (ego, frame) present and with a ragged item list (frames with fewer agents, shuffled order,
+    19 frames = not a multiple of the 8 XCDs)."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.utils.synthetic import synthetic_poses
+    A, Bt, C, H, W = 5, 19, 256, 32, 32
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(A * Bt, H, W, C, generator=g).to(torch.bfloat16).to(device)
+    T = torch.from_numpy(synthetic_poses(Bt, A, seed=3)).to(device)
+    items = [(a, f) for a in range(A) for f in range(Bt)]
+    if ragged:
+        items = [(a, f) for (a, f) in items if not (f % 3 == 1 and a >= 3)]
+        perm = torch.randperm(len(items), generator=g).tolist()
+        items = [items[i] for i in perm]
+    coef = torch.rand(len(items), A, generator=g)
+    coef[coef < 0.25] = 0
+    it = torch.tensor(items, dtype=torch.int32, device=device)
+    for mode in (0, 1):
+        tune("WARP_XCD", 0)
+        ref = ops.warp_fuse(x, A, Bt, T, it, coef.to(device), mode).clone()
+        tune("WARP_XCD", 1)
+        got = ops.warp_fuse(x, A, Bt, T, it, coef.to(device), mode)
+        assert hasattr(it, "_v2x_frame_order")
+        assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    # an (ego, frame) pair listed twice cannot be ordered by the table: the plain grid is taken and both outputs are computed
+    dup = torch.tensor(items[:7] + items[:3], dtype=torch.int32, device=device)
+    cd = torch.rand(10, A, generator=g).to(device)
+    tune("WARP_XCD", 1)
+    got = ops.warp_fuse(x, A, Bt, T, dup, cd, 0)
+    assert dup._v2x_frame_order is False
+    tune("WARP_XCD", 0)
+    assert torch.equal(ops.warp_fuse(x, A, Bt, T, dup, cd, 0), got)
+
+
 # ------------------------------------------------------------------------------------- a5
 def test_attention_golden(device):
     from v2x_sim_amd import ops

@@ -209,15 +209,30 @@ __global__ __launch_bounds__(256) void warp_fuse_lds_kernel(const uint16_t *__re
                                                             int C, const float *__restrict__ trans,
                                                             const int32_t *__restrict__ items,
                                                             const float *__restrict__ coef, int mode,
-                                                            uint16_t *__restrict__ out) {
+                                                            uint16_t *__restrict__ out, const int32_t *__restrict__ order, int order_stride,
+                                                            int n_out_total) {
     __shared__ float4 win[WL_R * WL_R * WL_POS4];
-    const int m = blockIdx.y;
+    int m = blockIdx.y, tile = blockIdx.x, cbi = blockIdx.z;
+    if (order) {
+        // 1-D grid, frame-major per XCD: the workgroups of XCD x (linear id % 8) walk the output maps order[k], k = x, x + 8, ... is NOT enough --
+        // the maps of one FRAME must share an XCD (each source map is read by every other agent of its frame): `order` lists the output maps
+        // sorted by frame, `per_frame` of them per frame slot; XCD x takes the frame slots x, x + 8, ...
+        const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+        const int tiles = (H / WL_T) * (W / WL_T), cbs = C / WL_CW;
+        const int per_slot = order_stride * tiles * cbs;
+        const int slot = (i / per_slot) * 8 + xcd, rest = i % per_slot;
+        const int e = rest / (tiles * cbs), r2 = rest % (tiles * cbs);
+        if (slot * order_stride + e >= n_out_total) return;
+        m = order[slot * order_stride + e];
+        if (m < 0) return;
+        cbi = r2 / tiles;
+        tile = r2 % tiles;
+    }
     const int ego = items[2 * m + 0];
     const int f = items[2 * m + 1];
     const int tiles_x = W / WL_T;
-    const int tile = blockIdx.x;
     const int h0 = (tile / tiles_x) * WL_T, w0 = (tile % tiles_x) * WL_T;
-    const int cb = blockIdx.z * WL_CW;
+    const int cb = cbi * WL_CW;
     const int tid = threadIdx.x;
     const size_t map_elems = (size_t)H * W * C;
     // phase-2 items of this thread: i = tid + 256 * s, pixel = i / WL_G, g = i % WL_G
@@ -347,9 +362,9 @@ __global__ __launch_bounds__(256) void warp_fuse_lds_kernel(const uint16_t *__re
     }
 }
 
-extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
-                             const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
-                             v2x_stream_t stream) {
+static int warp_fuse_impl(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
+                          const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
+                          const int32_t *order, int order_stride, int order_len, v2x_stream_t stream) {
     V2X_REQUIRE(feat && trans && items && coef && out, "v2x_warp_fuse: null pointer");
     V2X_REQUIRE(A > 0 && A <= 32 && Bt > 0 && H > 0 && W > 0, "v2x_warp_fuse: bad dims");
     V2X_REQUIRE(C > 0 && C % 8 == 0, "v2x_warp_fuse: C=%d must be a multiple of 8", C);
@@ -357,8 +372,18 @@ extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, 
     V2X_REQUIRE(n_out >= 0 && n_out <= 65535, "v2x_warp_fuse: n_out out of range");
     if (n_out == 0) return V2X_OK;
     if (v2x_tune(V2X_TUNE_WARP_LDS) != 0 && H % WL_T == 0 && W % WL_T == 0 && C % WL_CW == 0) {
-        hipLaunchKernelGGL(warp_fuse_lds_kernel, dim3((H / WL_T) * (W / WL_T), n_out, C / WL_CW), dim3(256), 0,
-                           (hipStream_t)stream, feat, A, Bt, H, W, C, trans, items, coef, mode, out);
+        if (order && order_stride > 0 && order_len > 0) {
+            // frame slots of order_stride output maps each (padded with -1); XCD x = linear workgroup id % 8 takes the slots x, x + 8, ...
+            const int slots = (order_len + order_stride - 1) / order_stride;
+            const int per_slot = order_stride * (H / WL_T) * (W / WL_T) * (C / WL_CW);
+            const long long blocks = (long long)((slots + 7) / 8) * per_slot * 8;
+            V2X_REQUIRE(blocks < (1ll << 31), "v2x_warp_fuse: grid too large");
+            hipLaunchKernelGGL(warp_fuse_lds_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, feat, A, Bt, H, W, C, trans, items, coef,
+                               mode, out, order, order_stride, order_len);
+        } else {
+            hipLaunchKernelGGL(warp_fuse_lds_kernel, dim3((H / WL_T) * (W / WL_T), n_out, C / WL_CW), dim3(256), 0,
+                               (hipStream_t)stream, feat, A, Bt, H, W, C, trans, items, coef, mode, out, nullptr, 0, 0);
+        }
         V2X_CHECK_LAUNCH("warp_fuse_lds_kernel");
         return V2X_OK;
     }
@@ -371,4 +396,17 @@ extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, 
                        trans, items, coef, mode, out);
     V2X_CHECK_LAUNCH("warp_fuse_kernel");
     return V2X_OK;
+}
+
+extern "C" int v2x_warp_fuse(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
+                             const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
+                             v2x_stream_t stream) {
+    return warp_fuse_impl(feat, A, Bt, H, W, C, trans, items, n_out, coef, mode, out, nullptr, 0, 0, stream);
+}
+
+extern "C" int v2x_warp_fuse_ordered(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
+                                     const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
+                                     const int32_t *order, int order_stride, int order_len, v2x_stream_t stream) {
+    V2X_REQUIRE(order && order_stride > 0 && order_len >= n_out, "v2x_warp_fuse_ordered: bad order table");
+    return warp_fuse_impl(feat, A, Bt, H, W, C, trans, items, n_out, coef, mode, out, order, order_stride, order_len, stream);
 }

@@ -540,12 +540,34 @@ def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
         out = torch.empty((n_out, H, W, Cc), dtype=torch.bfloat16, device=feat.device)
     lds = H % 8 == 0 and W % 8 == 0 and Cc % 128 == 0 and tuning.get("WARP_LDS") != 0
     prof = _Prof("warp_fuse_lds_kernel" if lds else "warp_fuse_kernel", 0, (n_out * (A - 1) + n_out) * H * W * Cc * 2)
-    rc = lib.v2x_warp_fuse(_dev(feat, torch.bfloat16, "feat"), A, Bt, H, W, Cc, _dev(trans, torch.float32, "trans"),
-                           _dev(items, torch.int32, "items"), n_out, _dev(coef, torch.float32, "coef"), mode,
-                           _dev(out, torch.bfloat16, "out"), _stream())
+    order = _warp_frame_order(items, A, Bt) if (lds and tuning.get("WARP_XCD") != 0) else None
+    if order is not None:
+        rc = lib.v2x_warp_fuse_ordered(_dev(feat, torch.bfloat16, "feat"), A, Bt, H, W, Cc, _dev(trans, torch.float32, "trans"),
+                                       _dev(items, torch.int32, "items"), n_out, _dev(coef, torch.float32, "coef"), mode,
+                                       _dev(out, torch.bfloat16, "out"), _dev(order, torch.int32, "order"), A, order.numel(), _stream())
+    else:
+        rc = lib.v2x_warp_fuse(_dev(feat, torch.bfloat16, "feat"), A, Bt, H, W, Cc, _dev(trans, torch.float32, "trans"),
+                               _dev(items, torch.int32, "items"), n_out, _dev(coef, torch.float32, "coef"), mode,
+                               _dev(out, torch.bfloat16, "out"), _stream())
     prof.done()
     _lib.check(rc, "v2x_warp_fuse")
     return out
+
+
+def _warp_frame_order(items, A, Bt):
+    """(Bt, A) int32 table: the output map of (frame, ego), -1 where there is none -- what v2x_warp_fuse_ordered walks so that the output maps
+    of one frame (which all read the same A source maps) are computed by one XCD and share its L2.  Built once per items tensor (the fusion plan
+    keeps it); never inside a hipGraph capture (the table would live in the graph's private pool): the caller then takes the unordered launch."""
+    order = getattr(items, "_v2x_frame_order", None)
+    if order is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        order = torch.full((Bt, A), -1, dtype=torch.int32, device=items.device)
+        order[items[:, 1].long(), items[:, 0].long()] = torch.arange(items.shape[0], dtype=torch.int32, device=items.device)
+        if int((order >= 0).sum()) != items.shape[0]:
+            order = False                        # an (ego, frame) pair listed twice: the table cannot hold both -> the plain grid, always
+        items._v2x_frame_order = order
+    return None if order is False else order
 
 
 # ------------------------------------------------------------------ a5
