@@ -720,3 +720,23 @@ def test_voxelize_counts_beyond_capacity_and_bad_jobs(device, tune):
     assert torch.equal(got[0], ref[0]) and int(got[1].abs().sum()) == 0
     with pytest.raises(ValueError, match="one count per cloud"):
         ops.voxelize_bits(pts, exact[:2], grid)
+
+
+def test_halo_xcd_walk_is_a_pure_reordering(device, tune):
+    """HALO_XCD permutes which workgroup of the halo kernels' persistent grids computes which tile (an XCD owns a contiguous eighth of the tiles):
+    identical bits for the single-buffer, ping-pong, chained and bit-input forms, with tile counts that are not multiples of 8 or of the grid."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(5)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    cases = [(0, 32, 32, ncu // 8 * 3 + 5, 24, 64), (64, 32, 32, 7, 32, 32), (0, 64, 64, ncu // 4 + 3, 16, 32)]
+    for cup, c, cout, N, H, W in cases:
+        w = torch.randn(cout, cup + c, 3, 3, generator=g) * 0.05
+        pc = packing.pack_conv_halo("h", w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, C0=cup if cup else c,
+                                    C1=c if cup else 0, relu=True, device=device)
+        x = torch.randn(N, H, W, c, generator=g).to(torch.bfloat16).to(device)
+        xu = torch.randn(N, H // 2, W // 2, cup, generator=g).to(torch.bfloat16).to(device) if cup else None
+        run = (lambda: ops.conv2d(pc, xu, x)) if cup else (lambda: ops.conv2d(pc, x))
+        tune("HALO_XCD", 0)
+        ref = run().clone()
+        tune("HALO_XCD", 1)
+        assert torch.equal(run(), ref), (cup, c, cout, N)

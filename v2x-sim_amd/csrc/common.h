@@ -31,6 +31,7 @@ enum v2x_tune_id {
     V2X_TUNE_WARP_LDS,        // 1: LDS-staged warp kernel; 0: the direct form
     V2X_TUNE_S2_G,            // 1: 8-wave three-tap stride-2 kernel (256-pixel tiles) for the 128-row layers when the launch has >= 4 tiles per CU; 0: the 1-tap kernel; 2: s2g whenever the shape allows
     V2X_TUNE_GRU_XCD_WALK,    // 1: the ConvGRU's persistent grid walks 8 pixel x 4 channel tiles per XCD and round (fabric reads -16 %, same time, same bits); 0: 4 x 8
+    V2X_TUNE_HALO_XCD,        // 1: the halo kernels' persistent grids give every XCD a contiguous eighth of the tiles (halo pixels cross the fabric once); 0: round-robin
     V2X_TUNE_WGRAD_TR,        // 1: weight-gradient kernel on LDS-DMA tiles + transpose reads; 0: the first form (VALU transposes)
     V2X_TUNE_COUNT
 };
@@ -99,3 +100,16 @@ __device__ __forceinline__ uint32_t v2x_relu_bf16x2_floor(uint32_t x, uint32_t f
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// XCD-aware persistent tile walk for kernels whose neighbouring tiles share input (halo rows / columns): the hardware deals consecutive
+// workgroup ids to the 8 XCDs round-robin, so with `tile = blockIdx.x; tile += gridDim.x` the two neighbours of a tile always sit on OTHER XCDs
+// and every halo pixel crosses the fabric twice.  Here XCD x (= blockIdx.x % 8) owns a CONTIGUOUS eighth of the tiles and its workgroups stride
+// through it: neighbouring tiles (whole maps) share an XCD and its L2.  A pure permutation of the workgroup -> tile map (same balance).
+struct v2x_tile_walk { int first, step, end; };
+__device__ __forceinline__ v2x_tile_walk v2x_xcd_tile_walk(int n_tiles, int enable) {
+    const int G = (int)gridDim.x, b = (int)blockIdx.x;
+    if (!enable || (G & 7) != 0 || n_tiles < 8) return {b, G, n_tiles};
+    const int xcd = b & 7, i = b >> 3, per = G >> 3;
+    const int q = n_tiles >> 3, r = n_tiles & 7;
+    const int lo = xcd * q + (xcd < r ? xcd : r);
+    return {lo + i, per, lo + q + (xcd < r ? 1 : 0)};
+}

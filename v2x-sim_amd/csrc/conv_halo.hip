@@ -57,6 +57,7 @@ struct HaloArgs {
     int32_t *det_counts;  // [N], zeroed by the caller
     float det_thr, det_margin;   // score threshold; logit(det_thr) - 1e-3 = the conservative pre-test on c1 - c0
     int det_cap;
+    int xcd_walk;         // 1: XCD-contiguous tile walk (common.h: v2x_xcd_tile_walk; tuning switch HALO_XCD)
 };
 
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
@@ -263,16 +264,17 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 w2f[i2][s] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * COUT + s * 32 + fq * 8);
     }
 
-    int tile = blockIdx.x;
+    const v2x_tile_walk walk = v2x_xcd_tile_walk(a.n_tiles, a.xcd_walk);
+    int tile = walk.first;
     int cur = 0;
     bool first_tile = true;
     // output-store instructions a wave issues per tile (static: every channel tile is written; the det heads' 48 real
     // channels fill their 3 tiles exactly -- other padded widths fall back to the full drain)
     // (the detection heads store only their rare candidates: full drain, which then waits for nothing but the next patch)
     constexpr int N_STORES = EPI2 == 3 ? 0 : (COUT2 == 0 ? TCO * 4 : ((COUT2 == 48 || COUT2 == 64) ? TCO2 * 4 : 0));
-    if (DB && tile < a.n_tiles) load_patch(tile, 0);
+    if (DB && tile < walk.end) load_patch(tile, 0);
 
-    for (; tile < a.n_tiles; tile += gridDim.x) {
+    for (; tile < walk.end; tile += walk.step) {
         if constexpr (DB) {
             // patch[cur] (and, first time, the weights) have landed; everyone left patch[cur^1].  After the first tile
             // this is a COUNTED wait + raw barrier: the only vector-memory operations younger than patch[cur]'s DMA are
@@ -288,8 +290,8 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
-            const int next = tile + gridDim.x;
-            if (next < a.n_tiles) load_patch(next, cur ^ 1);
+            const int next = tile + walk.step;
+            if (next < walk.end) load_patch(next, cur ^ 1);
         } else {
             load_patch(tile, 0);
             __syncthreads();  // this tile's patch (and, first time, the weights) have landed
@@ -950,8 +952,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // pairs of tiles (2p, 2p + 1): group g owns tile 2p + g;  p = blockIdx.x + k * gridDim.x
     const int n_pairs = a.n_tiles >> 1;
-    const int K = (n_pairs - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= n_pairs)
-    auto tile_of = [&](int k) { return 2 * ((int)blockIdx.x + k * (int)gridDim.x) + grp; };
+    const v2x_tile_walk walk = v2x_xcd_tile_walk(n_pairs, a.xcd_walk);      // (XCD-contiguous pairs: common.h)
+    const int K = walk.first < walk.end ? (walk.end - walk.first + walk.step - 1) / walk.step : 0;
+    auto tile_of = [&](int k) { return 2 * (walk.first + k * walk.step) + grp; };
 
     if (grp == 0) load_patch(tile_of(0));
     __syncthreads();   // weights, scale/shift and group 0's first patch have landed
@@ -1047,6 +1050,7 @@ static int launch_halo(const HaloArgs &a, hipStream_t s) {
 // to the gather kernel -- which needs the row-major weight layout, so callers decide at pack time).
 int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     HaloArgs a;
+    a.xcd_walk = v2x_tune(V2X_TUNE_HALO_XCD);
     a.in0 = d->C1 ? d->in0 : nullptr;
     a.in1 = d->C1 ? d->in1 : d->in0;
     a.bits = d->in_format == 1 ? reinterpret_cast<const uint32_t *>(d->in0) : nullptr;

@@ -41,6 +41,7 @@ struct PairArgs {
     uint16_t *out;                      // NHWC [N][H][W][out_cstride] (+out_coff)
     int out_cstride, out_coff;
     int tiles_x, tiles_y, n_tiles;
+    int xcd_walk;                       // 1: XCD-contiguous tile walk (common.h; tuning switch HALO_XCD)
 };
 
 namespace pair {
@@ -182,9 +183,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // tile's output stores (~1-2 us each).  So (1) everything loaded once is consumed here, before the loop -- otherwise
     // the compiler re-waits for it with vmcnt(0) in every iteration -- and (2) the occupancy words of the next tile are
     // requested BEFORE this tile's stores and expanded AFTER them, which the compiler resolves to vmcnt(8), not 0.
-    int tile = blockIdx.x;
+    const v2x_tile_walk walk = v2x_xcd_tile_walk(a.n_tiles, a.xcd_walk);
+    int tile = walk.first;
     uint32_t words[2] = {0u, 0u}, okmask = 0;
-    if (tile < a.n_tiles) {
+    if (tile < walk.end) {
         fetch_words(tile, words, okmask);
         expand_words(words, okmask);
     }
@@ -193,9 +195,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("" ::"v"(scA[i].x), "v"(scA[i].w), "v"(shA[i].x), "v"(shA[i].w), "v"(scB[i].x), "v"(scB[i].w), "v"(shB[i].x), "v"(shB[i].w));
     __syncthreads();   // input window of the first tile written; the weight DMA has landed
 
-    for (; tile < a.n_tiles; tile += gridDim.x) {
-        const int next = tile + gridDim.x;
-        if (next < a.n_tiles) fetch_words(next, words, okmask);   // lands under this tile's MFMAs
+    for (; tile < walk.end; tile += walk.step) {
+        const int next = tile + walk.step;
+        if (next < walk.end) fetch_words(next, words, okmask);   // lands under this tile's MFMAs
 
         const int n = tile / txy;
         const int rr_ = tile - n * txy;
@@ -335,6 +337,7 @@ extern "C" int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *
     V2X_REQUIRE((long long)first->N * first->H * first->W < (1ll << 31), "v2x_conv2d_pair: N*H*W must fit 31 bits");
     if (first->N == 0) return V2X_OK;
     PairArgs a;
+    a.xcd_walk = v2x_tune(V2X_TUNE_HALO_XCD);
     a.bits = reinterpret_cast<const uint32_t *>(first->in0);
     a.zbits = first->in_zbits;
     a.N = first->N;
