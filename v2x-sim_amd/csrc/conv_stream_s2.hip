@@ -50,6 +50,7 @@ struct S2Args {
     uint16_t *out;        // [N][H/2][W/2][out_cstride]
     int out_cstride, out_coff, Cout;
     int tiles_x, tiles_y, n_px_tiles, n_co_tiles;
+    int xcd_walk;         // resident form: 1 = XCD-contiguous tile walk (tuning switch HALO_XCD)
 };
 
 constexpr int S2_TH = 4, S2_TW = 32;
@@ -303,7 +304,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int Ho = a.H >> 1, Wo = a.W >> 1;
 
     bool first = true;
-    for (int tile = blockIdx.x; tile < a.n_px_tiles; tile += gridDim.x) {
+    const v2x_tile_walk walk = v2x_xcd_tile_walk(a.n_px_tiles, a.xcd_walk);     // neighbouring tiles (shared halo rows / columns) on one XCD: common.h
+    for (int tile = walk.first; tile < walk.end; tile += walk.step) {
         const int n = tile / txy;
         const int trem = tile - n * txy;
         const int ty = trem / a.tiles_x;
@@ -800,6 +802,7 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     const int rows = (d->Cout % 128 == 0) ? 128 : ((d->Cout % 64 == 0) ? 64 : 0);
     if (rows == 0 || d->w_rows != d->Cout) return 1;
     S2Args a;
+    a.xcd_walk = v2x_tune(V2X_TUNE_HALO_XCD);
     a.in = d->in0;
     a.C = d->C0;
     a.N = d->N;
