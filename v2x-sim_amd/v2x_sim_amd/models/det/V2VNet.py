@@ -74,7 +74,7 @@ class V2VNet(IntermediateModelBase):
                 if j != a:
                     coef[m, j] = 1.0
         full = len(items) == A * batch_size
-        return {"items": torch.tensor(items, dtype=torch.int32, device=device),
+        return {"items": ops.items_tensor(items, A, batch_size, device),
                 "coef": coef.to(device), "rows": None if full else torch.tensor(rows, device=device),
                 "n_items": len(items)}
 

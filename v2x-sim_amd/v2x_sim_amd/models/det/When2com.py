@@ -116,7 +116,7 @@ class When2com(IntermediateModelBase):
             mask[m, :counts[f]] = 1.0
         full = len(items) == A * batch_size
         it = torch.tensor(items, dtype=torch.int64)
-        return {"items": torch.tensor(items, dtype=torch.int32, device=device), "mask": mask.to(device),
+        return {"items": ops.items_tensor(items, A, batch_size, device), "mask": mask.to(device),
                 "rows": None if full else torch.tensor(rows, device=device),
                 "q_idx": it[:, 0].to(device), "f_idx": it[:, 1].to(device)}
 

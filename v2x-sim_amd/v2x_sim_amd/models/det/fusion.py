@@ -33,7 +33,7 @@ class FusionBase(IntermediateModelBase):
         for m, (a, f) in enumerate(items):
             coef[m, :counts[f]] = 1.0        # ego included
         full = len(items) == A * batch_size
-        return {"items": torch.tensor(items, dtype=torch.int32, device=device), "coef": coef.to(device),
+        return {"items": ops.items_tensor(items, A, batch_size, device), "coef": coef.to(device),
                 "rows": None if full else torch.tensor(rows, device=device)}
 
     def post_fusion(self, ego, fused, pk):

@@ -554,6 +554,21 @@ def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
     return out
 
 
+def items_tensor(items, A, Bt, device):
+    """(n_out, 2) int32 device tensor of the (ego, frame) pairs of a fusion plan, with the frame-ordered table v2x_warp_fuse_ordered walks
+    attached (built here on the host, where the list is: no device round trip later)."""
+    t = torch.tensor(items, dtype=torch.int32, device=device).view(-1, 2)
+    order = [-1] * (A * Bt)
+    ok = True
+    for m, (a, f) in enumerate(items):
+        if not (0 <= a < A and 0 <= f < Bt) or order[f * A + a] >= 0:
+            ok = False                       # outside the table, or listed twice: the plain grid
+            break
+        order[f * A + a] = m
+    t._v2x_frame_order = torch.tensor(order, dtype=torch.int32, device=device).view(Bt, A) if ok and len(items) else False
+    return t
+
+
 def _warp_frame_order(items, A, Bt):
     """(Bt, A) int32 table: the output map of (frame, ego), -1 where there is none -- what v2x_warp_fuse_ordered walks so that the output maps
     of one frame (which all read the same A source maps) are computed by one XCD and share its L2.  Built once per items tensor (the fusion plan

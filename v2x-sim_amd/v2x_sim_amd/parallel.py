@@ -54,7 +54,7 @@ class AgentShard:
                 coef.append([1.0 if (j != a and j < counts[f]) else 0.0 for j in range(self.A)])
         items = [self.items[i] for i in sel]
         full = len(sel) == self.per_rank
-        return {"items": torch.tensor(items, dtype=torch.int32, device=device).view(-1, 2),
+        return {"items": ops.items_tensor(items, self.A, self.Bt, device),
                 "coef": torch.tensor(coef, dtype=torch.float32, device=device).view(-1, self.A),
                 "local_rows": None if full else torch.tensor(sel, device=device), "n": len(sel)}
 
@@ -295,7 +295,7 @@ class ShardedWhen2com:
         for m, (a, f) in enumerate(items):
             mask[m, :counts[f]] = 1.0
         it = torch.tensor(items, dtype=torch.int64).view(-1, 2)
-        return {"items": torch.tensor(items, dtype=torch.int32, device=device).view(-1, 2), "mask": mask.to(device),
+        return {"items": ops.items_tensor(items, sh.A, sh.Bt, device), "mask": mask.to(device),
                 "local_rows": None if len(sel) == sh.per_rank else torch.tensor(sel, device=device),
                 "q_idx": it[:, 0].to(device), "f_idx": it[:, 1].to(device), "counts": counts}
 
