@@ -428,6 +428,16 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if mode in (1, 4) and active and not use_dist:
+        # the graphs' outputs (the last replay; the two halves ran concurrently in mode 1) against an eager, one-stream recomputation of the same
+        # step: every kernel is deterministic and the halves are independent, so the logits must agree bit for bit
+        ref = step()
+        torch.cuda.synchronize()
+        for h, r in zip(halves, ref):
+            for k in ("cls", "loc"):
+                if not torch.equal(h["out"][k], r[k]):
+                    raise SystemExit("bench.py: the hipGraph step's %s logits differ from the eager step's" % k)
+        del ref
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
