@@ -160,9 +160,9 @@ typedef struct v2x_conv_desc {
     int32_t *det_counts; /* V2X_EPI_DET only (else NULL / 0): candidate counters [N], score threshold, slots per map   */
     float det_thr;
     int32_t det_cap;     /*    <= 4096                                                                              */
-    int32_t splitk;      /* > 1 (w_layout 2, stride 1, no chained layer): small-batch form -- the 32-channel chunks are divided */
+    int32_t splitk;      /* > 1 (w_layout 2, stride 1 or 2, no chained layer): small-batch form -- the 32-channel chunks are divided */
     float *splitk_ws;    /*    into `splitk` contiguous ranges computed by different workgroups; fp32 workspace                   */
-                         /*    [splitk][N*H*W][w_rows], caller-owned.  The partial sums are added in range order (deterministic;  */
+                         /*    [splitk][N*Ho*Wo][w_rows] (output pixels), caller-owned.  The partial sums are added in range order (deterministic;  */
                          /*    fp32 summation order differs from the unsplit kernels: one bf16 rounding of the output).  Needs    */
                          /*    splitk <= (C0 + C1) / 32 with no empty range: ceil(chunks / splitk) * (splitk - 1) < chunks.        */
 } v2x_conv_desc;

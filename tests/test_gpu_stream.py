@@ -446,3 +446,37 @@ def test_gru_xcd_walk_is_a_pure_reordering(device, tune):
         ref = ops.conv2d(pc, x0, x1)
         tune("GRU_XCD_WALK", 1)
         assert torch.equal(ops.conv2d(pc, x0, x1), ref)
+
+
+@pytest.mark.parametrize("cfg", [(256, 512, 5, 32, 32), (128, 256, 5, 64, 64), (256, 128, 3, 16, 64), (128, 64, 2, 32, 32)])
+def test_stride2_split_k_form_vs_torch_and_unsplit(device, cfg, tune):
+    """Latency mode for the stride-2 layers (conv4_1 / conv3_1 at one frame): the 1-tap stride-2 kernel with the chunk range divided over
+    blockIdx.y + splitk_reduce_kernel.  Every legal split agrees with torch fp32 on the same bf16 operands and with the unsplit kernel to one bf16
+    rounding (fp32 summation order), is bit-stable, and ops.small_batch_splitk picks a split only with SMALL_BATCH = 1."""
+    from v2x_sim_amd import ops, packing
+    C, Cout, N, H, W = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = bf16r(torch.randn(N, C, H, W, generator=g))
+    w = torch.randn(Cout, C, 3, 3, generator=g) * (2.0 / (C * 9)) ** 0.5
+    scale, shift = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    ref = F.relu(F.conv2d(x, bf16r(w), None, 2, 1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = packing.pack_conv_stream("s2", w, scale, shift, C0=C, stride=2, device=device)
+    xd = nhwc(x, device)
+    tune("S2_G", 0)
+    base = ops.conv2d(pc, xd)
+    chunks = C // 32
+    for sk in range(2, chunks + 1):
+        if -(-chunks // sk) * (sk - 1) >= chunks:
+            continue                                   # an empty range: the library refuses it
+        y = ops.conv2d(pc, xd, splitk=sk)
+        assert torch.equal(ops.conv2d(pc, xd, splitk=sk), y)
+        got = back(y)
+        assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), (sk, float((got - ref).abs().max()))
+        assert torch.allclose(got, back(base), atol=2e-3, rtol=2 ** -7) and float((y != base).float().mean()) < 0.02
+    tune("SMALL_BATCH", 0)
+    assert ops.small_batch_splitk(pc, N, H, W) == 0
+    tune("SMALL_BATCH", 1)
+    sk = ops.small_batch_splitk(pc, N, H, W)
+    assert sk == 0 or (2 <= sk <= chunks // 2)
+    if C == 256 and Cout == 512:
+        assert sk == 4                                  # conv4_1 at one frame: 40 tiles, 8 chunks

@@ -1898,6 +1898,16 @@ static int launch_stream_splitk(const StreamArgs &a, hipStream_t s) {
     return V2X_OK;
 }
 
+// the plain-epilogue reduce of a split-K launch, for the stride-2 kernel's split form (conv_stream_s2.hip)
+int v2x_launch_splitk_reduce(const float *ws, int ksplit, long long npix, int w_rows, int Cout, const float *scale, const float *shift, int relu,
+                             uint16_t *out, int out_cstride, int out_coff, hipStream_t s) {
+    const long long threads = npix * (Cout / 4);
+    const int grid = (int)((threads + 255) / 256 < 4096 ? (threads + 255) / 256 : 4096);
+    hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(grid), dim3(256), 0, s, ws, ksplit, npix, w_rows, Cout, scale, shift, relu, out, out_cstride, out_coff);
+    V2X_CHECK_LAUNCH("splitk_reduce_kernel");
+    return V2X_OK;
+}
+
 // rows per channel tile the stream kernel uses for (Cout, epilogue); 0 = unsupported
 extern "C" int v2x_conv_stream_tile_rows(int Cout, int epilogue) {
     if (epilogue == V2X_EPI_GRU) return (Cout % 32 == 0) ? 96 : 0;

@@ -51,6 +51,11 @@ struct S2Args {
     int out_cstride, out_coff, Cout;
     int tiles_x, tiles_y, n_px_tiles, n_co_tiles;
     int xcd_walk;         // resident form: 1 = XCD-contiguous tile walk (tuning switch HALO_XCD)
+    // split-K (latency mode, conv3x3_s2_stream_kernel<..., SPLITK = true>): blockIdx.y walks `ksplit` contiguous ranges of the 32-channel chunks and
+    // stores its raw fp32 sums to ws[split][pixel][w_rows]; splitk_reduce_kernel (conv_stream.hip) adds them in split order and applies the epilogue
+    int ksplit;
+    float *ws;
+    int w_rows;
 };
 
 constexpr int S2_TH = 4, S2_TW = 32;
@@ -83,7 +88,7 @@ __device__ __forceinline__ void s2_wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BCO, int TH = S2_TH, int TW = S2_TW>
+template <int BCO, int TH = S2_TH, int TW = S2_TW, bool SPLITK = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void conv3x3_s2_stream_kernel(const S2Args a) {
     using G = S2Geom<TH, TW>;
     constexpr int TCO = BCO / 16;
@@ -117,8 +122,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int y0 = ty * TH, x0 = tx * TW;       // output coordinates
 
     const int nchunks = a.C >> 5;
-    const int S = nchunks * 9;
-    const uint16_t *wbase = a.w + (size_t)co_tile * nchunks * 9 * (BCO * 32);
+    // SPLITK: this workgroup walks the chunks [kc_lo, kc_hi) of the layer's K (blockIdx.y = its range)
+    const int kper = SPLITK ? (nchunks + a.ksplit - 1) / a.ksplit : nchunks;
+    const int kc_lo = SPLITK ? (int)blockIdx.y * kper : 0;
+    const int kc_hi = SPLITK ? (kc_lo + kper < nchunks ? kc_lo + kper : nchunks) : nchunks;
+    const int S = (kc_hi - kc_lo) * 9;
+    const uint16_t *wbase = a.w + ((size_t)co_tile * nchunks + kc_lo) * 9 * (BCO * 32);
     const void *zero_page = a.w + (size_t)a.n_co_tiles * nchunks * 9 * (BCO * 32);
     // scale/shift rows of this channel tile in LDS (read in the epilogue, many barriers later): a global load between the
     // stores of two channel tiles can only be waited for together with those stores (in-order vmcnt)
@@ -185,9 +194,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     issue_weights(2);
 
     int s = 0;
-    for (int kc = 0; kc < nchunks; ++kc) {
+    for (int kc = kc_lo; kc < kc_hi; ++kc) {
         // ---- chunk boundary: everyone has left the previous chunk's patch (and ring slot s-1) -> refill, drain, meet
-        if (kc > 0) __builtin_amdgcn_s_barrier();
+        if (kc > kc_lo) __builtin_amdgcn_s_barrier();
         issue_patch(kc);
         s2_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -224,6 +233,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     // ---- epilogue: BN / ReLU, bf16, 8-byte NHWC stores
     const int Ho = a.H >> 1, Wo = a.W >> 1;
+    if constexpr (SPLITK) {
+        // raw fp32 sums of this chunk range: ws[split][pixel][w_rows], 16 bytes per lane (4 channels of its pixel)
+        const size_t npix = (size_t)a.N * Ho * Wo;
+#pragma unroll
+        for (int i = 0; i < TCO; ++i) {
+            const int co = co_tile * BCO + i * 16 + fq * 4;
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const size_t pix = (size_t)(n * Ho + y0 + (f ? frow1 : frow0)) * Wo + x0 + (TW == 32 ? f * 16 : 0) + fj;
+                *reinterpret_cast<f32x4_t *>(a.ws + ((size_t)blockIdx.y * npix + pix) * a.w_rows + co) = acc[i][f];
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
         const int co = co_tile * BCO + i * 16 + fq * 4;
@@ -780,6 +803,23 @@ static int launch_s2_resident(const S2Args &a, hipStream_t s) {
     return V2X_OK;
 }
 
+int v2x_launch_splitk_reduce(const float *ws, int ksplit, long long npix, int w_rows, int Cout, const float *scale, const float *shift, int relu,
+                             uint16_t *out, int out_cstride, int out_coff, hipStream_t s);   // conv_stream.hip
+
+template <int BCO, int TH, int TW>
+static int launch_s2_splitk(const S2Args &a, hipStream_t s) {
+    constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES + 2 * BCO * 4;
+    static v2x_once_per_device attr_once;
+    auto kern = &conv3x3_s2_stream_kernel<BCO, TH, TW, true>;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_px_tiles * a.n_co_tiles, a.ksplit), dim3(256), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_s2_stream_kernel (split-K)");
+    return v2x_launch_splitk_reduce(a.ws, a.ksplit, (long long)a.N * (a.H / 2) * (a.W / 2), a.w_rows, a.Cout, a.scale, a.shift, a.relu, a.out,
+                                    a.out_cstride, a.out_coff, s);
+}
+
 template <int BCO, int TH = S2_TH, int TW = S2_TW>
 static int launch_s2(const S2Args &a, hipStream_t s) {
     constexpr int smem = S2_RING * BCO * 64 + S2_PATCH_BYTES + 2 * BCO * 4;
@@ -820,6 +860,17 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.tiles_y = (d->H / 2) / (t32 ? S2_TH : 8);
     a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
     a.n_co_tiles = d->Cout / rows;
+    a.ksplit = d->splitk;
+    a.ws = d->splitk_ws;
+    a.w_rows = d->w_rows;
+    if (d->splitk > 1) {
+        // latency mode: the 1-tap kernel with the chunk range divided over blockIdx.y + the reduce kernel (sums added in split order: results differ
+        // from the unsplit kernels in fp32 summation order).  Every split at least one chunk.
+        const int nchunks = d->C0 >> 5, per = (nchunks + d->splitk - 1) / d->splitk;
+        if (!d->splitk_ws || d->splitk > nchunks || per * (d->splitk - 1) >= nchunks) return 1;
+        if (t16) return rows == 128 ? launch_s2_splitk<128, 8, 16>(a, s) : launch_s2_splitk<64, 8, 16>(a, s);
+        return rows == 128 ? launch_s2_splitk<128, S2_TH, S2_TW>(a, s) : launch_s2_splitk<64, S2_TH, S2_TW>(a, s);
+    }
     // 8-wave three-tap form: 128-row tiles, >= 2 chunks, 256-pixel output tiles (8 x 32, or 16 x 16 for the 16 x 16 maps), and enough
     // tiles for four rounds of the persistent grid (one workgroup per CU: at 2.5 tiles per workgroup -- conv2_1 at 8 frames -- the
     // 128-pixel kernel with twice the workgroups is 20 % faster)

@@ -338,7 +338,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
         prof = _Prof(conv_kernel_name(pc, H, W, from_bits, N) if splitk <= 1 else
-                     "conv3x3_stream_kernel<%d, split-K %d> + splitk_reduce" % (lib.v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue), splitk),
+                     "conv3x3_%sstream_kernel<%d, split-K %d> + splitk_reduce" % ("s2_" if pc.stride == 2 else "", lib.v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue), splitk),
                      flops, nbytes, pc.name)
     rc = lib.v2x_conv2d(C.byref(d), _stream())
     if prof is not None:
@@ -758,11 +758,26 @@ def small_batch_splitk(pc, N, H, W):
     chunks divided over `splitk` workgroups per tile (partial sums added by splitk_reduce_kernel in range order) the same layer runs on
     ~240.  The switch is EXPLICIT, never derived from the batch inside a model: the split changes the fp32 summation order (one bf16
     rounding of the output), and kernel selection that followed the item count would break the R-rank == 1-rank bitwise equality."""
-    if pc.w_layout != 2 or pc.stride != 1 or tuning.get("SMALL_BATCH") == 0:
+    if pc.w_layout != 2 or pc.stride not in (1, 2) or tuning.get("SMALL_BATCH") == 0:
         return 0
     rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
     if rows not in (64, 96, 128):
         return 0
+    if pc.stride == 2:
+        # the 1-tap stride-2 kernel (128 output pixels per workgroup): conv4_1 at one frame is 20-40 workgroups walking 8 chunks each (34 us);
+        # conv1_1 (one chunk, resident form) and conv2_1 (two chunks) are never split
+        if pc.C1 or pc.up0 or pc.Cout2 or pc.epilogue != V2X_EPI_BF16 or pc.w_rows != pc.Cout:
+            return 0
+        if not ((H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0)):
+            return 0
+        tiles = N * ((H // 2) * (W // 2) // 128) * (pc.Cout // rows)
+        chunks = pc.C0 // 32
+        if tiles >= 200 or chunks < 8:                 # (conv3_1, 4 chunks: two ranges + the reduce launch 21 us against 20 unsplit)
+            return 0
+        want = min(chunks // 2, -(-320 // tiles))
+        while want > 1 and -(-chunks // want) * (want - 1) >= chunks:
+            want -= 1
+        return want if want > 1 else 0
     t16 = W % 32 != 0
     if (t16 and (W % 16 or H % 16)) or (not t16 and H % 8):
         return 0
@@ -805,7 +820,7 @@ def run_layer(layer, in0, in1=None, zbits=0):
     if h is not None and h.stride == 2:
         # stride-2 streamed kernel: 4x32 output tiles, or 8x16 ones for narrow maps (conv4_1: 16x16 outputs)
         if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and tuning.get("S2_T16") != 0):
-            return conv2d(h, in0, in1, split=layer.split)
+            return conv2d(h, in0, in1, split=layer.split, splitk=small_batch_splitk(h, in0.shape[0], H, W))
     elif h is not None and halo_eligible(H, W, h.w_layout, max(h.C0, h.C1 or 0)):
         use = True
         if h.w_layout == 2:
