@@ -152,3 +152,30 @@ def test_param_version_sees_fused_optimizer_steps():
         opt.step()
         v1 = packing.param_version(p)
         assert v1 != v0 and v1[1] == v0[1] + 1, (fused, v0, v1)
+
+
+def test_unhookable_optimizer_is_stamped_by_stepped():
+    """An optimizer object without register_step_post_hook cannot be watched; the training loops call packing.stepped(opt) after opt.step(), which
+    stamps the parameters itself (and does nothing for a watched optimizer, whose hook already did)."""
+    import torch
+    from v2x_sim_amd import packing
+
+    class Bare:                                  # the minimum the loops use
+        def __init__(self, params):
+            self.param_groups = [{"params": list(params)}]
+
+        def step(self):
+            pass
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = packing.watch_optimizer(Bare([p]))
+    assert not opt.__dict__.get("_v2x_watched")
+    v0 = packing.param_version(p)
+    opt.step()
+    packing.stepped(opt)
+    assert packing.param_version(p)[1] == v0[1] + 1
+    real = packing.watch_optimizer(torch.optim.SGD([p], lr=0.1))
+    p.grad = torch.ones(3)
+    v1 = packing.param_version(p)
+    real.step()
+    packing.stepped(real)
+    assert packing.param_version(p)[1] == v1[1] + 1       # once, by the hook

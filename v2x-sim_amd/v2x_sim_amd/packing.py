@@ -32,6 +32,14 @@ def note_params_changed(params):
         q._v2x_epoch = getattr(q, "_v2x_epoch", 0) + 1
 
 
+def stepped(opt):
+    """Call after opt.step() when the optimizer could not be hooked (watch_optimizer found no register_step_post_hook): stamps its parameters.
+    A no-op for a watched optimizer (its hook has already done it)."""
+    if opt is not None and not opt.__dict__.get("_v2x_watched"):
+        for g in opt.param_groups:
+            note_params_changed(g["params"])
+
+
 def watch_optimizer(opt):
     """Idempotent: after every opt.step() the packed-weight caches see the optimizer's parameters as changed."""
     if opt is None or opt.__dict__.get("_v2x_watched") or not hasattr(opt, "register_step_post_hook"):

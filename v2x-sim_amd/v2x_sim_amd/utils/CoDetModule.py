@@ -34,6 +34,7 @@ class FaFModule(object):
         """One optimisation step.  data: 'bev_seq' (A*B, 1, X, Y, Z), 'labels' (A*B, X, Y, A', 2), 'reg_targets'
         (A*B, X, Y, A', 1, 6), 'reg_loss_mask' (A*B, X, Y, A', 1), 'trans_matrices' (B, A, A, 4, 4), 'num_agent' (B, A)
         -> (loss, cls_loss, loc_loss) python floats, as upstream."""
+        from .. import packing
         from ..train import detection_loss, train_forward
         if self.optimizer is None:
             raise RuntimeError("FaFModule.step needs an optimizer")
@@ -59,6 +60,7 @@ class FaFModule(object):
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
+        packing.stepped(self.optimizer)       # (an optimizer without step hooks: stamp the parameters here)
         return loss.item(), cls_loss.item(), loc_loss.item()
 
     def _graph_key(self, data, batch_size):

@@ -26,6 +26,8 @@ class SegModule(object):
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
+        from .. import packing
+        packing.stepped(self.optimizer)       # (an optimizer without step hooks: stamp the parameters here)
         return loss.item()
 
     def predict(self, data, batch_size=1, label=None):
