@@ -867,3 +867,47 @@ def test_pack_conv1x1_device_equals_torch_packing(device, cout, cin, f32_out):
                (ref.C0, ref.C1, ref.Cout, ref.ksize, ref.stride, ref.pad, ref.epilogue, ref.relu, ref.w_rows, ref.w_kpad)
         assert torch.equal(got.weight.view(torch.int16).flatten(), ref.weight.view(torch.int16).flatten())
         assert torch.equal(got.scale, ref.scale) and torch.equal(got.shift, ref.shift)
+
+
+def test_eager_step_after_graph_replays_sees_the_replayed_weights(device, tune, monkeypatch):
+    """hipGraph replays update the parameters without touching Tensor._version.  An EAGER HIP-graph forward between / after replays (another batch
+    shape, the partial last batch of an epoch) must re-pack: its loss equals that of a fresh copy of the model (new parameter objects, nothing
+    cached).  Negative control: with the stamping of GraphedTrainStep.__call__ disabled the eager forward really does run on stale packed weights."""
+    import copy
+    from v2x_sim_amd import packing
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.graph_step import GraphedTrainStep
+    from v2x_sim_amd.train.loop import init_for_training, make_optimizer, synthetic_batch_on_device
+    tune("TRAIN_HIP", 1)
+    tune("TRAIN_GRAPH", 1)
+    cfg = Config("train", binary=True, only_det=True)
+    model = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=1).to(device).train()
+    opt, _ = make_optimizer(model, 1e-2, 100)
+    data = synthetic_batch_on_device(cfg, 1, 2, seed=3, device=device)
+
+    def eager_loss(m):
+        with torch.no_grad():
+            res = train_forward(m, data["bev_seq"], None, None, 1)
+            return float(detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0])
+    step = GraphedTrainStep(model, opt, data, 1)
+    for _ in range(2):
+        step(data)
+    l_mid = eager_loss(model)                          # fills the eager packing cache with the weights after two replays
+    real = packing.note_params_changed
+    monkeypatch.setattr(packing, "note_params_changed", lambda params: None)
+    for _ in range(3):
+        step(data)                                     # replays WITHOUT the stamp
+    torch.cuda.synchronize()
+    l_stale = eager_loss(model)
+    l_fresh_then = eager_loss(copy.deepcopy(model))
+    monkeypatch.setattr(packing, "note_params_changed", real)
+    step(data)                                         # one more replay, stamped
+    torch.cuda.synchronize()
+    l_after = eager_loss(model)
+    l_fresh = eager_loss(copy.deepcopy(model))
+    print("eager loss after 2 replays %.5f; after 3 more, unstamped: %.5f (a fresh copy of those weights: %.5f); after a stamped replay %.5f (fresh copy %.5f)"
+          % (l_mid, l_stale, l_fresh_then, l_after, l_fresh))
+    assert l_after == l_fresh
+    assert l_stale != l_fresh_then            # the control: without the stamp the convolutions ran on the packings of two replays ago

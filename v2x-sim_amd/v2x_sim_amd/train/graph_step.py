@@ -92,4 +92,9 @@ class GraphedTrainStep:
         # cache looks at (DetModelBase.packed): drop that cache so that the next model(...) call re-packs
         if hasattr(self.model, "repack"):
             self.model.repack()
+        # ... and the same for the training graph's own packed-weight cache (hip_graph._layer): an EAGER step after replays (another batch shape,
+        # the partial last batch) must not find the packings of the last eager step
+        from .. import packing
+        for g in self.optimizer.param_groups:
+            packing.note_params_changed(g["params"])
         return self.losses
