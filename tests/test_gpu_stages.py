@@ -465,7 +465,7 @@ def test_warp_fuse_frame_ordered_launch_is_bit_identical(device, ragged, tune):
     cd = torch.rand(10, A, generator=g).to(device)
     tune("WARP_XCD", 1)
     got = ops.warp_fuse(x, A, Bt, T, dup, cd, 0)
-    assert dup._v2x_frame_order is False
+    assert dup._v2x_frame_order[1] is False
     tune("WARP_XCD", 0)
     assert torch.equal(ops.warp_fuse(x, A, Bt, T, dup, cd, 0), got)
 

@@ -565,7 +565,7 @@ def items_tensor(items, A, Bt, device):
             ok = False                       # outside the table, or listed twice: the plain grid
             break
         order[f * A + a] = m
-    t._v2x_frame_order = torch.tensor(order, dtype=torch.int32, device=device).view(Bt, A) if ok and len(items) else False
+    t._v2x_frame_order = (t._version, torch.tensor(order, dtype=torch.int32, device=device).view(Bt, A) if ok and len(items) else False)
     return t
 
 
@@ -573,16 +573,17 @@ def _warp_frame_order(items, A, Bt):
     """(Bt, A) int32 table: the output map of (frame, ego), -1 where there is none -- what v2x_warp_fuse_ordered walks so that the output maps
     of one frame (which all read the same A source maps) are computed by one XCD and share its L2.  Built once per items tensor (the fusion plan
     keeps it); never inside a hipGraph capture (the table would live in the graph's private pool): the caller then takes the unordered launch."""
-    order = getattr(items, "_v2x_frame_order", None)
-    if order is None:
+    tag = getattr(items, "_v2x_frame_order", None)
+    if tag is None or tag[0] != items._version:            # (a table built for other contents of this tensor is not trusted)
         if torch.cuda.is_current_stream_capturing():
             return None
         order = torch.full((Bt, A), -1, dtype=torch.int32, device=items.device)
         order[items[:, 1].long(), items[:, 0].long()] = torch.arange(items.shape[0], dtype=torch.int32, device=items.device)
         if int((order >= 0).sum()) != items.shape[0]:
             order = False                        # an (ego, frame) pair listed twice: the table cannot hold both -> the plain grid, always
-        items._v2x_frame_order = order
-    return None if order is False else order
+        tag = (items._version, order)
+        items._v2x_frame_order = tag
+    return None if tag[1] is False else tag[1]
 
 
 # ------------------------------------------------------------------ a5
