@@ -63,6 +63,7 @@ def parse(argv=None):
     ap.add_argument("--gnn-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the streaming / MFMA calibration probes (the `calibration` sub-record)")
     ap.add_argument("--graph", type=int, default=1,
                     help="1: four hipGraph segments with the exchange between them, the two half-batches on two streams (every N); "
                          "4: the same on one stream; 0: eager launches; 2: the whole step as ONE hipGraph (N = 1 only, for comparison)")
@@ -507,6 +508,19 @@ def main():
                        "tflops": v["flops"] / max(v["ms"], 1e-9) / 1e9, "gbs": v["bytes"] / max(v["ms"], 1e-9) / 1e6}
                    for k, v in sorted(groups.items(), key=lambda kv: -kv[1]["ms"])}
 
+    # what THIS box sustains (v2x_calib_stream / v2x_calib_mfma, ~0.3 s): a streaming kernel at the read : write mixes of the HBM-bound layers and
+    # a register-resident MFMA loop on random operands, with the shader clock it held -- lets fractions and rounds be compared box-free
+    calibration = None
+    if rank == 0 and active and not args.no_calibration:
+        try:
+            from v2x_sim_amd.calibrate import calibrate
+            calibration = calibrate(dev)
+            if roofline is not None:
+                ceil = calibration["mfma_tflops"] if roofline["bound"] == "mfma" else 1e3 * min(calibration["copy_1_1_tbs"], calibration["copy_1_3_tbs"])
+                roofline["frac_of_measured_ceiling"] = roofline["achieved"] / ceil
+        except Exception as e:      # the headline record must not die with a side table
+            calibration = {"error": repr(e)}
+
     latency = configs = training = None
     if rank == 0 and world == 1 and not args.no_extras and not force_dist:
         # free the step's graphs and buffers first: the extras build their own
@@ -556,7 +570,7 @@ def main():
             "ranks_seen": ranks_seen, "exposed_exchange_ms_per_step": exposed_all,
             "exposed_exchange_note": "HIP-event time a half-batch's stream waits for its exchange; with the two half-batches on two streams the GPU runs "
                                      "the other half's kernels during that wait (one-stream order: --graph 4)",
-            "roofline": roofline, "cpu_baseline": cpu, "latency": latency, "configs": configs, "training": training, "kernels": kernels,
+            "roofline": roofline, "calibration": calibration, "cpu_baseline": cpu, "latency": latency, "configs": configs, "training": training, "kernels": kernels,
         }
     if use_dist:
         dist.destroy_process_group()

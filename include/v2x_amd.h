@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 12
+#define V2X_AMD_ABI_VERSION 13
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -165,6 +165,10 @@ typedef struct v2x_conv_desc {
                          /*    [splitk][N*Ho*Wo][w_rows] (output pixels), caller-owned.  The partial sums are added in range order (deterministic;  */
                          /*    fp32 summation order differs from the unsplit kernels: one bf16 rounding of the output).  Needs    */
                          /*    splitk <= (C0 + C1) / 32 with no empty range: ceil(chunks / splitk) * (splitk - 1) < chunks.        */
+    int32_t small_batch; /* 0 (default): the kernel form follows the layer SHAPE only, never N -- a rank that owns fewer items launches the    */
+                         /*    same kernels and produces the same bits (R-rank == 1-rank).  1: the CALLER declares a latency launch: forms    */
+                         /*    whose choice depends on the tile count may be taken (stride-2 layers: the 1-tap 128-pixel kernel instead of    */
+                         /*    the 8-wave three-tap one below 4 tiles per CU; fp32 summation order differs between the two).                 */
 } v2x_conv_desc;
 
 /* ---------------------------------------------------------------- weight layouts and their packers (HOST side)
@@ -403,6 +407,21 @@ int v2x_rotated_iou(const float *boxes_a, int na, const float *boxes_b, int nb, 
 int v2x_match_detections(const float *det_boxes, const int32_t *det_count, int det_cap, const float *gt_boxes,
                          const int32_t *gt_count, int gt_cap, int n_img, float iou_thr, int32_t *tp, float *best_iou,
                          v2x_stream_t stream);
+
+/* ---------------------------------------------------------------- d: calibration probes (measurement)
+ * No upstream counterpart.  The roofline fractions bench.py prints are graded against the datasheet peaks (8 TB/s, 2.5 PFLOP/s bf16);
+ * these two probes measure, on the box the bench runs on, what a pure streaming kernel and a pure MFMA loop sustain, so that fractions
+ * and rounds can be compared box-free (bench.py: "calibration").
+ * v2x_calib_stream: n_read read streams (src, n_read * units * 16 bytes) and n_write write streams (dst, n_write * units * 16 bytes),
+ *   16 bytes per lane, fully coalesced; mixes built: 1:1, 1:3 (the det heads), 2:1, 4:1 (conv1_1), 1:0, 0:1.  nontemporal != 0: nt loads /
+ *   stores.  wg_per_cu: persistent workgroups of 256 lanes per CU (<= 0: 8).  Bytes moved = (n_read + n_write) * units * 16.
+ * v2x_calib_mfma: one 512-lane workgroup per CU, every wave issues iters * 16 independent v_mfma_f32_16x16x32_bf16 (shape32 != 0: iters * 8
+ *   v_mfma_f32_32x32x16_bf16) on register operands; seed != 0: random operand bits (the power-limited rate), 0: constants.  *flops (HOST,
+ *   may be NULL) = FLOPs of the launch; clocks (DEVICE uint64[2], may be NULL) = shader cycles and 100-MHz ticks elapsed over one wave's loop
+ *   (sustained shader clock in MHz = 100 * clocks[0] / clocks[1]).  scratch: DEVICE, >= 512 floats. */
+int v2x_calib_stream(const void *src, void *dst, int64_t units, int n_read, int n_write, int nontemporal, int wg_per_cu,
+                     v2x_stream_t stream);
+int v2x_calib_mfma(float *scratch, int iters, uint32_t seed, int shape32, uint64_t *clocks, double *flops, v2x_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -352,7 +352,11 @@ class V2VNet(IntermediateModelBase):
         self.layer_channel = layer_channel
         self.gnn_iter_num = gnn_iter_times
         # "initial": every iteration warps the *encoder* features of the neighbours
-        # (recollected upstream behaviour); "updated": warps the previous iteration's.
+        # (recollected upstream behaviour); "updated": warps the previous iteration's;
+        # "frozen": the third reading (ASSUMPTIONS.md row 25) -- the inner loop takes the EGO map from
+        # local_com_mat[b, i] too, so every round recomputes the same update (rounds > 1 are idempotent).
+        if neighbor_source not in ("initial", "updated", "frozen"):
+            raise ValueError("neighbor_source must be 'initial', 'updated' or 'frozen'")
         self.neighbor_source = neighbor_source
         self.convgru = Conv2dGRUCell(layer_channel * 2, layer_channel, 3)
 
@@ -370,10 +374,11 @@ class V2VNet(IntermediateModelBase):
                     nb_list = []
                     for j in range(n):
                         if j != i:
-                            src = local_com_mat[b, j] if self.neighbor_source == "initial" else feats[j]
+                            src = feats[j] if self.neighbor_source == "updated" else local_com_mat[b, j]
                             nb_list.append(feature_transformation(src, all_warp[j], size))
                     mean_feat = _q(torch.mean(torch.stack(nb_list), dim=0), e)
-                    cat_feat = torch.cat([feats[i], mean_feat], dim=0).unsqueeze(0)
+                    ego = local_com_mat[b, i] if self.neighbor_source == "frozen" else feats[i]
+                    cat_feat = torch.cat([ego, mean_feat], dim=0).unsqueeze(0)
                     updated.append(self.convgru(cat_feat, None, e).squeeze(0))
                 feats = updated + feats[n:]
             for k in range(n):

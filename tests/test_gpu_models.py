@@ -105,7 +105,7 @@ def test_upperbound_full_size_points_to_logits(device):
             check(got["loc"], ref["loc"], tol, "upperbound loc emu=%s" % emu)
 
 
-@pytest.mark.parametrize("gnn_iter,source", [(1, "initial"), (2, "updated"), (3, "initial"), (3, "updated")])
+@pytest.mark.parametrize("gnn_iter,source", [(1, "initial"), (2, "updated"), (3, "initial"), (3, "updated"), (3, "frozen")])
 def test_v2vnet(device, gnn_iter, source):
     from v2x_sim_amd.models.det import V2VNet
     A, B = 5, 1

@@ -155,6 +155,16 @@ def _rand_boxes(rng, n, spread=3.0):
                      rng.uniform(0.5, 5.0, n), rng.uniform(-math.pi, math.pi, n)], 1).astype(np.float32)
 
 
+def test_rotated_iou_kernel_closed_form_known_answers(device):
+    """v2x_rotated_iou against the hand-computable answers of tests/iou_kats.py (fp32 boxes in, fp64 clip inside: 1e-6)."""
+    from iou_kats import IOU_KATS
+    a = torch.tensor([k[0] for k in IOU_KATS], dtype=torch.float32, device=device)
+    b = torch.tensor([k[1] for k in IOU_KATS], dtype=torch.float32, device=device)
+    got = ops.rotated_iou(a, b).cpu().numpy()
+    for i, (_, _, want, what) in enumerate(IOU_KATS):
+        assert abs(got[i, i] - want) < 2e-6, (what, got[i, i], want)
+
+
 def test_rotated_iou_kernel_vs_oracle(device):
     """v2x_rotated_iou (Sutherland-Hodgman in fp64 on the device) against the oracle's vertex-collection IoU on 60 x 50 random
     box pairs + the degenerate poses (identical, contained, edge contact, 90-degree turns)."""

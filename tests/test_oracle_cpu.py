@@ -186,6 +186,14 @@ def test_v2vnet_iterations_and_sources():
         om.neighbor_source = "updated"
         u_upd = om.fuse(lcm, T, torch.full((1, A), A), 1)
         assert not torch.allclose(u_init, u_upd)
+        # third reading (ASSUMPTIONS.md row 25): the ego map also from the encoder maps -> every round recomputes round 1
+        om.neighbor_source = "frozen"
+        u_frz = om.fuse(lcm, T, torch.full((1, A), A), 1)
+        om.gnn_iter_num, om.neighbor_source = 1, "initial"
+        u_one = om.fuse(lcm, T, torch.full((1, A), A), 1)
+        assert torch.equal(u_frz, u_one) and not torch.allclose(u_frz, u_init)
+        from v2x_sim_amd.configs import Config
+        assert type(pm)(Config("train"), gnn_iter_times=3, num_agent=A, neighbor_source="frozen").gnn_rounds() == 1
         # 2 real agents + 1 padding agent: the padding agent keeps its encoder features
         om.gnn_iter_num, om.neighbor_source = 1, "initial"
         u2 = om.fuse(lcm, T, torch.tensor([[2, 2, 2]]), 1)

@@ -42,6 +42,17 @@ def test_rotated_iou_three_algorithms_agree():
     assert P.rotated_iou(P.box_corners(np.array([base]))[0], P.box_corners(np.array([touch]))[0]) < 1e-9
 
 
+def test_rotated_iou_closed_form_known_answers():
+    """The referee itself anchored to arithmetic (tests/iou_kats.py): identical boxes, concentric squares at 30 / 45 / 60 degrees (octagon
+    formula), half-side shifts, a cross, containment, edge / corner contact, disjoint -- oracle, product and raster estimator."""
+    from iou_kats import IOU_KATS
+    for a, b, want, what in IOU_KATS:
+        a, b = tuple(float(v) for v in a), tuple(float(v) for v in b)
+        assert abs(PR.rotated_iou(PR.corners_of(a), PR.corners_of(b)) - want) < 1e-9, what
+        assert abs(P.rotated_iou(P.box_corners(np.array([a]))[0], P.box_corners(np.array([b]))[0]) - want) < 1e-9, what
+        assert abs(PR.raster_iou(a, b, n=1200) - want) < 3e-3, what
+
+
 def _blob_logits(rng, X, Y, A, n_obj):
     cls = np.zeros((X, Y, A, 2), np.float32)
     cls[..., 0] = 2.0 + rng.normal(0, 0.3, (X, Y, A))

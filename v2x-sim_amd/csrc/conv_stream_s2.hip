@@ -871,14 +871,18 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
         if (t16) return rows == 128 ? launch_s2_splitk<128, 8, 16>(a, s) : launch_s2_splitk<64, 8, 16>(a, s);
         return rows == 128 ? launch_s2_splitk<128, S2_TH, S2_TW>(a, s) : launch_s2_splitk<64, S2_TH, S2_TW>(a, s);
     }
-    // 8-wave three-tap form: 128-row tiles, >= 2 chunks, 256-pixel output tiles (8 x 32, or 16 x 16 for the 16 x 16 maps), and enough
-    // tiles for four rounds of the persistent grid (one workgroup per CU: at 2.5 tiles per workgroup -- conv2_1 at 8 frames -- the
-    // 128-pixel kernel with twice the workgroups is 20 % faster)
+    // 8-wave three-tap form: 128-row tiles, >= 2 chunks, 256-pixel output tiles (8 x 32, or 16 x 16 for the 16 x 16 maps).  The choice follows
+    // the layer SHAPE only: the two forms differ in fp32 summation order, and a choice that followed N (the items a rank owns) would break the
+    // R-rank == 1-rank bitwise equality and give one frame different bits in a small batch than in a large one.  Only a caller that DECLARES a
+    // latency launch (desc->small_batch, the host's SMALL_BATCH mode) gets the batch-dependent rule: below four rounds of the persistent grid
+    // (one workgroup per CU: at 2.5 tiles per workgroup -- conv2_1 at 8 frames) the 128-pixel kernel with twice the workgroups is 20 % faster.
+    // (The N * H * W bound is the kernel's 32-bit pixel arithmetic, 2^26 input pixels = 1 024 maps of 256 x 256: maps, not items per rank, in
+    // practice -- the host never batches that many, and a slice of such a batch falls under it on every rank alike.)
     if (rows == 128 && d->C0 >= 64 && v2x_tune(V2X_TUNE_S2_G) != 0 && (long long)d->N * d->H * d->W < (1ll << 26)) {
         const int Ho = d->H / 2, Wo = d->W / 2;
         const bool g32 = Ho % 8 == 0 && Wo % 32 == 0, g16 = !g32 && Ho % 16 == 0 && Wo % 16 == 0;
         const long long tiles = (long long)d->N * (Ho * Wo / 256) * (d->Cout / 128);
-        if ((g32 || g16) && (tiles >= 4 * v2x_num_cus() || v2x_tune(V2X_TUNE_S2_G) == 2)) {
+        if ((g32 || g16) && !(d->small_batch && tiles < 4 * v2x_num_cus())) {
             S2Args b = a;
             b.tiles_x = Wo / (g32 ? 32 : 16);
             b.tiles_y = Ho / (g32 ? 8 : 16);

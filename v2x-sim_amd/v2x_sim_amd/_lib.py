@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_EPI_DET = 0, 1, 2, 3
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ConvDesc(C.Structure):
@@ -31,7 +31,7 @@ class ConvDesc(C.Structure):
         ("weight2", C.c_void_p), ("scale2", C.c_void_p), ("shift2", C.c_void_p), ("relu2", C.c_int32),
         ("in_format", C.c_int32), ("in_zbits", C.c_int32),
         ("det_counts", C.c_void_p), ("det_thr", C.c_float), ("det_cap", C.c_int32),
-        ("splitk", C.c_int32), ("splitk_ws", C.c_void_p),
+        ("splitk", C.c_int32), ("splitk_ws", C.c_void_p), ("small_batch", C.c_int32),
     ]
 
 
@@ -108,6 +108,8 @@ SIGNATURES = {
     "v2x_rotated_iou": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_match_detections": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float,
                                         C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_calib_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "v2x_calib_mfma": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_void_p]),
     "v2x_seg_argmax_confusion": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                             C.c_void_p, C.c_void_p]),
 }

@@ -3,6 +3,7 @@
 share this network and differ only in the input cloud (ego-only vs. early-fused)."""
 import torch.nn as nn
 
+from ... import ops
 from .base import LidarDecoder, LidarEncoder, NonIntermediateModelBase
 
 
@@ -33,4 +34,5 @@ class FaFNet(NonIntermediateModelBase):
 
     def forward(self, bevs, maps=None, vis=None, batch_size=None):
         """bevs: (batch*agents, 1, 256, 256, 13) dense occupancy, as the reference Dataset yields."""
-        return self.forward_nhwc(self._input_nhwc(bevs))
+        with ops.latency_dispatch():     # the plain single-GPU entry: small batches take the latency forms (ops.latency_launches)
+            return self.forward_nhwc(self._input_nhwc(bevs))

@@ -40,8 +40,11 @@ class V2VNet(IntermediateModelBase):
                  compress_level=0, only_v2i=False, neighbor_source="initial"):
         super().__init__(config, layer, in_channels, kd_flag=0, num_agent=num_agent,
                          compress_level=compress_level, only_v2i=only_v2i)
-        if neighbor_source not in ("initial", "updated"):
-            raise ValueError("neighbor_source must be 'initial' or 'updated'")
+        # which maps a GNN round reads (oracle/ASSUMPTIONS.md row 25, three readings of upstream's inner loop): "initial" = neighbours from the
+        # encoder maps, ego from the previous round; "updated" = both from the previous round (the paper); "frozen" = both from the encoder maps,
+        # i.e. every round recomputes round 1 (idempotent) -- run once here, whatever gnn_iter_times says
+        if neighbor_source not in ("initial", "updated", "frozen"):
+            raise ValueError("neighbor_source must be 'initial', 'updated' or 'frozen'")
         self.layer_channel = layer_channel
         self.gnn_iter_num = gnn_iter_times
         self.neighbor_source = neighbor_source
@@ -58,6 +61,10 @@ class V2VNet(IntermediateModelBase):
                     packing.pack_gru_stream("convgru", g.weight_ih_l0, g.bias_ih_l0, g.bias_hh_l0,
                                             C0=self.layer_channel, C1=self.layer_channel, device=device)
                     if (self.layer_channel % 32 == 0 and packing.STREAM_KERNEL) else None, name="convgru")}
+
+    def gnn_rounds(self):
+        """Rounds that are actually computed: 'frozen' repeats round 1 bit for bit, so one."""
+        return 1 if self.neighbor_source == "frozen" else self.gnn_iter_num
 
     # ---- fusion stage (rows a3 + a4) ------------------------------------------------------
     def make_plan(self, num_agent_tensor, batch_size, device):
@@ -84,8 +91,8 @@ class V2VNet(IntermediateModelBase):
         trans = trans_matrices.to(torch.float32).contiguous()
         rows = plan["rows"]
         cur = feat
-        for _ in range(self.gnn_iter_num):
-            src = feat if self.neighbor_source == "initial" else cur
+        for _ in range(self.gnn_rounds()):
+            src = cur if self.neighbor_source == "updated" else feat
             mean = ops.warp_fuse(src, A, batch_size, trans, plan["items"], plan["coef"], V2X_FUSE_MEAN)
             ego = cur if rows is None else cur.index_select(0, rows)
             h = ops.run_layer(pk["gru"], ego, mean)
@@ -106,4 +113,5 @@ class V2VNet(IntermediateModelBase):
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
         """bevs (A*B, 1, 256, 256, 13) agent-major; trans_matrices (B, A, A, 4, 4); num_agent_tensor (B, A)."""
-        return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)
+        with ops.latency_dispatch():     # the plain single-GPU entry: small batches take the latency forms (ops.latency_launches)
+            return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)

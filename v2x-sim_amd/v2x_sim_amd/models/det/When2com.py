@@ -171,7 +171,8 @@ class When2com(IntermediateModelBase):
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, maps=None, vis=None, training=True, MO_flag=True,
                 inference="activated", batch_size=1):
-        res = self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, training, inference,
-                                batch_size)
+        with ops.latency_dispatch():
+            res = self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, training, inference,
+                                    batch_size)
         res["num_connect"] = self.num_connect(res["coef"], self.agent_num)
         return res

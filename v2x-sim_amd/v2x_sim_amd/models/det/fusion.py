@@ -60,7 +60,8 @@ class FusionBase(IntermediateModelBase):
         return self.decode_heads(pk, feats)
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
-        return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)
+        with ops.latency_dispatch():
+            return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)
 
 
 class SumFusion(FusionBase):

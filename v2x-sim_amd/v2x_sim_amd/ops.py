@@ -38,6 +38,33 @@ class _Prof:
             PROFILE.append(self.rec)
 
 
+# Latency dispatch.  Kernel forms whose choice depends on the NUMBER of maps in a launch (split-K of the streamed layers, the 1-tap stride-2
+# kernel below four tiles per CU) change the fp32 summation order, so they are never taken silently: the caller declares a latency launch.
+# tuning SMALL_BATCH: 0 never; 1 every launch of the process (the explicit pin, also for the sharded runners); 2 (default) only inside a
+# `with ops.latency_dispatch():` block -- the plain single-GPU model classes enter one in forward(), the sharded runners (R-rank == 1-rank
+# bitwise) never do.
+_latency_depth = 0
+
+
+class latency_dispatch:
+    """Context manager: launches inside are declared latency launches (see above)."""
+
+    def __enter__(self):
+        global _latency_depth
+        _latency_depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        global _latency_depth
+        _latency_depth -= 1
+        return False
+
+
+def latency_launches():
+    sb = tuning.get("SMALL_BATCH")
+    return sb == 1 or (sb == 2 and _latency_depth > 0)
+
+
 _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 128: (128, 128, 2, 2), 96: (96, 128, 2, 2)}
 
 
@@ -53,7 +80,7 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
             g32 = Ho % 8 == 0 and Wo % 32 == 0
             g16 = not g32 and Ho % 16 == 0 and Wo % 16 == 0
             tiles = N * (Ho * Wo // 256) * (pc.Cout // 128)
-            if (g32 or g16) and (s2g == 2 or tiles >= 4 * torch.cuda.get_device_properties(0).multi_processor_count):
+            if (g32 or g16) and not (latency_launches() and tiles < 4 * torch.cuda.get_device_properties(0).multi_processor_count):
                 return "conv3x3_s2g_kernel<%s>" % ("8, 32" if g32 else "16, 16")
         if not (H % 8 == 0 and W % 64 == 0):
             return "conv3x3_s2_stream_kernel<%d, 8, 16>" % rows    # 16 x 16 outputs (conv4_1)
@@ -329,6 +356,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
     if splitk > 1:
         ws = torch.empty((splitk, N * Ho * Wo, pc.w_rows), dtype=torch.float32, device=in0.device)
         d.splitk, d.splitk_ws = splitk, ws.data_ptr()
+    d.small_batch = 1 if latency_launches() else 0
     prof = None
     if PROFILE is not None:
         rows_logical = 3 * pc.Cout if pc.epilogue == V2X_EPI_GRU else pc.Cout
@@ -753,13 +781,14 @@ class Layer:
 
 
 def small_batch_splitk(pc, N, H, W):
-    """Latency mode (tuning switch SMALL_BATCH = 1, off by default): how many chunk ranges a streamed stride-1 layer is split into so
+    """Latency mode (a declared latency launch: latency_launches() above): how many chunk ranges a streamed stride-1 layer is split into so
     that a launch has about one workgroup per CU.  One collaborative frame is 5 maps: a 32x32 layer with 256 output channels is then 40
     tiles of 256 pixels x 128 channels on 256 CUs, each walking all its chunks (conv5_1: 216 steps) -- 117 us for 18 GFLOP.  With the
     chunks divided over `splitk` workgroups per tile (partial sums added by splitk_reduce_kernel in range order) the same layer runs on
-    ~240.  The switch is EXPLICIT, never derived from the batch inside a model: the split changes the fp32 summation order (one bf16
-    rounding of the output), and kernel selection that followed the item count would break the R-rank == 1-rank bitwise equality."""
-    if pc.w_layout != 2 or pc.stride not in (1, 2) or tuning.get("SMALL_BATCH") == 0:
+    ~240.  The mode is DECLARED by the caller, never derived from the batch inside a sharded runner: the split changes the fp32 summation
+    order (one bf16 rounding of the output), and kernel selection that followed the item count would break the R-rank == 1-rank bitwise
+    equality."""
+    if pc.w_layout != 2 or pc.stride not in (1, 2) or not latency_launches():
         return 0
     rows = _lib.load().v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue)
     if rows not in (64, 96, 128):

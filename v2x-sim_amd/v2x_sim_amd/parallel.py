@@ -226,8 +226,9 @@ class ShardedV2VNet:
         cur = local
         if gathered0 is None:
             gathered0 = self.exchange(local)
-        for it in range(m.gnn_iter_num):
-            src = gathered0 if (m.neighbor_source == "initial" or it == 0) else self.exchange_round(cur)
+        rounds = m.gnn_rounds() if hasattr(m, "gnn_rounds") else m.gnn_iter_num
+        for it in range(rounds):
+            src = gathered0 if (m.neighbor_source != "updated" or it == 0) else self.exchange_round(cur)
             mean = ops.warp_fuse(src, sh.A, sh.Bt, trans, plan["items"], plan["coef"], V2X_FUSE_MEAN)
             rows = plan["local_rows"]
             ego = cur if rows is None else cur.index_select(0, rows)

@@ -137,8 +137,8 @@ def v2v_fuse(model, feat, trans, num_agent_tensor, B, gru_conv=None):
     src, dst, tsel, cnt, rows_t = cache[key]
     Tp = trans.reshape(-1, 4, 4).index_select(0, tsel).to(feat.dtype)        # trans[f, a, j] of every (ego item, neighbour) pair
     cur = feat
-    for _ in range(model.gnn_iter_num):
-        base = feat if model.neighbor_source == "initial" else cur
+    for _ in range(model.gnn_rounds()):
+        base = cur if model.neighbor_source == "updated" else feat
         warped = warp_batch(base.index_select(0, src), Tp)
         mean = torch.zeros((len(items),) + tuple(feat.shape[1:]), device=dev, dtype=feat.dtype).index_add_(0, dst, warped) / cnt
         h = _gru_step(model.convgru, torch.cat([cur.index_select(0, rows_t), mean], 1), gru_conv)

@@ -7,8 +7,10 @@ Host-side switches (this module):
     S2_T16      1  stride-2 streamed kernel with 8x16 output tiles for narrow maps (conv4_1); 0: the gather kernel
     CONV_PAIR   1  conv_pre_1 -> conv_pre_2 as one launch from the bit grid; 0: two launches
     PP_64       1  pack the 64 -> 64 full-resolution layers for the ping-pong halo kernel (read when a model is packed)
-    SMALL_BATCH 0  latency mode: split-K for the streamed layers when a launch has fewer tiles than CUs (ops.small_batch_splitk; results
-                   differ from the default kernels by fp32 summation order), global-atomic voxeliser for fewer than 64 clouds (bit-identical)
+    SMALL_BATCH 2  latency dispatch: split-K for the streamed layers when a launch has fewer tiles than CUs (ops.small_batch_splitk) and the 1-tap
+                   stride-2 kernel below four tiles per CU; results differ from the default kernels by fp32 summation order.  0: never; 1: every
+                   launch of the process (explicit pin, also for the sharded runners); 2: only inside `with ops.latency_dispatch():`, which the
+                   plain single-GPU model classes enter in forward() -- the sharded runners never do (R-rank == 1-rank bitwise)
     TRAIN_HIP   1  training graph on the hand-written kernels (train/hip_graph.py: bf16 NHWC activations, fp32 master weights); 0: the fp32
                    PyTorch-ROCm (MIOpen) graph of train/graph.py -- upstream's precision, 5x slower
     TRAIN_GRAPH 0  with TRAIN_HIP: the whole step as one replayed hipGraph
@@ -22,7 +24,7 @@ The tests use the `tune` fixture (tests/conftest.py), which restores every value
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 0, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STREAM_M32", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR")
 
