@@ -73,6 +73,10 @@ def parse(argv=None):
                     help="spread (default): the agent-major (agent, frame) items in equal contiguous slices over ALL N ranks; "
                          "agent-per-gpu: the north_star's literal layout -- rank a < 5 owns agent a's frames, ranks >= 5 idle "
                          "(needs N >= 5; frames = frames_per_gpu * 5)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default, the headline): per-GPU work fixed, frames per step = frames_per_gpu * N; when N > 1 the strong workload is timed as "
+                         "well and printed as the sub-record `strong`.  strong: total work fixed at frames_per_gpu frames per step whatever N")
+    ap.add_argument("--no-shard-check", action="store_true", help="skip the sharded == unsharded recomputation after the timed region")
     ap.add_argument("--no-extras", action="store_true", help="skip the latency and other-config sub-records")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: launcher, rendezvous (gloo), shard plan, collective, JSON relay")
     return ap.parse_args(argv)
@@ -193,6 +197,17 @@ def dry_run(args, world, rank):
         # every map an owned ego reads (all agents of its frame) must sit at its agent-major row
         ok = torch.tensor([int(all(float(gathered[j * Bh + f, 0, 0, 0]) == j * Bh + f
                                    for _, f in plan["items"].tolist() for j in range(AGENTS)))])
+    # the rows bench.py's sharded == unsharded self-check would compare on this rank, at the weak and the strong geometry
+    n_pairs = None
+    if srank is not None:
+        n_pairs = []
+        for bh in (Bh, args.frames_per_gpu // 2):
+            if (AGENTS * bh) % sworld == 0:
+                rows = AgentShard(AGENTS, bh, srank, sworld).rows
+                frames, pairs = shard_check_plan(rows, bh)
+                good = bool(pairs) and all(rows[gi] == (ri // len(frames)) * bh + frames[ri % len(frames)] for ri, gi in pairs)
+                ok = torch.minimum(ok, torch.tensor([int(good)]))
+                n_pairs.append(len(pairs))
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
@@ -201,18 +216,22 @@ def dry_run(args, world, rank):
         print(json.dumps({"metric": "BEV frames/sec, V2VNet 5-agent detection (256x256 BEV)", "value": None, "unit": "frames/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": world,
                           "exchange_ok": bool(int(ok)), "transport": args.transport, "layout": args.layout, "active_ranks": sworld,
-                          "frames_per_step": 2 * Bh, "items_per_rank": per_rank, "elapsed_s": float(t)}), flush=True)
+                          "frames_per_step": 2 * Bh, "items_per_rank": per_rank, "elapsed_s": float(t),
+                          "strong_items_per_rank": (AGENTS * (args.frames_per_gpu // 2)) // sworld if (AGENTS * (args.frames_per_gpu // 2)) % sworld == 0 else None,
+                          "shard_check_pairs": n_pairs}), flush=True)
     return 0 if int(ok) else 1
 
 
 def measure_latency(model, dev, frames_list=(1, 8, 32), reps=30, small_batch=True):
-    """Latency mode (SURVEY.md 8d batch sizes): ONE hipGraph replay of points -> logits for `frames` collaborative frames,
-    host-synchronised per replay, median over `reps`.  small_batch: with the tuning switch SMALL_BATCH = 1 (split-K for the streamed layers
-    whose launch has fewer tiles than CUs; v2x_sim_amd/ops.py::small_batch_splitk) -- what a caller serving single frames turns on."""
+    """Latency mode (SURVEY.md 8d batch sizes): ONE hipGraph replay of points -> logits for `frames` collaborative frames, host-synchronised per
+    replay, median over `reps`.  small_batch=True: the sharded runner with the tuning switch SMALL_BATCH pinned to 1 (split-K for the streamed
+    layers whose launch has fewer tiles than CUs, v2x_sim_amd/ops.py::small_batch_splitk) -- what a sharded server turns on.  small_batch=False
+    ("default_dispatch"): the PLAIN model class out of the box -- model.forward_points(...) under the default tuning, which declares latency
+    launches by itself (SMALL_BATCH = 2)."""
     from v2x_sim_amd import tuning
-    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
-    from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
-    prev = tuning.set("SMALL_BATCH", 1 if small_batch else 0)
+    prev = tuning.get("SMALL_BATCH")
+    if small_batch:
+        tuning.set("SMALL_BATCH", 1)
     try:
         return _measure_latency(model, dev, frames_list, reps, small_batch)
     finally:
@@ -229,14 +248,20 @@ def _measure_latency(model, dev, frames_list, reps, small_batch):
         pts = torch.from_numpy(np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=5000 + r) for r in sh.rows])).to(dev)
         n_pts = torch.full((sh.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=dev)
         trans = torch.from_numpy(synthetic_poses(frames, AGENTS, seed=7)).to(dev)
-        plan = sh.fusion_plan(torch.full((frames, AGENTS), AGENTS), dev)
+        nat = torch.full((frames, AGENTS), AGENTS)
+        if small_batch:
+            plan = sh.fusion_plan(nat, dev)
+            fwd = lambda: rn.forward_points(pts, n_pts, trans, plan)     # noqa: E731
+        else:
+            plan = model.make_plan(nat, frames, dev)
+            fwd = lambda: model.forward_points(pts, n_pts, trans, nat, batch_size=frames, plan=plan)     # noqa: E731
         with torch.no_grad():
             for _ in range(2):
-                rn.forward_points(pts, n_pts, trans, plan)
+                fwd()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                res = rn.forward_points(pts, n_pts, trans, plan)
+                res = fwd()
         for _ in range(3):
             g.replay()
         torch.cuda.synchronize()
@@ -251,8 +276,259 @@ def _measure_latency(model, dev, frames_list, reps, small_batch):
         out["b%d_frames_per_s" % frames] = frames / ts[len(ts) // 2] * 1e3
         del g, res
     out["mode"] = "one hipGraph replay of points->logits per batch, host-synchronised, median of %d; %s" % (
-        reps, "SMALL_BATCH = 1 (split-K for launches with fewer tiles than CUs)" if small_batch else "default kernel dispatch (the throughput step's)")
+        reps, "sharded runner, SMALL_BATCH = 1 (split-K for launches with fewer tiles than CUs)" if small_batch else
+        "the plain model class out of the box: V2VNet.forward_points under the default tuning (SMALL_BATCH = 2: it declares latency launches itself)")
     return out
+
+
+def shard_check_plan(rows, Bh, n_frames=8):
+    """Which frames a rank recomputes unsharded, and which of its items they cover.  rows: the GLOBAL agent-major rows (agent * Bh + frame) the
+    rank owns in a half-batch of Bh frames.  -> (frames, pairs): `frames` = n_frames consecutive frames starting at the frame of the rank's first
+    item (wrapping); pairs = [(row in the unsharded n_frames-batch = agent * n_frames + k, index into the rank's own output rows)] for every
+    (agent, frames[k]) the rank owns -- never empty (the first item is always covered).  Pure host logic (tests/test_bench_launcher_cpu.py)."""
+    n_frames = min(n_frames, Bh)
+    f0 = rows[0] % Bh
+    frames = [(f0 + k) % Bh for k in range(n_frames)]
+    own = {r: i for i, r in enumerate(rows)}
+    pairs = [(a * n_frames + k, own[a * Bh + frames[k]]) for a in range(AGENTS) for k in range(n_frames) if a * Bh + frames[k] in own]
+    return frames, pairs
+
+
+class Workload:
+    """One benchmark workload: `frames_total` synthetic 5-agent frames per step over the whole job, run as two half-batches, agent-sharded over the
+    active ranks (v2x_sim_amd/parallel.py).  measure() = warm-up, hipGraph capture, the timed K steps between barriers, then the correctness
+    checks of what was timed: graph == eager (N = 1) and sharded == unsharded (every N; below)."""
+
+    def __init__(self, ctx, frames_total, capture=True):
+        from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+        from v2x_sim_amd.utils.synthetic import synthetic_points, synthetic_poses
+        self.__dict__.update(ctx)
+        args, dev, model = self.args, self.dev, self.model
+        self.capture = capture
+        self.Bt = frames_total                      # frames per step, whole job
+        self.Bh = Bh = frames_total // 2            # frames per half-batch
+        self.L = model.layer
+        # The step is two independent half-batches of Bh frames, each agent-sharded over all ranks.  Half A's exchange
+        # is started asynchronously and flies under half B's encoder; half B's flies under half A's fusion/decoder/heads.
+        # The decomposition is the same for every N (at N = 1 there is simply nothing to gather).
+        self.shard = shard = AgentShard(AGENTS, Bh, self.srank if self.active else 0, self.sworld)   # (an idle rank builds rank 0's tables and never launches)
+        self.runner = ShardedV2VNet(model, shard, group=self.sgroup, transport=args.transport)
+        if self.force_dist and self.world == 1:
+            class _ForcedWorld1(ShardedV2VNet):     # take the world > 1 code path (async RCCL all-gather) on one rank
+                def start_exchange(self, local, out=None, counts=None):
+                    local = local.contiguous()
+                    out = torch.empty_like(local) if out is None else out
+                    return out, dist.all_gather_into_tensor(out, local, async_op=True)
+            self.runner = _ForcedWorld1(model, shard)
+        self.halves = []
+        for h in range(2 if self.active else 0):
+            # synthetic sweeps of this rank's (agent, frame) items of half h, resident in HBM; the seed of an item is a function of its GLOBAL row,
+            # so that any rank can regenerate any item (check_sharding below)
+            pts = np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=self.point_seed(h, r)) for r in shard.rows])
+            self.halves.append({"points": torch.from_numpy(pts).to(dev),
+                                "n_pts": torch.full((shard.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=dev),
+                                "trans": torch.from_numpy(synthetic_poses(Bh, AGENTS, seed=99 + h)).to(dev),
+                                "plan": shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), dev)})
+        self.wait_events = []    # (start, end) HIP events around the stream-level wait for an exchange: the EXPOSED part of it
+        self.mode = args.graph if self.active else -1
+        self.exec_mode = None
+        self.run = None
+
+    @staticmethod
+    def point_seed(h, row):
+        return 1000 + 100000 * h + row
+
+    def timed_wait(self, work):
+        if work is None:
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self.runner.wait(work)
+        e1.record()
+        self.wait_events.append((e0, e1))
+
+    def step(self):
+        runner = self.runner
+        with torch.no_grad():
+            a, b = self.halves
+            fa, ga, wa = runner.begin(a["points"], a["n_pts"])
+            fb, gb, wb = runner.begin(b["points"], b["n_pts"])
+            self.timed_wait(wa)
+            out_a = runner.decode(fa, ga, a["trans"], a["plan"])
+            self.timed_wait(wb)
+            out_b = runner.decode(fb, gb, b["trans"], b["plan"])
+            return out_a, out_b
+
+    def barrier(self):
+        if self.use_dist:
+            dist.barrier()
+
+    def release(self):
+        """Drop the graphs and buffers (the next workload / the extras build their own)."""
+        for h in self.halves:
+            for k in ("g_enc", "g_dec", "feats", "out", "xbuf", "points"):
+                h.pop(k, None)
+        self.run = self.last_out = None
+        torch.cuda.empty_cache()
+
+    def build(self):
+        args, dev, runner, halves, shard, L = self.args, self.dev, self.runner, self.halves, self.shard, self.L
+        use_dist, mode = self.use_dist, self.mode
+        for _ in range((max(args.warmup, 1) if args.graph else args.warmup) if self.active else 0):
+            self.last_out = self.step()
+        torch.cuda.synchronize()
+        self.barrier()          # every rank's warm-up collectives are finished before anybody starts capturing
+        self.wait_events.clear()
+        if mode == 2 and use_dist:
+            raise SystemExit("--graph 2 (whole step in one hipGraph) is for N = 1 without V2X_FORCE_DIST")
+        if mode == 2:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.last_out = self.step()
+            self.run = g.replay
+            self._g = g
+            self.exec_mode = "one hipGraph per step"
+        elif mode in (1, 4):
+            # four collective-free segments (encoder A, encoder B, fusion + decoder + heads A, B), each a hipGraph; the exchange (RCCL, eager) runs
+            # between them on static buffers.  mode 1 (default): the two half-batches on TWO STREAMS -- kernels of one half fill the tails and the
+            # HBM-bound phases (heads, conv8_2, conv1_1) of the other: +2.3...3.0 % at N = 1 against the one-stream order (mode 4), same box;
+            # four quarter-batches on four streams: -1.4 %.  The halves of a step are joined before the next step starts.
+            # capture_error_mode="thread_local": RCCL's watchdog thread polls the events of earlier collectives while this
+            # thread captures -- under the default global mode that query is "operation not permitted when stream is
+            # capturing" and takes the process down (seen with V2X_FORCE_DIST=1 on one GPU)
+            two = mode == 1
+            shared_pool = torch.cuda.graph_pool_handle()
+            streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else [torch.cuda.current_stream()] * 2
+            with torch.no_grad():
+                for h, st in zip(halves, streams):
+                    h["xbuf"] = None
+                    h["stream"] = st
+                    # concurrent halves must not share intermediate buffers: one memory pool per half (one-stream order: one pool, replayed in capture order)
+                    h["cap"] = dict(pool=torch.cuda.graph_pool_handle() if two else shared_pool, capture_error_mode="thread_local")
+                    if use_dist:
+                        h["xbuf"] = torch.empty((self.sworld * shard.per_rank, 32, 32, 256), dtype=torch.bfloat16, device=dev)
+                for h in halves:
+                    h["g_enc"] = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(h["g_enc"], **h["cap"]):
+                        h["feats"] = runner.encode(h["points"], h["n_pts"])
+                for h in halves:
+                    h["g_dec"] = torch.cuda.CUDAGraph()
+                    gathered = h["xbuf"] if use_dist else h["feats"][L]
+                    with torch.cuda.graph(h["g_dec"], **h["cap"]):
+                        h["out"] = runner.decode(h["feats"], gathered, h["trans"], h["plan"])
+
+            def run():
+                cur = torch.cuda.current_stream()
+                works = []
+                for h in halves:                    # encoder A, exchange A (async), encoder B, exchange B: the same host order on every rank
+                    if two:
+                        h["stream"].wait_stream(cur)
+                    with torch.cuda.stream(h["stream"]):
+                        h["g_enc"].replay()
+                        works.append(runner.start_exchange(h["feats"][L], out=h["xbuf"])[1] if use_dist else None)
+                for h, w in zip(halves, works):
+                    with torch.cuda.stream(h["stream"]):
+                        self.timed_wait(w)
+                        h["g_dec"].replay()
+                if two:
+                    for h in halves:
+                        cur.wait_stream(h["stream"])
+            self.run = run
+            self.exec_mode = ("4 hipGraph segments per step (encoder A, encoder B, fusion+decoder+heads A, B); exchange between them; "
+                              + ("the two half-batches on two streams, joined at the end of the step" if two else "one stream"))
+        elif mode == 0:
+            def run():
+                self.last_out = self.step()
+            self.run = run
+            self.exec_mode = "eager launches"
+        else:
+            self.run = lambda: None     # a rank without items (agent-per-gpu, rank >= 5): barriers and timing only
+            self.exec_mode = "idle rank"
+
+    def outputs(self):
+        """Logits of the last step, per half-batch (this rank's items)."""
+        if self.mode in (1, 4):
+            return [h["out"] for h in self.halves]
+        return list(self.last_out)
+
+    def check_sharding(self, n_frames=8):
+        """R-rank == 1-rank ON THE GPUS (SURVEY 8e's oracle; also at N = 1, where it checks that a map's bits do not depend on the batch it rides in):
+        this rank regenerates, from the seeds, the sweeps of ALL five agents for `n_frames` of the frames it owns items of in half-batch 0, runs
+        them through an UNSHARDED 1-rank runner (its own encoder for every agent, no exchange), and compares the logits of its own (agent, frame)
+        items bit for bit with what the timed, sharded step produced from the exchanged maps.  -> True / False (None on an idle rank)."""
+        from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
+        from v2x_sim_amd.utils.synthetic import synthetic_points
+        if not self.active:
+            return None
+        sh, Bh, h0 = self.shard, self.Bh, self.halves[0]
+        frames, pairs = shard_check_plan(sh.rows, Bh, n_frames)
+        n_frames = len(frames)
+        one = AgentShard(AGENTS, n_frames, 0, 1)
+        pts = np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=self.point_seed(0, a * Bh + frames[k])) for a, k in one.items])
+        pts = torch.from_numpy(pts).to(self.dev)
+        n_pts = torch.full((one.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=self.dev)
+        trans = h0["trans"][torch.tensor(frames, device=self.dev)].contiguous()
+        plan = one.fusion_plan(torch.full((n_frames, AGENTS), AGENTS), self.dev)
+        with torch.no_grad():
+            ref = ShardedV2VNet(self.model, one).forward_points(pts, n_pts, trans, plan)
+        got = self.outputs()[0]
+        ri = torch.tensor([p[0] for p in pairs], device=self.dev)
+        gi = torch.tensor([p[1] for p in pairs], device=self.dev)
+        ok = all(torch.equal(ref[k].reshape(one.per_rank, -1)[ri], got[k].reshape(sh.per_rank, -1)[gi]) for k in ("cls", "loc"))
+        torch.cuda.synchronize()
+        return bool(ok)
+
+    def measure(self):
+        args, dev = self.args, self.dev
+        self.build()
+        if not self.capture:
+            return None
+        for _ in range(2):
+            self.run()
+        torch.cuda.synchronize()
+        self.wait_events.clear()
+
+        self.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            self.run()
+        torch.cuda.synchronize()
+        self.barrier()
+        elapsed = time.perf_counter() - t0
+        graph_equals_eager = None           # checked at N = 1 in the graph modes
+        if self.mode in (1, 4) and self.active and not self.use_dist:
+            # the graphs' outputs (the last replay; the two halves ran concurrently in mode 1) against an eager, one-stream recomputation of the same
+            # step: every kernel is deterministic and the halves are independent, so the logits must agree bit for bit
+            ref = self.step()
+            torch.cuda.synchronize()
+            graph_equals_eager = all(torch.equal(h["out"][k], r[k]) for h, r in zip(self.halves, ref) for k in ("cls", "loc"))
+            if not graph_equals_eager:      # reported in the record (never silently): the measurement above is of a step whose results are in doubt
+                print("bench.py: WARNING: the hipGraph step's logits differ from the eager step's", file=sys.stderr, flush=True)
+            del ref
+        # sharded == unsharded, on every rank, on what the timed step left in its output buffers
+        ok = self.check_sharding() if not args.no_shard_check else None
+        okt = torch.tensor([1 if ok in (True, None) else 0], dtype=torch.int32, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if self.use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        sharded_equals_unsharded = None if args.no_shard_check else bool(int(okt.item()))
+        if sharded_equals_unsharded is False:
+            print("bench.py: WARNING: a rank's sharded logits differ from its unsharded recomputation", file=sys.stderr, flush=True)
+        elapsed = float(t.item())
+        # exposed exchange time per step on every rank (0 when the collective finished under the other half's compute)
+        exposed = sum(e0.elapsed_time(e1) for e0, e1 in self.wait_events) / max(args.steps, 1)
+        self.wait_events.clear()
+        exposed_all = [exposed]
+        if self.use_dist:
+            ex = torch.tensor([exposed], dtype=torch.float64, device=dev)
+            gl = [torch.zeros_like(ex) for _ in range(self.world)]
+            dist.all_gather(gl, ex)
+            exposed_all = [float(x) for x in gl]
+        return {"fps": self.Bt * args.steps / elapsed, "ms_per_step": elapsed / args.steps * 1e3, "graph_equals_eager": graph_equals_eager,
+                "sharded_equals_unsharded": sharded_equals_unsharded, "exposed_all": exposed_all,
+                "ranks_seen": dist.get_world_size() if self.use_dist else 1}
 
 
 def main():
@@ -288,173 +564,46 @@ def main():
     from v2x_sim_amd import ops
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import V2VNet
-    from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
-    from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_points, synthetic_poses
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
 
     # layout of the (agent, frame) items over the ranks: all of them (spread) or one agent per rank on ranks 0..4 (agent-per-gpu)
     sworld, srank, sgroup = shard_layout(args, world, rank) if use_dist else (1, 0, None)
     active = srank is not None
-    Bt = args.frames_per_gpu * sworld           # frames per step, whole job (per-GPU work fixed: weak scaling)
-    Bh = Bt // 2                                # frames per half-batch
     model = init_synthetic_weights(V2VNet(Config("test"), gnn_iter_times=args.gnn_iters, num_agent=AGENTS), seed=0)
     state = {k: v.clone() for k, v in model.state_dict().items()}
     model = model.to(dev)
-    L = model.layer
-    # The step is two independent half-batches of Bh frames, each agent-sharded over all ranks.  Half A's exchange
-    # is started asynchronously and flies under half B's encoder; half B's flies under half A's fusion/decoder/heads.
-    # The decomposition is the same for every N (at N = 1 there is simply nothing to gather): weak scaling.
-    shard = AgentShard(AGENTS, Bh, srank if active else 0, sworld)      # (an idle rank builds rank 0's tables and never launches)
-    runner = ShardedV2VNet(model, shard, group=sgroup, transport=args.transport)
-    if force_dist and world == 1:
-        class _ForcedWorld1(ShardedV2VNet):     # take the world > 1 code path (async RCCL all-gather) on one rank
-            def start_exchange(self, local, out=None, counts=None):
-                local = local.contiguous()
-                out = torch.empty_like(local) if out is None else out
-                return out, dist.all_gather_into_tensor(out, local, async_op=True)
-        runner = _ForcedWorld1(model, shard)
-    halves = []
-    for h in range(2 if active else 0):
-        # synthetic sweeps of this rank's (agent, frame) items of half h, resident in HBM
-        pts = np.concatenate([synthetic_points(1, POINTS_PER_SWEEP, seed=1000 + 100000 * h + r) for r in shard.rows])
-        halves.append({"points": torch.from_numpy(pts).to(dev),
-                       "n_pts": torch.full((shard.per_rank,), POINTS_PER_SWEEP, dtype=torch.int32, device=dev),
-                       "trans": torch.from_numpy(synthetic_poses(Bh, AGENTS, seed=99 + h)).to(dev),
-                       "plan": shard.fusion_plan(torch.full((Bh, AGENTS), AGENTS), dev)})
     if active:
         model.packed(dev)
-    wait_events = []    # (start, end) HIP events around the stream-level wait for an exchange: the EXPOSED part of it
-
-    def timed_wait(work):
-        if work is None:
-            return
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        runner.wait(work)
-        e1.record()
-        wait_events.append((e0, e1))
-
-    def step():
-        with torch.no_grad():
-            a, b = halves
-            fa, ga, wa = runner.begin(a["points"], a["n_pts"])
-            fb, gb, wb = runner.begin(b["points"], b["n_pts"])
-            timed_wait(wa)
-            out_a = runner.decode(fa, ga, a["trans"], a["plan"])
-            timed_wait(wb)
-            out_b = runner.decode(fb, gb, b["trans"], b["plan"])
-            return out_a, out_b
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-
-    for _ in range((max(args.warmup, 1) if args.graph else args.warmup) if active else 0):
-        out = step()
-    torch.cuda.synchronize()
-    barrier()               # every rank's warm-up collectives are finished before anybody starts capturing
-    wait_events.clear()
-
-    mode = args.graph if active else -1
-    if mode == 2 and use_dist:
-        raise SystemExit("--graph 2 (whole step in one hipGraph) is for N = 1 without V2X_FORCE_DIST")
-    if mode == 2:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            out = step()
-        run = g.replay
-        exec_mode = "one hipGraph per step"
-    elif mode in (1, 4):
-        # four collective-free segments (encoder A, encoder B, fusion + decoder + heads A, B), each a hipGraph; the exchange (RCCL, eager) runs
-        # between them on static buffers.  mode 1 (default): the two half-batches on TWO STREAMS -- kernels of one half fill the tails and the
-        # HBM-bound phases (heads, conv8_2, conv1_1) of the other: +2.3...3.0 % at N = 1 against the one-stream order (mode 4), same box;
-        # four quarter-batches on four streams: -1.4 %.  The halves of a step are joined before the next step starts.
-        # capture_error_mode="thread_local": RCCL's watchdog thread polls the events of earlier collectives while this
-        # thread captures -- under the default global mode that query is "operation not permitted when stream is
-        # capturing" and takes the process down (seen with V2X_FORCE_DIST=1 on one GPU)
-        two = mode == 1
-        shared_pool = torch.cuda.graph_pool_handle()
-        streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else [torch.cuda.current_stream()] * 2
-        with torch.no_grad():
-            for h, st in zip(halves, streams):
-                h["xbuf"] = None
-                h["stream"] = st
-                # concurrent halves must not share intermediate buffers: one memory pool per half (one-stream order: one pool, replayed in capture order)
-                h["cap"] = dict(pool=torch.cuda.graph_pool_handle() if two else shared_pool, capture_error_mode="thread_local")
-                if use_dist:
-                    h["xbuf"] = torch.empty((sworld * shard.per_rank, 32, 32, 256), dtype=torch.bfloat16, device=dev)
-            for h in halves:
-                h["g_enc"] = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(h["g_enc"], **h["cap"]):
-                    h["feats"] = runner.encode(h["points"], h["n_pts"])
-            for h in halves:
-                h["g_dec"] = torch.cuda.CUDAGraph()
-                gathered = h["xbuf"] if use_dist else h["feats"][L]
-                with torch.cuda.graph(h["g_dec"], **h["cap"]):
-                    h["out"] = runner.decode(h["feats"], gathered, h["trans"], h["plan"])
-
-        def run():
-            cur = torch.cuda.current_stream()
-            works = []
-            for h in halves:                    # encoder A, exchange A (async), encoder B, exchange B: the same host order on every rank
-                if two:
-                    h["stream"].wait_stream(cur)
-                with torch.cuda.stream(h["stream"]):
-                    h["g_enc"].replay()
-                    works.append(runner.start_exchange(h["feats"][L], out=h["xbuf"])[1] if use_dist else None)
-            for h, w in zip(halves, works):
-                with torch.cuda.stream(h["stream"]):
-                    timed_wait(w)
-                    h["g_dec"].replay()
-            if two:
-                for h in halves:
-                    cur.wait_stream(h["stream"])
-        exec_mode = ("4 hipGraph segments per step (encoder A, encoder B, fusion+decoder+heads A, B); exchange between them; "
-                     + ("the two half-batches on two streams, joined at the end of the step" if two else "one stream"))
-    elif mode == 0:
-        run = step
-        exec_mode = "eager launches"
+    ctx = dict(args=args, dev=dev, world=world, use_dist=use_dist, force_dist=force_dist, sworld=sworld, srank=srank, sgroup=sgroup,
+               active=active, model=model)
+    # weak scaling (the headline, per-GPU work fixed): frames = frames_per_gpu * ranks; strong scaling (total work fixed): frames = frames_per_gpu
+    # whatever N.  `--scaling weak` (default) times the weak workload and, when N > 1, the strong one as well (sub-record `strong`).
+    if args.scaling == "strong":
+        if (args.frames_per_gpu // 2 * AGENTS) % sworld:
+            raise SystemExit("--scaling strong: %d items per half-batch do not divide over %d ranks" % (args.frames_per_gpu // 2 * AGENTS, sworld))
+        wl = Workload(ctx, args.frames_per_gpu)
     else:
-        run = lambda: None      # noqa: E731 -- a rank without items (agent-per-gpu, rank >= 5): barriers and timing only
-        exec_mode = "idle rank"
-    for _ in range(2):
-        run()
-    torch.cuda.synchronize()
-    wait_events.clear()
-
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        run()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    graph_equals_eager = None           # checked at N = 1 in the graph modes
-    if mode in (1, 4) and active and not use_dist:
-        # the graphs' outputs (the last replay; the two halves ran concurrently in mode 1) against an eager, one-stream recomputation of the same
-        # step: every kernel is deterministic and the halves are independent, so the logits must agree bit for bit
-        ref = step()
-        torch.cuda.synchronize()
-        graph_equals_eager = all(torch.equal(h["out"][k], r[k]) for h, r in zip(halves, ref) for k in ("cls", "loc"))
-        if not graph_equals_eager:      # reported in the record (never silently): the measurement above is of a step whose results are in doubt
-            print("bench.py: WARNING: the hipGraph step's logits differ from the eager step's", file=sys.stderr, flush=True)
-        del ref
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
-    ms_per_step = elapsed / args.steps * 1e3
-    fps = Bt * args.steps / elapsed
-    # exposed exchange time per step on every rank (0 when the collective finished under the other half's compute)
-    exposed = sum(e0.elapsed_time(e1) for e0, e1 in wait_events) / max(args.steps, 1)
-    wait_events.clear()
-    exposed_all = [exposed]
-    if use_dist:
-        ex = torch.tensor([exposed], dtype=torch.float64, device=dev)
-        gl = [torch.zeros_like(ex) for _ in range(world)]
-        dist.all_gather(gl, ex)
-        exposed_all = [float(x) for x in gl]
-    ranks_seen = dist.get_world_size() if use_dist else 1
+        wl = Workload(ctx, args.frames_per_gpu * sworld)
+    res = wl.measure()
+    Bt, fps, ms_per_step, exec_mode, mode = wl.Bt, res["fps"], res["ms_per_step"], wl.exec_mode, wl.mode
+    graph_equals_eager, sharded_equals_unsharded = res["graph_equals_eager"], res["sharded_equals_unsharded"]
+    exposed_all, ranks_seen = res["exposed_all"], res["ranks_seen"]
+    step, halves = wl.step, wl.halves
+    strong = None
+    if args.scaling == "weak" and world > 1 and (args.frames_per_gpu // 2 * AGENTS) % sworld == 0:
+        wl.release()
+        ws = Workload(ctx, args.frames_per_gpu)
+        rs = ws.measure()
+        strong = {"scaling": "strong", "frames_per_step": ws.Bt, "value": rs["fps"], "unit": "frames/s", "ms_per_step": rs["ms_per_step"],
+                  "items_per_rank_and_half_batch": ws.shard.per_rank, "sharded_equals_unsharded": rs["sharded_equals_unsharded"],
+                  "exposed_exchange_ms_per_step": rs["exposed_all"],
+                  "note": "total work fixed at --frames-per-gpu frames per step whatever N (the weak line keeps per-GPU work fixed)"}
+        ws.release()
+        wl = Workload(ctx, args.frames_per_gpu * sworld, capture=False)     # the weak workload again: eager steps for the instrumented roofline pass below
+        step, halves = wl.step, wl.halves
+        if active:
+            step()
+            torch.cuda.synchronize()
 
     roofline = None
     kernels = None
@@ -490,9 +639,11 @@ def main():
         roofline["traffic_source"] = None
         for tname in TRAFFIC_FILES:
             tfile = os.path.join(ROOT, "profiles", tname)
-            if os.path.exists(tfile) and args.frames_per_gpu == 128:  # 2 half-batches of 64 = the profiled launches
+            if os.path.exists(tfile) and args.frames_per_gpu == 128 and args.scaling == "weak":  # 2 half-batches of 64 = the profiled launches
                 with open(tfile) as fh:
-                    tk = json.load(fh)["kernels"].get(dom)
+                    tks = json.load(fh)["kernels"]
+                    # (round-3 files name stream8g with its removed fourth template argument)
+                    tk = tks.get(dom) or tks.get(dom.replace(", true>", ", true, false>").replace(", false>", ", false, false>"))
                 if tk:
                     roofline["traffic"] = tk["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc passes of this workload; not re-measured in this run)" % tname
@@ -521,14 +672,10 @@ def main():
         except Exception as e:      # the headline record must not die with a side table
             calibration = {"error": repr(e)}
 
-    latency = configs = training = None
+    latency = configs = training = host_streaming = None
     if rank == 0 and world == 1 and not args.no_extras and not force_dist:
         # free the step's graphs and buffers first: the extras build their own
-        for h in halves:
-            for k in ("g_enc", "g_dec", "feats", "out", "xbuf"):
-                h.pop(k, None)
-        out = run = None
-        torch.cuda.empty_cache()
+        wl.release()
         latency = measure_latency(model, dev)
         latency["default_dispatch"] = measure_latency(model, dev, small_batch=False)
         try:
@@ -544,6 +691,17 @@ def main():
             training = bc.run_training(dev)
         except Exception as e:
             training = {"error": repr(e)}
+        try:
+            # PCIe-inclusive rate (never `value`): the same 64-frame step fed from pinned host memory, copied inside the step or prefetched on a copy stream
+            torch.cuda.empty_cache()
+            spec = importlib.util.spec_from_file_location("stream_points", os.path.join(ROOT, "tools", "stream_points.py"))
+            sp = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(sp)
+            hs, _ = sp.main(64, 8)
+            host_streaming = {"frames_per_step": 64, "resident_frames_per_s": hs["resident"], "inline_copy_frames_per_s": hs["inline"],
+                              "prefetched_frames_per_s": hs["prefetch"], "prefetched_over_resident": hs["prefetch"] / hs["resident"]}
+        except Exception as e:
+            host_streaming = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -553,10 +711,10 @@ def main():
         rec = {
             "metric": "BEV frames/sec, V2VNet 5-agent detection (256x256 BEV)", "value": fps, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic (seeded 65536-pt sweeps per agent, random SE(2) poses, He-init weights)",
             "config": {"workload": "V2VNet 5-agent detection, points->logits (a1-a7), gnn_iter=%d" % args.gnn_iters,
-                       "agents": AGENTS, "frames_per_step": Bt, "frames_per_gpu": args.frames_per_gpu,
+                       "agents": AGENTS, "frames_per_step": Bt, "frames_per_gpu": Bt // max(sworld, 1),
                        "layout": args.layout, "active_ranks": sworld,
                        "half_batches": 2,
                        "points_per_agent": POINTS_PER_SWEEP, "bev": [256, 256, 13],
@@ -567,10 +725,14 @@ def main():
                        "exec_mode": exec_mode, "hip_graph": bool(mode)},
             "whole_step_frac": (GFLOP_PER_FRAME_BASE + GFLOP_PER_GNN_ROUND * args.gnn_iters) * 1e9 * fps / world / (PEAK_MFMA_TFLOPS * 1e12),
             "graph_equals_eager": graph_equals_eager,
+            "sharded_equals_unsharded": sharded_equals_unsharded,
+            "sharded_equals_unsharded_note": "every rank recomputes 8 frames of half-batch 0 UNSHARDED (all five agents' sweeps regenerated from their seeds, its own "
+                                             "encoder, no exchange) and compares the logits of its own items bit for bit with the timed sharded step's; min over ranks",
+            "strong": strong,
             "ranks_seen": ranks_seen, "exposed_exchange_ms_per_step": exposed_all,
             "exposed_exchange_note": "HIP-event time a half-batch's stream waits for its exchange; with the two half-batches on two streams the GPU runs "
                                      "the other half's kernels during that wait (one-stream order: --graph 4)",
-            "roofline": roofline, "calibration": calibration, "cpu_baseline": cpu, "latency": latency, "configs": configs, "training": training, "kernels": kernels,
+            "roofline": roofline, "calibration": calibration, "cpu_baseline": cpu, "latency": latency, "configs": configs, "training": training, "host_streaming": host_streaming, "kernels": kernels,
         }
     if use_dist:
         dist.destroy_process_group()

@@ -31,6 +31,10 @@ def test_self_launch_gloo_dry_run(gpus, transport):
     assert rec["n_gpus"] == gpus and rec["ranks_seen"] == gpus and rec["dry_run"] and rec["exchange_ok"]
     assert rec["items_per_rank"] == 5 * 64 and rec["transport"] == transport and rec["frames_per_step"] == 128 * gpus
     assert rec["layout"] == "spread" and rec["active_ranks"] == gpus
+    # the strong-scaling geometry (128 frames in total: 320 items per half-batch over the ranks) and the rows of the on-hardware
+    # sharded == unsharded self-check (8 frames x the agents a rank owns of them), weak and strong
+    assert rec["strong_items_per_rank"] == 320 // gpus
+    assert len(rec["shard_check_pairs"]) == 2 and all(8 <= n <= 40 for n in rec["shard_check_pairs"])
 
 
 @pytest.mark.parametrize("gpus,transport", [(5, "allgather"), (8, "allgather"), (8, "needed")])
@@ -71,3 +75,27 @@ def test_ranks_fail_loudly_without_a_gpu():
 def test_world_size_mismatch_is_refused():
     p = _run("--gpus", "2", "--dry-run", env_extra={"WORLD_SIZE": "4", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=4 but --gpus 2" in p.stderr
+
+
+def test_shard_check_plan_covers_owned_rows_at_every_world():
+    """bench.py::shard_check_plan (host logic of `sharded_equals_unsharded`): at every world size and both geometries the frames start at the
+    rank's first item, every pair points at the right global row, and nothing the rank does not own is compared."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "v2x-sim_amd"))
+    import bench
+    from v2x_sim_amd.parallel import AgentShard
+    for world in (1, 2, 4, 5, 8):
+        for bh in (64 * world, 64):
+            if (5 * bh) % world:
+                continue
+            covered = 0
+            for r in range(world):
+                rows = AgentShard(5, bh, r, world).rows
+                frames, pairs = bench.shard_check_plan(rows, bh)
+                assert len(frames) == min(8, bh) and frames[0] == rows[0] % bh and len(set(frames)) == len(frames)
+                assert pairs and len(set(p[0] for p in pairs)) == len(pairs)
+                for ri, gi in pairs:
+                    a, k = divmod(ri, len(frames))
+                    assert rows[gi] == a * bh + frames[k]
+                covered += len(pairs)
+            assert covered >= 8 * world or world == 1

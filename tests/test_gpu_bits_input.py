@@ -37,7 +37,10 @@ def test_first_layer_from_bits_equals_expanded(device):
     assert torch.equal(e, a[0] if False else ops.run_layer(pk["enc"][0][0], bits, zbits=13))
 
 
-def test_points_path_equals_dense_bev_path(device):
+def test_points_path_equals_dense_bev_path(device, tune):
+    """The upstream-style dense fp32 BEV entry, the sharded runner's points entry and the plain model's points entry give the same bits.  The
+    plain entries (forward, forward_points) declare latency launches (SMALL_BATCH = 2: split-K at one frame), the runner never does: compared
+    under the same dispatch -- SMALL_BATCH = 0 (throughput forms everywhere) and 1 (latency forms everywhere)."""
     from v2x_sim_amd.configs import Config
     from v2x_sim_amd.models.det import V2VNet
     from v2x_sim_amd.parallel import AgentShard, ShardedV2VNet
@@ -49,12 +52,26 @@ def test_points_path_equals_dense_bev_path(device):
     T = torch.from_numpy(synthetic_poses(B, A, seed=7)).to(device)
     nat = torch.full((B, A), A)
     shard = AgentShard(A, B, 0, 1)
+    ptd = torch.from_numpy(pts).to(device)
+    cnt = torch.full((A * B,), 20000, dtype=torch.int32, device=device)
+    outs = {}
+    for sb in (0, 1):
+        tune("SMALL_BATCH", sb)
+        with torch.no_grad():
+            dense = pm(bev.to(device), T, nat, batch_size=B)                         # upstream-style dense fp32 BEV
+            pts_out = ShardedV2VNet(pm, shard).forward_points(ptd, cnt, T, shard.fusion_plan(nat, device))   # points -> bits -> conv_pre_1
+            plain = pm.forward_points(ptd, cnt, T, nat, batch_size=B)
+        assert torch.equal(dense["cls"], pts_out["cls"]) and torch.equal(dense["loc"], pts_out["loc"])
+        assert torch.equal(plain["cls"], pts_out["cls"]) and torch.equal(plain["loc"], pts_out["loc"])
+        outs[sb] = pts_out
+    # the default (2): the plain entries take the latency forms (== SMALL_BATCH 1 everywhere), the runner the throughput forms (== 0)
+    tune("SMALL_BATCH", 2)
     with torch.no_grad():
-        dense = pm(bev.to(device), T, nat, batch_size=B)                         # upstream-style dense fp32 BEV
-        pts_out = ShardedV2VNet(pm, shard).forward_points(
-            torch.from_numpy(pts).to(device), torch.full((A * B,), 20000, dtype=torch.int32, device=device), T,
-            shard.fusion_plan(nat, device))                                      # points -> bits -> conv_pre_1
-    assert torch.equal(dense["cls"], pts_out["cls"]) and torch.equal(dense["loc"], pts_out["loc"])
+        plain = pm.forward_points(ptd, cnt, T, nat, batch_size=B)
+        rn = ShardedV2VNet(pm, shard).forward_points(ptd, cnt, T, shard.fusion_plan(nat, device))
+    assert torch.equal(plain["cls"], outs[1]["cls"]) and torch.equal(rn["cls"], outs[0]["cls"])
+    d = (outs[1]["cls"] - outs[0]["cls"]).abs().max() / outs[0]["cls"].abs().max()
+    assert float(d) < 2e-2          # the two dispatches differ by fp32 summation order only (one bf16 rounding per split layer)
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 256), (2, 8, 32), (5, 40, 96), (1, 64, 32)])

@@ -158,6 +158,7 @@ def _rand_boxes(rng, n, spread=3.0):
 def test_rotated_iou_kernel_closed_form_known_answers(device):
     """v2x_rotated_iou against the hand-computable answers of tests/iou_kats.py (fp32 boxes in, fp64 clip inside: 1e-6)."""
     from iou_kats import IOU_KATS
+    from v2x_sim_amd import ops
     a = torch.tensor([k[0] for k in IOU_KATS], dtype=torch.float32, device=device)
     b = torch.tensor([k[1] for k in IOU_KATS], dtype=torch.float32, device=device)
     got = ops.rotated_iou(a, b).cpu().numpy()

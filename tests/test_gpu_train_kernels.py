@@ -208,6 +208,32 @@ def test_hip_graph_conv_function_vs_autograd(device, N, H, W, Cin, Cout, stride,
     assert torch.allclose(conv_d.bias.grad.cpu(), conv_r.bias.grad, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("H,W,Cin,Cout,stride", [(24, 96, 64, 128, 2), (8, 32, 64, 128, 2), (40, 96, 128, 256, 2)])
+def test_hip_graph_conv_extents_without_a_kernel_take_the_torch_path(device, H, W, Cin, Cout, stride):
+    """pack_conv_device packs ONE layout and no gather fallback, so hip_eligible must be exactly run_layer's conditions.  These maps
+    tile by 8 x 32 (the old test) but have no stride-2 kernel (24 x 96, 8 x 32, 40 x 96: neither 8 x 64 nor 16 x 32 input tiles):
+    conv3x3 must route them through F.conv2d (they raised IndexError on the empty fallback list) and still match autograd."""
+    from v2x_sim_amd.train import hip_graph
+    g = torch.Generator().manual_seed(H + W + stride)
+    conv_r = torch.nn.Conv2d(Cin, Cout, 3, stride, 1)
+    conv_d = torch.nn.Conv2d(Cin, Cout, 3, stride, 1).to(device)
+    conv_d.load_state_dict(conv_r.state_dict())
+    assert not hip_graph.hip_eligible(conv_d.weight, stride, H, W, Cin)
+    x = torch.randn(2, H, W, Cin, generator=g).to(torch.bfloat16)
+    xr = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = conv_r(xr)
+    dy = torch.randn(2, H // stride, W // stride, Cout, generator=g).to(torch.bfloat16)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    xd = x.to(device).requires_grad_(True)
+    yd = hip_graph.conv3x3(xd, conv_d)
+    yd.backward(dy.to(device))
+    ybf = yr.detach().permute(0, 2, 3, 1)
+    assert float((yd.detach().cpu().float() - ybf).abs().max()) <= 2.0 ** -6 * float(ybf.abs().max())
+    dxr = xr.grad.permute(0, 2, 3, 1)
+    assert float((xd.grad.cpu().float() - dxr).abs().max()) <= 2.0 ** -6 * float(dxr.abs().max())
+    assert float((conv_d.weight.grad.cpu() - conv_r.weight.grad).abs().max()) <= 1e-2 * float(conv_r.weight.grad.abs().max())
+
+
 def test_hip_graph_training_step_vs_fp32_graph(device, monkeypatch, tune):
     """V2X_TRAIN_HIP=1: a FaFNet training step (batch-statistics BN) on the bf16 NHWC HIP graph against the fp32 MIOpen graph: the
     loss within 2 %, the running statistics of every BN within 2 % of their scale, and parameter gradients that point the same way:

@@ -90,39 +90,13 @@ extern "C" int v2x_debug_stream_timeline(unsigned *dst) {   // exists in the tim
     return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2x_stream_timeline), sizeof(unsigned) * 2 * SDBG_T_STEPS * 4);
 }
 #endif
-// Compile-time experiment switches of stream8g, all measured and left at their neutral values (tools/ab_build.sh):
-//   LPRIO: s_setprio for the load phase (0 = off; 1, 3: no effect beyond box drift);  PF: weight fragments read 1 or 2 blocks ahead (2 =
-//   inline-asm reads with counted lgkmcnt waits: +2.8-3.7 %, slower);  PRIO: s_setprio for the MFMA phase (-0.3 %);  H1: prefetch point (0.0 %);
-//   XCDCO: one channel tile per XCD instead of all channel tiles on every XCD (+0.1-0.7 %: weight locality in L2 does not matter);
-//   LORDER: 1 = the load phase reads its fragments first and issues its DMAs while they are in flight (+0.2-0.5 %: the LDS latency of the
-//   load phase is not on the critical path either).  What moves these kernels is the NUMBER of instructions per MFMA (taps per barrier,
-//   fragment reads per wave tile), not where their latencies fall.
-#ifndef V2X_STREAM_LPRIO_BUILD
-#define V2X_STREAM_LPRIO_BUILD 0
-#endif
+// Variants of stream8g that were built, measured and REMOVED from this file in round 4 (HISTORY.md "Round 3 -- measured and rejected" holds the
+// numbers, the code is in the git history up to commit 7e0187e): the 32x32x16-MFMA form (M32: bit-identical, 9-20 % slower), weight fragments
+// read two blocks ahead (PF = 2: +2.8-3.7 %), s_setprio in the load / MFMA phase (LPRIO, PRIO: no effect), the prefetch point inside a block
+// (H1: 0.0 %), one channel tile per XCD (XCDCO: +0.1-0.7 %), fragment reads before the DMA issue (LORDER: +0.2-0.5 %).  What moves these kernels
+// is the NUMBER of instructions per MFMA (taps per barrier, fragment reads per wave tile), not where their latencies fall.
 #ifndef V2X_STREAM_LSS_BUILD
 #define V2X_STREAM_LSS_BUILD 1
-#endif
-#ifndef V2X_STREAM_LORDER_BUILD
-#define V2X_STREAM_LORDER_BUILD 0
-#endif
-#ifndef V2X_STREAM_XCDCO_BUILD
-#define V2X_STREAM_XCDCO_BUILD 0
-#endif
-#ifndef V2X_STREAM_PF_BUILD
-#define V2X_STREAM_PF_BUILD 1
-#endif
-#ifndef V2X_STREAM_PRIO_BUILD
-#define V2X_STREAM_PRIO_BUILD 0
-#endif
-#ifndef V2X_STREAM_H1_BUILD
-#define V2X_STREAM_H1_BUILD 1
-#endif
-#ifndef V2X_STREAM_M32_BUILD
-#define V2X_STREAM_M32_BUILD 0     // 1: also instantiate the 32x32x16-MFMA form of stream8g (rejected, see the kernel's M32 comment)
-#endif
-#ifndef V2X_STREAM_M32PF_BUILD
-#define V2X_STREAM_M32PF_BUILD 2   // 32x32 form: MFMAs of a block issued before the next block's weight-fragment reads
 #endif
 
 template <int N>
@@ -296,74 +270,6 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
                 }
                 const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = o;
-            }
-        }
-    }
-}
-
-// Epilogue of the 32x32-MFMA form (conv3x3_stream8g_kernel<..., M32 = true>).  acc[mt][r]: row tile mt (32 channels; GRU: gate mt of 32
-// hidden channels), pixel row r of the wave; lane (jl = pixel column, hl): register i = channel 16 hl + i of the tile (the kernel permutes the
-// MFMA rows so) -> 16 consecutive channels = two 16-byte stores per (tile, row).  co0: first output channel of the wave's MT tiles (GRU: first
-// hidden channel of the workgroup's 32), lss0: the same as an index into the LDS table lss (scale at [c], shift at [lss_stride + c]).
-// yr = image row of the wave's first pixel row.
-template <int MT, int NR, int EPI>
-__device__ __forceinline__ void stream_epilogue32(const StreamArgs &a, f32x16_t (&acc)[MT][NR], int co0, int lss0, int n, int yr, int x0, int jl, int hl,
-                                                  lds_cf_t *lss, int lss_stride) {
-    uint16_t *outp = reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + yr) * a.W + x0 + jl) * a.out_cstride + a.out_coff;
-    const size_t row_stride = (size_t)a.W * a.out_cstride;
-    if constexpr (EPI == SEPI_GRU) {
-        static_assert(EPI != SEPI_GRU || MT == 3, "gates r, z, n");
-        const int hc = co0 + 16 * hl;
-        uint32_t o[NR][8];
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) {
-            float4 bias[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) bias[k] = reinterpret_cast<const float4 *>(a.scale)[hc + i4 * 4 + k];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                float h[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int i = i4 * 4 + k;
-                    const float rg = 1.0f / (1.0f + __expf(-(acc[0][r][i] + bias[k].x)));
-                    const float zg = 1.0f / (1.0f + __expf(-(acc[1][r][i] + bias[k].y)));
-                    const float ng = tanhf(acc[2][r][i] + bias[k].z + rg * bias[k].w);
-                    h[k] = ng + zg * (0.0f - ng);
-                }
-                o[r][i4 * 2] = pack_bf16x2(h[0], h[1]);
-                o[r][i4 * 2 + 1] = pack_bf16x2(h[2], h[3]);
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            uint16_t *q = outp + r * row_stride + hc;
-            *reinterpret_cast<uint4 *>(q) = make_uint4(o[r][0], o[r][1], o[r][2], o[r][3]);
-            *reinterpret_cast<uint4 *>(q + 8) = make_uint4(o[r][4], o[r][5], o[r][6], o[r][7]);
-        }
-    } else {
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int c = mt * 32 + 16 * hl;
-            float sc[16], sf[16];
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const float4 s4 = lss ? lds_ld4(lss + lss0 + c + i4 * 4) : *reinterpret_cast<const float4 *>(a.scale + co0 + c + i4 * 4);
-                const float4 t4 = lss ? lds_ld4(lss + lss_stride + lss0 + c + i4 * 4) : *reinterpret_cast<const float4 *>(a.shift + co0 + c + i4 * 4);
-                sc[i4 * 4] = s4.x, sc[i4 * 4 + 1] = s4.y, sc[i4 * 4 + 2] = s4.z, sc[i4 * 4 + 3] = s4.w;
-                sf[i4 * 4] = t4.x, sf[i4 * 4 + 1] = t4.y, sf[i4 * 4 + 2] = t4.z, sf[i4 * 4 + 3] = t4.w;
-            }
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                uint32_t o[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    o[i] = pack_bf16x2(acc[mt][r][2 * i] * sc[2 * i] + sf[2 * i], acc[mt][r][2 * i + 1] * sc[2 * i + 1] + sf[2 * i + 1]);
-                    if (a.relu) o[i] = v2x_relu_bf16x2(o[i]);
-                }
-                uint16_t *q = outp + r * row_stride + co0 + c;
-                *reinterpret_cast<uint4 *>(q) = make_uint4(o[0], o[1], o[2], o[3]);
-                *reinterpret_cast<uint4 *>(q + 8) = make_uint4(o[4], o[5], o[6], o[7]);
             }
         }
     }
@@ -933,8 +839,7 @@ _Pragma("unroll") \
 //   WT (wave tiling): false -- a wave owns ALL BCO channels x 64 pixels (2 rows) of its group's 8x32 pixels: 24 weight + 8 pixel fragment
 //   reads per step; true -- a wave owns HALF the channels x 128 pixels (4 rows): 12 + 12 reads per step for the same 96 MFMAs (-25 % LDS
 //   reads: -3.1...3.8 % per layer in the paired A/B).  Same K order, bit-identical results.
-//   M32: the MFMA phase on v_mfma_f32_32x32x16_bf16 (see "32x32 form" below the kernel's wave-tiling comment).
-template <int BCO, int EPI, bool WT = false, bool M32 = false>
+template <int BCO, int EPI, bool WT = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8g_kernel(const StreamArgs a) {
     constexpr int TH = 16, TW = 32;
     constexpr int PW = TW + 2, PH = TH + 2, PW0 = TW / 2 + 2, PH0 = TH / 2 + 2;
@@ -949,34 +854,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int NF = WT ? 8 : 4;
     constexpr int NB = WT ? 12 : 8;                        // pixel fragments a wave reads per step
     constexpr int BT = (HCO % 2 == 0) ? 2 : HCO;           // WT: channel tiles per MFMA block (2 -> blocks of 16 MFMAs, 3 -> of 24)
-    // ---- 32x32 form (M32) -- MEASURED AND REJECTED, round 3 (profiles/r03_m32_rejected.txt); instantiated only under -DV2X_STREAM_M32_BUILD=1 ----
-    // The same step on v_mfma_f32_32x32x16_bf16: a wave's tile is MT row tiles of 32 channels x NR pixel rows of 32 pixels (one
-    // accumulator = 16 registers), a 32-channel chunk is two K = 16 halves.  Same fragment-read counts (a b128 read is still
-    // 32 x 8 bf16 per k-slot pair), same accumulator registers, HALF the MFMA issues (48 per step at 128 rows, 36 for the GRU) at
-    // 32 cycles each.  Outcome: BIT-IDENTICAL to the 16x16x32 form, 29 % fewer VALU instructions, no LDS bank conflicts at either
-    // resolution (19.9 % conflict cycles in the 16x16 form's half-resolution reads) -- and 9-20 % SLOWER (conv5_1 698 -> 837 us, ConvGRU
-    // 1 591 -> 1 903 us per 320 maps, paired A/B).  Two reasons, both measured: (i) on random operands the pipe sustains the same
-    // power-limited ~2.13-2.22 PFLOP/s with either instruction (tools/mfma_clock_probe.hip), so there is no raw rate to gain; (ii) beside
-    // back-to-back 32x32x16 MFMAs a co-resident wave's LDS-DMA is starved -- 12.9x slower (16x16x32: 1.45x; tools/mfma_coissue_probe.hip), not
-    // cured by s_setprio -- and this kernel lives on the other group's DMAs landing during a group's MFMA phase.
-    // Lane (m = lane & 31, h = lane >> 5):
-    //   A (weights): MFMA row m of row tile mt, k-slot 2 kh + h of k-half kh.  MFMA rows are PERMUTED onto channels so that a lane's
-    //     16 accumulators are 16 CONSECUTIVE channels (32-B stores): D register i of lane half h is MFMA row (i & 3) + 8 (i >> 2) + 4 h,
-    //     and row m reads channel 16 ((m >> 2) & 1) + (m & 3) + 4 (m >> 3) = 16 h + i.  Conflict-free in the k-slot-major slice.
-    //     GRU: row tile = gate, the 32 hidden channels of a 96-row tile are its two (r, z, n) triples of 16 (packing unchanged).
-    //   B (pixels): pixel m of a 32-pixel patch row, k-slot 2 kh + h.  With the patch swizzle (pc >> 2) & 3 every read -- full and half
-    //     resolution, all three tap columns -- is conflict-free in the ds_read_b128 lane-group model (the 16-wide fragments of the
-    //     16x16 form: (pc >> 1) & 3, 2-way conflicts at half resolution).
-    //   K order inside a tap: channels 0-15, then 16-31 of the chunk (two accumulations instead of one 32-deep dot product): results
-    //   agree with the 16x16 form to fp32 summation order, i.e. one bf16 rounding of the output.
-    static_assert(!M32 || (EPI == SEPI_GRU ? (!WT && BCO == 96) : (WT && BCO == 128)), "32x32 form: 128-row plain layers (wave-tiled) and the 96-row ConvGRU");
-    constexpr int MT = WT ? BCO / 64 : BCO / 32;           // M32: row tiles of 32 channels per wave (2; GRU: 3 = the gates)
-    constexpr int NR = WT ? 4 : 2;                         // M32: pixel rows (32-pixel fragments) per wave
-    constexpr int AB = (EPI == SEPI_GRU) ? 3 : 2;          // M32: weight fragments per MFMA block (blocks of AB x NR MFMAs)
-    constexpr int PSH = M32 ? 2 : V2X_STREAM_PSWZ_BUILD;   // patch swizzle shift of this kernel
+    constexpr int PSH = V2X_STREAM_PSWZ_BUILD;             // patch swizzle shift
     // output-store instructions per wave and tile (the counted waits after an epilogue leave exactly these in flight): 8-byte stores per
-    // (16-channel tile, 16-pixel fragment) in the 16x16 form, two 16-byte stores per (32-channel tile, pixel row) in the 32x32 form
-    constexpr int N_ST = M32 ? ((EPI == SEPI_GRU) ? NR * 2 : MT * NR * 2) : ((EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4);
+    // (16-channel tile, 16-pixel fragment)
+    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_ring = smem;                                   // 3 x STEP_BYTES
@@ -999,15 +880,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // per 320 maps, time -0.1 +- 0.1 %, bit-identical (tools/gru_xcd_walk_probe.sh)
             const int x = bid >> 5, i = bid & 31;
             bid = (((x >> 1) * 8 + (i >> 2)) << 3) + (x & 1) * 4 + (i & 3);
-        }
-        if constexpr (V2X_STREAM_XCDCO_BUILD != 0) {
-            // EXPERIMENT: one channel tile per XCD (its weights stay in that XCD's L2) instead of all channel tiles on every XCD
-            const int nco = a.n_co_tiles;
-            if (r == 0 && nco > 1 && (8 % nco == 0 || nco % 8 == 0) && nco <= 8) {
-                const int x = bid / q, j = bid - x * q;          // XCD and index inside it
-                const int co = x % nco, slot = (x / nco) * q + j;
-                bid = slot * nco + co;
-            }
         }
     }
     const int n_tiles = a.n_px_tiles * a.n_co_tiles;
@@ -1161,12 +1033,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int nn = 0, ny0 = 0, nx0 = 0;
         if (has_next) tile_coords(next, nn, ny0, nx0);
 
-        using acc_t = std::conditional_t<M32, f32x16_t, f32x4_t>;
-        acc_t acc[M32 ? MT : AT][M32 ? NR : NF];
+        f32x4_t acc[AT][NF];
 #pragma unroll
-        for (int i = 0; i < (M32 ? MT : AT); ++i)
+        for (int i = 0; i < AT; ++i)
 #pragma unroll
-            for (int f = 0; f < (M32 ? NR : NF); ++f) acc[i][f] = (acc_t)(0.f);
+            for (int f = 0; f < NF; ++f) acc[i][f] = (f32x4_t)(0.f);
 
         for (int kc = 0; kc < nchunks; ++kc, ++gc) {
             const char *pb = s_patch + (gc & 1) * PATCH8_BYTES;
@@ -1204,27 +1075,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 };
                 stamp(0);
-                if constexpr (V2X_STREAM_LPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(V2X_STREAM_LPRIO_BUILD);   // load phase: win the issue arbitration
                 const int fjl = ln & 15, fql = ln >> 4;
                 // ---- L: group 1 streams the weights of step st+2 (wrapping into the next tile), group 0 the next chunk's patch
                 int nw = 0;   // weight DMAs this wave issues in this phase
-                if constexpr (V2X_STREAM_LORDER_BUILD == 0) { V2X_STREAM8G_ISSUE_DMAS }
+                V2X_STREAM8G_ISSUE_DMAS
                 __builtin_amdgcn_sched_barrier(0);
                 // pixel fragments of the tap column: B[q * 2 + ch], q = r + ky = 0..3
                 bf16x8_t B[NB];
-                const int jl = ln & 31, hl = ln >> 5;           // M32: MFMA row / pixel of the lane, k-slot half
-                if constexpr (M32) {
-                    // B[q * 2 + kh]: patch row q of the wave (q = r + ky), k-half kh: pixel jl + kx, k-slot 2 kh + hl
-                    const int col = jl + kx;
-                    const int pc = ((col - sh) >> sh) + sh;
-                    const int coff = ((pc << 2) + (hl ^ ((pc >> PSH) & 3))) * 16;   // k-half 1: slot ^ 2 = byte offset ^ 32
-#pragma unroll
-                    for (int q = 0; q < NB / 2; ++q) {
-                        const char *prow = pb + row0 + (((q - sh) >> sh) + sh) * row_bytes;
-                        B[q * 2] = *reinterpret_cast<const bf16x8_t *>(prow + coff);
-                        B[q * 2 + 1] = *reinterpret_cast<const bf16x8_t *>(prow + (coff ^ 32));
-                    }
-                } else {
 #pragma unroll
                 for (int ch = 0; ch < 2; ++ch) {
                     const int col = ch * 16 + fjl + kx;
@@ -1236,38 +1093,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         else B[q * 2 + ch] = __builtin_bit_cast(bf16x8_t, make_uint4(coff, q, st, ch));
                     }
                 }
-                }
-                // M32: channel row of MFMA row jl inside its 32-row tile (see the 32x32 comment above): 16 * ((jl >> 2) & 1) + (jl & 3) + 4 * (jl >> 3);
-                // the GRU's 32 hidden channels are rows {0..15} and {48..63} of the gate's 16-row blocks
-                const int prm = ((jl >> 2) & 1) * (EPI == SEPI_GRU ? 48 : 16) + (jl & 3) + 4 * (jl >> 3);
-                const char *ws = M32 ? s_ring + slot * STEP_BYTES + (hl * BCO + coh * 64 + prm) * 16
-                                     : s_ring + slot * STEP_BYTES + (fql * BCO + fjl) * 16 + coh * (HCO * 256);   // + compile-time offsets below
-                constexpr int PFD = M32 ? 1 : (WT ? V2X_STREAM_PF_BUILD : 1);   // WT: weight fragments are read PFD blocks ahead (A is a ring of PFD + 1 blocks)
-                bf16x8_t A[PFD + 1][M32 ? AB : (WT ? BT : HCO)];
-                // M32: weight fragment t = (ky * MT + mt) * 2 + kh at a compile-time offset from ws
-                auto a32_off = [](int t) constexpr -> int {
-                    const int ky = t / (2 * MT), mt = (t >> 1) % MT, kh = t & 1;
-                    return ky * SLICE_BYTES + kh * (2 * BCO * 16) + mt * (EPI == SEPI_GRU ? 256 : 512);
-                };
-                if constexpr (M32) {
-#pragma unroll
-                    for (int j = 0; j < AB; ++j) A[0][j] = *reinterpret_cast<const bf16x8_t *>(ws + a32_off(j));
-                } else {
+                const char *ws = s_ring + slot * STEP_BYTES + (fql * BCO + fjl) * 16 + coh * (HCO * 256);   // + compile-time offsets below
+                bf16x8_t A[2][WT ? BT : HCO];                    // two alternating sets: the next block's fragments land under this block's MFMAs
 #pragma unroll
                 for (int i = 0; i < (WT ? BT : HCO); ++i) {
                     if constexpr ((SDBG & 4) == 0) A[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
                     else A[0][i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, slot, ln));
-                }
-                }
-                if constexpr (WT && PFD == 2) {   // block 1 as well (tap 0, tiles BT.. or tap 1)
-#pragma unroll
-                    for (int i = 0; i < BT; ++i)
-                        A[1][i] = *reinterpret_cast<const bf16x8_t *>(ws + (BT / HCO) * SLICE_BYTES + ((BT % HCO) + i) * 256);
-                }
-                if constexpr (V2X_STREAM_LORDER_BUILD == 1) {   // fragment reads first, DMA issue while they are in flight
-                    __builtin_amdgcn_sched_barrier(0);
-                    V2X_STREAM8G_ISSUE_DMAS
-                    __builtin_amdgcn_sched_barrier(0);
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): fragments in registers before the patch / ring may be overwritten
                 // drain: group 1 -- the weights issued one step ago (everything but this phase's own NWD DMAs; right after an epilogue
@@ -1280,7 +1111,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
                 stamp(1);
-                if constexpr (V2X_STREAM_LPRIO_BUILD > 0) __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -1290,42 +1120,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // issued right before a block would be waited for at once -- six exposed LDS latencies per step (the first form:
                 // MFMA phases alone 458 us against 318 us of MFMA work).  Issued after the first part of the block they land under
                 // its second part.
-                if constexpr (V2X_STREAM_PRIO_BUILD > 0) __builtin_amdgcn_s_setprio(V2X_STREAM_PRIO_BUILD);
-                if constexpr (M32) {
-                    // 3 * MT * 2 weight fragments in blocks of AB; a fragment feeds NR MFMAs (one per pixel row).  The next block's AB
-                    // fragments are read after the first M32PF MFMAs of the block and land under the rest of it.
-                    constexpr int NBLK = 3 * MT * 2 / AB;
-                    constexpr int PF0 = V2X_STREAM_M32PF_BUILD;
-                    static_assert(3 * MT * 2 % AB == 0 && PF0 >= 1 && PF0 <= AB * NR, "whole blocks");
-#pragma unroll
-                    for (int b = 0; b < NBLK; ++b) {
-                        auto mma32 = [&](int i0, int i1) __attribute__((always_inline)) {   // MFMAs i0..i1-1 of the block, i = j * NR + r
-#pragma unroll
-                            for (int i = i0; i < i1; ++i) {
-                                const int j = i / NR, r = i - j * NR, t = b * AB + j;
-                                const int ky = t / (2 * MT), mt = (t >> 1) % MT, kh = t & 1;
-                                acc[mt][r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[b & 1][j], B[(r + ky) * 2 + kh], acc[mt][r], 0, 0, 0);
-                            }
-                        };
-                        __builtin_amdgcn_sched_barrier(0);
-                        mma32(0, PF0);
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (b + 1 < NBLK) {
-#pragma unroll
-                            for (int j = 0; j < AB; ++j) A[(b + 1) & 1][j] = *reinterpret_cast<const bf16x8_t *>(ws + a32_off((b + 1) * AB + j));
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        mma32(PF0, AB * NR);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                } else if constexpr (WT) {
-                    // blocks of BT channel tiles x 8 pixel fragments.  PFD = 1: the next block's BT weight fragments are read after the
+                if constexpr (WT) {
+                    // blocks of BT channel tiles x 8 pixel fragments.  The next block's BT weight fragments are read after the
                     // first tile's 8 MFMAs and land under the rest of the block (the compiler waits lgkmcnt(0) before their first use).
-                    // PFD = 2: fragments are read TWO blocks ahead.  The compiler only ever waits lgkmcnt(0) here, which would also
-                    // wait for the younger read, so these reads and their waits are inline asm it does not track: LDS returns in
-                    // order, lgkmcnt(BT) = "everything but the BT newest reads has arrived".
                     constexpr int NBLK = 3 * HCO / BT;
-                    const uint32_t ws32 = (uint32_t)(uintptr_t)(lptr_t)const_cast<char *>(ws);
 #pragma unroll
                     for (int b = 0; b < NBLK; ++b) {
                         const int ky = (b * BT) / HCO, i0 = (b * BT) % HCO;
@@ -1335,33 +1133,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                                 for (int f = 0; f < 8; ++f) {
                                     if constexpr ((SDBG & 8) == 0)
-                                        acc[i0 + j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b % (PFD + 1)][j], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i0 + j][f], 0, 0, 0);
+                                        acc[i0 + j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b & 1][j], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i0 + j][f], 0, 0, 0);
                                     else if (f == 0)
-                                        acc[i0 + j][0] += __builtin_bit_cast(f32x4_t, A[b % (PFD + 1)][j]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
+                                        acc[i0 + j][0] += __builtin_bit_cast(f32x4_t, A[b & 1][j]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
                                 }
                         };
                         __builtin_amdgcn_sched_barrier(0);
-                        if constexpr (PFD == 2) {
-                            // operands of block b: read two blocks ago (b >= 2) -- younger in flight: the reads of block b + 1, if any
-                            if (b >= 2) {
-                                if (b + 1 < NBLK) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(BT) : "memory");
-                                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
                         mma_tiles(0, 1);
                         __builtin_amdgcn_sched_barrier(0);
-                        if (b + PFD < NBLK) {
-                            const int ky1 = ((b + PFD) * BT) / HCO, j1 = ((b + PFD) * BT) % HCO;
+                        if (b + 1 < NBLK) {
+                            const int ky1 = ((b + 1) * BT) / HCO, j1 = ((b + 1) * BT) % HCO;
 #pragma unroll
                             for (int j = 0; j < BT; ++j) {
-                                if constexpr (PFD == 2) {
-                                    const uint32_t ad = ws32 + ky1 * SLICE_BYTES + (j1 + j) * 256;
-                                    asm volatile("ds_read_b128 %0, %1" : "=v"(A[(b + PFD) % (PFD + 1)][j]) : "v"(ad) : "memory");
-                                } else if constexpr ((SDBG & 4) == 0) {
-                                    A[(b + PFD) % (PFD + 1)][j] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (j1 + j) * 256);
+                                if constexpr ((SDBG & 4) == 0) {
+                                    A[(b + 1) & 1][j] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (j1 + j) * 256);
                                 } else {
-                                    A[(b + PFD) % (PFD + 1)][j] = __builtin_bit_cast(bf16x8_t, make_uint4(st, j, b, ln));
+                                    A[(b + 1) & 1][j] = __builtin_bit_cast(bf16x8_t, make_uint4(st, j, b, ln));
                                 }
                             }
                         }
@@ -1370,7 +1157,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 } else {
-                constexpr int H1 = V2X_STREAM_H1_BUILD < 0 ? (HCO + 1) / 2 : V2X_STREAM_H1_BUILD;   // channel tiles of the first part
+                constexpr int H1 = 1;   // channel tiles of the first part (the prefetch point inside a half tap: moving it measured 0.0 %)
 #pragma unroll
                 for (int h = 0; h < 6; ++h) {
                     const int ky = h >> 1, hh = h & 1;
@@ -1401,7 +1188,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 }
-                if constexpr (V2X_STREAM_PRIO_BUILD > 0) __builtin_amdgcn_s_setprio(0);
                 stamp(3);
                 if constexpr ((SDBG & 16) != 0) ++dbg_n;
                 __builtin_amdgcn_sched_barrier(0);
@@ -1411,14 +1197,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         constexpr bool LSS = V2X_STREAM_LSS_BUILD != 0 && EPI != SEPI_GRU;
         // (the GRU's table is float4 per hidden channel: a channel half of the tile starts BCO / 6 channels = 4 * BCO / 6 floats in)
-        if constexpr (M32) {
-            const int le = fresh_lane();
-            if constexpr (EPI == SEPI_GRU)
-                stream_epilogue32<MT, NR, EPI>(a, acc, co_tile * 32, 0, n, y0 + R0, x0, le & 31, le >> 5, (lds_cf_t *)nullptr, 0);
-            else
-                stream_epilogue32<MT, NR, EPI>(a, acc, co_tile * BCO + coh * 64, coh * 64, n, y0 + R0, x0, le & 31, le >> 5,
-                                               LSS ? (lds_cf_t *)s_ss : (lds_cf_t *)nullptr, BCO);
-        } else if constexpr (WT)
+        if constexpr (WT)
             stream_epilogue<BCO / 2, TW, EPI, 8, false>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr,
                                                         LSS ? (lds_cf_t *)s_ss + coh * (EPI == SEPI_GRU ? 4 * (BCO / 6) : BCO / 2) : (lds_cf_t *)nullptr, BCO);
         else stream_epilogue<BCO, TW, EPI, 4, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, LSS ? (lds_cf_t *)s_ss : (lds_cf_t *)nullptr, BCO);
@@ -1438,12 +1217,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #endif
 }
 
-template <int BCO, int EPI, bool WT = false, bool M32 = false>
+template <int BCO, int EPI, bool WT = false>
 static int launch_stream8g(const StreamArgs &a, hipStream_t s) {
     constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0) + 1024;   // 153 KiB at 128 rows, 135 KiB at 96 (+1 KiB: epilogue parameters)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static v2x_once_per_device attr_once;
-    auto kern = &conv3x3_stream8g_kernel<BCO, EPI, WT, M32>;
+    auto kern = &conv3x3_stream8g_kernel<BCO, EPI, WT>;
     if (v2x_first_use_on_device(attr_once)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     }
@@ -1981,13 +1760,6 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
             // pixels (with the new tiling 1 685 -> 1 699 us inside the step although +7 % in isolation).  V2X_STREAM_WT=0: old tiling
             // everywhere, =2: new tiling for the GRU too (A/B runs).
             const int wt = v2x_tune(V2X_TUNE_STREAM_WT);
-#if V2X_STREAM_M32_BUILD
-            // the MFMA phase on 32x32x16 -- MEASURED AND REJECTED (round 3; numbers at the M32 comment of the kernel): compiled only into
-            // libraries built with -DV2X_STREAM_M32_BUILD=1, and selected there by the tuning switch STREAM_M32 = 1
-            const bool m32 = v2x_tune(V2X_TUNE_STREAM_M32) != 0;
-            if (grouped && m32 && wt >= 1 && d->epilogue != V2X_EPI_GRU) return launch_stream8g<128, SEPI_BF16, true, true>(a, s);
-            if (grouped && m32 && wt < 2 && d->epilogue == V2X_EPI_GRU) return launch_stream8g<96, SEPI_GRU, false, true>(a, s);
-#endif
             if (grouped && wt >= 1 && d->epilogue != V2X_EPI_GRU) return launch_stream8g<128, SEPI_BF16, true>(a, s);
             if (grouped && wt >= 2 && d->epilogue == V2X_EPI_GRU) return launch_stream8g<96, SEPI_GRU, true>(a, s);
             if (d->epilogue == V2X_EPI_GRU) return grouped ? launch_stream8g<96, SEPI_GRU>(a, s) : launch_stream8<96, SEPI_GRU>(a, s);

@@ -70,19 +70,19 @@ def mfma_rate(ms_budget=120.0, random_operands=True, shape32=False, device=None)
 def calibrate(device=None, total_bytes=2 << 30, mfma_ms=120.0):
     """The record bench.py prints: {"mfma_tflops", "sclk_mhz", "copy_1_1_tbs", "copy_1_3_tbs", "copy_2_1_tbs", "copy_4_1_tbs"} (+ method)."""
     device = device or torch.device("cuda", torch.cuda.current_device())
-    units = total_bytes // 32
     # one pair of buffers large enough for every mix at this byte count
     src = torch.empty(total_bytes // 4, dtype=torch.int32, device=device).random_()
     dst = torch.empty(total_bytes // 4, dtype=torch.int32, device=device)
     out = {}
     for name in ("copy_1_1", "copy_1_3", "copy_2_1", "copy_4_1"):
         r, w = MIXES[name]
-        out[name + "_tbs"] = stream_rate(r, w, total_bytes, False, 8, 2, device, (src, dst))
+        # the ceiling is the best persistent-grid size: 1:1 peaks at 4 workgroups per CU, the write-heavy mixes at 2 (profiles/r04_hbm_mix_probe.txt)
+        out[name + "_tbs"] = max(stream_rate(r, w, total_bytes, False, wg, 2, device, (src, dst)) for wg in (2, 4, 8))
     del src, dst
     tf, mhz = mfma_rate(mfma_ms, True, False, device)
     out["mfma_tflops"] = tf
     out["sclk_mhz"] = mhz
-    out["method"] = ("v2x_calib_stream: %d MiB per launch, 16 B per lane, R read + W write streams, default cache policy, 8 workgroups per CU, best of 2 "
+    out["method"] = ("v2x_calib_stream: %d MiB per launch, 16 B per lane, R read + W write streams, default cache policy, best of 2 / 4 / 8 workgroups per CU x 2 launches "
                      "after a warm-up; v2x_calib_mfma: register-resident v_mfma_f32_16x16x32_bf16 loop, random operands, 2 waves per SIMD, ~%d ms "
                      "back to back (second half timed); sclk = s_memtime / s_memrealtime over one wave's loop" % (total_bytes >> 20, int(mfma_ms)))
     return out

@@ -27,6 +27,7 @@ class FaFNet(NonIntermediateModelBase):
                 "dec": self.stpn.decoder.pack("stpn.decoder.", device),
                 "heads": self._pack_heads(device)}
 
+    @ops.latency_entry     # the plain single-GPU entry: small batches take the latency forms (ops.latency_launches)
     def forward_nhwc(self, x0):
         pk = self.packed(x0.device)
         feats = LidarEncoder.run(pk["enc"], x0)
@@ -34,5 +35,4 @@ class FaFNet(NonIntermediateModelBase):
 
     def forward(self, bevs, maps=None, vis=None, batch_size=None):
         """bevs: (batch*agents, 1, 256, 256, 13) dense occupancy, as the reference Dataset yields."""
-        with ops.latency_dispatch():     # the plain single-GPU entry: small batches take the latency forms (ops.latency_launches)
-            return self.forward_nhwc(self._input_nhwc(bevs))
+        return self.forward_nhwc(self._input_nhwc(bevs))

@@ -103,15 +103,24 @@ class V2VNet(IntermediateModelBase):
                 cur.index_copy_(0, rows, h)
         return cur
 
-    def forward_nhwc(self, x0, trans_matrices, num_agent_tensor, batch_size=1, plan=None):
+    @ops.latency_entry     # the plain single-GPU entry: small batches take the latency forms (ops.latency_launches)
+    def forward_nhwc(self, x0, trans_matrices, num_agent_tensor, batch_size=1, plan=None, zbits=0):
+        """x0: (A*B, X, Y, 32) bf16 NHWC, or -- zbits > 0 -- the voxeliser's int32 bit grid (A*B, X, Y) with zbits height bins."""
         pk = self.packed(x0.device)
-        feats = LidarEncoder.run(pk["enc"], x0)
+        feats = LidarEncoder.run(pk["enc"], x0, zbits=zbits)
         if plan is None:
             plan = self.make_plan(num_agent_tensor, batch_size, x0.device)
         feats[self.layer] = self.fuse(feats[self.layer], trans_matrices, plan, batch_size, pk)
         return self.decode_heads(pk, feats)
 
+    def forward_points(self, points, n_pts, trans_matrices, num_agent_tensor, batch_size=1, grid=None, plan=None):
+        """points -> logits on ONE GPU, the plain entry for raw sweeps: points (A*B, max_pts, stride >= 3) fp32 agent-major, n_pts (A*B,) int32.
+        Voxel scatter (a1) -> bit grid -> forward_nhwc.  Like forward(), a declared latency entry: small batches take the latency forms."""
+        grid = grid or ops.VoxelGrid()
+        with ops.latency_dispatch():
+            bits = ops.voxelize_bits(points, n_pts, grid)
+            return self.forward_nhwc(bits, trans_matrices, num_agent_tensor, batch_size, plan=plan, zbits=grid.dims[2])
+
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
         """bevs (A*B, 1, 256, 256, 13) agent-major; trans_matrices (B, A, A, 4, 4); num_agent_tensor (B, A)."""
-        with ops.latency_dispatch():     # the plain single-GPU entry: small batches take the latency forms (ops.latency_launches)
-            return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)
+        return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)

@@ -129,6 +129,7 @@ class When2com(IntermediateModelBase):
         querys = KmGenerator.run(pk["query"], y)
         return ops.attn_handshake(keys, querys, pk["w_lin"], pk["b_lin"], self.agent_num, batch_size, mode)
 
+    @ops.latency_entry
     def forward_nhwc(self, x0, trans_matrices, num_agent_tensor, training=True, inference="activated",
                      batch_size=1, plan=None):
         pk = self.packed(x0.device)
@@ -171,8 +172,7 @@ class When2com(IntermediateModelBase):
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, maps=None, vis=None, training=True, MO_flag=True,
                 inference="activated", batch_size=1):
-        with ops.latency_dispatch():
-            res = self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, training, inference,
-                                    batch_size)
+        res = self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, training, inference,
+                                batch_size)
         res["num_connect"] = self.num_connect(res["coef"], self.agent_num)
         return res

@@ -51,6 +51,7 @@ class FusionBase(IntermediateModelBase):
         cur.index_copy_(0, rows, out)
         return cur
 
+    @ops.latency_entry
     def forward_nhwc(self, x0, trans_matrices, num_agent_tensor, batch_size=1, plan=None):
         pk = self.packed(x0.device)
         feats = LidarEncoder.run(pk["enc"], x0)
@@ -60,8 +61,7 @@ class FusionBase(IntermediateModelBase):
         return self.decode_heads(pk, feats)
 
     def forward(self, bevs, trans_matrices, num_agent_tensor, batch_size=1):
-        with ops.latency_dispatch():
-            return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)
+        return self.forward_nhwc(self._input_nhwc(bevs), trans_matrices, num_agent_tensor, batch_size)
 
 
 class SumFusion(FusionBase):

@@ -40,6 +40,7 @@ class V2VNetSeg(V2VNet):
         pk["seg"] = _pack_seg_head(self.outc, device)
         return pk
 
+    @ops.latency_entry
     def forward_nhwc(self, x0, trans_matrices, num_agent_tensor, batch_size=1, plan=None):
         pk = self.packed(x0.device)
         feats = LidarEncoder.run(pk["enc"], x0)
@@ -61,6 +62,7 @@ class FaFNetSeg(FaFNet):
         pk["seg"] = _pack_seg_head(self.outc, device)
         return pk
 
+    @ops.latency_entry
     def forward_nhwc(self, x0):
         pk = self.packed(x0.device)
         feats = LidarEncoder.run(pk["enc"], x0)

@@ -41,8 +41,8 @@ class _Prof:
 # Latency dispatch.  Kernel forms whose choice depends on the NUMBER of maps in a launch (split-K of the streamed layers, the 1-tap stride-2
 # kernel below four tiles per CU) change the fp32 summation order, so they are never taken silently: the caller declares a latency launch.
 # tuning SMALL_BATCH: 0 never; 1 every launch of the process (the explicit pin, also for the sharded runners); 2 (default) only inside a
-# `with ops.latency_dispatch():` block -- the plain single-GPU model classes enter one in forward(), the sharded runners (R-rank == 1-rank
-# bitwise) never do.
+# `with ops.latency_dispatch():` block -- the plain single-GPU model classes enter one in forward_nhwc() (@ops.latency_entry: the common entry
+# of forward(), forward_points() and the Seg / Det modules), the sharded runners (R-rank == 1-rank bitwise) never do.
 _latency_depth = 0
 
 
@@ -58,6 +58,17 @@ class latency_dispatch:
         global _latency_depth
         _latency_depth -= 1
         return False
+
+
+def latency_entry(fn):
+    """Decorator of the plain single-GPU model entries (forward_nhwc of every model class): launches inside are declared latency launches."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with latency_dispatch():
+            return fn(*a, **k)
+    return wrapped
 
 
 def latency_launches():
@@ -99,11 +110,9 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
             if epi != 1 and tuning.get("STREAM_G") != 0:
                 wt = tuning.get("STREAM_WT")   # wave tiling: half the channels x 128 pixels per wave
                 tiled = (wt >= 1 and epi == 0) or (wt >= 2 and epi == 2)
-                # 32x32x16 MFMA form: the wave-tiled plain layers and the (untiled) ConvGRU
-                m32 = tuning.get("STREAM_M32") != 0 and ((epi == 0 and tiled) or (epi == 2 and not tiled))
-                return "conv3x3_stream8g_kernel<%d, %d, %s, %s>" % (rows, epi, "true" if tiled else "false", "true" if m32 else "false")  # 8 waves, three taps per synchronisation
+                return "conv3x3_stream8g_kernel<%d, %d, %s>" % (rows, epi, "true" if tiled else "false")  # 8 waves, three taps per synchronisation
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
-        return "conv3x3_stream_kernel<%d, %d, %d, %d>" % (rows, th, tw, epi)
+        return "conv3x3_stream_kernel<%d, %d, %d, %d, false>" % (rows, th, tw, epi)
     if pc.w_layout == 1:
         c0, c1 = (pc.C0, pc.C1) if pc.C1 else (0, pc.C0)
         co2 = (pc.Cout2 + 15) // 16 * 16 if pc.Cout2 else 0

@@ -66,10 +66,28 @@ def _zero_insert(dy):
     return z
 
 
-def hip_eligible(weight, stride, H, W):
-    """3x3, stride 1 or 2, pad 1; the INPUT map tiles into 8x32-pixel tiles; Cout % 32 == 0 (Cin is padded to 32)."""
+def _layer_runs(cin_p, cout, stride, H, W):
+    """Will ops.run_layer find a kernel for the ONE packing packing.pack_conv_device makes for this layer (it packs no gather fallback beside
+    a halo / streamed layout)?  Mirrors run_layer's conditions exactly (a miss there is an IndexError on the empty fallback list)."""
+    layout = packing.train_layout(cin_p, cout, stride)
+    if layout == 0:
+        return True                                    # the gather kernel takes any extent
+    if stride == 2:
+        return (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and tuning.get("S2_T16") != 0)
+    return ops.halo_eligible(H, W, layout, cin_p) and (layout != 2 or H * W >= 256)
+
+
+def hip_eligible(weight, stride, H, W, cin_pad=None):
+    """3x3, stride 1 or 2, pad 1, Cout % 32 == 0 (Cin is padded to 32), and every launch of the layer's forward AND backward has a kernel at
+    this extent: the forward layer, the data-gradient layer (a stride-1 convolution Cout -> Cin' at the input extent) and the weight-gradient
+    kernel (H % 8 == 0, W % 32 == 0).  Anything else takes the F.conv2d path of conv3x3()."""
     cout, cin, kh, kw = weight.shape
-    return kh == 3 and kw == 3 and stride in (1, 2) and cout % 32 == 0 and H % 8 == 0 and W % 32 == 0
+    if not (kh == 3 and kw == 3 and stride in (1, 2) and cout % 32 == 0 and H % 8 == 0 and W % 32 == 0):
+        return False
+    cin_p = cin_pad if cin_pad is not None else (cin + 31) // 32 * 32
+    if cin_p % 32:
+        return False
+    return _layer_runs(cin_p, cout, stride, H, W) and _layer_runs(cout, cin_p, 1, H, W)
 
 
 class _Conv3x3(torch.autograd.Function):
@@ -128,9 +146,9 @@ class _BnRelu(torch.autograd.Function):
 def conv3x3(x, conv):
     """nn.Conv2d (3x3) on a bf16 NHWC map: the HIP kernels where the map tiles, MIOpen through a layout round trip otherwise."""
     s = conv.stride[0]
-    if hip_eligible(conv.weight, s, x.shape[1], x.shape[2]):
+    if hip_eligible(conv.weight, s, x.shape[1], x.shape[2], x.shape[3]):
         return _Conv3x3.apply(x.contiguous(), conv.weight, conv.bias, s)
-    if s == 1 and x.shape[2] % 32 == 16 and hip_eligible(conv.weight, s, x.shape[1], x.shape[2] + 16):
+    if s == 1 and x.shape[2] % 32 == 16 and hip_eligible(conv.weight, s, x.shape[1], x.shape[2] + 16, x.shape[3]):
         # a 16-pixel-wide map (conv4_2): widen it with 16 zero columns -- a zero column IS the layer's padding, so columns 0..W-1 of
         # the output, of dx and the whole of dW are unchanged (the slice's backward zero-fills dy over the extra columns)
         W = x.shape[2]
