@@ -16,50 +16,11 @@
 //     L2 byte, 3x the gather kernel.
 // LDS: 4 x 8 KiB ring + 2 x 24 KiB patch buffers = 80 KiB -> two workgroups per CU (160 KiB).
 // LDS layouts as conv_halo.hip (conflict-free: patch slot ^ ((x>>1)&3), weights k-slot-major).
-#include "common.h"
+#include "conv_stream.h"
 #include <cstdlib>
 #include <type_traits>
 
-typedef const __attribute__((address_space(1))) void *gptr_t;
-typedef __attribute__((address_space(3))) void *lptr_t;
-typedef const __attribute__((address_space(3))) float lds_cf_t;     // LDS-resident float (explicit address space: a generic pointer would be a FLAT load)
-typedef const __attribute__((address_space(3))) f32x4_t lds_cf4_t;   // (the builtin vector type: HIP's float4 class cannot be read through an address-space pointer)
-__device__ __forceinline__ float4 lds_ld4(lds_cf_t *p) {
-    const f32x4_t v = *reinterpret_cast<lds_cf4_t *>(p);
-    return make_float4(v[0], v[1], v[2], v[3]);
-}
 
-__device__ __forceinline__ void glds16s(const void *g, char *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
-}
-
-struct StreamArgs {
-    const uint16_t *in0, *in1;  // in0: first C0 channels (half resolution when up0), in1: next C1 channels
-    int C0, C1, up0;
-    int N, H, W;
-    const uint16_t *w;  // [n_co_tiles][n_chunks][9][4][BCO][8] bf16, followed by 64 B of zeros (the zero page)
-    const float *scale, *shift;
-    int relu;
-    void *out;
-    int out_cstride, out_coff, Cout;
-    int tiles_x, tiles_y, n_px_tiles, n_co_tiles;
-    // chained 1x1 (SEPI_CHAIN, BCO == Cout == 64): hidden = relu(acc*scale+shift) never leaves the registers
-    const uint16_t *w2;   // bf16 [64][64] row-major, K in the chain (kappa) order of conv_halo.hip
-    const float *scale2, *shift2;
-    int relu2;
-    // split-K (small batches, conv3x3_stream_kernel<..., SPLITK = true>): blockIdx.y walks `ksplit` contiguous ranges of the 32-channel
-    // chunks and stores its raw fp32 sums to ws[split][pixel][w_rows]; splitk_reduce_kernel adds them in split order and applies the epilogue
-    int ksplit;
-    float *ws;
-    int w_rows;
-    int xcd_walk;   // stream8g, 8 channel tiles on 256 workgroups: 1 = an XCD walks 8 pixel tiles x 4 channel tiles per round instead of 4 x 8 (tuning switch GRU_XCD_WALK; the ConvGRU)
-};
-
-constexpr int PATCH_PIECES = 24;             // wave instructions (1 KiB each) per patch buffer
-constexpr int PATCH_BYTES = PATCH_PIECES * 1024;
-constexpr int RING = 4;                      // weight slices in flight + 1 being read
-
-enum { SEPI_BF16 = 0, SEPI_CHAIN = 1, SEPI_GRU = 2 };
 
 // TIMING EXPERIMENTS ONLY (tools/stream8_phase_probe.sh builds the library with -DV2X_STREAM_DBG_BUILD=n): which part of the
 // 8-wave kernel's step is the long pole?  1 = no weight DMAs, 2 = no patch DMAs, 4 = no fragment reads, 8 = no MFMAs.  Results are
@@ -536,8 +497,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 // before its barrier); the first overwrite is issued in interval 2s.  (R3) the next chunk's patch goes to the
 // other buffer, last read in L(9kc-1), first written in L(9kc); its last piece is issued at tap 4, five steps
 // before it is read.  Every wave issues exactly 2 DMAs per step (dummies keep the count), so the counts are static.
-constexpr int PATCH8_PIECES = 40;            // 18 x 34 pixels x 64 B = 38.25 KiB; piece 39 is padding / dummy target
-constexpr int PATCH8_BYTES = PATCH8_PIECES * 1024;
 
 // PERSISTENT over tiles: a workgroup walks tiles bid, bid + gridDim.x, ... of ONE channel tile (the host makes gridDim.x a
 // multiple of n_co_tiles), and the K pipeline never drains between tiles: during the last chunk of a tile the idle patch
@@ -1760,6 +1719,13 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
             // pixels (with the new tiling 1 685 -> 1 699 us inside the step although +7 % in isolation).  V2X_STREAM_WT=0: old tiling
             // everywhere, =2: new tiling for the GRU too (A/B runs).
             const int wt = v2x_tune(V2X_TUNE_STREAM_WT);
+            // one-wave-per-SIMD 32x32x16 form (conv_stream_w1.hip; tuning switch STREAM_W1: 1 = the 128-row plain layers, 2 = the ConvGRU too):
+            // same tiles, same K order as stream8g; needs an even number of 32-channel chunks (its step loop is unrolled over two chunks)
+            const int w1 = v2x_tune(V2X_TUNE_STREAM_W1);
+            if (w1 != 0 && grouped && (((d->C0 + d->C1) >> 5) & 1) == 0) {
+                if (d->epilogue != V2X_EPI_GRU && rows == 128 && d->Cout % 128 == 0) return v2x_launch_stream_w1(a, 128, 0, s);
+                if (d->epilogue == V2X_EPI_GRU && rows == 96 && d->Cout % 32 == 0 && w1 >= 2) return v2x_launch_stream_w1(a, 96, 1, s);
+            }
             if (grouped && wt >= 1 && d->epilogue != V2X_EPI_GRU) return launch_stream8g<128, SEPI_BF16, true>(a, s);
             if (grouped && wt >= 2 && d->epilogue == V2X_EPI_GRU) return launch_stream8g<96, SEPI_GRU, true>(a, s);
             if (d->epilogue == V2X_EPI_GRU) return grouped ? launch_stream8g<96, SEPI_GRU>(a, s) : launch_stream8<96, SEPI_GRU>(a, s);
