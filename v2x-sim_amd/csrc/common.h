@@ -21,7 +21,6 @@ enum v2x_tune_id {
     V2X_TUNE_STREAM_WAVES,    // 8 (default): 8-wave ping-pong streamed kernels where they apply; 4: the 4-wave kernel everywhere
     V2X_TUNE_STREAM_G,        // 1: three taps per synchronisation (stream8g); 0: the 1-tap 8-wave kernel
     V2X_TUNE_STREAM_WT,       // stream8g wave tiling: 0 all channels x 64 pixels per wave everywhere, 1 (default) half x 128 for the plain layers, 2 also for the ConvGRU
-    V2X_TUNE_STREAM_W1,       // one-wave-per-SIMD 32x32x16 form of the 128-row streamed layers (conv_stream_w1.hip): 0 off, 1 plain layers, 2 also the ConvGRU
     V2X_TUNE_STREAM_PERSIST,  // 1: persistent stream8 grid; 0: one tile per workgroup
     V2X_TUNE_STREAM_WIDE,     // 1: the wide 4-wave form for 64-row layers; 0: the 256-pixel kernel
     V2X_TUNE_WIDE3,           // 1: three taps per synchronisation in the wide form (>= 3 chunks); 0: the 1-tap wide form

@@ -1,5 +1,5 @@
-// Declarations shared by the streamed-weights kernel families (conv_stream.hip: 4-wave, 8-wave ping-pong, wide forms; conv_stream_w1.hip: the
-// one-wave-per-SIMD 32x32x16 form): kernel arguments, LDS / LDS-DMA helpers, patch geometry.
+// Declarations of the streamed-weights kernel families of conv_stream.hip (4-wave, 8-wave ping-pong, wide forms): kernel arguments, LDS / LDS-DMA
+// helpers, patch geometry.
 #pragma once
 #include "common.h"
 
@@ -48,5 +48,3 @@ constexpr int PATCH8_PIECES = 40;            // 18 x 34 pixels x 64 B = 38.25 Ki
 constexpr int PATCH8_BYTES = PATCH8_PIECES * 1024;
 
 int v2x_num_cus();
-// conv_stream_w1.hip: launches the one-wave-per-SIMD form for the layer `a` describes; returns 1 when the shape is not covered
-int v2x_launch_stream_w1(const StreamArgs &a, int rows, int gru, hipStream_t s);

@@ -56,6 +56,9 @@ extern "C" int v2x_debug_stream_timeline(unsigned *dst) {   // exists in the tim
 // read two blocks ahead (PF = 2: +2.8-3.7 %), s_setprio in the load / MFMA phase (LPRIO, PRIO: no effect), the prefetch point inside a block
 // (H1: 0.0 %), one channel tile per XCD (XCDCO: +0.1-0.7 %), fragment reads before the DMA issue (LORDER: +0.2-0.5 %).  What moves these kernels
 // is the NUMBER of instructions per MFMA (taps per barrier, fragment reads per wave tile), not where their latencies fall.
+// Round 4: the one-wave-per-SIMD 32x32x16 form ("w1": 4 waves x 512 registers, each wave issuing its own reads and DMAs between its MFMAs) --
+// bit-identical, 23-35 % slower, and with all companion work compiled out only as fast as stream8g with all of its: the chip is power-limited
+// on these operands (profiles/r04_w1_rejected.txt; the kernel is conv_stream_w1.hip at commit a173db3).
 #ifndef V2X_STREAM_LSS_BUILD
 #define V2X_STREAM_LSS_BUILD 1
 #endif
@@ -1719,13 +1722,6 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
             // pixels (with the new tiling 1 685 -> 1 699 us inside the step although +7 % in isolation).  V2X_STREAM_WT=0: old tiling
             // everywhere, =2: new tiling for the GRU too (A/B runs).
             const int wt = v2x_tune(V2X_TUNE_STREAM_WT);
-            // one-wave-per-SIMD 32x32x16 form (conv_stream_w1.hip; tuning switch STREAM_W1: 1 = the 128-row plain layers, 2 = the ConvGRU too):
-            // same tiles, same K order as stream8g; needs an even number of 32-channel chunks (its step loop is unrolled over two chunks)
-            const int w1 = v2x_tune(V2X_TUNE_STREAM_W1);
-            if (w1 != 0 && grouped && (((d->C0 + d->C1) >> 5) & 1) == 0) {
-                if (d->epilogue != V2X_EPI_GRU && rows == 128 && d->Cout % 128 == 0) return v2x_launch_stream_w1(a, 128, 0, s);
-                if (d->epilogue == V2X_EPI_GRU && rows == 96 && d->Cout % 32 == 0 && w1 >= 2) return v2x_launch_stream_w1(a, 96, 1, s);
-            }
             if (grouped && wt >= 1 && d->epilogue != V2X_EPI_GRU) return launch_stream8g<128, SEPI_BF16, true>(a, s);
             if (grouped && wt >= 2 && d->epilogue == V2X_EPI_GRU) return launch_stream8g<96, SEPI_GRU, true>(a, s);
             if (d->epilogue == V2X_EPI_GRU) return grouped ? launch_stream8g<96, SEPI_GRU>(a, s) : launch_stream8<96, SEPI_GRU>(a, s);

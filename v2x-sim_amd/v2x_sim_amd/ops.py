@@ -108,9 +108,6 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
         if W % 32 == 0 and H % 16 == 0 and rows in (96, 128) \
                 and tuning.get("STREAM_WAVES") != 4:
             if epi != 1 and tuning.get("STREAM_G") != 0:
-                w1 = tuning.get("STREAM_W1")
-                if w1 != 0 and ((pc.C0 + pc.C1) // 32) % 2 == 0 and ((epi == 0 and rows == 128 and pc.Cout % 128 == 0) or (epi == 2 and w1 >= 2 and pc.Cout % 32 == 0)):
-                    return "conv3x3_w1_kernel<%d, %d>" % (rows, epi)   # one wave per SIMD, 32x32x16 MFMAs (conv_stream_w1.hip)
                 wt = tuning.get("STREAM_WT")   # wave tiling: half the channels x 128 pixels per wave
                 tiled = (wt >= 1 and epi == 0) or (wt >= 2 and epi == 2)
                 return "conv3x3_stream8g_kernel<%d, %d, %s>" % (rows, epi, "true" if tiled else "false")  # 8 waves, three taps per synchronisation
