@@ -19,7 +19,7 @@ extern "C" int v2x_abi_version(void) { return V2X_AMD_ABI_VERSION; }
 namespace {
 struct TuneEntry { const char *name; int def; };
 const TuneEntry kTune[V2X_TUNE_COUNT] = {
-    {"STREAM_WAVES", 8}, {"STREAM_G", 1}, {"STREAM_WT", 1}, {"STREAM_PERSIST", 1}, {"STREAM_WIDE", 1},
+    {"STREAM_WAVES", 8}, {"STREAM_G", 1}, {"STREAM_WT", 1}, {"STORE_X4", 1}, {"STREAM_PERSIST", 1}, {"STREAM_WIDE", 1},
     {"WIDE3", 1}, {"HALO_PP", 1}, {"S2_RESIDENT", 1}, {"VOXELIZE_LDS", 1}, {"WARP_LDS", 1}, {"S2_G", 1}, {"GRU_XCD_WALK", 1}, {"HALO_XCD", 1}, {"WGRAD_TR", 1},
 };
 std::atomic<int> g_tune[V2X_TUNE_COUNT];

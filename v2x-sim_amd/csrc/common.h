@@ -21,6 +21,7 @@ enum v2x_tune_id {
     V2X_TUNE_STREAM_WAVES,    // 8 (default): 8-wave ping-pong streamed kernels where they apply; 4: the 4-wave kernel everywhere
     V2X_TUNE_STREAM_G,        // 1: three taps per synchronisation (stream8g); 0: the 1-tap 8-wave kernel
     V2X_TUNE_STREAM_WT,       // stream8g wave tiling: 0 all channels x 64 pixels per wave everywhere, 1 (default) half x 128 for the plain layers, 2 also for the ConvGRU
+    V2X_TUNE_STORE_X4,        // 1: 16-byte output stores (two channel tiles exchanged with v_permlane16_swap_b32) in the epilogues that have the form; 0: 8-byte stores (same bytes)
     V2X_TUNE_STREAM_PERSIST,  // 1: persistent stream8 grid; 0: one tile per workgroup
     V2X_TUNE_STREAM_WIDE,     // 1: the wide 4-wave form for 64-row layers; 0: the 256-pixel kernel
     V2X_TUNE_WIDE3,           // 1: three taps per synchronisation in the wide form (>= 3 chunks); 0: the 1-tap wide form
@@ -97,6 +98,23 @@ __device__ __forceinline__ uint32_t v2x_relu_bf16x2(uint32_t x) {
 __device__ __forceinline__ uint32_t v2x_relu_bf16x2_floor(uint32_t x, uint32_t floor_bits) {
     const v2x_s16x2_t r = __builtin_elementwise_max(__builtin_bit_cast(v2x_s16x2_t, x), __builtin_bit_cast(v2x_s16x2_t, floor_bits));
     return __builtin_bit_cast(uint32_t, r);
+}
+
+// 16-byte output stores from the 16x16x32 MFMA result layout.  A lane (fj = pixel, fq = k-slot quarter) holds 4 consecutive channels (8 bytes) of
+// one pixel per 16-channel tile, and a vector store costs the memory pipeline about the same whatever its width (tools/tile_overhead.py: ~12 us
+// per 16 x 32 x 128 tile spent behind dwordx2 stores).  v_permlane16_swap_b32 (gfx950) swaps the odd 16-lane rows of its first operand with the
+// even rows of its second: applied to the packed bf16 pairs (x0, y0) of tile i and (x1, y1) of tile i + 1 it leaves the lanes of even fq with 8
+// consecutive channels of tile i (theirs, then their neighbour's) and the odd ones with 8 consecutive channels of tile i + 1 (the neighbour's,
+// then theirs): ONE dwordx4 store per tile pair, same bytes and values as the two dwordx2 stores.  p = the lane's own 8-byte slot in tile i
+// (channel 16 i + 4 fq of its pixel); needs 16-byte aligned rows (channel stride and offset multiples of 8) and whole tile pairs.
+__device__ __forceinline__ void v2x_store_pair_x4(uint16_t *p, int fq, uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+    const auto rx = __builtin_amdgcn_permlane16_swap(x0, x1, false, false);
+    const auto ry = __builtin_amdgcn_permlane16_swap(y0, y1, false, false);
+    *reinterpret_cast<uint4 *>(p + ((fq & 1) ? 12 : 0)) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+}
+// host side: may a layer's bf16 output view take the 16-byte form?
+static inline int v2x_x4_ok(const void *out, int out_cstride, int out_coff, int channels) {
+    return v2x_tune(V2X_TUNE_STORE_X4) != 0 && channels % 32 == 0 && out_cstride % 8 == 0 && out_coff % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;
 }
 
 // XCD-aware persistent tile walk for kernels whose neighbouring tiles share input (halo rows / columns): the hardware deals consecutive

@@ -58,6 +58,7 @@ struct HaloArgs {
     float det_thr, det_margin;   // score threshold; logit(det_thr) - 1e-3 = the conservative pre-test on c1 - c0
     int det_cap;
     int xcd_walk;         // 1: XCD-contiguous tile walk (common.h: v2x_xcd_tile_walk; tuning switch HALO_XCD)
+    int x4;               // bf16 outputs: 16-byte stores (common.h: v2x_store_pair_x4); set by the dispatch when the output view allows
 };
 
 constexpr int TH = 8, TW = 32, PH = TH + 2, PW = TW + 2;
@@ -496,6 +497,29 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 }
             }
         } else if constexpr (COUT2 == 0) {
+            if (a.x4) {   // 16-byte stores: channel tiles i, i + 1 exchanged between the k-slot quarters (common.h: v2x_store_pair_x4)
+#pragma unroll
+                for (int i = 0; i < TCO; i += 2) {
+                    float4 sc[2], sf[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        sc[h] = *reinterpret_cast<const float4 *>(s_ss + (i + h) * 16 + fq * 4);
+                        sf[h] = *reinterpret_cast<const float4 *>(s_ss + COUT + (i + h) * 16 + fq * 4);
+                    }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
+                        uint32_t ox[2], oy[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][0] * sc[h].x + sf[h].x, acc[i + h][f][1] * sc[h].y + sf[h].y), relu_floor);
+                            oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][2] * sc[h].z + sf[h].z, acc[i + h][f][3] * sc[h].w + sf[h].w), relu_floor);
+                        }
+                        v2x_store_pair_x4(reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + i * 16 + fq * 4, fq,
+                                          ox[0], oy[0], ox[1], oy[1]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < TCO; ++i) {
                 const int co = i * 16 + fq * 4;
@@ -906,6 +930,26 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
                 uint16_t *prow = reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff;
+                if (a.x4) {   // 16-byte stores: output tiles i2, i2 + 1 exchanged between the k-slot quarters (common.h: v2x_store_pair_x4)
+                    const uint32_t floor2 = a.relu2 ? 0u : 0x80008000u;
+#pragma unroll
+                    for (int i2 = 0; i2 + 1 < TCO2; i2 += 2) {
+                        uint32_t ox[2], oy[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const int co = (i2 + h) * 16 + fq * 4;
+                            const float4 s2 = *reinterpret_cast<const float4 *>(ss + 2 * COUT + co);
+                            const float4 t2 = *reinterpret_cast<const float4 *>(ss + 2 * COUT + COUT2 + co);
+                            f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < COUT / 32; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2 + h][ks], hb[ks], d, 0, 0, 0);
+                            ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(d[0] * s2.x + t2.x, d[1] * s2.y + t2.y), floor2);
+                            oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(d[2] * s2.z + t2.z, d[3] * s2.w + t2.w), floor2);
+                        }
+                        v2x_store_pair_x4(prow + i2 * 16 + fq * 4, fq, ox[0], oy[0], ox[1], oy[1]);
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int i2 = 0; i2 < TCO2; ++i2) {
                     const int co = i2 * 16 + fq * 4;
@@ -925,6 +969,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     o.x = pack_bf16x2(v0, v1);
                     o.y = pack_bf16x2(v2, v3);
                     *reinterpret_cast<uint2 *>(prow + co) = o;
+                }
+            }
+            return;
+        }
+        if (a.x4) {   // 16-byte stores: channel tiles i, i + 1 exchanged between the k-slot quarters (common.h: v2x_store_pair_x4)
+#pragma unroll
+            for (int i = 0; i < TCO; i += 2) {
+                float4 sc[2], sf[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    sc[h] = *reinterpret_cast<const float4 *>(ss + (i + h) * 16 + fq * 4);
+                    sf[h] = *reinterpret_cast<const float4 *>(ss + COUT + (i + h) * 16 + fq * 4);
+                }
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int y = y0 + 2 * wv + (f >> 1), x = x0 + (f & 1) * 16 + fj;
+                    uint32_t ox[2], oy[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][0] * sc[h].x + sf[h].x, acc[i + h][f][1] * sc[h].y + sf[h].y), relu_floor);
+                        oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][2] * sc[h].z + sf[h].z, acc[i + h][f][3] * sc[h].w + sf[h].w), relu_floor);
+                    }
+                    v2x_store_pair_x4(reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + i * 16 + fq * 4, fq,
+                                      ox[0], oy[0], ox[1], oy[1]);
                 }
             }
             return;
@@ -1051,6 +1119,8 @@ static int launch_halo(const HaloArgs &a, hipStream_t s) {
 int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     HaloArgs a;
     a.xcd_walk = v2x_tune(V2X_TUNE_HALO_XCD);
+    // 16-byte stores for the bf16 outputs (plain layers and the bf16 chain; the fp32 heads already store 16 bytes per lane)
+    a.x4 = (d->epilogue == V2X_EPI_BF16) ? v2x_x4_ok(d->out, d->out_cstride, d->out_coff, d->Cout2 > 0 ? d->Cout2 : d->Cout) : 0;
     a.in0 = d->C1 ? d->in0 : nullptr;
     a.in1 = d->C1 ? d->in1 : d->in0;
     a.bits = d->in_format == 1 ? reinterpret_cast<const uint32_t *>(d->in0) : nullptr;

@@ -42,6 +42,7 @@ struct PairArgs {
     int out_cstride, out_coff;
     int tiles_x, tiles_y, n_tiles;
     int xcd_walk;                       // 1: XCD-contiguous tile walk (common.h; tuning switch HALO_XCD)
+    int x4;                             // 16-byte output stores (common.h: v2x_store_pair_x4)
 };
 
 namespace pair {
@@ -287,6 +288,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (a.x4) {   // 16-byte stores: the two channel tiles exchanged between the k-slot quarters (common.h: v2x_store_pair_x4)
+                const uint32_t floorB = a.reluB ? 0u : 0x80008000u;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
+                    uint32_t ox[2], oy[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[h][f][0] * scB[h].x + shB[h].x, acc[h][f][1] * scB[h].y + shB[h].y), floorB);
+                        oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[h][f][2] * scB[h].z + shB[h].z, acc[h][f][3] * scB[h].w + shB[h].w), floorB);
+                    }
+                    v2x_store_pair_x4(a.out + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + fq * 4, fq, ox[0], oy[0], ox[1], oy[1]);
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int co = i * 16 + fq * 4;
@@ -338,6 +353,7 @@ extern "C" int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *
     if (first->N == 0) return V2X_OK;
     PairArgs a;
     a.xcd_walk = v2x_tune(V2X_TUNE_HALO_XCD);
+    a.x4 = v2x_x4_ok(second->out, second->out_cstride, second->out_coff, 32);
     a.bits = reinterpret_cast<const uint32_t *>(first->in0);
     a.zbits = first->in_zbits;
     a.N = first->N;

@@ -35,6 +35,7 @@ struct StreamArgs {
     int ksplit;
     float *ws;
     int w_rows;
+    int x4;         // plain epilogue: 16-byte output stores through v_permlane16_swap_b32 (conv_stream.hip: stream_epilogue X4); set by the dispatch when the output rows allow
     int xcd_walk;   // stream8g, 8 channel tiles on 256 workgroups: 1 = an XCD walks 8 pixel tiles x 4 channel tiles per round instead of 4 x 8 (tuning switch GRU_XCD_WALK; the ConvGRU)
 };
 

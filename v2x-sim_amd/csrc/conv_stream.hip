@@ -99,13 +99,58 @@ __device__ __forceinline__ void stage_chain(const StreamArgs &a, char *cl) {
 // PKRELU: ReLU on the packed bf16 pairs (one instruction per two values) instead of fmaxf on the fp32 values (two per value); identical
 // results.  Paired A/B, all bit-identical: streamed layers -0.3 ... -0.7 %, 64 -> 64 streamed -2.3 %, chained 128-row layer -1.9 %; only
 // conv3x3_wide3_kernel measured +1.6 % with it and passes false.
-template <int BCO, int TW, int EPI, int NF = 4, bool CL = false, bool PKRELU = true>
+// X4 (plain epilogue, with x4 = true at run time): 16-byte output stores.  A lane's accumulators of channel tile i are 4 consecutive channels
+// (8 bytes) of one pixel, so the plain path issues one dwordx2 store per (tile, fragment) -- 256 per workgroup and 16 x 32 tile, and a vector
+// store costs the memory pipeline about the same whatever its width: tools/tile_overhead.py measures ~12 us per tile beyond the K loop on the
+// 128-row layers (37 % of conv6_2's time).  v_permlane16_swap_b32 (gfx950) swaps the odd 16-lane rows of one register with the even rows of
+// another: applied to the packed results of tiles i and i + 1 it leaves the lanes of even k-slot quarter fq with 8 consecutive channels of
+// tile i (theirs + their neighbour's) and the odd ones with 8 consecutive channels of tile i + 1 -- ONE dwordx4 store per tile pair and
+// fragment, same bytes, same values.  Needs 16-byte aligned rows (out_cstride, out_coff multiples of 8 channels) and Cout % 32 == 0 (host: a.x4).
+template <int BCO, int TW, int EPI, int NF = 4, bool CL = false, bool PKRELU = true, bool X4 = false>
 __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&acc)[BCO / 16][NF], int co_tile, int n, int y0,
                                                 int x0, const int (&frow)[NF], int fj, int fq, const char *cl = nullptr,
-                                                lds_cf_t *lss = nullptr, int lss_stride = 0) {
+                                                lds_cf_t *lss = nullptr, int lss_stride = 0, bool x4 = false) {
     constexpr int TCO = BCO / 16;
     if constexpr (EPI == SEPI_GRU) {
         // rows are (r,z,n) triples of 16 hidden channels: tiles 3g, 3g+1, 3g+2  (packing.pack_gru_stream)
+        auto gate = [&](int g, int f, const float4 (&bias)[4], uint2 &o) __attribute__((always_inline)) {
+            float h[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float rg = 1.0f / (1.0f + __expf(-(acc[3 * g][f][r] + bias[r].x)));
+                const float zg = 1.0f / (1.0f + __expf(-(acc[3 * g + 1][f][r] + bias[r].y)));
+                const float ng = tanhf(acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w);
+                h[r] = ng + zg * (0.0f - ng);
+            }
+            o.x = pack_bf16x2(h[0], h[1]);
+            o.y = pack_bf16x2(h[2], h[3]);
+        };
+        if constexpr (X4 && (TCO / 3) % 2 == 0) {
+            if (x4) {   // 16-byte stores: the hidden-channel groups g, g + 1 exchanged between the k-slot quarters (see the plain path)
+#pragma unroll
+                for (int g = 0; g < TCO / 3; g += 2) {
+                    const int hb = (co_tile * (TCO / 3) + g) * 16 + fq * 4;
+                    float4 bias[2][4];
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            bias[h2][r] = lss ? lds_ld4(lss + ((g + h2) * 16 + fq * 4 + r) * 4) : reinterpret_cast<const float4 *>(a.scale)[hb + h2 * 16 + r];
+                    const int hc = hb + ((fq & 1) ? 12 : 0);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        uint2 o0, o1;
+                        gate(g, f, bias[0], o0);
+                        gate(g + 1, f, bias[1], o1);
+                        const auto rx = __builtin_amdgcn_permlane16_swap(o0.x, o1.x, false, false);
+                        const auto ry = __builtin_amdgcn_permlane16_swap(o0.y, o1.y, false, false);
+                        const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + hc) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int g = 0; g < TCO / 3; ++g) {
             const int hc = (co_tile * (TCO / 3) + g) * 16 + fq * 4;
@@ -182,6 +227,44 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             pix[f] = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
         // second GEMM: one output-channel tile at a time; its NKS weight fragments (L1/L2-resident, BCO*BCO*2 bytes in
         // all) are loaded once and serve the 4 pixel fragments
+        auto chain_tile = [&](int i2, bf16x8_t (&w2f)[NKS], float4 &s2, float4 &t2) __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks)
+                w2f[ks] = CL ? *reinterpret_cast<const bf16x8_t *>(cl + (((i2 * NKS + ks) * 4 + fq) * 16 + fj) * 16)
+                             : *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * BCO + ks * 32 + fq * 8);
+            const int co = i2 * 16 + fq * 4;
+            s2 = *reinterpret_cast<const float4 *>(CL ? reinterpret_cast<const float *>(cl + BCO * BCO * 2) + co : a.scale2 + co);
+            t2 = *reinterpret_cast<const float4 *>(CL ? reinterpret_cast<const float *>(cl + BCO * BCO * 2) + BCO + co : a.shift2 + co);
+        };
+        if constexpr (X4) {
+            if (x4) {   // 16-byte stores: output tiles i2, i2 + 1 exchanged between the k-slot quarters (see the plain path)
+                const uint32_t floor2 = a.relu2 ? 0u : 0x80008000u;
+#pragma unroll
+                for (int i2 = 0; i2 < TCO; i2 += 2) {
+                    bf16x8_t w2f[2][NKS];
+                    float4 s2[2], t2[2];
+                    chain_tile(i2, w2f[0], s2[0], t2[0]);
+                    chain_tile(i2 + 1, w2f[1], s2[1], t2[1]);
+                    const int co = i2 * 16 + fq * 4 + ((fq & 1) ? 12 : 0);
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        uint32_t ox[2], oy[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int ks = 0; ks < NKS; ++ks) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[h][ks], hb[f][ks], d, 0, 0, 0);
+                            ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(d[0] * s2[h].x + t2[h].x, d[1] * s2[h].y + t2[h].y), floor2);
+                            oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(d[2] * s2[h].z + t2[h].z, d[3] * s2[h].w + t2[h].w), floor2);
+                        }
+                        const auto rx = __builtin_amdgcn_permlane16_swap(ox[0], ox[1], false, false);
+                        const auto ry = __builtin_amdgcn_permlane16_swap(oy[0], oy[1], false, false);
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.out) + pix[f] * a.out_cstride + a.out_coff + co) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i2 = 0; i2 < TCO; ++i2) {
             bf16x8_t w2f[NKS];
@@ -209,6 +292,36 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             }
         }
     } else {
+        if constexpr (X4 && TCO % 2 == 0) {
+            if (x4) {
+                const uint32_t floor_bits = a.relu ? 0u : 0x80008000u;      // v2x_relu_bf16x2_floor: ReLU or identity, one instruction per pair either way
+#pragma unroll
+                for (int i = 0; i < TCO; i += 2) {
+                    const int cb = co_tile * BCO + i * 16 + fq * 4;         // this lane's channels in tile i (tile i + 1: + 16)
+                    float4 sc[2], sf[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        sc[h] = lss ? lds_ld4(lss + (i + h) * 16 + fq * 4) : *reinterpret_cast<const float4 *>(a.scale + cb + h * 16);
+                        sf[h] = lss ? lds_ld4(lss + lss_stride + (i + h) * 16 + fq * 4) : *reinterpret_cast<const float4 *>(a.shift + cb + h * 16);
+                    }
+                    const int co = cb + ((fq & 1) ? 12 : 0);                // even quarters: 8 channels of tile i from cb; odd: of tile i + 1 from cb + 16 - 4
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        uint32_t ox[2], oy[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][0] * sc[h].x + sf[h].x, acc[i + h][f][1] * sc[h].y + sf[h].y), floor_bits);
+                            oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][2] * sc[h].z + sf[h].z, acc[i + h][f][3] * sc[h].w + sf[h].w), floor_bits);
+                        }
+                        const auto rx = __builtin_amdgcn_permlane16_swap(ox[0], ox[1], false, false);
+                        const auto ry = __builtin_amdgcn_permlane16_swap(oy[0], oy[1], false, false);
+                        const size_t pix = (size_t)(n * a.H + y0 + frow[f]) * a.W + x0 + ((TW == 32) ? (f & 1) * 16 + fj : fj);
+                        *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + co) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    }
+                }
+                return;
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
             const int co = co_tile * BCO + i * 16 + fq * 4;
@@ -427,7 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 *reinterpret_cast<f32x4_t *>(a.ws + ((size_t)blockIdx.y * npix + pix) * a.w_rows + co_tile * BCO + i * 16 + fq * 4) = acc[i][f];
             }
     } else {
-        stream_epilogue<BCO, TW, EPI>(a, acc, co_tile, n, y0, x0, frow, fj, fq);
+        stream_epilogue<BCO, TW, EPI, 4, false, true, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, nullptr, 0, a.x4 != 0);
     }
 }
 
@@ -519,7 +632,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int TCO = BCO / 16;
     constexpr int W_PIECES = BCO / 16;
     constexpr int SLICE_BYTES = BCO * 64;
-    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;   // output-store instructions per wave and tile
+    // output-store instructions per wave and tile in the dwordx4 form (stream_epilogue X4; with dwordx2 stores -- unaligned rows -- the counted waits are merely stricter)
+    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 2 : (EPI == SEPI_CHAIN ? TCO * 4 : TCO * 2);
     static_assert(PH * PW * 4 <= (PATCH8_PIECES - 1) * 64, "patch must leave the last piece as padding");
     static_assert(W_PIECES <= 8, "at most one weight DMA per wave per step");
     static_assert(4 + N_ST <= 63, "vmcnt is a 6-bit counter");
@@ -736,7 +850,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        stream_epilogue<BCO, TW, EPI, 4, EPI == SEPI_CHAIN>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain);
+        stream_epilogue<BCO, TW, EPI, 4, EPI == SEPI_CHAIN, true, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain, nullptr, 0, a.x4 != 0);
         if (!has_next) break;
         tile = next;
         n = nn;
@@ -819,7 +933,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int PSH = V2X_STREAM_PSWZ_BUILD;             // patch swizzle shift
     // output-store instructions per wave and tile (the counted waits after an epilogue leave exactly these in flight): 8-byte stores per
     // (16-channel tile, 16-pixel fragment)
-    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;
+    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 2 : TCO * 2;   // dwordx4 stores (stream_epilogue X4); on the dwordx2 path (unaligned rows) the counted wait is merely stricter
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *s_ring = smem;                                   // 3 x STEP_BYTES
@@ -1160,9 +1274,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         constexpr bool LSS = V2X_STREAM_LSS_BUILD != 0 && EPI != SEPI_GRU;
         // (the GRU's table is float4 per hidden channel: a channel half of the tile starts BCO / 6 channels = 4 * BCO / 6 floats in)
         if constexpr (WT)
-            stream_epilogue<BCO / 2, TW, EPI, 8, false>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr,
-                                                        LSS ? (lds_cf_t *)s_ss + coh * (EPI == SEPI_GRU ? 4 * (BCO / 6) : BCO / 2) : (lds_cf_t *)nullptr, BCO);
-        else stream_epilogue<BCO, TW, EPI, 4, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, LSS ? (lds_cf_t *)s_ss : (lds_cf_t *)nullptr, BCO);
+            stream_epilogue<BCO / 2, TW, EPI, 8, false, true, true>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr,
+                                                                    LSS ? (lds_cf_t *)s_ss + coh * (EPI == SEPI_GRU ? 4 * (BCO / 6) : BCO / 2) : (lds_cf_t *)nullptr, BCO, a.x4 != 0);
+        else stream_epilogue<BCO, TW, EPI, 4, false, true, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, LSS ? (lds_cf_t *)s_ss : (lds_cf_t *)nullptr, BCO, a.x4 != 0);
         if (!has_next) break;
         tile = next;
         n = nn;
@@ -1393,7 +1507,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
-    stream_epilogue<BCO, TW, EPI, NF, EPI == SEPI_CHAIN>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain);
+    stream_epilogue<BCO, TW, EPI, NF, EPI == SEPI_CHAIN, true, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain, nullptr, 0, a.x4 != 0);
 }
 
 // ---- "wide3": the wide form with THREE taps per synchronisation (round 2) -------------------------------------------
@@ -1572,7 +1686,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
-    stream_epilogue<BCO, TW, SEPI_BF16, NF, false, false>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr);
+    stream_epilogue<BCO, TW, SEPI_BF16, NF, false, false, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, nullptr, 0, a.x4 != 0);
 }
 
 template <int BCO>
@@ -1693,6 +1807,9 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.ws = d->splitk_ws;
     a.w_rows = d->w_rows;
     a.xcd_walk = (d->epilogue == V2X_EPI_GRU) ? v2x_tune(V2X_TUNE_GRU_XCD_WALK) : 0;
+    // 16-byte output stores (stream_epilogue X4): rows of the output view 16-byte aligned, whole 32-channel pairs of tiles
+    a.x4 = (v2x_tune(V2X_TUNE_STORE_X4) != 0 && (d->epilogue == V2X_EPI_BF16 || d->epilogue == V2X_EPI_GRU) && (d->Cout2 > 0 ? d->Cout2 : d->Cout) % 32 == 0 &&
+            d->out_cstride % 8 == 0 && d->out_coff % 8 == 0 && (reinterpret_cast<uintptr_t>(d->out) & 15) == 0) ? 1 : 0;
     const bool chain = d->Cout2 > 0;
     if (d->splitk > 1) {
         // small-batch form: the 4-wave kernel with the chunk range divided over blockIdx.y + the reduce kernel.  Plain and GRU epilogues,

@@ -51,6 +51,7 @@ struct S2Args {
     int out_cstride, out_coff, Cout;
     int tiles_x, tiles_y, n_px_tiles, n_co_tiles;
     int xcd_walk;         // resident form: 1 = XCD-contiguous tile walk (tuning switch HALO_XCD)
+    int x4;               // 16-byte output stores (common.h: v2x_store_pair_x4); set by the dispatch when the output view allows
     // split-K (latency mode, conv3x3_s2_stream_kernel<..., SPLITK = true>): blockIdx.y walks `ksplit` contiguous ranges of the 32-channel chunks and
     // stores its raw fp32 sums to ws[split][pixel][w_rows]; splitk_reduce_kernel (conv_stream.hip) adds them in split order and applies the epilogue
     int ksplit;
@@ -247,6 +248,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         }
         return;
     }
+    if (a.x4) {   // 16-byte stores: channel tiles i, i + 1 exchanged between the k-slot quarters (common.h: v2x_store_pair_x4)
+#pragma unroll
+        for (int i = 0; i < TCO; i += 2) {
+            float4 sc[2], sf[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                sc[h] = *reinterpret_cast<const float4 *>(s_ss + (i + h) * 16 + fq * 4);
+                sf[h] = *reinterpret_cast<const float4 *>(s_ss + BCO + (i + h) * 16 + fq * 4);
+            }
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                uint32_t ox[2], oy[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][0] * sc[h].x + sf[h].x, acc[i + h][f][1] * sc[h].y + sf[h].y), relu_floor);
+                    oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][2] * sc[h].z + sf[h].z, acc[i + h][f][3] * sc[h].w + sf[h].w), relu_floor);
+                }
+                const size_t pix = (size_t)(n * Ho + y0 + (f ? frow1 : frow0)) * Wo + x0 + (TW == 32 ? f * 16 : 0) + fj;
+                v2x_store_pair_x4(a.out + pix * a.out_cstride + a.out_coff + co_tile * BCO + i * 16 + fq * 4, fq, ox[0], oy[0], ox[1], oy[1]);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TCO; ++i) {
         const int co = co_tile * BCO + i * 16 + fq * 4;
@@ -372,6 +396,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
             }
         }
+        if (a.x4) {   // 16-byte stores (common.h: v2x_store_pair_x4)
+#pragma unroll
+            for (int i = 0; i < TCO; i += 2) {
+                float4 sc[2], sf[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    sc[h] = *reinterpret_cast<const float4 *>(s_ss + (i + h) * 16 + fq * 4);
+                    sf[h] = *reinterpret_cast<const float4 *>(s_ss + 64 + (i + h) * 16 + fq * 4);
+                }
+#pragma unroll
+                for (int f = 0; f < 2; ++f) {
+                    uint32_t ox[2], oy[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][0] * sc[h].x + sf[h].x, acc[i + h][f][1] * sc[h].y + sf[h].y), relu_floor);
+                        oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][2] * sc[h].z + sf[h].z, acc[i + h][f][3] * sc[h].w + sf[h].w), relu_floor);
+                    }
+                    const size_t pix = (size_t)(n * Ho + y0 + wave) * Wo + x0 + f * 16 + fj;
+                    v2x_store_pair_x4(a.out + pix * a.out_cstride + a.out_coff + i * 16 + fq * 4, fq, ox[0], oy[0], ox[1], oy[1]);
+                }
+            }
+        } else
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
             const int co = i * 16 + fq * 4;
@@ -736,6 +782,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int le = fresh_lane();
             const int fje = le & 15, fqe = le >> 4;
             const int Ho = a.H >> 1, Wo = a.W >> 1;
+            if (a.x4) {   // 16-byte stores (common.h: v2x_store_pair_x4)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    const int cl = coh * 64 + i * 16 + fqe * 4;
+                    float4 sc[2], sf[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        sc[h] = *reinterpret_cast<const float4 *>(s_ss + cl + h * 16);
+                        sf[h] = *reinterpret_cast<const float4 *>(s_ss + BCO + cl + h * 16);
+                    }
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        uint32_t ox[2], oy[2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][0] * sc[h].x + sf[h].x, acc[i + h][f][1] * sc[h].y + sf[h].y), relu_floor);
+                            oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][f][2] * sc[h].z + sf[h].z, acc[i + h][f][3] * sc[h].w + sf[h].w), relu_floor);
+                        }
+                        const size_t pix = (size_t)(n * Ho + y0 + R0 + f / G::NCF) * Wo + x0 + (f % G::NCF) * 16 + fje;
+                        v2x_store_pair_x4(a.out + pix * a.out_cstride + a.out_coff + co_tile * BCO + cl, fqe, ox[0], oy[0], ox[1], oy[1]);
+                    }
+                }
+            } else
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int cl = coh * 64 + i * 16 + fqe * 4;
@@ -843,6 +912,7 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     if (rows == 0 || d->w_rows != d->Cout) return 1;
     S2Args a;
     a.xcd_walk = v2x_tune(V2X_TUNE_HALO_XCD);
+    a.x4 = v2x_x4_ok(d->out, d->out_cstride, d->out_coff, d->Cout);
     a.in = d->in0;
     a.C = d->C0;
     a.N = d->N;
