@@ -25,14 +25,43 @@ __global__ __launch_bounds__(256) void attn_handshake_kernel(const float *__rest
     float *qp = reinterpret_cast<float *>(smem_raw);  // [A][key_size] projected queries
     float *sc = qp + (size_t)A * key_size;             // [A(k)][A(q)] scores
     const int f = blockIdx.x;
-    // 1. query projection: qp[q][d] = b[d] + sum_s w[d][s] * query[q][s]
-    for (int i = threadIdx.x; i < A * key_size; i += blockDim.x) {
-        const int q = i / key_size, d = i - q * key_size;
-        const float *qv = querys + ((size_t)q * Bt + f) * query_size;
-        const float *wr = w_lin + (size_t)d * query_size;
-        float s = 0.f;
-        for (int t = 0; t < query_size; ++t) s += wr[t] * qv[t];
-        qp[i] = s + b_lin[d];
+    // 1. query projection: qp[q][d] = b[d] + sum_s w[d][s] * query[q][s].  A thread owns output dimension d for ALL queries: row d of the
+    // weight is read once, as independent 16-byte loads (the first form walked it with query_size dependent 4-byte loads per (q, d): 20 rounds
+    // of 32 load latencies = the whole 120 us of the launch); the A query vectors are staged in LDS.  Sums in the order t = 0, 1, ...: same bits.
+    float *qs = sc + A * A;                            // [A][query_size]
+    for (int i = threadIdx.x; i < A * query_size; i += blockDim.x) {
+        const int q = i / query_size, t = i - q * query_size;
+        qs[i] = querys[((size_t)q * Bt + f) * query_size + t];
+    }
+    __syncthreads();
+    if (query_size == 32 && A <= 8) {
+        for (int d = threadIdx.x; d < key_size; d += blockDim.x) {
+            float4 w[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = reinterpret_cast<const float4 *>(w_lin + (size_t)d * 32)[j];
+            const float b = b_lin[d];
+            for (int q = 0; q < A; ++q) {
+                const float *qv = qs + q * 32;
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    s += w[j].x * qv[4 * j];
+                    s += w[j].y * qv[4 * j + 1];
+                    s += w[j].z * qv[4 * j + 2];
+                    s += w[j].w * qv[4 * j + 3];
+                }
+                qp[(size_t)q * key_size + d] = s + b;
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < A * key_size; i += blockDim.x) {
+            const int q = i / key_size, d = i - q * key_size;
+            const float *qv = qs + q * query_size;
+            const float *wr = w_lin + (size_t)d * query_size;
+            float s = 0.f;
+            for (int t = 0; t < query_size; ++t) s += wr[t] * qv[t];
+            qp[i] = s + b_lin[d];
+        }
     }
     __syncthreads();
     // 2. scores[k][q] = key_k . qp_q   (one wave per pair)
@@ -81,7 +110,7 @@ extern "C" int v2x_attn_handshake(const float *keys, const float *querys, const 
     V2X_REQUIRE(keys && querys && w_lin && b_lin && prob && coef, "v2x_attn_handshake: null pointer");
     V2X_REQUIRE(A > 0 && A <= 32 && Bt > 0 && key_size > 0 && query_size > 0, "v2x_attn_handshake: bad dims");
     V2X_REQUIRE(mode >= 0 && mode <= 2, "v2x_attn_handshake: mode must be 0 (softmax), 1 (activated) or 2 (argmax_test)");
-    const size_t smem = ((size_t)A * key_size + (size_t)A * A) * sizeof(float);
+    const size_t smem = ((size_t)A * key_size + (size_t)A * A + (size_t)A * query_size) * sizeof(float);
     V2X_REQUIRE(smem <= 64 * 1024, "v2x_attn_handshake: A*key_size too large for LDS staging");
     hipLaunchKernelGGL(attn_handshake_kernel, dim3(Bt), dim3(256), smem, (hipStream_t)stream, keys, querys, w_lin,
                        b_lin, A, Bt, key_size, query_size, mode, thres, prob, coef);

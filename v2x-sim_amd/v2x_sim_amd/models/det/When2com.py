@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops, packing
-from ..._lib import V2X_EPI_F32, V2X_FUSE_WSUM
+from ..._lib import V2X_EPI_BF16, V2X_EPI_F32, V2X_FUSE_WSUM
 from .base import IntermediateModelBase, LidarDecoder, LidarEncoder, _ParamsOnly
 
 
@@ -55,6 +55,38 @@ class KmGenerator(_ParamsOnly):
         return [packing.pack_linear(prefix + "fc.0", self.fc[0], relu=True, col_perm=perm, device=device),
                 packing.pack_linear(prefix + "fc.2", self.fc[2], relu=True, device=device),
                 packing.pack_linear(prefix + "fc.4", self.fc[4], relu=False, epilogue=V2X_EPI_F32, device=device)]
+
+    @staticmethod
+    def pack_pair(key_net, query_net, prefix_k, prefix_q, device):
+        """The key and the query MLP as ONE chain of three launches instead of two chains of three: both read the same flattened tower output,
+        so the first layers' rows are stacked (4096 -> 256 | 256) and the later layers are block-diagonal (512 -> 128 | 128, 256 -> 1024 | 32).
+        The zero blocks add exact zeros to the fp32 sums in whole 32-channel K chunks: the results are the separate MLPs' bit for bit.
+        -> (plan of three packed layers, key_size)."""
+        S = key_net.feat_map_sz
+        hw = torch.arange(S * S).view(S * S, 1)
+        c = torch.arange(256).view(1, 256)
+        perm = (c * (S * S) + hw).reshape(-1)  # nhwc position -> nchw column
+        k, q = key_net.fc, query_net.fc
+        f32 = lambda t: t.detach().float().cpu()   # noqa: E731
+
+        def blockdiag(a, b):
+            w = torch.zeros((a.shape[0] + b.shape[0], a.shape[1] + b.shape[1]), dtype=torch.float32)
+            w[:a.shape[0], :a.shape[1]] = a
+            w[a.shape[0]:, a.shape[1]:] = b
+            return w
+        layers = [(torch.cat([f32(k[0].weight)[:, perm], f32(q[0].weight)[:, perm]], 0), torch.cat([f32(k[0].bias), f32(q[0].bias)]), True, V2X_EPI_BF16),
+                  (blockdiag(f32(k[2].weight), f32(q[2].weight)), torch.cat([f32(k[2].bias), f32(q[2].bias)]), True, V2X_EPI_BF16),
+                  (blockdiag(f32(k[4].weight), f32(q[4].weight)), torch.cat([f32(k[4].bias), f32(q[4].bias)]), False, V2X_EPI_F32)]
+        plan = [packing.pack_conv("%s+%sfc.%d" % (prefix_k, prefix_q, 2 * i), w[:, :, None, None], torch.ones(w.shape[0]), b, stride=1, pad=0, relu=relu,
+                                  epilogue=epi, device=device) for i, (w, b, relu, epi) in enumerate(layers)]
+        return plan, k[4].out_features
+
+    @staticmethod
+    def run_pair(pair, x):
+        """x: (N, S, S, 256) bf16 -> (keys (N, key_size), querys (N, query_size)) fp32, contiguous."""
+        plan, key_size = pair
+        y = KmGenerator.run(plan, x)
+        return y[:, :key_size].contiguous(), y[:, key_size:].contiguous()
 
     @staticmethod
     def run(plan, x):
@@ -105,6 +137,7 @@ class When2com(IntermediateModelBase):
                 "tower": tower,
                 "key": self.key_net.pack("key_net.", device),
                 "query": self.query_net.pack("query_net.", device),
+                "keyquery": KmGenerator.pack_pair(self.key_net, self.query_net, "key_net.", "query_net.", device),
                 "w_lin": lin.weight.detach().float().to(device).contiguous(),
                 "b_lin": lin.bias.detach().float().to(device).contiguous()}
 
@@ -125,8 +158,7 @@ class When2com(IntermediateModelBase):
         y = LidarEncoder.run(pk["tower"]["enc"], x0)[4]
         for layer in pk["tower"]["convs"]:
             y = ops.run_layer(layer, y)
-        keys = KmGenerator.run(pk["key"], y)
-        querys = KmGenerator.run(pk["query"], y)
+        keys, querys = KmGenerator.run_pair(pk["keyquery"], y)     # (the separate MLPs pk["key"], pk["query"] give the same bits: tests)
         return ops.attn_handshake(keys, querys, pk["w_lin"], pk["b_lin"], self.agent_num, batch_size, mode)
 
     @ops.latency_entry

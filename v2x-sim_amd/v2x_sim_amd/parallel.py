@@ -335,8 +335,9 @@ class ShardedWhen2com:
         y = LidarEncoder.run(pk["tower"]["enc"], bits, zbits=zbits)[4]
         for layer in pk["tower"]["convs"]:
             y = ops.run_layer(layer, y)
-        keys = self.exchange(KmGenerator.run(pk["key"], y).contiguous())       # (A*Bt, 1024) on every rank
-        querys = self.exchange(KmGenerator.run(pk["query"], y).contiguous())   # (A*Bt, 32)
+        k_loc, q_loc = KmGenerator.run_pair(pk["keyquery"], y)     # both MLPs as one chain of three launches
+        keys = self.exchange(k_loc)                                # (A*Bt, 1024) on every rank
+        querys = self.exchange(q_loc)                              # (A*Bt, 32)
         mode = "softmax" if (training or inference == "softmax") else inference
         prob, coef = ops.attn_handshake(keys, querys, pk["w_lin"], pk["b_lin"], sh.A, sh.Bt, mode)
         coef_items = coef[plan["f_idx"], :, plan["q_idx"]].contiguous() * plan["mask"]
