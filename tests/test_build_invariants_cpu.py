@@ -91,15 +91,20 @@ def test_stream_kernel_waits_are_counted(tmp_path):
 def test_pair_kernel_never_drains_its_stores_inside_the_tile_loop(tmp_path):
     """conv_halo_pair.hip: vmcnt is in-order, so a vmcnt(0) inside the tile loop would wait for the previous tile's output
     stores (that was 6 us per tile before the loop was restructured).  Past the prologue barrier the only vector-memory
-    waits are vmcnt(9) / vmcnt(8): the next tile's two occupancy words, requested before this tile's 8 stores."""
+    waits are for the next tile's two occupancy words, requested before this tile's stores: vmcnt(9) / vmcnt(8) with the eight
+    8-byte stores, vmcnt(5) / vmcnt(4) with the four 16-byte ones (the store form is a TEMPLATE parameter for exactly this
+    reason: behind a run-time branch the compiler could not count and drained the stores in every tile)."""
     asm = _asm("conv_halo_pair.hip", tmp_path)
     bodies, _ = _kernels(asm)
-    body = bodies[[n for n in bodies if n.startswith("_Z24conv3x3_pair_bits_kernel")][0]]
-    lines = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(";")]
-    end = next(i for i, ln in enumerate(lines) if ln.startswith("s_endpgm"))
-    bars = [i for i, ln in enumerate(lines[:end]) if ln.startswith("s_barrier")]
-    assert len(bars) == 4, bars                       # LUT, prologue, and the two per-tile barriers
-    loop = lines[bars[1]:end]
-    waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(loop))
-    assert waits and set(waits) <= {"8", "9"}, waits    # word 0: one younger load + 8 stores; word 1: the 8 stores
-    assert sum(ln.startswith("v_mfma_f32_16x16x32_bf16") for ln in loop) == 132   # 5 x 6 x 2 (layer A) + 3 x 24 (layer B)
+    names = sorted(n for n in bodies if n.startswith("_Z24conv3x3_pair_bits_kernel"))
+    assert len(names) == 2, names
+    for n, allowed in zip(names, ({"8", "9"}, {"4", "5"})):          # <false> (ILb0E) sorts before <true>
+        body = bodies[n]
+        lines = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(";")]
+        end = next(i for i, ln in enumerate(lines) if ln.startswith("s_endpgm"))
+        bars = [i for i, ln in enumerate(lines[:end]) if ln.startswith("s_barrier")]
+        assert len(bars) == 4, bars                       # LUT, prologue, and the two per-tile barriers
+        loop = lines[bars[1]:end]
+        waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(loop))
+        assert waits and set(waits) <= allowed, (n, waits)
+        assert sum(ln.startswith("v_mfma_f32_16x16x32_bf16") for ln in loop) == 132   # 5 x 6 x 2 (layer A) + 3 x 24 (layer B)

@@ -311,6 +311,30 @@ def _heads_model(device, seed=3, fg_bias=-2.5):
     return m.to(device)
 
 
+@pytest.mark.parametrize("thr", [0.5, 0.99, 0.99995, 0.9999999, 1.0])
+def test_fused_detection_heads_candidate_counts_at_thresholds_near_one(device, thr):
+    """the fused heads pre-test c1 - c0 against logit(thr) minus a slack before the exact fp32 softmax test.  Near 1 one ulp of the score
+    is a large logit step and the score saturates at exactly 1.0f: the slack scales with 1 / (thr (1 - thr)) and the pre-test is capped at 16.
+    The candidate COUNTS must equal the logits path's at every threshold, also where scores saturate (logits scaled up for that)."""
+    from v2x_sim_amd import ops
+    m = _heads_model(device, fg_bias=6.0)
+    with torch.no_grad():
+        m.classification.conv2.weight *= 4.0          # wide score distribution: many scores within an ulp of 1
+    m.repack()
+    pk = m.packed(device)
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(2, 64, 96, 32, generator=g) * 0.7).relu().to(torch.bfloat16).to(device)
+    anchors = torch.randn(64 * 96 * 6, 6, generator=g).to(device)
+    anchors[:, 2:4] = anchors[:, 2:4].abs() + 1.0
+    cap = 4096
+    cls, loc = ops.run_layer(pk["heads"], x)
+    cls, loc = cls.reshape(2, -1, 2), loc.reshape(2, -1, 6)
+    want = (torch.softmax(cls, -1)[..., 1] >= thr).sum(1)          # informational: torch's softmax may differ from the kernels' formula by an ulp
+    keys, codes, counts = ops.conv2d_det(pk["heads"].det, x, thr, cap)
+    ref_counts = ops.det_postprocess(cls, loc, anchors, thr, 1.0, cap)[3].abs()      # (overflow: minus the true count)
+    assert torch.equal(counts.abs(), ref_counts), (thr, counts.tolist(), ref_counts.tolist(), want.tolist())
+
+
 @pytest.mark.parametrize("N,H,W", [(3, 256, 256), (2, 64, 96), (5, 8, 32)])
 def test_fused_detection_heads_equal_logits_then_postprocess(device, N, H, W):
     """The heads with the score threshold in the epilogue + v2x_det_nms_candidates against the heads' logits + v2x_det_postprocess:

@@ -154,6 +154,27 @@ def test_param_version_sees_fused_optimizer_steps():
         assert v1 != v0 and v1[1] == v0[1] + 1, (fused, v0, v1)
 
 
+def test_unwatched_optimizer_is_stamped_by_the_global_hook():
+    """a caller who builds his own (fused) optimizer and never calls watch_optimizer must not train on stale packed weights: the
+    process-wide post-step hook packing installs at import stamps the parameters of ANY optimizer; a watched one is not stamped twice."""
+    import torch
+    from v2x_sim_amd import packing
+    assert packing.GLOBAL_OPTIMIZER_HOOK
+    p = torch.nn.Parameter(torch.randn(4, 4))
+    for fused in (False, True):
+        opt = torch.optim.Adam([p], lr=1e-3, fused=fused)           # never handed to packing
+        p.grad = torch.ones_like(p)
+        v0 = packing.param_version(p)
+        opt.step()
+        v1 = packing.param_version(p)
+        assert v1 != v0 and v1[1] == v0[1] + 1, (fused, v0, v1)
+    sgd = torch.optim.SGD([p], lr=0.1)
+    p.grad = torch.ones_like(p)
+    e0 = packing.param_version(p)[1]
+    sgd.step()
+    assert packing.param_version(p)[1] == e0 + 1
+
+
 def test_unhookable_optimizer_is_stamped_by_stepped():
     """An optimizer object without register_step_post_hook cannot be watched; the training loops call packing.stepped(opt) after opt.step(), which
     stamps the parameters itself (and does nothing for a watched optimizer, whose hook already did)."""

@@ -59,12 +59,39 @@ def main():
              ("halo conv8_1: (64 half-res + 32) -> 32 @256", 64, 32, 32, 256, 1, "halo"),
              ("halo heads: 32 -> 64 -> 12 | 36 fp32 @256", 32, 0, 64, 256, 0, "heads"),
              ("s2 conv2_1: 64 -> 128 @128 -> 64", 64, 0, 128, 128, 0, "s2"), ("s2 conv3_1: 128 -> 256 @64 -> 32", 128, 0, 256, 64, 0, "s2"),
-             ("s2 conv4_1: 256 -> 512 @32 -> 16", 256, 0, 512, 32, 0, "s2")]
+             ("s2 conv4_1: 256 -> 512 @32 -> 16", 256, 0, 512, 32, 0, "s2"), ("pair conv_pre_1 -> conv_pre_2 from the bit grid @256", 32, 0, 32, 256, 0, "pair")]
     if only:
         cases = [c for c in cases if only in c[0]]
     n = 320
     for name, c0, c1, cout, hw, up, gru in cases:
         split = 0
+        if gru == "pair":
+            pa = packing.pack_conv_halo(name + ".a", torch.randn(32, 32, 3, 3, generator=g) * 0.05, torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1, relu=True, device=dev)
+            pb = packing.pack_conv_halo(name + ".b", torch.randn(32, 32, 3, 3, generator=g) * 0.05, torch.rand(32, generator=g) + 0.5, torch.randn(32, generator=g) * 0.1, relu=True, device=dev)
+            bits = (torch.rand(n // 8, hw, hw, generator=g) < 0.3).to(torch.int32) * (torch.randint(0, 1 << 13, (n // 8, hw, hw), generator=g, dtype=torch.int32))
+            bits = bits.to(dev)
+            outs = []
+            for v in (0, 1):
+                use(v)
+                outs.append(ops.conv2d_pair(pa, pb, bits, 13).clone())
+            same = torch.equal(outs[0], outs[1])
+            reps = 40
+            t = np.zeros((reps, 2))
+            for r in range(-3, reps):
+                for v in ((0, 1) if r % 2 == 0 else (1, 0)):
+                    use(v)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    ops.conv2d_pair(pa, pb, bits, 13)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r >= 0:
+                        t[r, v] = e0.elapsed_time(e1) * 1e3
+            d = t[:, 1] - t[:, 0]
+            print("%-44s A %.1f us  B %.1f us  B-A %+.1f us (%+.2f %%, s.e. %.2f %%)  outputs %s" % (
+                name, t[:, 0].mean(), t[:, 1].mean(), d.mean(), 100 * d.mean() / t[:, 0].mean(), 100 * d.std() / np.sqrt(reps) / t[:, 0].mean(),
+                "bit-identical" if same else "DIFFER"))
+            continue
         if gru == "heads":
             from v2x_sim_amd._lib import V2X_EPI_F32
             w = torch.randn(64, 32, 3, 3, generator=g) * 0.05

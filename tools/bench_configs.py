@@ -246,4 +246,29 @@ def run_training(device, frames=2, agents=5, reps=5):
     finally:
         for k, v in saved.items():
             tuning.set(k, v)
+    # the HIP engine's step at 20 and 40 maps as well: the 10-map step is launch-bound (~500 launches of a few us each)
+    try:
+        tuning.set("TRAIN_HIP", 1)
+        for fr in (4, 8):
+            d2 = synthetic_batch_on_device(cfg, fr, agents, seed=1, device=device)
+            rec = {}
+            for name, cls, kw in (("FaFNet", FaFNet, dict(kd_flag=0, num_agent=agents)), ("V2VNet", V2VNet, dict(num_agent=agents))):
+                model = init_for_training(cls(cfg, **kw), seed=0).to(device).train()
+                opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+
+                def step2():
+                    res = train_forward(model, d2["bev_seq"], d2["trans_matrices"], d2["num_agent"], fr)
+                    loss = detection_loss(res, d2["labels"], d2["reg_targets"], d2["reg_loss_mask"])[0]
+                    opt.zero_grad(set_to_none=True)
+                    loss.backward()
+                    opt.step()
+                rec[name + " bf16 NHWC graph on the HIP kernels ms"] = timed(step2)
+                del model, opt
+            out["maps_%d" % (fr * agents)] = rec
+            del d2
+    except Exception as e:      # a side table
+        out["larger_batches_error"] = repr(e)
+    finally:
+        for k, v in saved.items():
+            tuning.set(k, v)
     return out

@@ -285,9 +285,14 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 __syncthreads();
                 first_tile = false;
             } else {
-                if constexpr (N_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else if constexpr (N_STORES == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-                else if constexpr (N_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                // (a.x4: the 16-byte form issues HALF as many stores -- the count must follow, or the wait would let patch pieces stay in flight)
+                if constexpr (N_STORES == 8) {
+                    if (a.x4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else if constexpr (N_STORES == 16) {
+                    if (a.x4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                } else if constexpr (N_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // (fp32 heads: never x4)
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -1038,9 +1043,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (m + 1 < K) load_patch(tile_of(m + 1));     // its previous compute is behind the last barrier
             if (m >= 0) {
                 epilogue(tile_of(m));
-                // the DMAs are OLDER than the N_STORES stores: they have landed, the stores may stay in flight
-                if constexpr (N_STORES == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                // the DMAs are OLDER than the N_STORES stores (half as many in the 16-byte form, a.x4): they have landed, the stores may stay in flight
+                if constexpr (N_STORES == 8) {
+                    if (a.x4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                } else {
+                    if (a.x4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                }
             } else {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
@@ -1148,7 +1158,15 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.det_thr = d->det_thr;
     {
         const double t = d->det_thr;
-        a.det_margin = (t > 0.0 && t < 1.0) ? (float)(log(t / (1.0 - t)) - 1e-3) : (t <= 0.0 ? -3.0e38f : 80.0f);   // thr <= 0: every anchor; >= 1: practically none
+        // The exact test is the fp32 softmax fg >= thr.  One ulp of fg (6e-8) moves the logit by 6e-8 / (thr (1 - thr)): the slack grows with it
+        // near 1 (a fixed 1e-3 dropped candidates the logits path keeps once thr > 0.9999), and fg is exactly 1.0f from c1 - c0 ~ 16.7
+        // on, whatever thr <= 1 says -- so the pre-test never asks for more than 16.  thr <= 0: every anchor; thr > 1: nothing passes the exact test.
+        if (t <= 0.0) a.det_margin = -3.0e38f;
+        else if (t >= 1.0) a.det_margin = 16.0f;
+        else {
+            const double slack = fmax(1e-3, 4e-7 / (t * (1.0 - t)));
+            a.det_margin = (float)fmin(log(t / (1.0 - t)) - slack, 16.0);
+        }
     }
     a.det_cap = d->det_cap;
     {   // the packed DMA tables hold the lane's element offset inside the patch in 20 bits

@@ -78,6 +78,10 @@ __device__ __forceinline__ void lds_barrier() {
 }
 }  // namespace pair
 
+// X4: 16-byte output stores (common.h: v2x_store_pair_x4).  A TEMPLATE parameter, not a run-time flag: the compiler counts this kernel's vector-memory
+// operations itself (the next tile's occupancy words are requested before this tile's stores: vmcnt(4 / 5) here, vmcnt(8 / 9) with 8-byte stores), and
+// with both store paths behind a run-time branch it can no longer count -- it drained the stores in every tile (tests/test_build_invariants_cpu.py).
+template <bool X4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_pair_bits_kernel(const PairArgs a) {
     using namespace pair;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -288,7 +292,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (a.x4) {   // 16-byte stores: the two channel tiles exchanged between the k-slot quarters (common.h: v2x_store_pair_x4)
+            if constexpr (X4) {   // 16-byte stores: the two channel tiles exchanged between the k-slot quarters (common.h: v2x_store_pair_x4)
                 const uint32_t floorB = a.reluB ? 0u : 0x80008000u;
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
@@ -301,7 +305,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     v2x_store_pair_x4(a.out + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + fq * 4, fq, ox[0], oy[0], ox[1], oy[1]);
                 }
-            } else
+            } else {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int co = i * 16 + fq * 4;
@@ -320,6 +324,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     *reinterpret_cast<uint2 *>(a.out + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + co) = o;
                 }
+            }
             }
         }
         // the next tile's input window: every wave is past the barrier above, i.e. done reading s_in for this tile
@@ -375,11 +380,13 @@ extern "C" int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *
     a.n_tiles = a.N * a.tiles_x * a.tiles_y;
     static v2x_once_per_device attr_once;
     if (v2x_first_use_on_device(attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_pair_bits_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pair::SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_pair_bits_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, pair::SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_pair_bits_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, pair::SMEM);
     }
     int grid = v2x_num_cus() * 2;
     if (grid > a.n_tiles) grid = a.n_tiles;
-    hipLaunchKernelGGL(conv3x3_pair_bits_kernel, dim3(grid), dim3(256), pair::SMEM, (hipStream_t)stream, a);
+    if (a.x4) hipLaunchKernelGGL(conv3x3_pair_bits_kernel<true>, dim3(grid), dim3(256), pair::SMEM, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(conv3x3_pair_bits_kernel<false>, dim3(grid), dim3(256), pair::SMEM, (hipStream_t)stream, a);
     V2X_CHECK_LAUNCH("conv3x3_pair_bits_kernel");
     return V2X_OK;
 }

@@ -632,8 +632,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int TCO = BCO / 16;
     constexpr int W_PIECES = BCO / 16;
     constexpr int SLICE_BYTES = BCO * 64;
-    // output-store instructions per wave and tile in the dwordx4 form (stream_epilogue X4; with dwordx2 stores -- unaligned rows -- the counted waits are merely stricter)
-    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 2 : (EPI == SEPI_CHAIN ? TCO * 4 : TCO * 2);
+    // output-store instructions per wave and tile.  (Only the chained epilogue of this kernel takes the 16-byte form, stream_epilogue X4: the plain
+    // 128-row instantiation -- the STREAM_G = 0 comparison form -- spills with both store paths compiled in, and a spill breaks the vmcnt counts.)
+    constexpr int N_ST = (EPI == SEPI_GRU) ? (TCO / 3) * 4 : TCO * 4;
     static_assert(PH * PW * 4 <= (PATCH8_PIECES - 1) * 64, "patch must leave the last piece as padding");
     static_assert(W_PIECES <= 8, "at most one weight DMA per wave per step");
     static_assert(4 + N_ST <= 63, "vmcnt is a 6-bit counter");
@@ -850,7 +851,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         }
-        stream_epilogue<BCO, TW, EPI, 4, EPI == SEPI_CHAIN, true, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain, nullptr, 0, a.x4 != 0);
+        stream_epilogue<BCO, TW, EPI, 4, EPI == SEPI_CHAIN, true, EPI == SEPI_CHAIN>(a, acc, co_tile, n, y0, x0, frow, fj, fq, s_chain, nullptr, 0, a.x4 != 0);
         if (!has_next) break;
         tile = next;
         n = nn;

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     using G = S2GGeom<TH, TW>;
     constexpr int BCO = 128;
     constexpr int SLICE_BYTES = BCO * 64, STEP_BYTES = 3 * SLICE_BYTES;
-    constexpr int N_ST = 16;                               // output stores per wave and tile
+    constexpr int N_ST = 8;                                // output stores per wave and tile in the 16-byte form (a.x4); with 8-byte stores (16) the relaxed waits are merely stricter
     constexpr int NWD = 6;                                 // weight DMAs per wave of group 1 and step
     constexpr int DBG = V2X_S2G_DBG_BUILD;
 

@@ -419,7 +419,7 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
     if PROFILE is not None:
         M = N * H * W
         # algorithmic FLOPs: the first layer has `zbits` (13) real input channels -- the 32 of the packed layout are zero padding
-        prof = _Prof("conv3x3_pair_bits_kernel", 2.0 * M * 9 * (pa.Cout * zbits + pb.Cout * pb.C0),
+        prof = _Prof("conv3x3_pair_bits_kernel<%s>" % ("true" if tuning.get("STORE_X4") != 0 else "false"), 2.0 * M * 9 * (pa.Cout * zbits + pb.Cout * pb.C0),
                      bits.numel() * 4 + out.numel() * 2 + (pa.weight.numel() + pb.weight.numel()) * 2, pa.name + "+" + pb.name)
     rc = lib.v2x_conv2d_pair(C.byref(da), C.byref(db), _stream())
     if prof is not None:

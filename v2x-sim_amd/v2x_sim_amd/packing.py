@@ -53,6 +53,27 @@ def watch_optimizer(opt):
     return opt
 
 
+# The per-optimizer hook above needs the caller's cooperation (make_optimizer, FaFModule, SegModule, GraphedTrainStep install it).  A caller
+# who builds torch.optim.Adam(fused=True) himself and calls train_forward / backward / opt.step() directly would train on the packed weights of
+# step 0 -- silently.  torch.optim.optimizer.register_optimizer_step_post_hook is a GLOBAL post-step hook for every optimizer of
+# the process: installed once, at import, it stamps the parameters of whatever optimizer stepped (one attribute write per parameter per step).
+def _install_global_optimizer_hook():
+    try:
+        from torch.optim.optimizer import register_optimizer_step_post_hook
+    except ImportError:      # (older torch: the per-optimizer hook and packing.stepped remain the way)
+        return False
+
+    def _global_hook(o, *_a, **_k):
+        if not o.__dict__.get("_v2x_watched"):          # (a watched optimizer has stamped its parameters already)
+            for g in o.param_groups:
+                note_params_changed(g["params"])
+    register_optimizer_step_post_hook(_global_hook)
+    return True
+
+
+GLOBAL_OPTIMIZER_HOOK = _install_global_optimizer_hook()
+
+
 def _ceil_to(x, m):
     return (x + m - 1) // m * m
 

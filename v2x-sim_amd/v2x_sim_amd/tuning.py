@@ -3,6 +3,8 @@ libv2x_amd.so for the kernel-selection ones) and changed afterwards only through
 
 Kernel-selection switches live in the library (include/v2x_amd.h: v2x_tuning_set / v2x_tuning_get; defaults = the measured-fastest forms):
     STREAM_WAVES STREAM_G STREAM_WT STORE_X4 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP S2_RESIDENT VOXELIZE_LDS WARP_LDS S2_G GRU_XCD_WALK HALO_XCD WGRAD_TR
+    (STORE_X4 1: 16-byte output stores -- two channel tiles exchanged between the k-slot quarters with v_permlane16_swap_b32 -- in every bf16 epilogue
+     that has the form; 0: 8-byte stores, same bytes and values)
 Host-side switches (this module):
     S2_T16      1  stride-2 streamed kernel with 8x16 output tiles for narrow maps (conv4_1); 0: the gather kernel
     CONV_PAIR   1  conv_pre_1 -> conv_pre_2 as one launch from the bit grid; 0: two launches
