@@ -283,6 +283,36 @@ def test_v2vnet_seg(device):
     assert agree > 0.97
 
 
+@pytest.mark.parametrize("cls_name,N,H,W", [("V2VNetSeg", 5, 256, 256), ("FaFNetSeg", 3, 64, 96), ("FaFNetSeg", 2, 48, 80)])
+def test_seg_fused_head_equals_two_layers(device, tune, cls_name, N, H, W):
+    """conv8_2 chained with the 1x1 class head in one halo launch (SEG_FUSE = 1, the default) against the two layers (SEG_FUSE = 0): the hidden map is
+    rounded to bf16 as the stand-alone layer stores it, so the fp32 logits agree bit for bit; a map that does not tile by 8 x 32 takes the two-layer
+    path either way; the bit-grid input (zbits) equals the expanded NHWC input."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models import seg as S
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_poses
+    pm = init_synthetic_weights(getattr(S, cls_name)(Config("test"), **({"num_agent": N} if cls_name == "V2VNetSeg" else {})), seed=5).to(device)
+    g = torch.Generator().manual_seed(H)
+    bits = ((torch.rand(N, H, W, generator=g) < 0.3).to(torch.int32) * torch.randint(0, 1 << 13, (N, H, W), generator=g, dtype=torch.int32)).to(device)
+    x0 = ops.bits_to_nhwc(bits, 13, 32)
+    if cls_name == "V2VNetSeg":
+        T = torch.from_numpy(synthetic_poses(1, N, seed=3)).to(device)
+        nat = torch.full((1, N), N)
+        run = lambda inp, **kw: pm.forward_nhwc(inp, T, nat, batch_size=1, **kw)     # noqa: E731
+    else:
+        run = lambda inp, **kw: pm.forward_nhwc(inp, **kw)                            # noqa: E731
+    with torch.no_grad():
+        tune("SEG_FUSE", 0)
+        two = run(x0)
+        tune("SEG_FUSE", 1)
+        one = run(x0)
+        from_bits = run(bits, zbits=13) if (H % 8 == 0 and W % 32 == 0) else one
+    assert one.shape == (N, H, W, 8) and one.dtype == torch.float32
+    assert torch.equal(one, two) and torch.equal(from_bits, one)
+    assert float(one.abs().max()) > 0
+
+
 def test_points_to_logits_path(device):
     """a1 -> a7 without the dense fp32 BEV: voxelize on the GPU and feed the network directly."""
     from v2x_sim_amd import ops

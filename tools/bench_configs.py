@@ -104,7 +104,7 @@ class ConfigSet:
 
             def seg_step():
                 bits = ops.voxelize_bits(self.pts, self.n_pts, self.grid)
-                logits = seg.forward_nhwc(ops.bits_to_nhwc(bits, self.Z, 32), self.trans, self.nat, batch_size=B, plan=plan4)
+                logits = seg.forward_nhwc(bits, self.trans, self.nat, batch_size=B, plan=plan4, zbits=self.Z)   # the bit grid goes straight into conv_pre_1 o conv_pre_2
                 return ops.seg_argmax_confusion(logits, label)
             return seg_step
         raise ValueError("unknown config %r (one of %s)" % (name, ", ".join(CONFIG_NAMES)))

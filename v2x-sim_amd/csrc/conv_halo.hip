@@ -272,7 +272,8 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
     // output-store instructions a wave issues per tile (static: every channel tile is written; the det heads' 48 real
     // channels fill their 3 tiles exactly -- other padded widths fall back to the full drain)
     // (the detection heads store only their rare candidates: full drain, which then waits for nothing but the next patch)
-    constexpr int N_STORES = EPI2 == 3 ? 0 : (COUT2 == 0 ? TCO * 4 : ((COUT2 == 48 || COUT2 == 64) ? TCO2 * 4 : 0));
+    // (COUT2 == 16: the seg head, 8 real classes of one padded tile -- lanes of the upper two k-slot quarters are masked off, the store instruction is issued)
+    constexpr int N_STORES = EPI2 == 3 ? 0 : (COUT2 == 0 ? TCO * 4 : ((COUT2 == 48 || COUT2 == 64 || COUT2 == 16) ? TCO2 * 4 : 0));
     if (DB && tile < walk.end) load_patch(tile, 0);
 
     for (; tile < walk.end; tile += walk.step) {
@@ -293,6 +294,7 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                     if (a.x4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
                 } else if constexpr (N_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // (fp32 heads: never x4)
+                else if constexpr (N_STORES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (fp32 seg head)
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
             }
@@ -1202,6 +1204,7 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     // may depend on the batch without breaking the R-rank == 1-rank equality.
     HALO_CASE(0, 64, 64, 64, 1)
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
+    HALO_CASE(0, 32, 32, 16, 2)   // seg: conv8_2 chained with the 1x1 class head (<= 16 classes, fp32 logits)
     if (e2 == 3) {                // det heads with the score threshold in the epilogue: candidates instead of logits
         if (!(C0 == 0 && C1 == 32 && d->Cout == 64 && d->Cout2 == 64 && d->det_counts && d->out && d->out2 && d->det_cap > 0 &&
               d->det_cap <= 4096 && (long long)d->H * d->W * 6 < (1 << 20)))
