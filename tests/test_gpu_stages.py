@@ -495,6 +495,19 @@ def test_seg_argmax_confusion_exact(device):
     assert torch.equal(pred.cpu().long(), ref_pred)
     assert torch.equal(conf.cpu(), R.confusion_matrix(ref_pred, label))   # integer-exact
     assert int(conf.sum()) == 3 * 64 * 64
+    # the generic kernel (other class counts; also labels >= n_cls are ignored) and the 8-class form agree with torch on ties and ignore labels
+    lg = torch.round(torch.randn(2, 16, 32, 8, generator=g) * 2) / 2             # many exact ties: the FIRST maximum wins
+    lb = torch.randint(0, 10, (2, 16, 32), generator=g).to(torch.uint8)          # 8, 9 = ignore
+    p8, c8 = ops.seg_argmax_confusion(lg.to(device), lb.to(device))
+    assert torch.equal(p8.cpu().long(), lg.argmax(-1))
+    keep = lb < 8
+    assert torch.equal(c8.cpu(), R.confusion_matrix(lg.argmax(-1)[keep], lb[keep])) and int(c8.sum()) == int(keep.sum())
+    lg5 = torch.randn(2, 16, 32, 5, generator=g)
+    lb5 = torch.randint(0, 5, (2, 16, 32), generator=g).to(torch.uint8)
+    p5, c5 = ops.seg_argmax_confusion(lg5.to(device), lb5.to(device))
+    assert torch.equal(p5.cpu().long(), lg5.argmax(-1)) and int(c5.sum()) == 2 * 16 * 32
+    p_only, none = ops.seg_argmax_confusion(lg.to(device), None)
+    assert none is None and torch.equal(p_only, p8)
 
 
 # ------------------------------------------------------------------------------------- halo-tile kernel

@@ -149,6 +149,50 @@ __global__ __launch_bounds__(256) void seg_argmax_confusion_kernel(const float *
             if (bins[i]) atomicAdd(&conf[i], (unsigned long long)bins[i]);
 }
 
+// The 8-class form (V2X-Sim): a thread owns FOUR consecutive pixels -- 128 contiguous bytes of logits as eight 16-byte loads, the four labels and
+// the four predictions as one 32-bit word each (the generic kernel: eight strided 4-byte loads and 1-byte accesses per pixel) -- and the
+// workgroup keeps 16 copies of the 64-bin histogram (copy = lane & 15; the single copy ran at 89 % LDS bank conflicts).  Same integers.
+__global__ __launch_bounds__(256) void seg_argmax_confusion8_kernel(const float4 *__restrict__ logits, const uint32_t *__restrict__ label4,
+                                                                    size_t n_quads, uint32_t *__restrict__ pred4,
+                                                                    unsigned long long *__restrict__ conf) {
+    __shared__ unsigned int bins[16][64];
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) (&bins[0][0])[i] = 0u;
+    __syncthreads();
+    const int copy = threadIdx.x & 15;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n_quads; q += (size_t)gridDim.x * 256) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = logits[q * 8 + j];
+        const uint32_t lb = label4 ? label4[q] : 0u;
+        uint32_t out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float l[8] = {v[2 * k].x, v[2 * k].y, v[2 * k].z, v[2 * k].w, v[2 * k + 1].x, v[2 * k + 1].y, v[2 * k + 1].z, v[2 * k + 1].w};
+            int arg = 0;
+            float best = l[0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c)
+                if (l[c] > best) {  // first maximum wins, as torch.argmax
+                    best = l[c];
+                    arg = c;
+                }
+            out |= (uint32_t)arg << (8 * k);
+            if (label4) {
+                const uint32_t b = (lb >> (8 * k)) & 0xffu;
+                if (b < 8u) atomicAdd(&bins[copy][b * 8 + arg], 1u);
+            }
+        }
+        if (pred4) pred4[q] = out;
+    }
+    __syncthreads();
+    if (label4 && threadIdx.x < 64) {
+        unsigned int t = 0;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t += bins[c][threadIdx.x];
+        if (t) atomicAdd(&conf[threadIdx.x], (unsigned long long)t);
+    }
+}
+
 extern "C" int v2x_seg_argmax_confusion(const float *logits, const uint8_t *label, int n, int H, int W, int n_cls,
                                         uint8_t *pred, long long *conf, v2x_stream_t stream) {
     V2X_REQUIRE(logits, "v2x_seg_argmax_confusion: null logits");
@@ -157,6 +201,16 @@ extern "C" int v2x_seg_argmax_confusion(const float *logits, const uint8_t *labe
     V2X_REQUIRE(pred || label, "v2x_seg_argmax_confusion: nothing to compute");
     if (n == 0) return V2X_OK;
     const size_t n_pix = (size_t)n * H * W;
+    if (n_cls == 8 && n_pix % 4 == 0 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0 && (reinterpret_cast<uintptr_t>(label) & 3) == 0 &&
+        (reinterpret_cast<uintptr_t>(pred) & 3) == 0) {
+        const size_t nq = n_pix / 4;
+        size_t g8 = (nq + 255) / 256;
+        if (g8 > 4096) g8 = 4096;
+        hipLaunchKernelGGL(seg_argmax_confusion8_kernel, dim3((unsigned)g8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4 *>(logits),
+                           reinterpret_cast<const uint32_t *>(label), nq, reinterpret_cast<uint32_t *>(pred), reinterpret_cast<unsigned long long *>(conf));
+        V2X_CHECK_LAUNCH("seg_argmax_confusion8_kernel");
+        return V2X_OK;
+    }
     size_t g = (n_pix + 255) / 256;
     if (g > 2048) g = 2048;
     hipLaunchKernelGGL(seg_argmax_confusion_kernel, dim3((unsigned)g), dim3(256), n_cls * n_cls * sizeof(unsigned int),
