@@ -664,10 +664,13 @@ def test_halo_chain_heads_split_f32(device):
 
 
 # ------------------------------------------------------------------------------------- a1, early fusion (upperbound)
-def test_voxelize_early_fusion_bit_exact(device):
+@pytest.mark.parametrize("lds", [0, 2])
+def test_voxelize_early_fusion_bit_exact(device, tune, lds):
     """BASELINE.json config 1: every ego grid = union of all agents' sweeps moved into the ego frame.  Bit-exact vs the
-    oracle's fp32 transform (separately rounded ops) + voxelize_occupy; also checks jobs sharing a target grid."""
+    oracle's fp32 transform (separately rounded ops) + voxelize_occupy; also checks jobs sharing a target grid.  Both forms: the
+    global-atomic scatter (VOXELIZE_LDS = 0) and the LDS-binned one workgroup per target grid (= 2; the default takes it from 48 grids on)."""
     from v2x_sim_amd import ops
+    tune("VOXELIZE_LDS", lds)
     from v2x_sim_amd.utils.synthetic import synthetic_poses
     A, n = 5, 30000
     clouds = [VR.synthetic_points(n, seed=70 + a, n_edge=32) for a in range(A)]
@@ -693,6 +696,18 @@ def test_voxelize_early_fusion_bit_exact(device):
     one = ops.voxelize_fused_bits(pts, cnt, eye, torch.tensor([2], dtype=torch.int32, device=device),
                                   torch.tensor([0], dtype=torch.int32, device=device), 1, grid)
     assert torch.equal(one[0], ops.voxelize_bits(pts, cnt, grid)[2])
+    # jobs in ANY order, a grid nobody writes (all zeros), a job naming a grid that does not exist (skipped), a pt_stride of 3
+    order = torch.randperm(A * A, generator=torch.Generator().manual_seed(1))
+    xf_t = torch.tensor(np.stack(xf), dtype=torch.float32)[order].contiguous().to(device)
+    src_t = torch.tensor(src, dtype=torch.int32)[order].contiguous().to(device)
+    dst_t = torch.tensor(dst, dtype=torch.int32)[order].contiguous()
+    dst_t[dst_t == 3] = 77                                   # ego 3's jobs point nowhere
+    shuffled = ops.voxelize_fused_bits(pts, cnt, xf_t, src_t, dst_t.to(device), A, grid)
+    for i in range(A):
+        assert torch.equal(shuffled[i], bits[i]) if i != 3 else int(shuffled[i].abs().sum()) == 0, i
+    pts3 = pts[..., :3].contiguous()
+    assert torch.equal(ops.voxelize_fused_bits(pts3, cnt, torch.tensor(np.stack(xf), dtype=torch.float32, device=device), torch.tensor(src, dtype=torch.int32, device=device),
+                                               torch.tensor(dst, dtype=torch.int32, device=device), A, grid), bits)
 
 
 def test_pixel_weighted_fuse_vs_torch(device):

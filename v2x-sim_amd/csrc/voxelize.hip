@@ -183,6 +183,66 @@ __global__ __launch_bounds__(256) void voxelize_fused_scatter_kernel(const float
     }
 }
 
+// LDS-binned form of the early fusion (round 4): ONE workgroup per TARGET grid keeps that grid in LDS as 16-bit words, like voxelize_lds_kernel,
+// and streams every job whose dst is its grid through it -- it scans the whole job list for them (<= 65 535 ints, broadcast loads), so the jobs need
+// no order.  The scatter kernel above does 5 x 65 536 device-scope atomicOr per grid into L2 (1.18 ms per 320 grids, 1.1 TB/s: the one kernel of
+// the upperbound config far from any roof); here every atomic is a ds_or_b32 and the grid leaves the CU once, as linear 16-byte stores -- no memset
+// pass.  Arithmetic per point is the scatter kernel's (same fp32 transform with separately rounded operations, same fp64 indexing): bit-identical.
+template <bool VEC4>
+__global__ __launch_bounds__(VOX_LDS_THREADS) void voxelize_fused_lds_kernel(const float *__restrict__ pts, const int32_t *__restrict__ n_pts,
+                                                                             int max_pts, int pt_stride, const float *__restrict__ xform,
+                                                                             const int32_t *__restrict__ src, const int32_t *__restrict__ dst,
+                                                                             int n_jobs, VoxParams vp, uint32_t *__restrict__ bits, int n_clouds) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sgrid[];   // [X*Y/2]: two 16-bit pixels per word
+    const int g = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int n_words = (vp.X * vp.Y) >> 1;
+    for (int i = tid * 4; i < n_words; i += VOX_LDS_THREADS * 4) *reinterpret_cast<uint4 *>(&sgrid[i]) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int job = 0; job < n_jobs; ++job) {
+        if (dst[job] != g) continue;                       // workgroup-uniform
+        const int cloud = src[job];
+        if ((unsigned)cloud >= (unsigned)n_clouds) continue;
+        const int n = min(n_pts[cloud], max_pts);
+        const float *base = pts + (size_t)cloud * max_pts * pt_stride;
+        float m[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) m[k] = xform[(size_t)job * 12 + k];
+        for (int i0 = 0; i0 < n; i0 += VOX_LDS_THREADS * VOX_LDS_UNR) {
+            float px[VOX_LDS_UNR], py[VOX_LDS_UNR], pz[VOX_LDS_UNR];
+#pragma unroll
+            for (int u = 0; u < VOX_LDS_UNR; ++u) {          // unconditional loads (index clamped): all UNR of them in flight
+                const int i = min(i0 + u * VOX_LDS_THREADS + tid, n - 1);
+                if (VEC4) {
+                    const float4 p = reinterpret_cast<const float4 *>(base)[i];
+                    px[u] = p.x;
+                    py[u] = p.y;
+                    pz[u] = p.z;
+                } else {
+                    px[u] = base[(size_t)i * pt_stride + 0];
+                    py[u] = base[(size_t)i * pt_stride + 1];
+                    pz[u] = base[(size_t)i * pt_stride + 2];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < VOX_LDS_UNR; ++u) {
+                float t[3];
+#pragma unroll
+                for (int r = 0; r < 3; ++r)
+                    t[r] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(px[u], m[4 * r + 0]), __fmul_rn(py[u], m[4 * r + 1])), __fmul_rn(pz[u], m[4 * r + 2])),
+                                     m[4 * r + 3]);
+                vox_lds_point(i0 + u * VOX_LDS_THREADS + tid < n, (double)t[0], (double)t[1], (double)t[2], vp, sgrid);
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t *grid = bits + (size_t)g * vp.X * vp.Y;
+    for (int k = tid; k < (n_words >> 1); k += VOX_LDS_THREADS) {
+        const uint2 w = *reinterpret_cast<const uint2 *>(&sgrid[2 * k]);
+        *reinterpret_cast<uint4 *>(&grid[4 * k]) = make_uint4(w.x & 0xffffu, w.x >> 16, w.y & 0xffffu, w.y >> 16);
+    }
+}
+
 // [n][X][Y] words -> [n][X][Y][Z] fp32, one thread per output element (coalesced 4-B stores)
 __global__ __launch_bounds__(256) void bits_to_dense_f32_kernel(const uint32_t *__restrict__ bits, size_t n_pix,
                                                                 int Z, float *__restrict__ out) {
@@ -480,6 +540,26 @@ extern "C" int v2x_voxelize_fused_bits(const float *pts, const int32_t *n_pts, i
     vp.X = dims_xyz[0];
     vp.Y = dims_xyz[1];
     vp.Z = dims_xyz[2];
+    // LDS-binned form: one workgroup per target grid (the grid as 16-bit words must fit one CU's LDS); VOXELIZE_LDS = 0 keeps the global-atomic form
+    // (the bitwise-equality test compares the two), = 1 takes it from 48 grids on like v2x_voxelize_bits, = 2 always
+    const size_t lds_bytes = (size_t)vp.X * vp.Y * 2;
+    const int lds_mode = v2x_tune(V2X_TUNE_VOXELIZE_LDS);
+    if (lds_mode != 0 && !(lds_mode == 1 && n_grids <= 48) && vp.Z <= 16 && lds_bytes <= 128 * 1024 && ((size_t)vp.X * vp.Y) % 8 == 0 && max_pts > 0 &&
+        n_jobs > 0) {
+        static v2x_once_per_device attr_once;
+        if (v2x_first_use_on_device(attr_once)) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(voxelize_fused_lds_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(voxelize_fused_lds_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        }
+        if (pt_stride == 4 && (reinterpret_cast<uintptr_t>(pts) & 15) == 0)
+            hipLaunchKernelGGL(voxelize_fused_lds_kernel<true>, dim3(n_grids), dim3(VOX_LDS_THREADS), lds_bytes, s, pts, n_pts, max_pts, pt_stride, xform,
+                               src_cloud, dst_grid, n_jobs, vp, bits, n_clouds);
+        else
+            hipLaunchKernelGGL(voxelize_fused_lds_kernel<false>, dim3(n_grids), dim3(VOX_LDS_THREADS), lds_bytes, s, pts, n_pts, max_pts, pt_stride, xform,
+                               src_cloud, dst_grid, n_jobs, vp, bits, n_clouds);
+        V2X_CHECK_LAUNCH("voxelize_fused_lds_kernel");
+        return V2X_OK;
+    }
     if (hipMemsetAsync(bits, 0, (size_t)n_grids * vp.X * vp.Y * sizeof(uint32_t), s) != hipSuccess) {
         v2x_set_error("v2x_voxelize_fused_bits: memset failed");
         return V2X_EIO;
