@@ -85,6 +85,35 @@ def test_stream_gru_vs_oracle(device, hw):
     assert torch.allclose(h, h2, atol=2 ** -7, rtol=2 ** -7)
 
 
+@pytest.mark.parametrize("gain", [1e-3, 0.3, 3.0, 40.0])
+def test_gru_gate_arithmetic_over_its_whole_range(device, gain):
+    """common.h: v2x_gru_h0 -- sigmoid / tanh on v_exp_f32 / v_rcp_f32 with the series below |x| = 2^-6.  Weight gain 1e-3 puts every
+    pre-activation in the series branch, 0.3 straddles its switch at 2^-6, 40 saturates the gates (exp overflows to inf -> rcp 0 -> exactly
+    0 / 1 / +-1).  All three kernels that emit GRU output (streamed 8-wave, streamed 4-wave, gather) against torch's fp32 gates."""
+    from v2x_sim_amd import ops, packing
+    torch.manual_seed(11)
+    cell = R.Conv2dGRUCell(512, 256, 3)
+    gen = torch.Generator().manual_seed(12)
+    with torch.no_grad():
+        for name, p in cell.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=gen) * 0.02 * gain * (0.05 if (gain < 1 and "bias" in name) else 1.0))
+        xx = bf16r(torch.randn(2, 512, 16, 32, generator=gen))
+        ref = cell(xx, None, emulate=True)
+    assert torch.isfinite(ref).all()
+    pc = packing.pack_gru_stream("gru", cell.weight_ih_l0, cell.bias_ih_l0, cell.bias_hh_l0, C0=256, C1=256, device=device)
+    pg = packing.pack_gru("gru", cell.weight_ih_l0, cell.bias_ih_l0, cell.bias_hh_l0, C0=256, C1=256, device=device)
+    x0, x1 = nhwc(xx[:, :256], device), nhwc(xx[:, 256:], device)
+    outs = [back(ops.conv2d(pc, x0, x1)), back(ops.conv2d(pg, x0, x1))]
+    for h in outs:
+        assert torch.isfinite(h).all()
+        # one bf16 rounding of the result + the fp32 sums' order: relative 2^-7, absolute a bf16 ulp of the smallest normal scale met here
+        assert torch.allclose(h, ref, atol=2 ** -7 * max(float(ref.abs().max()), 1e-6), rtol=2 ** -7), float((h - ref).abs().max())
+    if gain >= 40.0:
+        assert float((ref.abs() > 0.99).float().mean()) > 0.2     # the saturated branch really is exercised
+    if gain <= 1e-3:
+        assert float(ref.abs().max()) < 2 ** -6
+
+
 @pytest.mark.parametrize("hw", [(16, 32), (16, 16), (8, 32)])
 @pytest.mark.parametrize("ch", [64, 128])
 def test_stream_chain_conv1x1(device, hw, ch, tune):

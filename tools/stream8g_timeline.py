@@ -56,6 +56,24 @@ def main():
             print("  group %d (%s): period %.0f ns | load phase %.0f | wait at barrier 1 %.0f | MFMA phase (96 MFMAs) %.0f | barrier 2 + loop %.0f   [median period %.0f, max %.0f]"
                   % (g, "patch filler" if g == 0 else "weight streamer", period[sl].mean(), load[sl].mean(), bar1[sl].mean(), mfma[sl].mean(), bar2[sl].mean(),
                      np.median(period[sl]), period[sl].max()))
+        # tile boundaries (round 4): steps S3 - 1 -> S3: "barrier 2 + loop" of the last step of a tile contains the epilogue, its stores and the tile switch
+        S3 = 3 * cin // 32
+        for g in range(2):
+            tg = t[g]
+            k = int((tg[:, 3] > 0).sum())
+            tg = tg[:k]
+            period = tg[1:, 0] - tg[:-1, 0]
+            bar2 = tg[1:, 0] - tg[:-1, 3]
+            load = tg[:, 1] - tg[:, 0]
+            bar1 = tg[:, 2] - tg[:, 1]
+            last = [i for i in range(S3 - 1, k - 2, S3)]
+            inner = [i for i in range(4, k - 2) if (i + 1) % S3 and i % S3 > 1]
+            if last:
+                print("  group %d tile boundary: epilogue + tile switch (barrier 2 + loop of a tile's last step) %.0f ns against %.0f inside a tile; the next tile's first step: load phase %.0f "
+                      "(inner %.0f), wait at barrier 1 %.0f (inner %.0f); period of a tile's last step %.0f, of the next tile's first two steps %.0f / %.0f (inner %.0f)"
+                      % (g, np.mean([bar2[i] for i in last]), np.mean([bar2[i] for i in inner]), np.mean([load[i + 1] for i in last]), np.mean([load[i] for i in inner]),
+                         np.mean([bar1[i + 1] for i in last]), np.mean([bar1[i] for i in inner]), np.mean([period[i] for i in last]), np.mean([period[i + 1] for i in last]),
+                         np.mean([period[i + 2] for i in last if i + 2 < len(period)]), np.mean([period[i] for i in inner])))
         print("  96 MFMAs back to back = %.0f ns at 2.1 GHz" % (96 * 16 / 2.1))
 
 

@@ -39,24 +39,25 @@ def main(Bt=64, steps=12, keep_outputs=False):
     for _ in range(3):
         out = step(resident)
     torch.cuda.synchronize()
-    res = {}
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = step(resident)
-    torch.cuda.synchronize()
-    res["resident"] = Bt * steps / (time.perf_counter() - t0)
-    t0 = time.perf_counter()
-    for s in range(steps):
-        out = step(host[s % 3].to(dev, non_blocking=True))
-    torch.cuda.synchronize()
-    res["inline"] = Bt * steps / (time.perf_counter() - t0)
-    t0 = time.perf_counter()
-    for batch in DevicePrefetcher(({"points": host[s % 3]} for s in range(steps)), dev, depth=2):
-        out = step(batch["points"])
-    torch.cuda.synchronize()
-    res["prefetch"] = Bt * steps / (time.perf_counter() - t0)
+    res = {"resident": 0.0, "inline": 0.0, "prefetch": 0.0}
+    for _rep in range(2):   # best of two passes per arm: 8 eager steps are short enough for one host hiccup to halve an arm
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step(resident)
+        torch.cuda.synchronize()
+        res["resident"] = max(res["resident"], Bt * steps / (time.perf_counter() - t0))
+        t0 = time.perf_counter()
+        for s in range(steps):
+            out = step(host[s % 3].to(dev, non_blocking=True))
+        torch.cuda.synchronize()
+        res["inline"] = max(res["inline"], Bt * steps / (time.perf_counter() - t0))
+        t0 = time.perf_counter()
+        for batch in DevicePrefetcher(({"points": host[s % 3]} for s in range(steps)), dev, depth=2):
+            out = step(batch["points"])
+        torch.cuda.synchronize()
+        res["prefetch"] = max(res["prefetch"], Bt * steps / (time.perf_counter() - t0))
     print("%d frames/step, %.0f MB of sweeps per step: resident %.0f frames/s, inline copy %.0f, prefetched %.0f (%.0f %% of resident)"
-          % (Bt, mb, res["resident"], res["inline"], res["prefetch"], 100 * res["prefetch"] / res["resident"]))
+          % (Bt, mb, res["resident"], res["inline"], res["prefetch"], 100 * res["prefetch"] / res["resident"]), file=sys.stderr)
     if keep_outputs:
         # the last step of every arm read ring slot (steps - 1) % 3: its logits must equal the resident run on that slot's sweeps
         outs = {"inline": None, "prefetch": out, "resident_same_ring_slot": step(host[(steps - 1) % 3].to(dev))}

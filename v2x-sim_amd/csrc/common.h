@@ -100,6 +100,26 @@ __device__ __forceinline__ uint32_t v2x_relu_bf16x2_floor(uint32_t x, uint32_t f
     return __builtin_bit_cast(uint32_t, r);
 }
 
+// ConvGRU gate arithmetic (a4; upstream calls convgru(x, None): h0 = 0, so h = n + z (0 - n)).  fp32 on the hardware's 1-ulp v_exp_f32 /
+// v_rcp_f32: sigmoid(x) = rcp(1 + exp(-x)); tanh(x) = 1 - 2 rcp(1 + exp(2x)), below |x| = 2^-6 the series x (1 - x^2 / 3) (the closed form
+// cancels there; the series' own error is x^4 * 2/15 < 8e-9 relative).  Within a few fp32 ulp of libm's -- 2^-14 of the bf16 rounding that
+// follows.  Rounds 1-3 divided in IEEE (v_div_scale / fmas / fixup) and called libm's branchy tanhf: ~64 instructions per hidden value, 9.4 % of
+// the ConvGRU kernel's time went to its epilogue (profiles/r04_epilogue_phase.txt); this form is ~22.  ONE definition for every kernel that
+// produces GRU output (streamed, gather, split-K reduce): the forms stay bit-consistent with each other.
+__device__ __forceinline__ float v2x_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float v2x_tanh(float x) {
+    const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x));
+    const float small = x * (1.0f - x * x * 0.33333334f);
+    return __builtin_fabsf(x) < 0.015625f ? small : big;
+}
+// pre-activations ar, az, an (W_i* x, no bias), b = (b_ir + b_hr, b_iz + b_hz, b_in, b_hn)
+__device__ __forceinline__ float v2x_gru_h0(float ar, float az, float an, const float4 &b) {
+    const float rg = v2x_sigmoid(ar + b.x);
+    const float zg = v2x_sigmoid(az + b.y);
+    const float ng = v2x_tanh(an + b.z + rg * b.w);
+    return ng + zg * (0.0f - ng);
+}
+
 // 16-byte output stores from the 16x16x32 MFMA result layout.  A lane (fj = pixel, fq = k-slot quarter) holds 4 consecutive channels (8 bytes) of
 // one pixel per 16-channel tile, and a vector store costs the memory pipeline about the same whatever its width (tools/tile_overhead.py: ~12 us
 // per 16 x 32 x 128 tile spent behind dwordx2 stores).  v_permlane16_swap_b32 (gfx950) swaps the odd 16-lane rows of its first operand with the

@@ -42,8 +42,6 @@ struct ConvArgs {
 
 enum { EPI_BF16 = V2X_EPI_BF16, EPI_F32 = V2X_EPI_F32, EPI_GRU = V2X_EPI_GRU };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
-
 // 64 B of zeros: padding taps / K-tail slots / out-of-range pixels point their LDS-DMA source here.
 static __device__ __attribute__((aligned(64))) unsigned int g_zero_page[16];
 
@@ -227,10 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
                 float h[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float rg = sigmoidf_(acc[0][j][r] + bias[r].x);
-                    const float zg = sigmoidf_(acc[1][j][r] + bias[r].y);
-                    const float ng = tanhf(acc[2][j][r] + bias[r].z + rg * bias[r].w);
-                    h[r] = ng + zg * (0.0f - ng);  // h0 = 0:  n + z*(h0 - n)
+                    h[r] = v2x_gru_h0(acc[0][j][r], acc[1][j][r], acc[2][j][r], bias[r]);  // h0 = 0:  n + z*(h0 - n)
                 }
                 uint2 o;
                 o.x = pack_bf16x2(h[0], h[1]);

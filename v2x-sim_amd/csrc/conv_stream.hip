@@ -23,7 +23,8 @@
 
 
 // TIMING EXPERIMENTS ONLY (tools/stream8_phase_probe.sh builds the library with -DV2X_STREAM_DBG_BUILD=n): which part of the
-// 8-wave kernel's step is the long pole?  1 = no weight DMAs, 2 = no patch DMAs, 4 = no fragment reads, 8 = no MFMAs.  Results are
+// 8-wave kernel's step is the long pole?  1 = no weight DMAs, 2 = no patch DMAs, 4 = no fragment reads, 8 = no MFMAs, 16 = per-phase time stamps
+// (tools/stream8g_timeline.sh), 64 = stream8g's epilogue replaced by a sum of the accumulators (what does a tile's epilogue cost in all?).  Results are
 // garbage in those builds; the default build (0) compiles every branch away.
 #ifndef V2X_STREAM_DBG_BUILD
 #define V2X_STREAM_DBG_BUILD 0
@@ -117,10 +118,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
             float h[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float rg = 1.0f / (1.0f + __expf(-(acc[3 * g][f][r] + bias[r].x)));
-                const float zg = 1.0f / (1.0f + __expf(-(acc[3 * g + 1][f][r] + bias[r].y)));
-                const float ng = tanhf(acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w);
-                h[r] = ng + zg * (0.0f - ng);
+                h[r] = v2x_gru_h0(acc[3 * g][f][r], acc[3 * g + 1][f][r], acc[3 * g + 2][f][r], bias[r]);
             }
             o.x = pack_bf16x2(h[0], h[1]);
             o.y = pack_bf16x2(h[2], h[3]);
@@ -164,10 +162,7 @@ __device__ __forceinline__ void stream_epilogue(const StreamArgs &a, f32x4_t (&a
                 float h[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float rg = 1.0f / (1.0f + __expf(-(acc[3 * g][f][r] + bias[r].x)));
-                    const float zg = 1.0f / (1.0f + __expf(-(acc[3 * g + 1][f][r] + bias[r].y)));
-                    const float ng = tanhf(acc[3 * g + 2][f][r] + bias[r].z + rg * bias[r].w);
-                    h[r] = ng + zg * (0.0f - ng);
+                    h[r] = v2x_gru_h0(acc[3 * g][f][r], acc[3 * g + 1][f][r], acc[3 * g + 2][f][r], bias[r]);
                 }
                 uint2 o;
                 o.x = pack_bf16x2(h[0], h[1]);
@@ -568,10 +563,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float4 b = reinterpret_cast<const float4 *>(scale)[c + r];   // (b_ir + b_hr, b_iz + b_hz, b_in, b_hn)
-                const float rg = 1.0f / (1.0f + __expf(-(g[0][r] + b.x)));
-                const float zg = 1.0f / (1.0f + __expf(-(g[1][r] + b.y)));
-                const float ng = tanhf(g[2][r] + b.z + rg * b.w);
-                h[r] = ng + zg * (0.0f - ng);
+                h[r] = v2x_gru_h0(g[0][r], g[1][r], g[2][r], b);
             }
             uint2 o;
             o.x = pack_bf16x2(h[0], h[1]);
@@ -1274,7 +1266,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         constexpr bool LSS = V2X_STREAM_LSS_BUILD != 0 && EPI != SEPI_GRU;
         // (the GRU's table is float4 per hidden channel: a channel half of the tile starts BCO / 6 channels = 4 * BCO / 6 floats in)
-        if constexpr (WT)
+        if constexpr ((SDBG & 64) != 0) {   // timing experiment: the epilogue replaced by a sum of the accumulators (128 adds) and a store that never happens
+            f32x4_t sum = (f32x4_t)(0.f);
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) sum += acc[i][f];
+            if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.678f) reinterpret_cast<uint16_t *>(a.out)[(size_t)tile * 64 + lane] = 1;
+        } else if constexpr (WT)
             stream_epilogue<BCO / 2, TW, EPI, 8, false, true, true>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr,
                                                                     LSS ? (lds_cf_t *)s_ss + coh * (EPI == SEPI_GRU ? 4 * (BCO / 6) : BCO / 2) : (lds_cf_t *)nullptr, BCO, a.x4 != 0);
         else stream_epilogue<BCO, TW, EPI, 4, false, true, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, LSS ? (lds_cf_t *)s_ss : (lds_cf_t *)nullptr, BCO, a.x4 != 0);
