@@ -41,7 +41,44 @@ static int g_eval(int g, int pc) {
     return 0;
 }
 
-int main() {
+// `lds_probe counters`: one dispatch per (swizzle, resolution, alignment) of the 4-slot patch, in a fixed order, so that a
+//   rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS --output-format csv -- /tmp/lds_probe counters
+// pass gives the COUNTERS of exactly the patterns whose TIME the default mode prints (tools/lds_probe_counters.sh joins the two): does
+// a counted conflict cost time?
+static int counters_mode() {
+    int *d_table;
+    uint32_t *d_out;
+    (void)hipMalloc(&d_table, 64 * 4);
+    (void)hipMalloc(&d_out, 1024);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int iters = 4000;
+    for (int g = 0; g < 2; ++g)
+        for (int half = 0; half < 2; ++half)
+            for (int ch = 0; ch < 2; ++ch)
+                for (int kx = 0; kx < 3; ++kx) {
+                    int table[64];
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int fj = lane & 15, fq = lane >> 4;
+                        const int c = 16 * ch + kx;
+                        const int pc = half ? ((c + fj - 1) >> 1) + 1 : c + fj;
+                        table[lane] = (pc * 4 + ((fq ^ g_eval(g, pc)) & 3)) * 16;
+                    }
+                    (void)hipMemcpy(d_table, table, sizeof(table), hipMemcpyHostToDevice);
+                    (void)hipEventRecord(e0, 0);
+                    hipLaunchKernelGGL(read_loop, dim3(256), dim3(256), 65536, 0, d_table, iters, d_out);
+                    (void)hipEventRecord(e1, 0);
+                    (void)hipEventSynchronize(e1);
+                    float ms = 0;
+                    (void)hipEventElapsedTime(&ms, e0, e1);
+                    printf("dispatch g=%s %s ch=%d kx=%d : %.1f ns per read\n", g ? "(pc>>2)&3" : "(pc>>1)&3", half ? "half-res" : "full-res", ch, kx, ms * 1e6 / (iters * 8.0));
+                }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    if (argc > 1 && argv[1][0] == 'c') return counters_mode();
     int *d_table;
     uint32_t *d_out;
     (void)hipMalloc(&d_table, 64 * 4);
