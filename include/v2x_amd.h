@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 13
+#define V2X_AMD_ABI_VERSION 14
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -214,6 +214,21 @@ int v2x_pack_conv(const v2x_pack_spec *spec, const float *w_oihw, uint16_t *dst)
  * W'[o][c][ky][kx] = W[c][o][2-ky][2-kx] are read from the convolution's own tensor W [spec->Cin][spec->Cout][k][k].  Plain layers only
  * (no V2X_EPI_GRU regrouping, chain = 0). */
 int v2x_pack_conv_device(const v2x_pack_spec *spec, const float *w_oihw_dev, int transform, uint16_t *dst_dev, v2x_stream_t stream);
+/* Many layers in ONE launch (a training step re-packs ~55 layers after its optimizer step; one launch each was 0.23 ms of a 6-ms step on the
+ * launch floor).  v2x_pack_conv_device_job fills ONE job on the HOST for the packing v2x_pack_conv_device would do -- same arguments;
+ * block_begin = the sum of the n_blocks of the jobs in front of it -- and returns its block count in *n_blocks.  The caller copies the job array
+ * to the device once (jobs hold device pointers: valid while the parameters and destination buffers stay where they are) and calls
+ * v2x_pack_conv_device_batch(jobs_dev, n_jobs, total_blocks) after every update.  Bit-identical to the per-layer launches. */
+typedef struct v2x_pack_job {
+    const float *w;       /* DEVICE fp32 parameter            */
+    uint16_t *dst;        /* DEVICE packed bf16 destination   */
+    int32_t rows_src, cin, cin_p, taps, K, w_kpad, tile, cout, layout, transform;
+    int64_t groups, data_groups;   /* 16-byte groups of the destination; of them real rows */
+    int64_t block_begin;  /* first workgroup of this job in the batched launch */
+} v2x_pack_job;
+int v2x_pack_conv_device_job(const v2x_pack_spec *spec, const float *w_oihw_dev, int transform, uint16_t *dst_dev, int64_t block_begin,
+                             v2x_pack_job *job_host, int64_t *n_blocks);
+int v2x_pack_conv_device_batch(const v2x_pack_job *jobs_dev, int32_t n_jobs, int64_t total_blocks, v2x_stream_t stream);
 /* Chained 1x1: w2 HOST fp32 [Cout2][Cout] -> dst_w bf16 [ceil16(Cout2)][Cout]; scale2 / shift2 (NULL = ones / zeros)
  * -> fp32 [ceil16(Cout2)], zero beyond Cout2. */
 int v2x_pack_chain_1x1(int Cout2, int Cout, const float *w2, const float *scale2, const float *shift2, uint16_t *dst_w,

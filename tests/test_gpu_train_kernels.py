@@ -937,3 +937,87 @@ def test_eager_step_after_graph_replays_sees_the_replayed_weights(device, tune, 
           % (l_mid, l_stale, l_fresh_then, l_after, l_fresh))
     assert l_after == l_fresh
     assert l_stale != l_fresh_then            # the control: without the stamp the convolutions ran on the packings of two replays ago
+
+
+@pytest.mark.parametrize("family", ["FaFNet", "V2VNet"])
+def test_batched_repack_changes_no_bit(device, tune, family):
+    """TRAIN_PACK_BATCH (all stale packings rebuilt in place by ONE launch at the start of a step) only changes in HOW MANY launches the same
+    packing runs: four SGD steps from the same start give bit-identical losses and parameters with it on and off."""
+    import copy
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet, V2VNet
+    from v2x_sim_amd.train import detection_loss, train_forward, hip_graph
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    tune("TRAIN_HIP", 1)
+    cfg = Config("train")
+    cls, kw = (FaFNet, dict(kd_flag=0, num_agent=2)) if family == "FaFNet" else (V2VNet, dict(num_agent=2))
+    base = init_for_training(cls(cfg, **kw), seed=3).to(device)
+    batches = [synthetic_batch_on_device(cfg, 1, 2, seed=20 + i, device=device) for i in range(4)]
+
+    def run(batch):
+        tune("TRAIN_PACK_BATCH", batch)
+        hip_graph._CACHE.clear()
+        hip_graph._PLANS.clear()
+        m = copy.deepcopy(base).train()
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3, momentum=0.9)
+        losses = []
+        for d in batches:
+            res = train_forward(m, d["bev_seq"], d["trans_matrices"], d["num_agent"], 1)
+            loss = detection_loss(res, d["labels"], d["reg_targets"], d["reg_loss_mask"])[0]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach().clone())
+        torch.cuda.synchronize()
+        return torch.stack(losses), {k: v.detach().clone() for k, v in m.state_dict().items()}, len(hip_graph._PLANS)
+
+    ref_l, ref_p, n_plans = run(0)
+    assert n_plans == 0
+    l, p, n_plans = run(1)
+    assert n_plans >= 1, "the batched re-pack must really have run"
+    assert torch.equal(l, ref_l), (l, ref_l)
+    for k in ref_p:
+        assert torch.equal(p[k], ref_p[k]), k
+
+
+def test_repack_plan_equals_the_per_layer_device_packer(device):
+    """packing.RepackPlan (v2x_pack_conv_device_job / _batch): every layout the training graph packs (gather, halo, streamed; forward and
+    data-gradient; 3x3 and 1x1; a padded bias), rebuilt in place after the parameters changed == a fresh per-layer packing, bit for bit."""
+    from v2x_sim_amd import packing
+    g = torch.Generator().manual_seed(5)
+    specs = [(32, 13, 1, 32, False), (64, 32, 2, None, False), (128, 64, 1, None, False), (256, 128, 2, None, False), (512, 256, 1, None, False),
+             (64, 128, 1, None, True), (32, 64, 1, None, True), (256, 512, 1, None, True)]
+    params, packs = [], []
+    for cout, cin, stride, cin_pad, dgrad in specs:
+        co_w, ci_w = (cin, cout) if dgrad else (cout, cin)
+        w = torch.randn(co_w, ci_w, 3, 3, generator=g).to(device)
+        b = None if dgrad else torch.randn(cout, generator=g).to(device)
+        layer = packing.pack_conv_device("t", w, b, stride=stride, cin_pad=cin_pad, dgrad=dgrad)
+        params.append((w, b, dict(stride=stride, cin_pad=cin_pad, dgrad=dgrad), "3x3"))
+        packs += ([layer.halo] if layer.halo is not None else []) + list(layer.fallback)
+    for cout, cin, dgrad, f32 in ((12, 32, False, True), (36, 32, False, True), (64, 64, False, False), (64, 64, True, False), (12, 32, True, False)):
+        w = torch.randn(cout, cin, 1, 1, generator=g).to(device)
+        b = None if dgrad else torch.randn(cout, generator=g).to(device)
+        kw = dict(dgrad=dgrad, cout_pad=32 if dgrad else 0, f32_out=f32)
+        packs.append(packing.pack_conv1x1_device("t1", w, b, **kw))
+        params.append((w, b, kw, "1x1"))
+    plan = packing.RepackPlan(packs)
+    assert plan.valid() and plan.n_jobs == len(packs)
+    with torch.no_grad():
+        for w, b, _, _ in params:
+            w.mul_(-0.5).add_(0.125)
+            if b is not None:
+                b.add_(1.0)
+    plan.launch()
+    torch.cuda.synchronize()
+    for (w, b, kw, kind), pc in zip(params, packs):
+        if kind == "3x3":
+            layer = packing.pack_conv_device("t", w, b, **kw)
+            fresh = layer.halo if layer.halo is not None else layer.fallback[0]
+        else:
+            fresh = packing.pack_conv1x1_device("t1", w, b, **kw)
+        assert torch.equal(pc.weight.view(-1).view(torch.int16), fresh.weight.view(-1).view(torch.int16)), (kind, kw)
+        assert torch.equal(pc.shift, fresh.shift) and torch.equal(pc.scale, fresh.scale), (kind, kw)
+    # a parameter that moved invalidates the plan
+    params[0][0].data = params[0][0].data.clone()
+    assert not plan.valid()

@@ -2,6 +2,5 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r04_gpu_suite_e.txt
-timeout 900 python bench.py > gpurun_out/r04_bench_n1_h.json 2> gpurun_out/r04_bench_n1_h.err
-tail -3 gpurun_out/r04_gpu_suite_e.txt; cut -c1-600 gpurun_out/r04_bench_n1_h.json
+{ timeout 600 python tools/train_switch_ab.py FaFNet 2; timeout 600 python tools/train_switch_ab.py V2VNet 2; timeout 600 python tools/train_switch_ab.py FaFNet 8; } 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_train_switch_ab.txt
+cat gpurun_out/r04_train_switch_ab.txt

@@ -135,64 +135,83 @@ extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16
 // layer and packing: 336 fills and 181 copies per FaFNet training step.  transform = 1 builds the DATA-GRADIENT layer of a convolution:
 // `spec` then describes that layer (Cout = the convolution's Cin, Cin = its Cout) and W'[o][c][ky][kx] = W[c][o][2-ky][2-kx] is read
 // from the convolution's own weight tensor.  Plain layers only (no GRU row regrouping, no chain order).
-struct DevPackGeom {
-    int rows_src, cin, cin_p, taps, K, w_kpad, tile, cout, layout, transform;
-    long long groups, data_groups;   // 16-byte groups of the destination; of them real rows (layout 2: the rest is the zero page)
-};
+// the geometry of one device packing IS the public job struct (include/v2x_amd.h: v2x_pack_job); w / dst / block_begin are used by the batched form
+typedef v2x_pack_job DevPackGeom;
 
-__global__ __launch_bounds__(256) void pack_conv_device_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, const DevPackGeom g) {
-    for (long long grp = (long long)blockIdx.x * 256 + threadIdx.x; grp < g.groups; grp += (long long)gridDim.x * 256) {
-        int row = -1, k0 = 0;
-        if (g.layout == 0) {
-            const int per = g.w_kpad / 8;
-            row = (int)(grp / per);
-            k0 = (int)(grp - (long long)row * per) * 8;
-            if (row >= g.rows_src || k0 >= g.K) row = -1;
-        } else if (g.layout == 1) {
-            const int s = (int)(grp / g.cout);
-            row = (int)(grp - (long long)s * g.cout);
-            k0 = 8 * s;
-        } else if (grp < g.data_groups) {
-            long long o = grp;
-            const int r = (int)(o % g.tile);
-            o /= g.tile;
-            const int slot = (int)(o & 3);
-            o >>= 2;
-            const int tap = (int)(o % 9);
-            o /= 9;
-            const int n_chunks = g.cin_p / 32;
-            const int ch = (int)(o % n_chunks);
-            const int t = (int)(o / n_chunks);
-            row = t * g.tile + r;
-            k0 = tap * g.cin_p + ch * 32 + slot * 8;
-        }
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row >= 0) {
-            const int tap = k0 / g.cin_p, c0 = k0 - tap * g.cin_p;   // cin_p % 8 == 0: the 8 k of a group share their tap
-            float f[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int c = c0 + j;
-                float x = 0.0f;
-                if (c < g.cin)
-                    x = g.transform ? w[((size_t)c * g.rows_src + row) * g.taps + (g.taps - 1 - tap)] : w[((size_t)row * g.cin + c) * g.taps + tap];
-                f[j] = x;
-            }
-            v = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
-        }
-        *reinterpret_cast<uint4 *>(dst + grp * 8) = v;
+// 16-byte group `grp` of one packing
+__device__ __forceinline__ void pack_group(const float *__restrict__ w, uint16_t *__restrict__ dst, const DevPackGeom &g, long long grp) {
+    int row = -1, k0 = 0;
+    if (g.layout == 0) {
+        const int per = g.w_kpad / 8;
+        row = (int)(grp / per);
+        k0 = (int)(grp - (long long)row * per) * 8;
+        if (row >= g.rows_src || k0 >= g.K) row = -1;
+    } else if (g.layout == 1) {
+        const int s = (int)(grp / g.cout);
+        row = (int)(grp - (long long)s * g.cout);
+        k0 = 8 * s;
+    } else if (grp < g.data_groups) {
+        long long o = grp;
+        const int r = (int)(o % g.tile);
+        o /= g.tile;
+        const int slot = (int)(o & 3);
+        o >>= 2;
+        const int tap = (int)(o % 9);
+        o /= 9;
+        const int n_chunks = g.cin_p / 32;
+        const int ch = (int)(o % n_chunks);
+        const int t = (int)(o / n_chunks);
+        row = t * g.tile + r;
+        k0 = tap * g.cin_p + ch * 32 + slot * 8;
     }
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (row >= 0) {
+        const int tap = k0 / g.cin_p, c0 = k0 - tap * g.cin_p;   // cin_p % 8 == 0: the 8 k of a group share their tap
+        float f[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            float x = 0.0f;
+            if (c < g.cin)
+                x = g.transform ? w[((size_t)c * g.rows_src + row) * g.taps + (g.taps - 1 - tap)] : w[((size_t)row * g.cin + c) * g.taps + tap];
+            f[j] = x;
+        }
+        v = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
+    }
+    *reinterpret_cast<uint4 *>(dst + grp * 8) = v;
 }
 
-extern "C" int v2x_pack_conv_device(const v2x_pack_spec *p, const float *w_oihw_dev, int transform, uint16_t *dst_dev, v2x_stream_t stream) {
+__global__ __launch_bounds__(256) void pack_conv_device_kernel(const float *__restrict__ w, uint16_t *__restrict__ dst, const DevPackGeom g) {
+    for (long long grp = (long long)blockIdx.x * 256 + threadIdx.x; grp < g.groups; grp += (long long)gridDim.x * 256) pack_group(w, dst, g, grp);
+}
+
+// many packings, one launch: workgroup b belongs to the job with the largest block_begin <= b (jobs sorted by block_begin)
+__global__ __launch_bounds__(256) void pack_conv_device_batch_kernel(const v2x_pack_job *__restrict__ jobs, int n_jobs) {
+    __shared__ v2x_pack_job job;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = n_jobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].block_begin <= (long long)blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        job = jobs[lo];
+    }
+    __syncthreads();
+    const long long grp = ((long long)blockIdx.x - job.block_begin) * 256 + threadIdx.x;
+    if (grp < job.groups) pack_group(job.w, job.dst, job, grp);
+}
+
+static int fill_pack_job(const v2x_pack_spec *p, const float *w_oihw_dev, int transform, uint16_t *dst_dev, DevPackGeom &d, const char *who) {
     PackGeom g;
     const int rc = pack_geometry(p, &g);
     if (rc != V2X_OK) return rc;
-    V2X_REQUIRE(w_oihw_dev && dst_dev, "v2x_pack_conv_device: null pointer");
-    V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain, "v2x_pack_conv_device: plain layers only (no GRU regrouping, no chain order)");
-    V2X_REQUIRE(transform == 0 || transform == 1, "v2x_pack_conv_device: transform must be 0 or 1");
-    V2X_REQUIRE(g.elems % 8 == 0, "v2x_pack_conv_device: internal: destination not a whole number of 16-byte groups");
-    DevPackGeom d;
+    V2X_REQUIRE(w_oihw_dev && dst_dev, "%s: null pointer", who);
+    V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain, "%s: plain layers only (no GRU regrouping, no chain order)", who);
+    V2X_REQUIRE(transform == 0 || transform == 1, "%s: transform must be 0 or 1", who);
+    V2X_REQUIRE(g.elems % 8 == 0, "%s: internal: destination not a whole number of 16-byte groups", who);
+    d.w = w_oihw_dev;
+    d.dst = dst_dev;
     d.rows_src = g.rows_src;
     d.cin = p->Cin;
     d.cin_p = g.cin_p;
@@ -205,9 +224,34 @@ extern "C" int v2x_pack_conv_device(const v2x_pack_spec *p, const float *w_oihw_
     d.transform = transform;
     d.groups = (long long)(g.elems / 8);
     d.data_groups = p->w_layout == 2 ? (long long)g.rows_src * g.K / 8 : d.groups;
+    d.block_begin = 0;
+    return V2X_OK;
+}
+
+extern "C" int v2x_pack_conv_device(const v2x_pack_spec *p, const float *w_oihw_dev, int transform, uint16_t *dst_dev, v2x_stream_t stream) {
+    DevPackGeom d;
+    const int rc = fill_pack_job(p, w_oihw_dev, transform, dst_dev, d, "v2x_pack_conv_device");
+    if (rc != V2X_OK) return rc;
     const long long blocks = (d.groups + 255) / 256;
     hipLaunchKernelGGL(pack_conv_device_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, dst_dev, d);
     V2X_CHECK_LAUNCH("pack_conv_device_kernel");
+    return V2X_OK;
+}
+
+extern "C" int v2x_pack_conv_device_job(const v2x_pack_spec *p, const float *w_oihw_dev, int transform, uint16_t *dst_dev, int64_t block_begin,
+                                        v2x_pack_job *job_host, int64_t *n_blocks) {
+    V2X_REQUIRE(job_host && n_blocks && block_begin >= 0, "v2x_pack_conv_device_job: bad arguments");
+    const int rc = fill_pack_job(p, w_oihw_dev, transform, dst_dev, *job_host, "v2x_pack_conv_device_job");
+    if (rc != V2X_OK) return rc;
+    job_host->block_begin = block_begin;
+    *n_blocks = (job_host->groups + 255) / 256;
+    return V2X_OK;
+}
+
+extern "C" int v2x_pack_conv_device_batch(const v2x_pack_job *jobs_dev, int32_t n_jobs, int64_t total_blocks, v2x_stream_t stream) {
+    V2X_REQUIRE(jobs_dev && n_jobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31), "v2x_pack_conv_device_batch: bad arguments");
+    hipLaunchKernelGGL(pack_conv_device_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, jobs_dev, (int)n_jobs);
+    V2X_CHECK_LAUNCH("pack_conv_device_batch_kernel");
     return V2X_OK;
 }
 

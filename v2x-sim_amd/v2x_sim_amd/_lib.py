@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_EPI_DET = 0, 1, 2, 3
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 
 class ConvDesc(C.Structure):
@@ -33,6 +33,14 @@ class ConvDesc(C.Structure):
         ("det_counts", C.c_void_p), ("det_thr", C.c_float), ("det_cap", C.c_int32),
         ("splitk", C.c_int32), ("splitk_ws", C.c_void_p), ("small_batch", C.c_int32),
     ]
+
+
+class PackJob(C.Structure):
+    """Mirror of `struct v2x_pack_job` (include/v2x_amd.h): one packing of the batched device packer."""
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p),
+                ("rows_src", C.c_int32), ("cin", C.c_int32), ("cin_p", C.c_int32), ("taps", C.c_int32), ("K", C.c_int32), ("w_kpad", C.c_int32),
+                ("tile", C.c_int32), ("cout", C.c_int32), ("layout", C.c_int32), ("transform", C.c_int32),
+                ("groups", C.c_int64), ("data_groups", C.c_int64), ("block_begin", C.c_int64)]
 
 
 class PackSpec(C.Structure):
@@ -64,6 +72,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "v2x_pack_conv_size": (C.c_size_t, [C.POINTER(PackSpec), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "v2x_pack_conv_device": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_pack_conv_device_job": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.POINTER(PackJob), C.POINTER(C.c_int64)]),
+    "v2x_pack_conv_device_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
     "v2x_channel_sum_workspace_size": (C.c_longlong, [C.c_longlong, C.c_int]),
     "v2x_channel_sum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_warp_affine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -266,7 +266,8 @@ class PackedConv:
     """Device-resident packed parameters of one conv layer (see packing.py)."""
 
     __slots__ = ("weight", "scale", "shift", "C0", "C1", "Cout", "ksize", "stride", "pad", "up0", "epilogue", "relu",
-                 "w_rows", "w_kpad", "name", "w_layout", "Cout2", "weight2", "scale2", "shift2", "relu2")
+                 "w_rows", "w_kpad", "name", "w_layout", "Cout2", "weight2", "scale2", "shift2", "relu2",
+                 "repack")   # packing.pack_conv_device: what packing.RepackPlan needs to rebuild `weight` in place (None otherwise)
 
     def __init__(self, **kw):
         for k in self.__slots__:

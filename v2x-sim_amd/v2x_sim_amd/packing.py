@@ -214,6 +214,62 @@ def train_layout(cin_p, cout, stride):
     return 0
 
 
+def _repack_info(spec, weight, w, dgrad, buf, shift, bias, cout):
+    """What RepackPlan needs to rebuild this packing in place after the parameter changed; None when the packer read a converted COPY of the
+    parameter (not fp32 / not contiguous: its pointer is not the parameter's)."""
+    import weakref
+    if w.data_ptr() != weight.data_ptr():
+        return None
+    copy_bias = bias is not None and shift.data_ptr() != bias.data_ptr()     # shift is a padded copy of the bias (else: the parameter itself)
+    return {"spec": spec, "weight": weakref.ref(weight), "ptr": weight.data_ptr(), "transform": 1 if dgrad else 0, "buf": buf,
+            "bias": weakref.ref(bias) if copy_bias else None, "shift": shift if copy_bias else None, "cout": cout}
+
+
+class RepackPlan:
+    """ONE launch that rebuilds the packed weights of many layers in place (v2x_pack_conv_device_batch) -- a training step re-packs every layer
+    after its optimizer step (train/hip_graph.py), one small launch each before this.  Built once from the PackedConv objects of a step (their
+    `repack` records); valid while every parameter is alive and where it was.  The job table is copied to the device at construction (not
+    inside a stream capture); launch() itself issues the one kernel (+ one small copy per layer whose shift vector is a padded copy of the bias)."""
+
+    def __init__(self, packs):
+        import ctypes as C
+        from ._lib import PackJob
+        lib = _lib.load()
+        infos = [pc.repack for pc in packs]
+        if not infos or any(i is None for i in infos):
+            raise ValueError("RepackPlan: every packing must come from pack_conv_device / pack_conv1x1_device on the parameter itself")
+        self.packs = list(packs)
+        jobs = (PackJob * len(infos))()
+        begin = 0
+        for k, i in enumerate(infos):
+            nb = C.c_int64(0)
+            _lib.check(lib.v2x_pack_conv_device_job(C.byref(i["spec"]), C.c_void_p(i["ptr"]), i["transform"], C.c_void_p(i["buf"].data_ptr()), begin,
+                                                    C.byref(jobs[k]), C.byref(nb)), "v2x_pack_conv_device_job")
+            begin += nb.value
+        self.total_blocks = begin
+        dev = infos[0]["buf"].device
+        self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(dev)
+        self.n_jobs = len(infos)
+
+    def valid(self):
+        for pc in self.packs:
+            i = pc.repack
+            w = i["weight"]()
+            if w is None or w.data_ptr() != i["ptr"] or (i["bias"] is not None and i["bias"]() is None):
+                return False
+        return True
+
+    def launch(self):
+        import ctypes as C
+        lib = _lib.load()
+        _lib.check(lib.v2x_pack_conv_device_batch(C.c_void_p(self.jobs.data_ptr()), self.n_jobs, self.total_blocks,
+                                                  C.c_void_p(torch.cuda.current_stream().cuda_stream)), "v2x_pack_conv_device_batch")
+        for pc in self.packs:
+            i = pc.repack
+            if i["bias"] is not None:
+                i["shift"][:i["cout"]].copy_(i["bias"]().detach())
+
+
 def pack_conv_device(name, weight, bias, *, stride=1, cin_pad=None, dgrad=False):
     """One-launch device packing of a plain 3x3 layer for the training graph (v2x_pack_conv_device): weight = the fp32 parameter ON THE
     DEVICE, [Cout, Cin, 3, 3].  dgrad: the layer that computes the convolution's data gradient (stride-1 convolution of dy with the flipped,
@@ -250,6 +306,7 @@ def pack_conv_device(name, weight, bias, *, stride=1, cin_pad=None, dgrad=False)
         shift = _const(n_par, 0.0, w.device)
     pc = PackedConv(name=name, weight=buf, scale=scale, shift=shift, C0=cin_p, C1=0, Cout=cout, ksize=3, stride=1 if dgrad else stride, pad=1,
                     up0=0, epilogue=V2X_EPI_BF16, relu=False, w_rows=n_par, w_kpad=kpad.value, w_layout=layout or None, Cout2=0)
+    pc.repack = _repack_info(spec, weight, w, dgrad, buf, shift, bias, cout)
     return Layer([pc], None, name=name) if layout == 0 else Layer([], pc, name=name)
 
 
@@ -289,8 +346,10 @@ def pack_conv1x1_device(name, weight, bias, *, dgrad=False, cout_pad=0, f32_out=
             shift[:cout] = bias.detach().float()
     else:
         shift = _const(n_par, 0.0, w.device)
-    return PackedConv(name=name, weight=buf.view(n_par, kpad.value), scale=scale, shift=shift, C0=cin_p, C1=0, Cout=cout, ksize=1, stride=1, pad=0,
-                      up0=0, epilogue=epi, relu=False, w_rows=n_par, w_kpad=kpad.value)
+    pc = PackedConv(name=name, weight=buf.view(n_par, kpad.value), scale=scale, shift=shift, C0=cin_p, C1=0, Cout=cout, ksize=1, stride=1, pad=0,
+                    up0=0, epilogue=epi, relu=False, w_rows=n_par, w_kpad=kpad.value)
+    pc.repack = _repack_info(spec, weight, w, dgrad, buf, shift, bias if not dgrad else None, cout)
+    return pc
 
 
 def det_row_order(n_anchor=6, n_cls=2, n_code=6):

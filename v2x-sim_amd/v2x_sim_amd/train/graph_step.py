@@ -59,6 +59,10 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self.losses = self._step_body()
         from . import hip_graph
+        # the captured step rebuilds its packed weights IN PLACE in the buffers the warm-up steps allocated (hip_graph._repack_stale): they must
+        # live as long as the graph does, whatever happens to the module-level caches
+        self._repack_plans = list(hip_graph._PLANS.values())
+        hip_graph._PLANS.clear()
         hip_graph._CACHE.clear()     # the packed weights recorded in the graph are rewritten by every replay; eager callers re-pack
 
     def _step_body(self):

@@ -43,10 +43,14 @@ def _conv_like(weight, bias, stride):
                                  out_channels=weight.shape[0])
 
 
+def _versions(weight, bias):
+    return (packing.param_version(weight), None if bias is None else packing.param_version(bias))
+
+
 def _layer(kind, weight, bias, stride, cin_pad):
     # keyed on the parameter OBJECT (weak reference checked on a hit): a data_ptr can be reused by another model's tensor
     key = (kind, id(weight), stride, cin_pad)
-    ver = (packing.param_version(weight), None if bias is None else packing.param_version(bias))
+    ver = _versions(weight, bias)
     hit = _CACHE.get(key)
     if hit is not None and hit[0] == ver and hit[2]() is weight:
         return hit[1]
@@ -54,8 +58,61 @@ def _layer(kind, weight, bias, stride, cin_pad):
     layer = packing.pack_conv_device("train." + kind, weight, bias, stride=stride, cin_pad=cin_pad, dgrad=kind == "dgrad")
     if len(_CACHE) > 512:
         _CACHE.clear()
-    _CACHE[key] = (ver, layer, weakref.ref(weight))
+        _PLANS.clear()
+    _CACHE[key] = (ver, layer, weakref.ref(weight), None if bias is None else weakref.ref(bias))
     return layer
+
+
+# After an optimizer step EVERY cached packing is stale (~55 per model: forward and data-gradient layers).  Re-packed lazily, one launch each, that
+# was 47-55 launches of ~5 us on the launch floor (0.23-0.27 ms of a 6-ms FaFNet step).  train_forward calls _repack_stale() first: the stale
+# packings whose parameters are still alive and in place are rebuilt IN PLACE by one launch (packing.RepackPlan: the job table lives on the
+# device, keyed by the set of cache entries) and their cache entries marked fresh; anything else takes the lazy path above.  Bit-identical.
+_PLANS = {}
+
+
+def _entry_packs(obj):
+    if isinstance(obj, ops.PackedConv):
+        return [obj]
+    return ([obj.halo] if obj.halo is not None else []) + list(obj.fallback)
+
+
+def _repack_stale():
+    if tuning.get("TRAIN_PACK_BATCH") == 0 or not _CACHE:
+        return
+    stale = []
+    for key, ent in _CACHE.items():
+        w = ent[2]()
+        b = None if ent[3] is None else ent[3]()
+        if w is None or (ent[3] is not None and b is None):
+            continue
+        ver = _versions(w, b)
+        if ver != ent[0]:
+            stale.append((key, ent, ver))
+    if len(stale) < 2:
+        return
+    pkey = tuple(k for k, _, _ in stale)
+    plan = _PLANS.get(pkey)
+    if plan is None or not plan.valid():
+        if torch.cuda.is_current_stream_capturing():
+            return                                     # the job table cannot be uploaded inside a capture: lazy path (the warm-up steps build the plan)
+        packs = [pc for _, ent, _ in stale for pc in _entry_packs(ent[1])]
+        if any(pc.repack is None for pc in packs):
+            return
+        if len(_PLANS) > 16:
+            _PLANS.clear()
+        plan = _PLANS[pkey] = packing.RepackPlan(packs)
+        if not plan.valid():
+            return
+    plan.launch()
+    for key, ent, ver in stale:
+        _CACHE[key] = (ver,) + ent[1:]
+
+
+# (Round 4, measured and removed: the weight-gradient launches on a side stream forked when dy exists and joined at the end of the backward pass.
+#  Bit-identical -- once the 1x1 layers' centre-tap slices were made contiguous ON the side stream: AccumulateGrad clones a gradient that has not
+#  the parameter's layout at once, on the backward stream -- but a captured step replays 0.3 ms SLOWER with the fork (FaFNet 5.77 -> 6.07 ms,
+#  V2VNet 7.18 -> 7.53 at 10 maps: one hipGraph does not run its branches side by side here), and the eager step is host-bound.
+#  profiles/r04_train_switch_ab.txt; the code is at commit "Training: batched re-pack ..." minus one.)
 
 
 def _zero_insert(dy):
@@ -196,7 +253,7 @@ def _layer_1x1(kind, weight, bias, f32_out, cout_pad):
     # one device launch per packing (v2x_pack_conv_device, gather layout); dgrad: dx = dy . W, the gradient's channels zero-padded to cout_pad
     pc = packing.pack_conv1x1_device("train." + kind + "1x1", weight, bias if kind == "fwd" else None, dgrad=kind != "fwd", cout_pad=cout_pad,
                                      f32_out=f32_out)
-    _CACHE[key] = (ver, pc, weakref.ref(weight))
+    _CACHE[key] = (ver, pc, weakref.ref(weight), None if bias is None else weakref.ref(bias))
     return pc
 
 
@@ -349,6 +406,7 @@ def _fused_on_fp32_graph(fuse, model, feat, *args):
 def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
     """See _train_forward; the BatchNorm layers' num_batches_tracked counters are bumped together, in one launch, when the forward is complete."""
     prev, _DEFER_COUNTERS[0] = _DEFER_COUNTERS[0], True
+    _repack_stale()
     try:
         return _train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size, inference)
     finally:
