@@ -358,6 +358,20 @@ int v2x_pixel_weighted_fuse(const float *scores, int score_stride, const float *
 long long v2x_channel_sum_workspace_size(long long M, int C);
 int v2x_channel_sum_bf16(const uint16_t *x, long long M, int C, float *out, float *workspace, v2x_stream_t stream);
 
+/* Row f-3, the detection loss of a training step, forward and backward (replaces coperception/utils/loss.py's SoftmaxFocalClassificationLoss +
+ * WeightedSmoothL1LocalizationLoss as combined by coperception/utils/CoDetModule.py::FaFModule.loss_calculator -- not in /root/reference,
+ * README.md:101 names the scripts that call them; restated in v2x_sim_amd/train/loss.py): DEVICE fp32 cls [n][2] logits, labels [n][2] one-hot,
+ * loc / targets [n][6] box codes, mask [n] bytes (bool).  cls = sum -alpha_t (1 - p_t)^2 sum_k l_k log softmax(cls)_k with alpha_t = alpha l_1 +
+ * (1 - alpha) l_0; loc = sum over masked anchors of smooth-L1 (beta); out4 = {cls / n + loc / n, cls / n, loc / n, n = max(sum l_1, 1)}.
+ * Forward = two launches (per-workgroup partials in workspace -- v2x_det_loss_workspace_size(n) bytes -- added in a fixed order: bit-reproducible);
+ * backward = one launch writing dcls [n][2] and dloc [n][6] for the incoming gradients of the three outputs (DEVICE scalars, NULL = 0). */
+long long v2x_det_loss_workspace_size(long long n_anchors);
+int v2x_det_loss_forward(const float *cls, const float *labels, const float *loc, const float *targets, const uint8_t *mask, long long n_anchors,
+                         float alpha, float beta, float *out4, float *workspace, v2x_stream_t stream);
+int v2x_det_loss_backward(const float *cls, const float *labels, const float *loc, const float *targets, const uint8_t *mask, long long n_anchors,
+                          float alpha, float beta, const float *out4, const float *g_loss, const float *g_cls, const float *g_loc, float *dcls,
+                          float *dloc, v2x_stream_t stream);
+
 /* ---------------------------------------------------------------- f-3: the cross-agent warp of the TRAINING graph, forward and data gradient
  * Replaces F.affine_grid + F.grid_sample(mode="bilinear", padding_mode="zeros", align_corners=False) of
  * coperception/models/det/base/IntermediateModelBase.py::feature_transformation (applied twice there: rotation, then translation) and its

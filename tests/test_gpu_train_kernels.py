@@ -1021,3 +1021,61 @@ def test_repack_plan_equals_the_per_layer_device_packer(device):
     # a parameter that moved invalidates the plan
     params[0][0].data = params[0][0].data.clone()
     assert not plan.valid()
+
+
+@pytest.mark.parametrize("case", ["scene", "no_positive", "all_masked_in", "soft_and_empty_labels"])
+def test_fused_detection_loss_equals_the_torch_ops(device, tune, case):
+    """csrc/det_loss.hip (v2x_det_loss_forward / _backward behind train/loss.py::detection_loss) against the PyTorch-op specification in the same
+    file: the three losses and both gradients, for a synthetic scene's targets, a batch without a positive anchor (n clamps to 1), every anchor
+    selected by the regression mask, and label pairs that are not one-hot (0, 0) / (0.3, 0.7) -- the gradient formulas hold for any pair.
+    Also the incoming gradients of the two partial losses (a caller that logs or weights them) and bit-reproducibility."""
+    from v2x_sim_amd.train.loss import detection_loss
+    g = torch.Generator().manual_seed(7)
+    N, X, Y, A = 3, 32, 64, 6
+    cls = (torch.randn(N, X * Y * A, 2, generator=g) * 3.0).to(device).requires_grad_(True)
+    loc = (torch.randn(N, X, Y, A, 1, 6, generator=g) * 0.5).to(device).requires_grad_(True)
+    lab = torch.zeros(N, X, Y, A, 2)
+    pos = torch.rand(N, X, Y, A, generator=g) < 0.02
+    lab[..., 1] = pos.float()
+    lab[..., 0] = 1.0 - lab[..., 1]
+    tgt = torch.where(pos[..., None, None], torch.randn(N, X, Y, A, 1, 6, generator=g) * 0.4, torch.zeros(()))
+    mask = pos[..., None].clone()
+    if case == "no_positive":
+        lab[..., 1], lab[..., 0] = 0.0, 1.0
+        mask[:] = False
+    elif case == "all_masked_in":
+        mask[:] = True
+        tgt = torch.randn(N, X, Y, A, 1, 6, generator=g) * 0.4
+    elif case == "soft_and_empty_labels":
+        lab[0, :8] = 0.0
+        lab[1, :8, :, :, 0], lab[1, :8, :, :, 1] = 0.3, 0.7
+    lab, tgt, mask = lab.to(device), tgt.to(device), mask.to(device)
+    w = torch.tensor([1.0, 0.25, -0.5], device=device)
+
+    def run(flag):
+        tune("TRAIN_HIP", 1)
+        tune("TRAIN_LOSS_HIP", flag)
+        cls.grad = loc.grad = None
+        out = detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask)
+        (out[0] * w[0] + out[1] * w[1] + out[2] * w[2]).backward()
+        return [o.detach().clone() for o in out], cls.grad.clone(), loc.grad.clone()
+
+    ref, ref_dc, ref_dl = run(0)
+    got, dc, dl = run(1)
+    for a, b in zip(got, ref):
+        assert abs(float(a) - float(b)) <= 2e-6 * max(abs(float(b)), 1e-3), (case, float(a), float(b))
+    for a, b in ((dc, ref_dc), (dl, ref_dl)):
+        assert float((a - b).abs().max()) <= 2e-6 * max(float(b.abs().max()), 1e-12) + 1e-9, (case, float((a - b).abs().max()), float(b.abs().max()))
+    if case == "no_positive":
+        assert float(got[2]) == 0.0 and float(dl.abs().max()) == 0.0
+    again, dc2, dl2 = run(1)
+    assert all(torch.equal(a, b) for a, b in zip(again, got)) and torch.equal(dc, dc2) and torch.equal(dl, dl2), "fixed-order sums: bit-reproducible"
+    # only `loss` used (the training loop): the partial losses' gradients arrive as None
+    cls.grad = loc.grad = None
+    detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask)[0].backward()
+    tune("TRAIN_LOSS_HIP", 0)
+    g1, g2 = cls.grad.clone(), loc.grad.clone()
+    cls.grad = loc.grad = None
+    detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask)[0].backward()
+    assert float((g1 - cls.grad).abs().max()) <= 2e-6 * float(cls.grad.abs().max()) + 1e-9
+    assert float((g2 - loc.grad).abs().max()) <= 2e-6 * max(float(loc.grad.abs().max()), 1e-12) + 1e-9

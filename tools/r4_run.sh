@@ -2,7 +2,18 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-timeout 1500 bash tools/profile_round.sh r04h > gpurun_out/r04h_profile.log 2>&1
-for c in v2vnet seg upperbound; do timeout 600 bash tools/profile_round.sh --config $c r04h > gpurun_out/r04h_$c.log 2>&1; done
-timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r04_gpu_suite_e.txt
-tail -3 gpurun_out/r04_gpu_suite_e.txt; cut -c1-300 gpurun_out/prof_r04h/bench.json | tail -1
+{
+timeout 1500 python -m pytest tests/test_gpu_train_kernels.py tests/test_gpu_train.py -x -q -m gpu 2>&1 | tail -12
+python - <<'PY'
+import sys, os
+sys.path.insert(0, "tools"); sys.path.insert(0, "."); sys.path.insert(0, "v2x-sim_amd")
+import torch
+import bench_configs as bc
+from v2x_sim_amd import tuning
+for flag in (0, 1, 0, 1):
+    tuning.set("TRAIN_LOSS_HIP", flag)
+    r = bc.run_training(torch.device("cuda:0"))
+    print("TRAIN_LOSS_HIP=%d" % flag, {k: {kk: round(vv, 3) for kk, vv in v.items() if "MIOpen" not in kk} for k, v in r.items() if isinstance(v, dict)}, flush=True)
+PY
+} 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_train_tests.txt
+cat gpurun_out/r04_train_tests.txt

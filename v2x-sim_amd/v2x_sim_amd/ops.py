@@ -454,6 +454,34 @@ def conv3x3_wgrad(x, dy, cin_out=None):
     return dw
 
 
+def det_loss_forward(cls, labels, loc, targets, mask, alpha, beta):
+    """v2x_det_loss_forward: fp32 contiguous device tensors cls / labels (n, 2), loc / targets (n, 6), mask (n,) bool or uint8 ->
+    out4 (4,) fp32 = (loss, cls_loss, loc_loss, n_pos clamped to >= 1)."""
+    lib = _lib.load()
+    n = cls.numel() // 2
+    ws = torch.empty((lib.v2x_det_loss_workspace_size(n) // 4,), dtype=torch.float32, device=cls.device)
+    out = torch.empty((4,), dtype=torch.float32, device=cls.device)
+    m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    _lib.check(lib.v2x_det_loss_forward(_dev(cls, torch.float32, "cls"), _dev(labels, torch.float32, "labels"), _dev(loc, torch.float32, "loc"),
+                                        _dev(targets, torch.float32, "targets"), _dev(m8, torch.uint8, "mask"), n, alpha, beta,
+                                        _dev(out, torch.float32, "out4"), _dev(ws, torch.float32, "workspace"), _stream()), "v2x_det_loss_forward")
+    return out
+
+
+def det_loss_backward(cls, labels, loc, targets, mask, alpha, beta, out4, g_loss, g_cls, g_loc):
+    """v2x_det_loss_backward: -> (dcls like cls, dloc like loc) for the incoming gradients of (loss, cls_loss, loc_loss) (fp32 device scalars or None)."""
+    lib = _lib.load()
+    n = cls.numel() // 2
+    dcls, dloc = torch.empty_like(cls), torch.empty_like(loc)
+    m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+    gs = [None if g is None else _dev(g, torch.float32, "grad") for g in (g_loss, g_cls, g_loc)]
+    _lib.check(lib.v2x_det_loss_backward(_dev(cls, torch.float32, "cls"), _dev(labels, torch.float32, "labels"), _dev(loc, torch.float32, "loc"),
+                                         _dev(targets, torch.float32, "targets"), _dev(m8, torch.uint8, "mask"), n, alpha, beta,
+                                         _dev(out4, torch.float32, "out4"), gs[0], gs[1], gs[2], _dev(dcls, torch.float32, "dcls"),
+                                         _dev(dloc, torch.float32, "dloc"), _stream()), "v2x_det_loss_backward")
+    return dcls, dloc
+
+
 def channel_sum(x):
     """x (..., C) bf16 NHWC -> (C,) fp32 = the sum over every other axis, in a fixed order (the bias gradient of a convolution)."""
     lib = _lib.load()
