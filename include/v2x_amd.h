@@ -389,6 +389,9 @@ int v2x_warp_affine_bwd_f32(const float *dout, const float *theta, int P, int C,
  * C0, C1 multiples of 8. */
 int v2x_upcat_bf16(const uint16_t *lo, const uint16_t *skip, int N, int H, int W, int C0, int C1, uint16_t *out, v2x_stream_t stream);
 int v2x_upcat_bwd_bf16(const uint16_t *dcat, int N, int H, int W, int C0, int C1, uint16_t *d_lo, uint16_t *d_skip, v2x_stream_t stream);
+/* f-3: dy bf16 [N][Ho][Wo][C] of a stride-2 layer -> out bf16 [N][2Ho][2Wo][C] with dy at the even positions and zeros elsewhere (the operand of
+ * the layer's data and weight gradients as stride-1 computations; replaces torch.zeros + a strided copy).  C % 8 == 0. */
+int v2x_zero_insert_bf16(const uint16_t *dy, int N, int Ho, int Wo, int C, uint16_t *out, v2x_stream_t stream);
 
 /* ---------------------------------------------------------------- f-1: detection post-processing
  * Replaces coperception/utils/postprocess.py::apply_nms_det per (agent, frame) map: foreground softmax score, score

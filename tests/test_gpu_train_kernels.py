@@ -1079,3 +1079,15 @@ def test_fused_detection_loss_equals_the_torch_ops(device, tune, case):
     detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask)[0].backward()
     assert float((g1 - cls.grad).abs().max()) <= 2e-6 * float(cls.grad.abs().max()) + 1e-9
     assert float((g2 - loc.grad).abs().max()) <= 2e-6 * max(float(loc.grad.abs().max()), 1e-12) + 1e-9
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 32, 64), (1, 8, 8, 8), (2, 5, 7, 136)])
+def test_zero_insert_equals_the_torch_ops_bitwise(device, shape):
+    """v2x_zero_insert_bf16 (the operand of a stride-2 layer's gradients) == torch.zeros + strided copy."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(sum(shape))
+    dy = torch.randn(*shape, generator=g).to(torch.bfloat16).to(device)
+    N, Ho, Wo, C = shape
+    ref = torch.zeros((N, 2 * Ho, 2 * Wo, C), dtype=torch.bfloat16, device=device)
+    ref[:, ::2, ::2] = dy
+    assert torch.equal(ops.zero_insert(dy), ref)

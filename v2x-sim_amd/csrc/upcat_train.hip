@@ -102,3 +102,31 @@ extern "C" int v2x_upcat_bwd_bf16(const uint16_t *dcat, int N, int H, int W, int
     V2X_CHECK_LAUNCH("v2x_upcat_bwd_bf16");
     return V2X_OK;
 }
+
+// ---- zero insertion: the gradient of a stride-2 convolution's output, spread onto the input grid ------------------------------------------------
+// The data gradient of a 3x3 stride-2 layer runs as a stride-1 convolution (flipped, transposed weights) over dy with zeros between its
+// pixels: out[n][2y][2x] = dy[n][y][x], everything else 0.  As torch ops that is a fill of the 4x tensor plus a strided copy into it (two
+// launches, the big tensor written twice: 4 layers per FaFNet step); here one pass writes every 16-byte vector once.
+__global__ __launch_bounds__(256) void zero_insert_kernel(const uint16_t *__restrict__ dy, uint16_t *__restrict__ out, int N, int Ho, int Wo, int C8) {
+    const long long total = (long long)N * 2 * Ho * 2 * Wo * C8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % C8);
+        long long p = i / C8;
+        const int x = (int)(p % (2 * Wo));
+        p /= 2 * Wo;
+        const int y = (int)(p % (2 * Ho));
+        const int n = (int)(p / (2 * Ho));
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (((x | y) & 1) == 0) v = reinterpret_cast<const uint4 *>(dy)[(((long long)n * Ho + (y >> 1)) * Wo + (x >> 1)) * C8 + c];
+        reinterpret_cast<uint4 *>(out)[i] = v;
+    }
+}
+
+extern "C" int v2x_zero_insert_bf16(const uint16_t *dy, int N, int Ho, int Wo, int C, uint16_t *out, v2x_stream_t stream) {
+    V2X_REQUIRE(dy && out, "v2x_zero_insert_bf16: null pointer");
+    V2X_REQUIRE(N >= 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0, "v2x_zero_insert_bf16: needs C %% 8 == 0 and positive extents");
+    if (N == 0) return V2X_OK;
+    hipLaunchKernelGGL(zero_insert_kernel, dim3(upcat_grid((long long)N * 4 * Ho * Wo * (C / 8))), dim3(256), 0, (hipStream_t)stream, dy, out, N, Ho, Wo, C / 8);
+    V2X_CHECK_LAUNCH("v2x_zero_insert_bf16");
+    return V2X_OK;
+}

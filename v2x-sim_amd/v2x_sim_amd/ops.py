@@ -538,6 +538,15 @@ def upcat_backward(dcat, C0):
     return d_lo, d_skip
 
 
+def zero_insert(dy):
+    """dy (N, Ho, Wo, C) bf16 of a stride-2 layer -> (N, 2Ho, 2Wo, C) with dy at the even positions, zeros elsewhere (one launch)."""
+    lib = _lib.load()
+    N, Ho, Wo, Cc = dy.shape
+    out = torch.empty((N, 2 * Ho, 2 * Wo, Cc), dtype=torch.bfloat16, device=dy.device)
+    _lib.check(lib.v2x_zero_insert_bf16(_dev(dy, torch.bfloat16, "dy"), N, Ho, Wo, Cc, _dev(out, torch.bfloat16, "out"), _stream()), "v2x_zero_insert_bf16")
+    return out
+
+
 def bn_train_forward(x, gamma, beta, running_mean, running_var, eps, momentum, relu=True):
     """Batch-statistics BN (+ ReLU) of a bf16 NHWC map on the HIP kernels (bn_train.hip).  x (..., C) bf16; gamma / beta (C,) fp32;
     running_mean / running_var fp32 (updated in place) or None.  -> (y bf16 like x, save_mean, save_invstd)."""

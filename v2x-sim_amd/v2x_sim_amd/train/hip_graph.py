@@ -118,6 +118,8 @@ def _repack_stale():
 def _zero_insert(dy):
     """dy (N, Ho, Wo, C) of a stride-2 layer -> (N, 2Ho, 2Wo, C) with dy at the even positions."""
     N, Ho, Wo, C = dy.shape
+    if dy.dtype == BF16 and C % 8 == 0 and dy.is_cuda and tuning.get("UPCAT_HIP") != 0:
+        return ops.zero_insert(dy.contiguous())            # one pass (v2x_zero_insert_bf16) instead of a fill and a strided copy
     z = torch.zeros((N, 2 * Ho, 2 * Wo, C), dtype=dy.dtype, device=dy.device)
     z[:, ::2, ::2] = dy
     return z
@@ -330,6 +332,8 @@ def upcat(lo, skip):
 def nhwc_input(bevs):
     """bevs (A*B, 1, X, Y, Z) dense occupancy -> (A*B, X, Y, 32) bf16 (the Z heights are the channels; zero-padded to 32)."""
     x = bevs[:, 0]
+    if x.dtype == torch.float32 and x.is_cuda and x.is_contiguous() and x.shape[-1] <= 32:
+        return ops.dense_to_nhwc(x, c_pad=32)               # one launch (v2x_dense_f32_to_nhwc_bf16) instead of pad + cast (+ copy)
     return F.pad(x, (0, 32 - x.shape[-1])).to(BF16).contiguous()
 
 
