@@ -2,16 +2,12 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
+F="--steps 40 --warmup 5 --no-cpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline"
 {
-timeout 1500 python -m pytest tests/test_gpu_train_kernels.py tests/test_gpu_train.py -x -q -m gpu 2>&1 | tail -4
-python - <<'PY'
-import sys, os
-sys.path.insert(0, "tools"); sys.path.insert(0, "."); sys.path.insert(0, "v2x-sim_amd")
-import torch
-import bench_configs as bc
-r = bc.run_training(torch.device("cuda:0"))
-print({k: {kk[:22]: round(vv, 3) for kk, vv in v.items() if "MIOpen" not in kk} for k, v in r.items() if isinstance(v, dict)}, flush=True)
-PY
-timeout 300 python tools/train_small_ops.py FaFNet 2>&1 | grep -v "amdgpu.ids\|Warn\|warn"
-} 2>&1 | grep -v amdgpu.ids > gpurun_out/r04_train_tests.txt
-cat gpurun_out/r04_train_tests.txt
+for i in 1 2 3; do
+  for wt in 1 2; do
+    V2X_STREAM_WT=$wt timeout 300 python bench.py $F 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('STREAM_WT=$wt', round(r['value'],1), 'frames/s', round(r['ms_per_step'],3), 'ms')"
+  done
+done
+} > gpurun_out/r04_gru_wt_ab.txt 2>&1
+cat gpurun_out/r04_gru_wt_ab.txt
