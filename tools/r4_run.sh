@@ -2,12 +2,7 @@
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-F="--steps 40 --warmup 5 --no-cpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline"
-{
-for i in 1 2 3; do
-  for wt in 1 2; do
-    V2X_STREAM_WT=$wt timeout 300 python bench.py $F 2>/dev/null | python -c "import sys,json; r=json.loads(sys.stdin.read()); print('STREAM_WT=$wt', round(r['value'],1), 'frames/s', round(r['ms_per_step'],3), 'ms')"
-  done
-done
-} > gpurun_out/r04_gru_wt_ab.txt 2>&1
-cat gpurun_out/r04_gru_wt_ab.txt
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -8 > gpurun_out/r04_gpu_suite_e.txt
+timeout 900 python bench.py > gpurun_out/r04_bench_n1_i.json 2> gpurun_out/r04_bench_n1_i.err
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+tail -3 gpurun_out/r04_gpu_suite_e.txt; wc -l gpurun_out/r04_bench_n1_i.json; cut -c1-200 gpurun_out/r04_bench_n1_i.json
