@@ -1828,7 +1828,11 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     }
     // 8-wave ping-pong form: 16x32 tiles, the wide channel tiles.  V2X_STREAM_WAVES=4 forces the 4-wave kernel
     // (A/B runs and the bitwise-equality test; the choice never depends on the batch size).
-    if (!t16 && d->H % 16 == 0 && (rows == 128 || rows == 96)) {
+    // (the chained layer on a handful of maps: its 8-wave form has one channel tile, i.e. N * H * W / 512 workgroups -- 40 for one 5-agent frame at
+    // 64 x 64 -- so below 3/4 of a round of the CUs it takes the 4-wave kernel's twice as many, half as large tiles: same K order, same epilogue, the
+    // same bits (tests/test_gpu_stream.py::test_stream_chain_conv1x1), which is why this choice may look at the batch)
+    const bool few_chain_tiles = chain && (long long)d->N * (d->H / 16) * (d->W / 32) * 4 < 3ll * v2x_num_cus();
+    if (!t16 && d->H % 16 == 0 && (rows == 128 || rows == 96) && !few_chain_tiles) {
         if (v2x_tune(V2X_TUNE_STREAM_WAVES) != 4) {
             a.tiles_y = d->H / 16;
             a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
