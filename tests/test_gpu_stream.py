@@ -85,6 +85,34 @@ def test_stream_gru_vs_oracle(device, hw):
     assert torch.allclose(h, h2, atol=2 ** -7, rtol=2 ** -7)
 
 
+def test_stream_chain_8wave_form_on_a_full_launch(device, tune):
+    """The chained 128 -> 128 -> 128 layer takes the 8-wave kernel only when its launch fills 3/4 of a round of the CUs (a handful of maps takes
+    the 4-wave kernel's smaller tiles: same K order, same epilogue).  24 maps of 64 x 64 = 192 tiles is such a launch: bit-identical to the
+    4-wave kernel on the same input (so the choice may follow the batch), and right against torch on the first two maps."""
+    from v2x_sim_amd import ops, packing
+    ch, N, H, W = 128, 24, 64, 64
+    g = torch.Generator().manual_seed(77)
+    x = bf16r(torch.randn(N, ch, H, W, generator=g))
+    w1 = torch.randn(ch, ch, 3, 3, generator=g) * (2.0 / (ch * 9)) ** 0.5
+    s1, t1 = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g) * 0.2
+    w2 = torch.randn(ch, ch, 1, 1, generator=g) * (2.0 / ch) ** 0.5
+    s2, t2 = torch.rand(ch, generator=g) + 0.5, torch.randn(ch, generator=g) * 0.2
+    pc = packing.pack_conv_stream("c", w1, s1, t1, relu=True, chain=(w2, s2, t2, True), device=device)
+    xd = nhwc(x, device)
+    y8 = ops.conv2d(pc, xd).clone()
+    tune("STREAM_WAVES", 4)
+    y4 = ops.conv2d(pc, xd).clone()
+    assert torch.equal(y8.view(torch.int16), y4.view(torch.int16))
+    small = ops.conv2d(pc, xd[:2].contiguous())        # two maps alone: the 4-wave kernel by the launch-size rule -- the same bits again
+    tune.reset("STREAM_WAVES")
+    small_default = ops.conv2d(pc, xd[:2].contiguous())
+    assert torch.equal(small.view(torch.int16), y8[:2].view(torch.int16)) and torch.equal(small_default.view(torch.int16), y8[:2].view(torch.int16))
+    hid = bf16r(F.relu(F.conv2d(x[:2], bf16r(w1), None, 1, 1) * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1)))
+    ref = F.relu(F.conv2d(hid, bf16r(w2)) * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1))
+    got = back(y8[:2])
+    assert torch.allclose(got, ref, atol=3e-2, rtol=2 ** -6), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("gain", [1e-3, 0.3, 3.0, 40.0])
 def test_gru_gate_arithmetic_over_its_whole_range(device, gain):
     """common.h: v2x_gru_h0 -- sigmoid / tanh on v_exp_f32 / v_rcp_f32 with the series below |x| = 2^-6.  Weight gain 1e-3 puts every
