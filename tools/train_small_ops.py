@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where do the small PyTorch launches of a HIP-graph training step come from (row f-3)?  One eager FaFNet / V2VNet step under torch.profiler
 with Python stacks: device kernels that are not this library's, grouped by the innermost frame inside this repository.
-usage: python tools/train_small_ops.py [FaFNet|V2VNet]"""
+usage: python tools/train_small_ops.py [FaFNet|V2VNet] [capturable]"""
 import collections
 import os
 import sys
@@ -23,7 +23,9 @@ cfg = Config("train")
 data = synthetic_batch_on_device(cfg, 2, 5, seed=1, device=dev)
 cls, kw = (FaFNet, dict(kd_flag=0, num_agent=5)) if family == "FaFNet" else (V2VNet, dict(num_agent=5))
 model = init_for_training(cls(cfg, **kw), seed=0).to(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-4, fused=True)
+capturable = len(sys.argv) > 2 and sys.argv[2] == "capturable"      # the optimizer of a captured step (train/graph_step.py)
+opt = (torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True, fused=True) if capturable
+       else torch.optim.Adam(model.parameters(), lr=1e-4, fused=True))
 tuning.set("TRAIN_HIP", 1)
 
 
@@ -54,6 +56,12 @@ for ev in prof.events():
         if "/v2x" in fr or "/tools/" in fr:
             site = fr.split("/root/repo/")[-1] if "/root/repo/" in fr else fr
             break
+    if site == "?":                                  # no Python stack: name the enclosing ops instead
+        chain, par = [], ev.cpu_parent
+        while par is not None and len(chain) < 3:
+            chain.append(par.name)
+            par = par.cpu_parent
+        site = "inside " + " < ".join(chain) if chain else "top level"
     n = len(ev.kernels)
     us = sum(k.duration for k in ev.kernels)
     by_site[(name, site)] += n

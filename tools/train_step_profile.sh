@@ -4,18 +4,20 @@ cd "$(dirname "$0")/.."
 O=gpurun_out/train_prof
 mkdir -p $O
 export TMPDIR=/tmp
-for m in faf v2v; do
-  rocprofv3 --kernel-trace --stats -d $O/$m -o t --output-format csv -- python3 tools/train_step_run.py $m > $O/$m.log 2>&1
+for m in faf v2v faf40; do
+  A=$m; F=2
+  if [ $m = faf40 ]; then A=faf; F=8; fi
+  rocprofv3 --kernel-trace --stats -d $O/$m -o t --output-format csv -- python3 tools/train_step_run.py $A $F > $O/$m.log 2>&1
   python3 - $(find $O/$m -name "*kernel_stats.csv") > $O/${m}_kernels.txt <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-print("total kernel time per step: %.2f ms (8 steps traced)" % (tot / 8e6))
+print("total kernel time per step: %.2f ms (24 steps traced, the first one with the lazy packings and the optimizer-state fills)" % (tot / 24e6))
 lib = [r for r in rows if any(t in r["Name"].lower() for t in ("miopen", "cijk", "naive_conv", "igemm_fwd", "igemm_bwd", "igemm_wrw", "gridwise"))]
 print("vendor-library convolution / GEMM kernels in the step: %s" % (", ".join(sorted(set(r["Name"][:60] for r in lib))) or "none"))
 for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:45]:
-    print("%8.1f us/step  x%-5.1f %5.1f %%  %s" % (float(r["TotalDurationNs"]) / 8e3, int(r["Calls"]) / 8.0, 100 * float(r["TotalDurationNs"]) / tot, r["Name"][:150]))
+    print("%8.1f us/step  x%-5.1f %5.1f %%  %s" % (float(r["TotalDurationNs"]) / 24e3, int(r["Calls"]) / 24.0, 100 * float(r["TotalDurationNs"]) / tot, r["Name"][:150]))
 PY
   rm -rf $O/$m
 done
-head -50 $O/faf_kernels.txt; head -50 $O/v2v_kernels.txt
+head -50 $O/faf_kernels.txt; head -50 $O/v2v_kernels.txt; head -30 $O/faf40_kernels.txt
