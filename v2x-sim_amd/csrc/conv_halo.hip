@@ -293,6 +293,9 @@ __device__ __forceinline__ void conv3x3_halo_body(const HaloArgs &a) {
                 } else if constexpr (N_STORES == 16) {
                     if (a.x4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                } else if constexpr (N_STORES == 24) {
+                    if (a.x4) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
                 } else if constexpr (N_STORES == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // (fp32 heads: never x4)
                 else if constexpr (N_STORES == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");      // (fp32 seg head)
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1203,6 +1206,10 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     // tiles.  Same K order and epilogue -> the same bits (tests/test_gpu_stages.py::test_halo_chain_odd_tile_count), so the choice
     // may depend on the batch without breaking the R-rank == 1-rank equality.
     HALO_CASE(0, 64, 64, 64, 1)
+    // row f-3: the data gradient of conv1_1 (64 -> 32 over the zero-inserted dy at 256 x 256) had only the gather kernel.  (Its two companions
+    // there, conv8_1 on the concatenated 96-channel map and conv8_1's data gradient 32 -> 96, do not fit: <0, 32, 96> spills 232 bytes beside 24
+    // accumulator tiles, the single-buffer <0, 96, 32> 192 bytes under its 128-register budget -- and a spill breaks the counted waits.)
+    HALO_CASE(0, 64, 32, 0, 0)
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
     HALO_CASE(0, 32, 32, 16, 2)   // seg: conv8_2 chained with the 1x1 class head (<= 16 classes, fp32 logits)
     if (e2 == 3) {                // det heads with the score threshold in the epilogue: candidates instead of logits

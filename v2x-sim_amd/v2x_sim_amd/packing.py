@@ -205,7 +205,7 @@ def _const(n, value, device, n_real=None):
 def train_layout(cin_p, cout, stride):
     """Which packed layout the training graph's single-source 3x3 layers take (the rule of layer_conv_bn): 1 = halo kernel, 2 = streamed
     kernels (stride 1 and 2), 0 = gather kernel."""
-    if stride == 1 and (cin_p, cout) in ((32, 32), (64, 64)):
+    if stride == 1 and (cin_p, cout) in ((32, 32), (64, 64), (64, 32)):   # (64 -> 32: the data gradient of conv1_1)
         return 1
     if stride == 1 and cin_p >= (64 if STREAM_64 else 128) and cin_p % 32 == 0 and cout % 64 == 0 and STREAM_KERNEL:
         return 2
@@ -481,7 +481,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
         cin_h = _ceil_to(cin_p, 32)
         key = (fb.C0 if fb.C1 else 0, fb.C1 if fb.C1 else cin_h, conv.out_channels)
-        if key in ((0, 32, 32), (64, 32, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):
+        if key in ((0, 32, 32), (64, 32, 32), (0, 64, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):   # (0, 64, 32): no model layer; the data gradient of conv1_1 (train_layout)
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
         elif (cin_p >= (64 if STREAM_64 else 128) and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
