@@ -365,6 +365,13 @@ int v2x_channel_sum_bf16(const uint16_t *x, long long M, int C, float *out, floa
  * (1 - alpha) l_0; loc = sum over masked anchors of smooth-L1 (beta); out4 = {cls / n + loc / n, cls / n, loc / n, n = max(sum l_1, 1)}.
  * Forward = two launches (per-workgroup partials in workspace -- v2x_det_loss_workspace_size(n) bytes -- added in a fixed order: bit-reproducible);
  * backward = one launch writing dcls [n][2] and dloc [n][6] for the incoming gradients of the three outputs (DEVICE scalars, NULL = 0). */
+/* Row f-3, the ConvGRU's gate arithmetic in the training graph (convolutional_rnn.Conv2dGRU with hidden = None as V2VNet.py calls it; restated in
+ * v2x_sim_amd/train/graph.py::_gru_step): gi fp32 [P][3C][HW] = the input convolution's output (bias_ih included), bias_hh fp32 [3C] ->
+ * h fp32 [P][C][HW] = n - z n with r = sigmoid(gi_r + bh_r), z = sigmoid(gi_z + bh_z), n = tanh(gi_n + r bh_n).  Backward: dh -> dgi [P][3C][HW]
+ * and dn_r [P][C][HW] = d(pre-activation of n) * r; d bias_hh = (channel sums of dgi's r and z planes, channel sums of dn_r).  HW % 4 == 0. */
+int v2x_gru_gates_f32(const float *gi, const float *bias_hh, long long P, int C, int HW, float *h, v2x_stream_t stream);
+int v2x_gru_gates_bwd_f32(const float *gi, const float *bias_hh, const float *dh, long long P, int C, int HW, float *dgi, float *dn_r,
+                          v2x_stream_t stream);
 long long v2x_det_loss_workspace_size(long long n_anchors);
 int v2x_det_loss_forward(const float *cls, const float *labels, const float *loc, const float *targets, const uint8_t *mask, long long n_anchors,
                          float alpha, float beta, float *out4, float *workspace, v2x_stream_t stream);

@@ -1091,3 +1091,35 @@ def test_zero_insert_equals_the_torch_ops_bitwise(device, shape):
     ref = torch.zeros((N, 2 * Ho, 2 * Wo, C), dtype=torch.bfloat16, device=device)
     ref[:, ::2, ::2] = dy
     assert torch.equal(ops.zero_insert(dy), ref)
+
+
+@pytest.mark.parametrize("shape", [(10, 256, 32, 32), (3, 16, 8, 4), (1, 64, 16, 16)])
+def test_fused_gru_gates_equal_the_torch_ops(device, tune, shape):
+    """csrc/gru_train.hip (v2x_gru_gates_f32 / _bwd_f32 behind train/graph.py::_gru_step) against the PyTorch ops of the same function: h, the
+    gradient of the pre-activations and the gradient of bias_hh (its n part needs d pre_n * r summed per channel), to fp32 rounding; large
+    pre-activations saturate the gates without NaNs."""
+    import types
+    from v2x_sim_amd.train import graph
+    P, C, H, W = shape
+    g = torch.Generator().manual_seed(P + C)
+    gi0 = (torch.randn(P, 3 * C, H, W, generator=g) * 2.0)
+    gi0[0, :, 0, 0] = 60.0
+    gi0[0, :, 0, 1] = -60.0
+    bhh = (torch.randn(3 * C, generator=g) * 0.5).to(device).requires_grad_(True)
+    dh = torch.randn(P, C, H, W, generator=g).to(device)
+    cell = types.SimpleNamespace(weight_ih_l0=None, bias_ih_l0=None, bias_hh_l0=bhh, kernel_size=3)
+
+    def run(flag):
+        tune("TRAIN_GATES_HIP", flag)
+        gi = gi0.to(device).requires_grad_(True)
+        bhh.grad = None
+        h = graph._gru_step(cell, None, conv=lambda x, w, b: gi)
+        h.backward(dh)
+        return h.detach(), gi.grad.clone(), bhh.grad.clone()
+
+    ref = run(0)
+    got = run(1)
+    for name, a, b in zip(("h", "dgi", "dbias_hh"), got, ref):
+        assert torch.isfinite(a).all(), name
+        scale = max(float(b.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 3e-6 * scale + 1e-7, (name, float((a - b).abs().max()), scale)

@@ -73,6 +73,8 @@ SIGNATURES = {
     "v2x_pack_conv_size": (C.c_size_t, [C.POINTER(PackSpec), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "v2x_pack_conv_device": (C.c_int, [C.POINTER(PackSpec), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_zero_insert_bf16": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_gru_gates_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_gru_gates_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_det_loss_workspace_size": (C.c_longlong, [C.c_longlong]),
     "v2x_det_loss_forward": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_det_loss_backward": (C.c_int, [C.c_void_p] * 5 + [C.c_longlong, C.c_float, C.c_float] + [C.c_void_p] * 7),

@@ -454,6 +454,28 @@ def conv3x3_wgrad(x, dy, cin_out=None):
     return dw
 
 
+def gru_gates(gi, bias_hh):
+    """v2x_gru_gates_f32: gi (P, 3C, H, W) fp32 contiguous, bias_hh (3C,) fp32 -> h (P, C, H, W) fp32 (h0 = 0: h = n - z n)."""
+    lib = _lib.load()
+    P, C3, H, W = gi.shape
+    h = torch.empty((P, C3 // 3, H, W), dtype=torch.float32, device=gi.device)
+    _lib.check(lib.v2x_gru_gates_f32(_dev(gi, torch.float32, "gi"), _dev(bias_hh, torch.float32, "bias_hh"), P, C3 // 3, H * W,
+                                     _dev(h, torch.float32, "h"), _stream()), "v2x_gru_gates_f32")
+    return h
+
+
+def gru_gates_backward(gi, bias_hh, dh):
+    """v2x_gru_gates_bwd_f32: -> (dgi like gi, dn_r (P, C, H, W)): d bias_hh = cat(dgi[:, :2C].sum((0, 2, 3)), dn_r.sum((0, 2, 3)))."""
+    lib = _lib.load()
+    P, C3, H, W = gi.shape
+    dgi = torch.empty_like(gi)
+    dn_r = torch.empty((P, C3 // 3, H, W), dtype=torch.float32, device=gi.device)
+    _lib.check(lib.v2x_gru_gates_bwd_f32(_dev(gi, torch.float32, "gi"), _dev(bias_hh, torch.float32, "bias_hh"), _dev(dh, torch.float32, "dh"),
+                                         P, C3 // 3, H * W, _dev(dgi, torch.float32, "dgi"), _dev(dn_r, torch.float32, "dn_r"), _stream()),
+               "v2x_gru_gates_bwd_f32")
+    return dgi, dn_r
+
+
 def det_loss_forward(cls, labels, loc, targets, mask, alpha, beta):
     """v2x_det_loss_forward: fp32 contiguous device tensors cls / labels (n, 2), loc / targets (n, 6), mask (n,) bool or uint8 ->
     out4 (4,) fp32 = (loss, cls_loss, loc_loss, n_pos clamped to >= 1)."""

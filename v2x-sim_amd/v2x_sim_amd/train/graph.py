@@ -103,10 +103,35 @@ def warp_batch(feat, T):
     return F.grid_sample(y, g2, mode="bilinear", padding_mode="zeros", align_corners=False)
 
 
+class _GruGatesHip(torch.autograd.Function):
+    """The gate arithmetic of _gru_step as one launch forward and one backward (csrc/gru_train.hip) instead of 8 + ~14 elementwise PyTorch ops."""
+
+    @staticmethod
+    def forward(ctx, gi, bias_hh):
+        from .. import ops
+        gi = gi.contiguous()
+        bhh = bias_hh.detach().contiguous()
+        ctx.save_for_backward(gi, bhh)
+        return ops.gru_gates(gi, bhh)
+
+    @staticmethod
+    def backward(ctx, dh):
+        from .. import ops
+        gi, bhh = ctx.saved_tensors
+        dgi, dn_r = ops.gru_gates_backward(gi, bhh, dh.contiguous())
+        C = bhh.numel() // 3
+        dbhh = torch.cat((dgi[:, :2 * C].sum((0, 2, 3)), dn_r.sum((0, 2, 3)))) if ctx.needs_input_grad[1] else None
+        return dgi, dbhh
+
+
 def _gru_step(g, x, conv=None):
     """convolutional_rnn.Conv2dGRU cell with hidden=None (h0 = 0): gh = b_hh exactly, h = n + z*(0 - n).
     conv: optional replacement of the input convolution (train/hip_graph.py runs it on the hand-written kernels)."""
     gi = F.conv2d(x, g.weight_ih_l0, g.bias_ih_l0, 1, g.kernel_size // 2) if conv is None else conv(x, g.weight_ih_l0, g.bias_ih_l0)
+    if conv is not None and gi.is_cuda and gi.dtype == torch.float32 and (gi.shape[2] * gi.shape[3]) % 4 == 0 and g.bias_hh_l0.dtype == torch.float32:
+        from .. import tuning
+        if tuning.get("TRAIN_GATES_HIP") != 0:            # the HIP engine's fusion stage (hip_graph passes its convolution): gates on the kernels too
+            return _GruGatesHip.apply(gi, g.bias_hh_l0)
     i_r, i_z, i_n = gi.chunk(3, 1)
     h_r, h_z, h_n = g.bias_hh_l0.view(1, -1, 1, 1).chunk(3, 1)
     r = torch.sigmoid(i_r + h_r)

@@ -22,6 +22,7 @@ Host-side switches (this module):
     WARP_XCD    1  inference warp + fuse: the output maps of one frame on one XCD (v2x_warp_fuse_ordered: each source map is fetched once per frame
                    instead of once per ego; bit-identical); 0: the plain grid
     SEG_FUSE    1  segmentation models: conv8_2 and the 1x1 class head as one halo launch (the 32-channel map never reaches HBM; bit-identical); 0: two layers
+    TRAIN_GATES_HIP 1  with TRAIN_HIP: the ConvGRU's gate arithmetic of the fusion stage as one launch forward and one backward (csrc/gru_train.hip)
     TRAIN_LOSS_HIP 1  with TRAIN_HIP: the detection loss and its gradients as three launches of csrc/det_loss.hip (0: ~45 PyTorch-ROCm ops)
     TRAIN_PACK_BATCH 1  with TRAIN_HIP: the packed weights of all layers rebuilt by ONE launch after an optimizer step (0: one launch per layer)
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
@@ -29,7 +30,7 @@ The tests use the `tune` fixture (tests/conftest.py), which restores every value
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR")
 
