@@ -371,8 +371,9 @@ def _gru_conv_hip(x, weight, bias):
     N, Cc, H, W = x.shape
     if not hip_eligible(weight, 1, H, W) or Cc % 32:
         return F.conv2d(x, weight, bias, 1, 1)
-    y = _Conv3x3.apply(x.permute(0, 2, 3, 1).to(BF16).contiguous(), weight, bias, 1)
-    return y.permute(0, 3, 1, 2).float()
+    # (layout + precision in ONE copy each way: .to(dtype) alone keeps the permuted strides and a second copy would follow)
+    y = _Conv3x3.apply(x.permute(0, 2, 3, 1).to(dtype=BF16, memory_format=torch.contiguous_format), weight, bias, 1)
+    return y.permute(0, 3, 1, 2).to(dtype=torch.float32, memory_format=torch.contiguous_format)
 
 
 class _AffineSample(torch.autograd.Function):
@@ -398,13 +399,13 @@ def _fused_on_fp32_graph(fuse, model, feat, *args):
     prev = graph._affine_sample_override
     graph._affine_sample_override = _AffineSample.apply if tuning.get("WARP_HIP") != 0 else None
     try:
-        out = fuse(model, feat.permute(0, 3, 1, 2).float(), *args)
+        out = fuse(model, feat.permute(0, 3, 1, 2).to(dtype=torch.float32, memory_format=torch.contiguous_format), *args)
     finally:
         graph._affine_sample_override = prev
     extra = ()
     if isinstance(out, tuple):
         out, extra = out[0], out[1:]
-    return (out.permute(0, 2, 3, 1).to(BF16).contiguous(),) + tuple(extra)
+    return (out.permute(0, 2, 3, 1).to(dtype=BF16, memory_format=torch.contiguous_format),) + tuple(extra)
 
 
 def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch_size=1, inference="softmax"):
