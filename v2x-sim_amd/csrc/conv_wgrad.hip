@@ -331,12 +331,15 @@ extern "C" int v2x_conv3x3_wgrad_reduce(const float *workspace, int n_split, int
 }
 
 extern "C" int v2x_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout) {
-    // number of workspace slots the library would use: enough blocks for two rounds of the 256 CUs, at most one block per pixel tile
+    // number of workspace slots the library would use: enough blocks for one and a half rounds of the 256 CUs, at most one block per pixel tile
     if (N <= 0 || H <= 0 || W <= 0 || H % WG_TH || W % WG_TW || Cin <= 0 || Cin % WG_CI || Cout <= 0 || Cout % 32) return 0;
     const bool rows32 = Cout % WG_CO != 0;
     const long long tiles = (long long)N * (H / WG_TH) * (W / WG_TW);
     const long long pairs = (long long)(Cout / (rows32 ? 32 : WG_CO)) * (Cin / WG_CI);
-    long long n = (512 + pairs - 1) / pairs;
+    // (384 workgroups = one and a half rounds of the CUs: every workgroup writes a 74-KiB partial that the reduce reads back -- 0.9 GB each way per
+    // 10-map FaFNet step at 512 -- so fewer, longer workgroups win until the chip under-fills: captured step 5.19 / 5.13 / 5.17 / 5.20 ms at
+    // 512 / 384 / 320 / 256, V2VNet 6.34 / 6.26 / 6.28 / 6.33)
+    long long n = (384 + pairs - 1) / pairs;
     if (n > 256) n = 256;
     if (n > tiles) n = tiles;
     if (n < 1) n = 1;

@@ -140,6 +140,23 @@ def _gru_step(g, x, conv=None):
     return n - zg * n
 
 
+class _GatherRowsDup(torch.autograd.Function):
+    """base.index_select(0, src) where every row of `base` is selected exactly K times (a frame's map is warped into each of its K = A - 1
+    neighbours' frames).  index_select's own backward is index_add_ -- atomic fp32 adds, a different sum order every run; here the gradient of
+    row r is the dense sum over its K uses in pair order (inv[r]): the V2VNet training step becomes bit-reproducible run to run."""
+
+    @staticmethod
+    def forward(ctx, base, src, inv):
+        ctx.save_for_backward(inv)
+        return base.index_select(0, src)
+
+    @staticmethod
+    def backward(ctx, dy):
+        inv, = ctx.saved_tensors
+        R, K = inv.shape
+        return dy.index_select(0, inv.reshape(-1)).view((R, K) + tuple(dy.shape[1:])).sum(1), None, None
+
+
 def v2v_fuse(model, feat, trans, num_agent_tensor, B, gru_conv=None):
     """feat (A*B, C, H, W) agent-major -> updated maps (same shape).  gru_conv: see _gru_step."""
     A = model.agent_num
@@ -155,16 +172,24 @@ def v2v_fuse(model, feat, trans, num_agent_tensor, B, gru_conv=None):
     if key not in cache:
         pairs = [(m, j * B + f, f, a, j) for m, (a, f) in enumerate(items) for j in range(counts[f]) if j != a]
         cache.clear()
+        # inv[r] = the pairs that read row r of the maps, in pair order -- defined when every row is read equally often (every frame full)
+        uses = {}
+        for pi, p in enumerate(pairs):
+            uses.setdefault(p[1], []).append(pi)
+        K = len(pairs) // max(feat.shape[0], 1)
+        inv = None
+        if K >= 1 and len(uses) == feat.shape[0] and all(len(v) == K for v in uses.values()):
+            inv = torch.tensor([uses[r] for r in range(feat.shape[0])], device=dev)
         cache[key] = (torch.tensor([p[1] for p in pairs], device=dev), torch.tensor([p[0] for p in pairs], device=dev),
                       torch.tensor([(f * A1 + a) * A2 + j for (_, _, f, a, j) in pairs], device=dev),
                       torch.tensor([counts[f] - 1 for (_, f) in items], device=dev, dtype=feat.dtype).view(-1, 1, 1, 1),
-                      torch.tensor(rows, device=dev))
-    src, dst, tsel, cnt, rows_t = cache[key]
+                      torch.tensor(rows, device=dev), inv)
+    src, dst, tsel, cnt, rows_t, inv = cache[key]
     Tp = trans.reshape(-1, 4, 4).index_select(0, tsel).to(feat.dtype)        # trans[f, a, j] of every (ego item, neighbour) pair
     cur = feat
     for _ in range(model.gnn_rounds()):
         base = cur if model.neighbor_source == "updated" else feat
-        warped = warp_batch(base.index_select(0, src), Tp)
+        warped = warp_batch(_GatherRowsDup.apply(base, src, inv) if inv is not None else base.index_select(0, src), Tp)
         if min(counts) == max(counts):
             # every frame has the same number of agents: the pairs of an ego item are consecutive (see `pairs`), so the mean over its neighbours is
             # a reduction over a dense axis -- one deterministic kernel instead of zeros + index_add_ (atomic adds) + a division
