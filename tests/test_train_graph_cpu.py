@@ -105,3 +105,49 @@ def test_step_refuses_cpu():
     mod = FaFModule(m, None, cfg, torch.optim.SGD(m.parameters(), lr=0.1), 0)
     with pytest.raises(RuntimeError):
         mod.step({"bev_seq": torch.zeros((1, 1, 64, 64, 13))}, 1, 1)
+
+
+def test_v2v_fuse_dense_sums_and_ragged_fallback():
+    """train/graph.py::v2v_fuse: with every frame full, the mean over an ego's neighbours is a dense reduction and the gather of the neighbours'
+    maps has a dense backward (_GatherRowsDup) instead of index_add_'s atomic adds -- same values and gradients as the index form (which a batch
+    with a shorter frame still takes: no row-use table exists there)."""
+    from v2x_sim_amd.train import graph
+    g = torch.Generator().manual_seed(3)
+    base = torch.randn(6, 4, 8, 8, generator=g, requires_grad=True)
+    src = torch.tensor([2, 4, 0, 4, 0, 2, 3, 5, 1, 5, 1, 3])          # every row read exactly twice
+    uses = {}
+    for pi, r in enumerate(src.tolist()):
+        uses.setdefault(r, []).append(pi)
+    inv = torch.tensor([uses[r] for r in range(6)])
+    w = torch.randn(12, 4, 8, 8, generator=g)
+    (graph._GatherRowsDup.apply(base, src, inv) * w).sum().backward()
+    got = base.grad.clone()
+    base.grad = None
+    (base.index_select(0, src) * w).sum().backward()
+    assert torch.allclose(got, base.grad, rtol=1e-6, atol=1e-6)
+
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights, synthetic_poses
+    cfg = Config("train")
+    A, B = 3, 2
+    model = init_synthetic_weights(V2VNet(cfg, num_agent=A), seed=2).train()
+    feat = torch.randn(A * B, 256, 8, 8, generator=g)
+    T = torch.from_numpy(synthetic_poses(B, A, seed=4))
+    for nat, dense in ((torch.full((B, A), A), True), (torch.tensor([[3, 3, 3], [2, 2, 0]]), False)):
+        model.__dict__.pop("_v2v_plan_cache", None)
+        f = feat.clone().requires_grad_(True)
+        out = graph.v2v_fuse(model, f, T, nat, B)
+        out.square().sum().backward()
+        inv = next(iter(model.__dict__["_v2v_plan_cache"].values()))[5]
+        assert (inv is not None) == dense
+        assert torch.isfinite(out).all() and torch.isfinite(f.grad).all()
+        if dense:
+            # the same batch with the gather's index_select backward (a plan without the row-use table): same values, same gradients
+            key = next(iter(model.__dict__["_v2v_plan_cache"]))
+            plan = model.__dict__["_v2v_plan_cache"][key]
+            f2 = feat.clone().requires_grad_(True)
+            model.__dict__["_v2v_plan_cache"][key] = plan[:5] + (None,)
+            out2 = graph.v2v_fuse(model, f2, T, nat, B)
+            out2.square().sum().backward()
+            assert torch.allclose(out, out2, rtol=1e-5, atol=1e-6) and torch.allclose(f.grad, f2.grad, rtol=1e-4, atol=1e-5)
