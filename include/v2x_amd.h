@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 14
+#define V2X_AMD_ABI_VERSION 15
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -145,7 +145,9 @@ typedef struct v2x_conv_desc {
     int32_t split;       /* multiple of 4; 0 = no split (out2 ignored)                           */
     int32_t out2_cstride;
     /* --- halo-tile kernel (conv_halo.hip): 3x3 stride-1 layers with <= 96 input channels ------ */
-    int32_t w_layout;    /* 0: row-major [w_rows][w_kpad] (gather kernel)                          */
+    int32_t w_layout;    /* 3: parity-class form of a decoder layer cat(up(in0), in1) -> 3x3 (conv_halo.hip, conv8_1's shape   */
+                         /*    C0 = 64, C1 = 32, Cout = 32; H%8==0, W%32==0): see "weight layouts"; w_kpad = 16*C0 + 9*C1     */
+                         /* 0: row-major [w_rows][w_kpad] (gather kernel)                          */
                          /* 1: k-slot-major [9*Cin/8][Cout][8] (halo kernel; H%8==0, W%32==0)      */
                          /* 2: streamed slices [co_tile][Cin/32][9][4][rows][8] (conv_stream.hip:    */
                          /*    3x3 stride 1, C0,C1 % 32 == 0, tiles 8x32 / 16x32 / 16x16;           */
@@ -173,7 +175,7 @@ typedef struct v2x_conv_desc {
 
 /* ---------------------------------------------------------------- weight layouts and their packers (HOST side)
  * A checkpoint holds conv weights as fp32 OIHW [Cout][Cin][k][k] (the ConvGRU: weight_ih [3*hidden][Cin][3][3], gates in
- * (r, z, n) order).  Every kernel reads bf16 (round-to-nearest-even) in one of three layouts, selected by
+ * (r, z, n) order).  Every kernel reads bf16 (round-to-nearest-even) in one of four layouts, selected by
  * v2x_conv_desc.w_layout.  With Cin' = Cin zero-padded to `cin_pad`, K = k*k*Cin' and the reduction index
  * kk = (ky*k + kx)*Cin' + c  (tap-major, channels fastest, matching NHWC activations):
  *
@@ -188,6 +190,15 @@ typedef struct v2x_conv_desc {
  *       [co_tile][Cin'/32][9 taps][4 slots][rows][8] with rows = v2x_conv_stream_tile_rows(Cout, epilogue): element
  *       (t, ch, tap, slot, r, j) = W[t*rows + r][kk = tap*Cin' + 32*ch + 8*slot + j], followed by 64 B of zeros (the
  *       kernel's zero page).  GRU rows in the (r, z, n)-triple order above (w_rows = 3*hidden); w_kpad = K.
+ *   w_layout 3 (parity-class halo kernel; decoder layers F.interpolate(x, 2) + torch.cat + 3x3 of Backbone.py::LidarDecoder, Cin = c_up + C1):
+ *       for an output pixel (2Y + py, 2X + px) the three tap rows of the 3x3 read only TWO rows of the half-resolution source -- ky in
+ *       G(py, a), a = 0, 1, with G(0,0) = {0}, G(0,1) = {1,2}, G(1,0) = {0,1}, G(1,1) = {2} -- and likewise the columns, so per parity class
+ *       (py, px) the upsampled half of the layer is a 2x2-tap convolution on the half-resolution map with the weights
+ *       W'[py][px][a][b][co][c] = sum over ky in G(py,a), kx in G(px,b) of W[co][c][ky][kx]  (c < c_up), added in fp32 in (ky, kx) ascending
+ *       order and rounded to bf16 ONCE: 4 c_up + 9 C1 instead of 9 (c_up + C1) multiply-adds per output.  Buffer:
+ *       [class 2*py+px][tap 2*a+b][c_up/8][Cout][8] followed by the skip half [tap 3*ky+kx][C1/8][Cout][8];  w_rows = Cout,
+ *       w_kpad = 16*c_up + 9*C1.  (No upstream counterpart: an exact identity in real arithmetic; the tests hold the kernel to the
+ *       unmodified fp32 9-tap layer at the tolerance of the 9-tap kernel.)
  *   chained layers (Cout2 > 0; layouts 1 and 2): the rows of the FIRST layer are stored in "chain order": packed row
  *       rho = 16*i + 4*q + r holds output channel kappa = 32*(i>>1) + 8*q + 4*(i&1) + r (a lane's accumulators of the first
  *       GEMM are then exactly its B fragment of the second); its scale / shift stay in natural channel order.  The chained
@@ -202,6 +213,7 @@ typedef struct v2x_pack_spec {
     int32_t w_layout; /* 0, 1 or 2 (above)                                                               */
     int32_t epilogue; /* V2X_EPI_*: selects the row tile; V2X_EPI_GRU = (r, z, n) row regrouping           */
     int32_t chain;    /* 1: the layer is followed by a chained 1x1 (Cout2 > 0): rows in chain order       */
+    int32_t c_up;     /* w_layout 3 only: the first c_up input channels are the x2-upsampled source (v2x_conv_desc.C0); else 0 */
 } v2x_pack_spec;
 
 /* Bytes of the packed bf16 buffer (0 = unsupported spec, see v2x_last_error) and the w_rows / w_kpad to put in the descriptor. */

@@ -77,7 +77,7 @@ int main(int argc, char **argv) {
     size_t bytes[3];
     int32_t rows[3], kpad[3];
     for (int layout = 0; layout < 3; ++layout) {
-        v2x_pack_spec spec = {COUT, CIN, 3, 0, layout, V2X_EPI_BF16, 0};
+        v2x_pack_spec spec = {COUT, CIN, 3, 0, layout, V2X_EPI_BF16, 0, 0};
         bytes[layout] = v2x_pack_conv_size(&spec, &rows[layout], &kpad[layout]);
         CHECK(bytes[layout] > 0, "pack_conv_size(layout %d): %s", layout, v2x_last_error());
         packed[layout] = (uint16_t *)malloc(bytes[layout]);

@@ -11,12 +11,12 @@ from v2x_sim_amd import _lib, packing
 from v2x_sim_amd._lib import PackSpec, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU
 
 
-def c_pack(w, *, layout, epilogue=V2X_EPI_BF16, cin_pad=0, chain=0, gru=False):
+def c_pack(w, *, layout, epilogue=V2X_EPI_BF16, cin_pad=0, chain=0, gru=False, c_up=0):
     lib = _lib.load()
     w = np.ascontiguousarray(w.detach().float().numpy())
     rows, cin, k, _ = w.shape
     spec = PackSpec(Cout=rows // 3 if gru else rows, Cin=cin, ksize=k, cin_pad=cin_pad, w_layout=layout,
-                    epilogue=V2X_EPI_GRU if gru else epilogue, chain=chain)
+                    epilogue=V2X_EPI_GRU if gru else epilogue, chain=chain, c_up=c_up)
     w_rows, w_kpad = C.c_int32(), C.c_int32()
     nbytes = lib.v2x_pack_conv_size(C.byref(spec), C.byref(w_rows), C.byref(w_kpad))
     assert nbytes > 0, lib.v2x_last_error()
@@ -73,6 +73,33 @@ def test_layout2_stream(cout, cin, chain):
     got, rows, kpad = c_pack(w, layout=2, chain=chain)
     assert (rows, kpad) == (pc.w_rows, pc.w_kpad)
     assert np.array_equal(got, bits(pc.weight))
+
+
+@pytest.mark.parametrize("cout,c_up,c1", [(32, 64, 32), (64, 128, 64), (32, 32, 32)])
+def test_layout3_parity_class(cout, c_up, c1):
+    """Parity-class packing (pre-summed 2x2-tap weights for the upsampled source): C packer == torch packer bit for bit -- the fp32 sums are
+    added in the same (ky, kx) order and rounded once -- and the class sums reproduce the 9-tap layer on a nearest-upsampled operand."""
+    w = rnd(cout, c_up + c1, 3, 3, seed=cout + c_up)
+    pc = packing.pack_conv_halo_parity("t", w, torch.ones(cout), torch.zeros(cout), C0=c_up, C1=c1, device="cpu")
+    got, rows, kpad = c_pack(w, layout=3, c_up=c_up)
+    assert (rows, kpad) == (pc.w_rows, pc.w_kpad) == (cout, 16 * c_up + 9 * c1)
+    assert np.array_equal(got, bits(pc.weight))
+    # the identity the layout rests on, in fp64: four 2x2-tap class convolutions on the half-resolution map == 3x3 on the upsampled map
+    import torch.nn.functional as F
+    wc = packing.parity_class_weights(w[:, :c_up].double())
+    lo = torch.randn(2, c_up, 5, 7, dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    ref = F.conv2d(F.interpolate(lo, scale_factor=(2, 2)), w[:, :c_up].double(), None, 1, 1)
+    out = torch.zeros_like(ref)
+    lop = F.pad(lo, (1, 1, 1, 1))
+    for py in range(2):
+        for px in range(2):
+            k = wc[py * 2 + px].view(2, 2, cout, c_up).permute(2, 3, 0, 1).contiguous()
+            out[:, :, py::2, px::2] = F.conv2d(lop, k)[:, :, py:py + 5, px:px + 7]
+    assert float((out - ref).abs().max()) <= 1e-12 * float(ref.abs().max())
+    # unsupported specs are refused with a message
+    lib = _lib.load()
+    bad = PackSpec(Cout=32, Cin=96, ksize=3, cin_pad=0, w_layout=3, epilogue=V2X_EPI_BF16, chain=0, c_up=0)
+    assert lib.v2x_pack_conv_size(C.byref(bad), None, None) == 0 and b"layout 3" in lib.v2x_last_error()
 
 
 def test_gru_layouts_and_bias():

@@ -1085,6 +1085,260 @@ static int launch_halo_pp(const HaloArgs &a, hipStream_t s) {
     return V2X_OK;
 }
 
+// ---- parity-class ("sub-pixel") form of the decoder's upsample -> concat -> 3x3 layers (conv8_1) ---------------------------------
+// The x2 NEAREST-upsampled half of the operand takes only (H/2) x (W/2) distinct values: for an output pixel (2Y + py, 2X + px) the three
+// tap rows ky of the 3x3 read the half-resolution rows {Y-1, Y, Y} (py = 0) or {Y, Y, Y+1} (py = 1), and likewise the columns.  Per output
+// PARITY CLASS (py, px) the up-half of the layer is therefore a 2 x 2-tap convolution on the half-resolution map whose weights are sums of
+// the 3x3's: W'[py][px][a][b] = sum over ky in G(py, a), kx in G(px, b) of W[ky][kx], G(0,0) = {0}, G(0,1) = {1,2}, G(1,0) = {0,1},
+// G(1,1) = {2}  --  C0 x 4 + C1 x 9 instead of (C0 + C1) x 9 MACs per pixel (conv8_1: -37 %), an exact identity in real arithmetic.  The sums
+// are formed in fp32 from the fp32 parameters and rounded to bf16 ONCE by the packer (w_layout 3: v2x_pack_conv / packing.pack_conv_halo_parity).
+// The oracle is NOT changed: tests compare this kernel with the unmodified fp32 9-tap layer (tolerance = bf16 rounding of the weights, as for
+// the 9-tap kernel) and, as a kernel check, with a torch evaluation of the same bf16 operands.
+// Tiling: the 8-wave ping-pong kernel above with WAVE = CLASS: wave wv of a group owns class (py, px) = (wv >> 1, wv & 1) of the group's 8 x 32 tile,
+// i.e. the 4 x 16 pixels (2Y + py, 2X + px) = 4 fragments of 16 lanes (lane = X), so that a weight fragment still stands in front of 4 MFMAs (split
+// the other way -- every wave all four classes -- each would serve ONE).  The full-resolution (skip) half keeps its 9 taps, read with a column stride
+// of 2 pixels: its patch is stored as two COLUMN-PARITY planes (the DMA descriptors permute the pixels on their way in), so a fragment is again 16
+// consecutive pixels of one plane row and the swizzle of the dense form applies.  Per tile and wave: 136 MFMAs from 81 fragment reads (216 from 114).
+constexpr int PWH = PW / 2;   // columns per parity plane of the full-resolution patch
+
+template <int C0, int C1, int COUT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_halo_ppc_kernel(const HaloArgs a) {
+    constexpr int SPP0 = C0 / 8, SPP1 = C1 / 8;
+    constexpr int NS1 = round64(2 * PH * PWH * SPP1);
+    constexpr int NS0 = round64(PH0 * PW0 * SPP0);
+    constexpr int PATCH_BYTES = (NS0 + NS1) * 16;
+    constexpr int W_UP_BYTES = 16 * SPP0 * COUT * 16;      // [class][tap a*2+b][k-slot][COUT][8]
+    constexpr int W_BYTES = W_UP_BYTES + 9 * SPP1 * COUT * 16;   // + [tap ky*3+kx][k-slot][COUT][8]
+    constexpr int TCO = COUT / 16;
+    constexpr int KC0 = C0 / 32, KC1 = C1 / 32;
+    static_assert(C0 % 32 == 0 && C1 % 32 == 0 && C0 > 0 && C1 > 0 && TCO == 2, "parity-class form: two sources, 32 output channels");
+    static_assert(W_BYTES % 1024 == 0, "weights are moved 1 KiB per wave instruction");
+    constexpr int N_STORES = TCO * 4;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t relu_floor = a.relu ? 0u : 0x80008000u;
+    char *s_w = smem;
+    char *s_patch = smem + W_BYTES;                       // [group][PATCH_BYTES]
+    float *s_ss = reinterpret_cast<float *>(smem + W_BYTES + 2 * PATCH_BYTES);
+    for (int i = threadIdx.x; i < COUT; i += 512) {
+        s_ss[i] = a.scale[i];
+        s_ss[COUT + i] = a.shift[i];
+    }
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
+    const int grp = wave >> 2, wv = wave & 3;
+    const int py = wv >> 1, px = wv & 1;                          // the wave's parity class
+    const int fj = lane & 15, fq = lane >> 4;
+    char *pb = s_patch + grp * PATCH_BYTES;
+
+    for (int off = wave * 1024; off < W_BYTES; off += 8192)
+        glds16h(reinterpret_cast<const char *>(a.w) + off + lane * 16, s_w + off);
+
+    // per-lane DMA tables (see conv3x3_halo_body).  Full-resolution patch: LDS slot L -> (plane q, row pr, plane column cc, physical slot);
+    // the pixel it holds is patch column pc = 2 cc + q.
+    constexpr int NP1 = (NS1 + 255) / 256, NP0 = (NS0 + 255) / 256;
+    int tb1[NP1], tb0[NP0];
+#pragma unroll
+    for (int t = 0; t < NP1; ++t) {
+        const int L = wv * 64 + t * 256 + lane;
+        const int pix = L / SPP1, phys = L - pix * SPP1;
+        const int q = pix / (PH * PWH), rem = pix - q * (PH * PWH);
+        const int pr = rem / PWH, cc = rem - pr * PWH;
+        const int pc = 2 * cc + q;
+        tb1[t] = pix < 2 * PH * PWH ? (((pr * a.W + pc) * C1 + swz<SPP1>(phys, cc) * 8) | (pr << 20) | (pc << 24)) : -1;
+    }
+#pragma unroll
+    for (int t = 0; t < NP0; ++t) {
+        const int L = wv * 64 + t * 256 + lane;
+        const int pix = L / SPP0, phys = L - pix * SPP0;
+        const int pr = pix / PW0, pc = pix - pr * PW0;
+        tb0[t] = pix < PH0 * PW0 ? (((pr * (a.W >> 1) + pc) * C0 + swz<SPP0>(phys, pc) * 8) | (pr << 20) | (pc << 24)) : -1;
+    }
+
+    const int txy = a.tiles_x * a.tiles_y;
+    auto coords = [&](int tile, int &n, int &y0, int &x0) {
+        n = tile / txy;
+        const int r = tile - n * txy;
+        const int ty = r / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (r - ty * a.tiles_x) * TW;
+    };
+    auto load_patch = [&](int tile) {   // this group's patch <- tile; NP1 + NP0 DMAs per wave at most
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+        {
+            const unsigned base = ((unsigned)(n * a.H + y0 - 1) * (unsigned)a.W + (unsigned)(x0 - 1)) * (unsigned)C1;
+#pragma unroll
+            for (int t = 0; t < NP1; ++t) {
+                if (wv * 64 + t * 256 >= NS1) break;   // wave-uniform
+                const int y = y0 - 1 + ((tb1[t] >> 20) & 15), x = x0 - 1 + ((tb1[t] >> 24) & 63);
+                const bool ok = tb1[t] >= 0 && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                glds16h(ok ? (const void *)(a.in1 + (base + (unsigned)(tb1[t] & 0xfffff))) : (const void *)g_zero_page_h,
+                        pb + NS0 * 16 + (wv * 64 + t * 256) * 16);
+            }
+        }
+        {
+            const int Hs = a.H >> 1, Ws = a.W >> 1;
+            const unsigned base = ((unsigned)(n * Hs + (y0 >> 1) - 1) * (unsigned)Ws + (unsigned)((x0 >> 1) - 1)) * (unsigned)C0;
+#pragma unroll
+            for (int t = 0; t < NP0; ++t) {
+                if (wv * 64 + t * 256 >= NS0) break;   // wave-uniform
+                const int y = (y0 >> 1) - 1 + ((tb0[t] >> 20) & 15), x = (x0 >> 1) - 1 + ((tb0[t] >> 24) & 63);
+                const bool ok = tb0[t] >= 0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+                glds16h(ok ? (const void *)(a.in0 + (base + (unsigned)(tb0[t] & 0xfffff))) : (const void *)g_zero_page_h,
+                        pb + (wv * 64 + t * 256) * 16);
+            }
+        }
+    };
+
+    // K walk: groups g < 2 KC0 = (up chunk kc = g >> 1, class tap column b = g & 1): the two class tap rows a share their 5 half-resolution patch
+    // rows; then (tap column kx, skip chunk kc): the three tap rows ky share the 9 full-resolution rows py .. py + 8 of one column-parity plane.
+    f32x4_t acc[TCO][4];
+    constexpr int NG = 2 * KC0 + 3 * KC1;
+    struct Frags {
+        bf16x8_t A[3 * TCO];
+        bf16x8_t B[9];
+    };
+    auto load_group = [&](int g, Frags &F) {
+        if (g < 2 * KC0) {
+            const int kc = g >> 1, b = g & 1;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    F.A[t * TCO + i] = *reinterpret_cast<const bf16x8_t *>(s_w + ((((wv * 4 + t * 2 + b) * SPP0 + kc * 4 + fq) * COUT) + i * 16 + fj) * 16);
+            const int pc = fj + b + px;
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+                F.B[r] = *reinterpret_cast<const bf16x8_t *>(pb + (((py + r) * PW0 + pc) * SPP0 + swz<SPP0>(kc * 4 + fq, pc)) * 16);
+        } else {
+            const int h = g - 2 * KC0, kx = h / KC1, kc = h - kx * KC1;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+                    F.A[ky * TCO + i] = *reinterpret_cast<const bf16x8_t *>(s_w + W_UP_BYTES + ((((ky * 3 + kx) * SPP1 + kc * 4 + fq) * COUT) + i * 16 + fj) * 16);
+            const int q = (px + kx) & 1, cc = fj + ((px + kx) >> 1);
+#pragma unroll
+            for (int r = 0; r < 9; ++r)
+                F.B[r] = *reinterpret_cast<const bf16x8_t *>(pb + NS0 * 16 + ((((q * PH) + py + r) * PWH + cc) * SPP1 + swz<SPP1>(kc * 4 + fq, cc)) * 16);
+        }
+    };
+    auto mma_group = [&](int g, const Frags &F) {
+        if (g < 2 * KC0) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.A[t * TCO + i], F.B[f + t], acc[i][f], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(F.A[ky * TCO + i], F.B[2 * f + ky], acc[i][f], 0, 0, 0);
+        }
+    };
+    auto compute = [&]() {
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        Frags fr[2];   // fragments of group g+1 are read while the MFMAs of group g issue (register double-buffer)
+        load_group(0, fr[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) load_group(g + 1, fr[(g + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_group(g, fr[g & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto epilogue = [&](int tile) {
+        int n, y0, x0;
+        coords(tile, n, y0, x0);
+        int zo = 0;
+        asm volatile("" : "+v"(zo));   // opaque zero: keeps the loop-invariant scale/shift reads out of the MFMA interval (see the kernel above)
+        const float *ss = s_ss + zo;
+        float4 sc[2], sf[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            sc[h] = *reinterpret_cast<const float4 *>(ss + h * 16 + fq * 4);
+            sf[h] = *reinterpret_cast<const float4 *>(ss + COUT + h * 16 + fq * 4);
+        }
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const int y = y0 + 2 * f + py, x = x0 + 2 * fj + px;
+            uint32_t ox[2], oy[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[h][f][0] * sc[h].x + sf[h].x, acc[h][f][1] * sc[h].y + sf[h].y), relu_floor);
+                oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[h][f][2] * sc[h].z + sf[h].z, acc[h][f][3] * sc[h].w + sf[h].w), relu_floor);
+            }
+            uint16_t *prow = reinterpret_cast<uint16_t *>(a.out) + ((size_t)(n * a.H + y) * a.W + x) * a.out_cstride + a.out_coff + fq * 4;
+            if (a.x4) {
+                v2x_store_pair_x4(prow, fq, ox[0], oy[0], ox[1], oy[1]);
+            } else {
+                *reinterpret_cast<uint2 *>(prow) = make_uint2(ox[0], oy[0]);
+                *reinterpret_cast<uint2 *>(prow + 16) = make_uint2(ox[1], oy[1]);
+            }
+        }
+    };
+
+    // pairs of tiles (2p, 2p + 1): group g owns tile 2p + g (an odd tile count leaves group 1 without a tile in the last pair)
+    const int n_pairs = (a.n_tiles + 1) >> 1;
+    const v2x_tile_walk walk = v2x_xcd_tile_walk(n_pairs, a.xcd_walk);
+    const int K = walk.first < walk.end ? (walk.end - walk.first + walk.step - 1) / walk.step : 0;
+    auto tile_of = [&](int k) { return 2 * (walk.first + k * walk.step) + grp; };
+    auto has = [&](int k) { return k < K && tile_of(k) < a.n_tiles; };
+
+    if (grp == 0 && has(0)) load_patch(tile_of(0));
+    __syncthreads();   // weights, scale/shift and group 0's first patch have landed
+
+    for (int i = 0; i <= 2 * K; ++i) {
+        if ((i & 1) == grp) {
+            if (has(i >> 1)) compute();
+        } else {
+            const int m = (i - grp - 1) / 2;               // -1 in group 1's first interval (truncating division)
+            if (has(m + 1)) load_patch(tile_of(m + 1));
+            if (m >= 0 && has(m)) {
+                epilogue(tile_of(m));
+                // the DMAs are OLDER than the stores: they have landed, the stores may stay in flight
+                if (a.x4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    static_assert(N_STORES == 8, "the counted waits above know 8 (4 in the 16-byte form) stores per tile and wave");
+}
+
+template <int C0, int C1, int COUT>
+static int launch_halo_ppc(const HaloArgs &a, hipStream_t s) {
+    constexpr int NS1 = round64(2 * PH * PWH * (C1 / 8));
+    constexpr int NS0 = round64(PH0 * PW0 * (C0 / 8));
+    constexpr int smem = (16 * C0 + 9 * C1) / 8 * COUT * 16 + 2 * (NS0 + NS1) * 16 + 2 * COUT * 4;
+    static_assert(smem <= 160 * 1024, "LDS budget");
+    static v2x_once_per_device attr_once;
+    auto kern = &conv3x3_halo_ppc_kernel<C0, C1, COUT>;
+    if (v2x_first_use_on_device(attr_once)) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    }
+    int grid = 256;                       // one 8-wave workgroup per CU, persistent over tile pairs
+    if (grid > (a.n_tiles + 1) / 2) grid = (a.n_tiles + 1) / 2;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, s, a);
+    V2X_CHECK_LAUNCH("conv3x3_halo_ppc_kernel");
+    return V2X_OK;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 template <int C0, int C1, int COUT, int COUT2, int EPI2, bool BITS>
 static int launch_halo_sb(const HaloArgs &a, hipStream_t s) {
@@ -1189,6 +1443,10 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     if (C0 == 0 && C1 == 32 && d->Cout == 32 && co2 == 0 && e2 == 0)
         return d->in_format == 1 ? launch_halo_sb<0, 32, 32, 0, 0, true>(a, s) : launch_halo_sb<0, 32, 32, 0, 0, false>(a, s);
     if (d->in_format == 1) return 1;  // bit-grid input exists for the 32 -> 32 first layer only
+    if (d->w_layout == 3) {   // parity-class packing (pre-summed 2x2-tap weights for the upsampled source): its own kernel, whatever the tile count
+        if (C0 == 64 && C1 == 32 && d->Cout == 32 && co2 == 0 && e2 == 0) return launch_halo_ppc<64, 32, 32>(a, s);
+        return 1;
+    }
     if (C0 == 64 && C1 == 32 && d->Cout == 32 && co2 == 0 && e2 == 0 && a.n_tiles >= 2 && a.n_tiles % 2 == 0) {
         // conv8_1: 8-wave ping-pong form (tuning switch HALO_PP = 0 keeps the 4-wave kernel: A/B runs and the bitwise-equality test)
         if (v2x_tune(V2X_TUNE_HALO_PP) != 0) return launch_halo_pp<64, 32, 32>(a, s);

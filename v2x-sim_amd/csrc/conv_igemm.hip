@@ -326,8 +326,11 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s);  // conv
 
 extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
     V2X_REQUIRE(d, "v2x_conv2d: null descriptor");
-    if (d->w_layout == 1) {
+    if (d->w_layout == 1 || d->w_layout == 3) {
         V2X_REQUIRE(d->in0 && d->weight && d->scale && d->shift && d->out, "v2x_conv2d(halo): null tensor pointer");
+        V2X_REQUIRE(d->w_layout == 1 || (d->C1 > 0 && d->up0 == 1 && d->Cout2 == 0 && d->in_format == 0 && d->epilogue == V2X_EPI_BF16 &&
+                                         d->w_kpad == 16 * d->C0 + 9 * d->C1),
+                    "v2x_conv2d(halo, parity-class weights): needs the upsampled + skip source pair, a plain bf16 epilogue and w_kpad = 16 C0 + 9 C1");
         V2X_REQUIRE(d->ksize == 3 && d->stride == 1 && d->pad == 1, "v2x_conv2d(halo): 3x3 stride 1 pad 1 only");
         V2X_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->H % 8 == 0 && d->W % 32 == 0,
                     "v2x_conv2d(halo): H=%d must be a multiple of 8 and W=%d of 32", d->H, d->W);

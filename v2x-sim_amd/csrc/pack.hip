@@ -73,6 +73,15 @@ static int pack_geometry(const v2x_pack_spec *p, PackGeom *g) {
         g->elems = (size_t)g->rows_src * g->K + 32;   // + 64 B of zeros: the kernel's zero page
         return V2X_OK;
     }
+    case 3: {
+        const int c_up = p->c_up, c1 = g->cin_p - c_up;
+        V2X_REQUIRE(p->ksize == 3 && !gru && !p->chain && g->cin_p == p->Cin && c_up > 0 && c1 > 0 && c_up % 32 == 0 && c1 % 32 == 0 && p->Cout % 32 == 0,
+                    "v2x_pack_conv: layout 3 (parity-class halo kernel) needs 3x3, no padding, c_up and Cin - c_up multiples of 32 (both > 0), Cout %% 32 == 0");
+        g->w_rows = p->Cout;
+        g->w_kpad = 16 * c_up + 9 * c1;
+        g->elems = (size_t)g->w_kpad * p->Cout;
+        return V2X_OK;
+    }
     default:
         v2x_set_error("v2x_pack_conv: w_layout=%d unknown", p->w_layout);
         return V2X_EINVAL;
@@ -94,6 +103,34 @@ extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16
     V2X_REQUIRE(w_oihw && dst, "v2x_pack_conv: null pointer");
     const int ks = p->ksize, taps = ks * ks, cin = p->Cin, cin_p = g.cin_p, K = g.K;
     const bool gru = p->epilogue == V2X_EPI_GRU;
+    if (p->w_layout == 3) {   // parity-class form: pre-summed 2x2-tap weights for the upsampled source (fp32 sums, (ky, kx) ascending, ONE rounding)
+#pragma clang fp contract(off)
+        static const int G[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};   // [parity][class tap] -> first and last 3x3 tap
+        const int c_up = p->c_up, c1 = cin - c_up, cout = p->Cout;
+        size_t o = 0;
+        for (int cls = 0; cls < 4; ++cls)
+            for (int t = 0; t < 4; ++t) {
+                const int py = cls >> 1, px = cls & 1, a = t >> 1, b = t & 1;
+                for (int s = 0; s < c_up / 8; ++s)
+                    for (int co = 0; co < cout; ++co)
+                        for (int j = 0; j < 8; ++j, ++o) {
+                            const float *ws = w_oihw + ((size_t)co * cin + s * 8 + j) * 9;
+                            float acc = 0.0f;
+                            bool first = true;
+                            for (int ky = G[py][a][0]; ky <= G[py][a][1]; ++ky)
+                                for (int kx = G[px][b][0]; kx <= G[px][b][1]; ++kx) {
+                                    acc = first ? ws[ky * 3 + kx] : acc + ws[ky * 3 + kx];
+                                    first = false;
+                                }
+                            dst[o] = host_bf16_rne(acc);
+                        }
+            }
+        for (int tap = 0; tap < 9; ++tap)
+            for (int s = 0; s < c1 / 8; ++s)
+                for (int co = 0; co < cout; ++co)
+                    for (int j = 0; j < 8; ++j, ++o) dst[o] = host_bf16_rne(w_oihw[((size_t)co * cin + c_up + s * 8 + j) * 9 + tap]);
+        return V2X_OK;
+    }
     const int hid = p->Cout;
     // wk[row][k], k = (ky*ks + kx)*cin_p + c, rows in the order the kernel wants them
     std::vector<uint16_t> wk((size_t)g.rows_src * K, 0);
@@ -207,7 +244,7 @@ static int fill_pack_job(const v2x_pack_spec *p, const float *w_oihw_dev, int tr
     const int rc = pack_geometry(p, &g);
     if (rc != V2X_OK) return rc;
     V2X_REQUIRE(w_oihw_dev && dst_dev, "%s: null pointer", who);
-    V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain, "%s: plain layers only (no GRU regrouping, no chain order)", who);
+    V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain && p->w_layout != 3, "%s: plain layers only (no GRU regrouping, no chain order, no parity-class sums)", who);
     V2X_REQUIRE(transform == 0 || transform == 1, "%s: transform must be 0 or 1", who);
     V2X_REQUIRE(g.elems % 8 == 0, "%s: internal: destination not a whole number of 16-byte groups", who);
     d.w = w_oihw_dev;

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_EPI_DET = 0, 1, 2, 3
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 
 class ConvDesc(C.Structure):
@@ -46,7 +46,7 @@ class PackJob(C.Structure):
 class PackSpec(C.Structure):
     """Mirror of `struct v2x_pack_spec` (include/v2x_amd.h)."""
     _fields_ = [("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("cin_pad", C.c_int32),
-                ("w_layout", C.c_int32), ("epilogue", C.c_int32), ("chain", C.c_int32)]
+                ("w_layout", C.c_int32), ("epilogue", C.c_int32), ("chain", C.c_int32), ("c_up", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/v2x_amd.h declares

@@ -113,6 +113,8 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
                 return "conv3x3_stream8g_kernel<%d, %d, %s>" % (rows, epi, "true" if tiled else "false")  # 8 waves, three taps per synchronisation
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
         return "conv3x3_stream_kernel<%d, %d, %d, %d, false>" % (rows, th, tw, epi)
+    if pc.w_layout == 3:
+        return "conv3x3_halo_ppc_kernel<%d, %d, %d>" % (pc.C0, pc.C1, pc.Cout)   # parity-class form (pre-summed 2x2-tap weights for the upsampled source)
     if pc.w_layout == 1:
         c0, c1 = (pc.C0, pc.C1) if pc.C1 else (0, pc.C0)
         co2 = (pc.Cout2 + 15) // 16 * 16 if pc.Cout2 else 0
@@ -375,6 +377,8 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
         nbytes = in0.numel() * (4 if from_bits else 2) + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
+        if pc.w_layout == 3:   # parity-class form: the FLOPs the kernel EXECUTES (4 taps on the upsampled source); the reference's 9-tap count is
+            flops = 2.0 * M * pc.Cout * (4 * pc.C0 + 9 * pc.C1)   # reported separately (bench.py: reference_flops)
         prof = _Prof(conv_kernel_name(pc, H, W, from_bits, N) if splitk <= 1 else
                      "conv3x3_%sstream_kernel<%d, split-K %d> + splitk_reduce" % ("s2_" if pc.stride == 2 else "", lib.v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue), splitk),
                      flops, nbytes, pc.name)
@@ -896,7 +900,7 @@ def small_batch_splitk(pc, N, H, W):
 def halo_eligible(H, W, w_layout=1, cmax=0):
     """cmax: the widest source's channel count -- the halo kernel's packed DMA tables hold a lane's element offset inside the patch rows
     in 20 bits (conv_halo.hip: (10 W + 34) cmax < 2^20, i.e. W < 1 635 at 64 channels); wider maps take the layer's fallback."""
-    if w_layout == 1 and (10 * W + 34) * cmax >= (1 << 20):
+    if w_layout in (1, 3) and (10 * W + 34) * cmax >= (1 << 20):
         return False
     if H % 8 == 0 and W % 32 == 0:
         return True

@@ -468,6 +468,47 @@ def pack_conv_halo(name, weight, scale, shift, *, C0=None, C1=0, relu=True, cin_
     return pc
 
 
+# taps of the 3x3 that fall on the same half-resolution source pixel, per output parity p and class tap t: PARITY_TAPS[p][t]
+PARITY_TAPS = (((0,), (1, 2)), ((0, 1), (2,)))
+
+
+def parity_class_weights(w_up):
+    """The x2 nearest-upsampled half of a decoder layer as four 2x2-tap convolutions on the half-resolution map (conv_halo.hip,
+    conv3x3_halo_ppc_kernel): w_up fp32 [Cout][C0][3][3] -> fp32 [4 classes (py, px)][4 taps (a, b)][Cout][C0] with
+    W'[py][px][a][b] = sum over ky in PARITY_TAPS[py][a], kx in PARITY_TAPS[px][b] of W[ky][kx], added in fp32 in (ky, kx) ascending order
+    (the C packer v2x_pack_conv adds in the same order: bit-identical buffers).  Exact in real arithmetic; the caller rounds to bf16 ONCE."""
+    cout, c0 = w_up.shape[0], w_up.shape[1]
+    out = torch.empty((4, 4, cout, c0), dtype=w_up.dtype, device=w_up.device)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):
+                    acc = None
+                    for ky in PARITY_TAPS[py][a]:
+                        for kx in PARITY_TAPS[px][b]:
+                            acc = w_up[:, :, ky, kx].clone() if acc is None else acc + w_up[:, :, ky, kx]
+                    out[py * 2 + px, a * 2 + b] = acc
+    return out
+
+
+def pack_conv_halo_parity(name, weight, scale, shift, *, C0, C1, relu=True, device="cuda"):
+    """Decoder layer cat(up(in0) [C0], in1 [C1]) -> 3x3 in the parity-class form (w_layout 3): up half = [class][tap][C0 / 8][Cout][8] with the
+    pre-summed weights above, skip half = [tap ky*3+kx][C1 / 8][Cout][8]; bf16, rounded once from the fp32 sums."""
+    w = _home(weight)
+    cout, cin, k, _ = w.shape
+    if k != 3 or C0 + C1 != cin or C0 % 32 or C1 % 32 or not C0 or not C1 or cout % 32:
+        raise ValueError("%s: the parity-class form needs a 3x3 layer on cat(up(C0), C1) with C0, C1, Cout multiples of 32" % name)
+    up = parity_class_weights(w[:, :C0])                                            # [4][4][cout][C0]
+    up = up.view(16, cout, C0 // 8, 8).permute(0, 2, 1, 3).contiguous().view(-1)     # [class*4 + tap][kslot][cout][8]
+    sk = w[:, C0:].permute(2, 3, 0, 1).contiguous()                                 # [ky][kx][cout][C1]
+    sk = sk.view(9, cout, C1 // 8, 8).permute(0, 2, 1, 3).contiguous().view(-1)      # [tap][kslot][cout][8]
+    wp = torch.cat([up, sk])
+    return PackedConv(name=name, weight=wp.to(torch.bfloat16).to(device).contiguous(),
+                      scale=scale.detach().float().to(device).contiguous(), shift=shift.detach().float().to(device).contiguous(),
+                      C0=C0, C1=C1, Cout=cout, ksize=3, stride=1, pad=1, up0=1, epilogue=V2X_EPI_BF16, relu=relu, w_rows=cout,
+                      w_kpad=16 * C0 + 9 * C1, w_layout=3, Cout2=0)
+
+
 def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
     """conv+BN(+ReLU) as an ops.Layer: gather-kernel packing always, plus the packing of the patch-based kernel that
     covers the layer -- halo (3x3 stride 1, <= 96 input channels), streamed (3x3 stride 1, >= 128 input channels),
@@ -481,7 +522,9 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         scale, shift = fold_bn(conv.bias, bn, conv.out_channels)
         cin_h = _ceil_to(cin_p, 32)
         key = (fb.C0 if fb.C1 else 0, fb.C1 if fb.C1 else cin_h, conv.out_channels)
-        if key in ((0, 32, 32), (64, 32, 32), (0, 64, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):   # (0, 64, 32): no model layer; the data gradient of conv1_1 (train_layout)
+        if key == (64, 32, 32) and fb.up0 == 1 and tuning.get("PARITY_CLASS") != 0:   # conv8_1: parity-class form
+            h = pack_conv_halo_parity(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, relu=relu, device=device)
+        elif key in ((0, 32, 32), (64, 32, 32), (0, 64, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):   # (0, 64, 32): no model layer; the data gradient of conv1_1 (train_layout)
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
         elif (cin_p >= (64 if STREAM_64 else 128) and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
