@@ -313,6 +313,26 @@ def test_seg_fused_head_equals_two_layers(device, tune, cls_name, N, H, W):
     assert float(one.abs().max()) > 0
 
 
+@pytest.mark.parametrize("n_classes,fused", [(6, False), (10, False), (12, True), (4, True)])
+def test_seg_head_class_counts_other_than_8(device, tune, n_classes, fused):
+    """the chained halo epilogue stores whole float4s per k-slot quarter, so only class counts that are multiples of 4 (<= 16) take the
+    fused conv8_2 + head launch; any other count keeps the two-layer path instead of failing in v2x_conv2d -- and both give the SEG_FUSE = 0 logits."""
+    from v2x_sim_amd import ops
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models import seg as S
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    pm = init_synthetic_weights(S.FaFNetSeg(Config("test"), n_classes=n_classes), seed=n_classes).to(device)
+    g = torch.Generator().manual_seed(n_classes)
+    bits = ((torch.rand(2, 64, 96, generator=g) < 0.3).to(torch.int32) * torch.randint(0, 1 << 13, (2, 64, 96), generator=g, dtype=torch.int32)).to(device)
+    x0 = ops.bits_to_nhwc(bits, 13, 32)
+    assert (pm.packed(device).get("seg_fused") is not None) == fused
+    with torch.no_grad():
+        one = pm.forward_nhwc(x0)
+        tune("SEG_FUSE", 0)
+        two = pm.forward_nhwc(x0)
+    assert one.shape == (2, 64, 96, n_classes) and torch.equal(one, two) and float(one.abs().max()) > 0
+
+
 def test_points_to_logits_path(device):
     """a1 -> a7 without the dense fp32 BEV: voxelize on the GPU and feed the network directly."""
     from v2x_sim_amd import ops

@@ -43,6 +43,10 @@ def test_streaming_from_host_gives_the_resident_logits(device):
     spec.loader.exec_module(mod)
     res, outs = mod.main(8, 6, keep_outputs=True)
     assert set(res) == {"resident", "inline", "prefetch"} and all(v > 0 for v in res.values())
+    # a loose STRUCTURAL bound, not a performance claim: a regression that serialises the copy stream behind the compute stream -- or
+    # blocks the producer thread -- would show as the prefetched arm falling far below the resident one (each arm is the best of two passes;
+    # measured 0.85-0.95 at this size).  The gated number stays bench.py's `host_streaming`.
+    assert res["prefetch"] >= 0.4 * res["resident"], res
     for arm in ("inline", "prefetch"):
         for k in ("cls", "loc"):
             assert torch.isfinite(outs[arm][k]).all() and torch.equal(outs[arm][k], outs["resident_same_ring_slot"][k]), (arm, k)

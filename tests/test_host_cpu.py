@@ -200,3 +200,37 @@ def test_unhookable_optimizer_is_stamped_by_stepped():
     real.step()
     packing.stepped(real)
     assert packing.param_version(p)[1] == v1[1] + 1       # once, by the hook
+
+
+def test_latency_dispatch_is_per_thread():
+    """the declared-latency state is thread-local -- a forward in one thread inside `with ops.latency_dispatch()` must not switch
+    launches of another thread (a sharded runner, a training step) to the split-K / 1-tap forms."""
+    import threading
+    from v2x_sim_amd import ops, tuning
+    old = tuning.set("SMALL_BATCH", 2)
+    try:
+        seen = {}
+        inside, release = threading.Event(), threading.Event()
+
+        def worker():
+            with ops.latency_dispatch():
+                seen["worker_in"] = ops.latency_launches()
+                inside.set()
+                release.wait(5)
+            seen["worker_out"] = ops.latency_launches()
+
+        t = threading.Thread(target=worker)
+        t.start()
+        assert inside.wait(5)
+        seen["main_while_worker_inside"] = ops.latency_launches()
+        with ops.latency_dispatch():
+            with ops.latency_dispatch():
+                seen["main_nested"] = ops.latency_launches()
+            seen["main_in"] = ops.latency_launches()
+        seen["main_out"] = ops.latency_launches()
+        release.set()
+        t.join()
+        assert seen == {"worker_in": True, "main_while_worker_inside": False, "main_nested": True, "main_in": True, "main_out": False,
+                        "worker_out": False}, seen
+    finally:
+        tuning.set("SMALL_BATCH", old)

@@ -102,8 +102,10 @@ __device__ __forceinline__ uint32_t v2x_relu_bf16x2_floor(uint32_t x, uint32_t f
 
 // ConvGRU gate arithmetic (a4; upstream calls convgru(x, None): h0 = 0, so h = n + z (0 - n)).  fp32 on the hardware's 1-ulp v_exp_f32 /
 // v_rcp_f32: sigmoid(x) = rcp(1 + exp(-x)); tanh(x) = 1 - 2 rcp(1 + exp(2x)), below |x| = 2^-6 the series x (1 - x^2 / 3) (the closed form
-// cancels there; the series' own error is x^4 * 2/15 < 8e-9 relative).  Within a few fp32 ulp of libm's -- 2^-14 of the bf16 rounding that
-// follows.  Rounds 1-3 divided in IEEE (v_div_scale / fmas / fixup) and called libm's branchy tanhf: ~64 instructions per hidden value, 9.4 % of
+// cancels there; the series' own error is x^4 * 2/15 < 8e-9 relative).  Error against libm: a few fp32 ulp for |x| >~ 0.5, growing towards the
+// switch point, where 1 - 2 rcp(..) cancels against 1.0: absolute ~1e-7 on a result of ~0.016 = ~1e-5 relative (~100 fp32 ulp) -- still
+// 2^-8 of the bf16 rounding that follows (2^-9 relative).  The training graph's gates (gru_train.hip) use libm expf / tanhf: the two agree to that
+// 1e-5, not bitwise.  Rounds 1-3 divided in IEEE (v_div_scale / fmas / fixup) and called libm's branchy tanhf: ~64 instructions per hidden value, 9.4 % of
 // the ConvGRU kernel's time went to its epilogue (profiles/r04_epilogue_phase.txt); this form is ~22.  ONE definition for every kernel that
 // produces GRU output (streamed, gather, split-K reduce): the forms stay bit-consistent with each other.
 __device__ __forceinline__ float v2x_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }

@@ -29,10 +29,12 @@ def _pack_seg_head(outc, device):
 def _pack_seg_fused(decoder, outc, device):
     """conv8_2 (3x3 32 -> 32, BN, ReLU) chained with the 1x1 class head in ONE halo launch (conv_halo.hip: <0, 32, 32, 16, 2>): the 32-channel
     map is rounded to bf16 exactly as the stand-alone layer stores it but never reaches HBM (-1.3 GB written and read back per 320 maps, and the
-    gather kernel's two launches for the head).  None when the head has more than 16 classes (one padded channel tile)."""
+    gather kernel's two launches for the head).  None when the head has more than 16 classes (one padded channel tile) or a class count that
+    is not a multiple of 4 (the chained fp32 epilogue stores whole float4s per k-slot quarter; v2x_conv2d(halo) requires Cout2 % 4 == 0): such
+    heads keep the two-layer path."""
     import torch
     n_cls = outc.conv.out_channels
-    if n_cls > 16 or decoder.conv8_2.out_channels != 32 or decoder.conv8_2.in_channels != 32:
+    if n_cls > 16 or n_cls % 4 != 0 or decoder.conv8_2.out_channels != 32 or decoder.conv8_2.in_channels != 32:
         return None
     s1, t1 = packing.fold_bn(decoder.conv8_2.bias, decoder.bn8_2, 32)
     w2 = outc.conv.weight.detach().float().cpu()

@@ -43,20 +43,21 @@ class _Prof:
 # tuning SMALL_BATCH: 0 never; 1 every launch of the process (the explicit pin, also for the sharded runners); 2 (default) only inside a
 # `with ops.latency_dispatch():` block -- the plain single-GPU model classes enter one in forward_nhwc() (@ops.latency_entry: the common entry
 # of forward(), forward_points() and the Seg / Det modules), the sharded runners (R-rank == 1-rank bitwise) never do.
-_latency_depth = 0
+import threading as _threading
+
+_latency = _threading.local()   # per THREAD: a latency forward in one thread must not switch a sharded runner or a training step in another
+                                # thread to the split-K / 1-tap forms (that would break their R-rank == 1-rank bitwise guarantee)
 
 
 class latency_dispatch:
-    """Context manager: launches inside are declared latency launches (see above)."""
+    """Context manager: launches of THIS thread inside the block are declared latency launches (see above)."""
 
     def __enter__(self):
-        global _latency_depth
-        _latency_depth += 1
+        _latency.depth = getattr(_latency, "depth", 0) + 1
         return self
 
     def __exit__(self, *exc):
-        global _latency_depth
-        _latency_depth -= 1
+        _latency.depth -= 1
         return False
 
 
@@ -73,7 +74,7 @@ def latency_entry(fn):
 
 def latency_launches():
     sb = tuning.get("SMALL_BATCH")
-    return sb == 1 or (sb == 2 and _latency_depth > 0)
+    return sb == 1 or (sb == 2 and getattr(_latency, "depth", 0) > 0)
 
 
 _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 128: (128, 128, 2, 2), 96: (96, 128, 2, 2)}
