@@ -76,3 +76,113 @@ def test_tile_rows_and_validation_without_gpu():
     assert lib.v2x_attn_handshake(None, None, None, None, 5, 1, 1024, 32, 0, 0.2, None, None, None) == -22
     with pytest.raises(_lib.V2XLibraryError):
         _lib.check(-22, "probe")
+
+
+# ---- every prototype of the header against the ctypes signature table, argument by argument -------------------------
+_INT = {"int": 4, "int32_t": 4, "uint32_t": 4, "unsigned": 4, "unsigned int": 4, "int64_t": 8, "long long": 8, "unsigned long long": 8, "size_t": 8,
+        "uint64_t": 8}
+_STRUCTS = {"v2x_conv_desc": "ConvDesc", "v2x_pack_spec": "PackSpec", "v2x_pack_job": "PackJob"}
+
+
+def _c_kind(ctype_text):
+    """C parameter / return type -> (kind, size, pointee): kind in {"int", "float", "ptr", "void"}; pointee = struct name, scalar type or None."""
+    t = " ".join(ctype_text.replace("const", " ").split())
+    if t.endswith("*") or t == "v2x_stream_t":
+        base = t.rstrip("* ").strip()
+        return ("ptr", 8, base if t != "v2x_stream_t" else "void")
+    if t == "void":
+        return ("void", 0, None)
+    if t in ("float",):
+        return ("float", 4, None)
+    if t in ("double",):
+        return ("float", 8, None)
+    assert t in _INT, "unknown C type %r in the header" % ctype_text
+    return ("int", _INT[t], None)
+
+
+def _ctypes_kind(ct):
+    import ctypes as C
+    from v2x_sim_amd import _lib
+    if ct is None:
+        return ("void", 0, None)
+    if ct in (C.c_void_p, C.c_char_p):
+        return ("ptr", 8, "char" if ct is C.c_char_p else None)
+    if isinstance(ct, type) and issubclass(ct, C._Pointer):
+        tgt = ct._type_
+        for cname, pyname in _STRUCTS.items():
+            if tgt is getattr(_lib, pyname):
+                return ("ptr", 8, cname)
+        return ("ptr", 8, {C.c_double: "double", C.c_int32: "int32_t", C.c_int: "int", C.c_int64: "int64_t", C.c_float: "float"}.get(tgt, "?"))
+    if ct in (C.c_float,):
+        return ("float", 4, None)
+    if ct in (C.c_double,):
+        return ("float", 8, None)
+    return ("int", C.sizeof(ct), None)
+
+
+def _prototypes():
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    src = re.sub(r"typedef struct.*?\}\s*\w+;", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^\s*((?:const\s+)?(?:unsigned\s+)?[a-z_0-9]+(?:\s+long)?\s*\**)\s*(v2x_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.M | re.S):
+        ret, name, params = m.group(1), m.group(2), " ".join(m.group(3).split())
+        plist = []
+        if params and params != "void":
+            for prm in params.split(","):
+                prm = prm.strip()
+                mm = re.match(r"^(.*?[\s\*])([A-Za-z_][A-Za-z_0-9]*)$", prm)
+                assert mm, (name, prm)
+                plist.append(mm.group(1).strip())
+        out[name] = (ret.strip(), plist)
+    return out
+
+
+def test_every_ctypes_signature_matches_its_header_prototype():
+    """The per-function argtypes / restype of v2x_sim_amd/_lib.py::SIGNATURES are hand-written; a slip (an int where the header takes a pointer, a
+    missing argument, a float passed as an int) would corrupt a call silently.  Every prototype of include/v2x_amd.h is parsed and compared
+    with its table entry: argument count, and per argument the machine class ctypes will marshal (integer of N bytes / float / pointer);
+    pointers to the ABI structs must be typed as that struct (or left opaque for DEVICE arrays of them), typed scalar pointers must name the
+    header's scalar."""
+    from v2x_sim_amd import _lib
+    protos = _prototypes()
+    assert set(protos) == set(_lib.SIGNATURES), sorted(set(protos) ^ set(_lib.SIGNATURES))
+    checked = 0
+    for name, (ret, params) in sorted(protos.items()):
+        res, args = _lib.SIGNATURES[name]
+        assert len(args) == len(params), "%s: header has %d parameters, ctypes table %d" % (name, len(params), len(args))
+        rk, ck = _c_kind(ret), _ctypes_kind(res)
+        assert rk[:2] == ck[:2], "%s: return type %r vs %r" % (name, ret, res)
+        for i, (ptxt, ct) in enumerate(zip(params, args)):
+            hk, pk = _c_kind(ptxt), _ctypes_kind(ct)
+            assert hk[:2] == pk[:2], "%s: parameter %d is `%s` in the header, %r in the ctypes table" % (name, i, ptxt, ct)
+            if hk[0] == "ptr" and hk[2] in _STRUCTS:
+                assert pk[2] in (hk[2], None), "%s: parameter %d points to %s, the table types it as %r" % (name, i, hk[2], pk[2])
+            elif hk[0] == "ptr" and pk[2] not in (None, "char"):
+                assert _c_kind(pk[2])[:2] == _c_kind(hk[2])[:2], "%s: parameter %d is `%s`, typed pointer to %s in the table" % (name, i, ptxt, pk[2])
+            checked += 1
+    assert checked > 400, checked
+
+
+def test_pack_structs_mirror_the_header():
+    """v2x_pack_spec / v2x_pack_job field order and sizes against their ctypes mirrors."""
+    import ctypes as C
+    from v2x_sim_amd import _lib
+    src = open(HEADER).read()
+    for cname, pyname in (("v2x_pack_spec", "PackSpec"), ("v2x_pack_job", "PackJob")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), src, flags=re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        fields = []
+        for decl in body.split(";"):
+            decl = " ".join(decl.split())
+            if not decl:
+                continue
+            tokens = decl.replace("const ", "").split(" ", 1)
+            base, rest = tokens[0], tokens[1]
+            for n in rest.split(","):
+                n = n.strip()
+                fields.append((n.replace("*", "").strip(), ("ptr", 8) if "*" in n else _c_kind(base)[:2]))
+        mirror = getattr(_lib, pyname)._fields_
+        assert [f[0] for f in fields] == [f[0] for f in mirror], (cname, fields, mirror)
+        for (n, k), (_, ct) in zip(fields, mirror):
+            assert k == _ctypes_kind(ct)[:2], (cname, n, k, ct)
+        assert C.sizeof(getattr(_lib, pyname)) % 4 == 0

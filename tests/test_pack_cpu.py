@@ -120,8 +120,10 @@ def test_gru_layouts_and_bias():
 
 def test_fold_bn_correctly_rounded():
     """scale = gamma / sqrt(var + eps), shift = beta + scale*(bias - mean), every op rounded to fp32 separately.  The C packer
-    is IEEE-exact (checked op by op against float64); torch's CPU sqrt (MKL VML) is off by one ulp in ~0.6 % of the elements,
-    so packing.fold_bn is held to 2 ulp of the C result, not to bit equality."""
+    is IEEE-exact (checked op by op against float64).  torch's vectorised CPU sqrt is off by one ulp in 1-15 % of the elements depending on the
+    CPU model, so packing.fold_bn CALLS the library (round 5: one definition for every host -- a C host's packed parameters are then
+    bit-identical to the Python host's on any machine, tests/test_c_abi.py) and is held to bit equality; the plain torch expression stays
+    within 2 ulp."""
     C_ = 96
     conv = torch.nn.Conv2d(8, C_, 3)
     bn = torch.nn.BatchNorm2d(C_)
@@ -140,8 +142,10 @@ def test_fold_bn_correctly_rounded():
     want_s = (g_.astype(f64) / np.sqrt(v.astype(f64)).astype(f32).astype(f64)).astype(f32)
     want_t = (b_.astype(f64) + (want_s.astype(f64) * (cb_.astype(f64) - mu_.astype(f64)).astype(f32).astype(f64)).astype(f32).astype(f64)).astype(f32)
     assert np.array_equal(ds[:C_], want_s) and np.array_equal(dt[:C_], want_t)
-    ulp = np.abs(ds[:C_].view(np.int32) - s.numpy().view(np.int32))
-    assert ulp.max() <= 2 and np.allclose(dt[:C_], t.numpy(), rtol=1e-6, atol=1e-9)   # a 1-ulp sqrt error can double through the division
+    assert np.array_equal(ds[:C_], s.numpy()) and np.array_equal(dt[:C_], t.numpy())
+    s_torch = bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)
+    ulp = np.abs(ds[:C_].view(np.int32) - s_torch.numpy().view(np.int32))
+    assert ulp.max() <= 2   # a 1-ulp sqrt error can double through the division
     assert not ds[C_:].any() and not dt[C_:].any()
     assert lib.v2x_fold_bn(C_, 128, a[0].ctypes.data, None, None, None, None, C.c_float(0), ds.ctypes.data, dt.ctypes.data) == 0
     assert np.array_equal(ds[:C_], np.ones(C_, np.float32)) and np.array_equal(dt[:C_], a[0])

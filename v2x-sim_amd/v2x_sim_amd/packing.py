@@ -107,17 +107,24 @@ def _zeros(*shape):
 
 
 def fold_bn(conv_bias, bn, cout):
-    """-> (scale, shift) fp32 on CPU for y = acc*scale + shift."""
+    """-> (scale, shift) fp32 on CPU for y = acc*scale + shift: eval-mode BatchNorm folded behind the fp32 accumulation,
+    scale = gamma / sqrt(var + eps), shift = beta + scale * (conv_bias - mean).  ONE definition for every host: the arithmetic is the library's
+    v2x_fold_bn (IEEE sqrtf / division, separately rounded product and sum) -- torch's vectorised CPU sqrt is not correctly rounded and not
+    even the same from one CPU model to the next (1 ulp on ~1-15 % of the channels), which made a C host's packed parameters differ from this
+    one's on the GPU box (tests/test_c_abi.py compares the two hosts bit for bit)."""
     if bn is None:
         scale = _zeros(cout) + 1.0
         shift = _home(conv_bias) if conv_bias is not None else _zeros(cout)
         return scale, shift
-    g, b = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
-    mu, var = bn.running_mean.detach().float().cpu(), bn.running_var.detach().float().cpu()
-    scale = g / torch.sqrt(var + bn.eps)
-    cb = conv_bias.detach().float().cpu() if conv_bias is not None else torch.zeros(cout)
-    shift = b + scale * (cb - mu)
-    return scale, shift
+    import ctypes as C
+    import numpy as np
+    f = lambda t: np.ascontiguousarray(t.detach().float().cpu().numpy())   # noqa: E731
+    g, b, mu, var = f(bn.weight), f(bn.bias), f(bn.running_mean), f(bn.running_var)
+    cb = f(conv_bias) if conv_bias is not None else np.zeros(cout, np.float32)
+    scale, shift = np.empty(cout, np.float32), np.empty(cout, np.float32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)   # noqa: E731
+    _lib.check(_lib.load().v2x_fold_bn(cout, cout, p(cb), p(g), p(b), p(mu), p(var), C.c_float(bn.eps), p(scale), p(shift)), "v2x_fold_bn")
+    return torch.from_numpy(scale), torch.from_numpy(shift)
 
 
 def pack_conv(name, weight, scale, shift, *, stride=1, pad=None, C0=None, C1=0, up0=0, relu=True,
