@@ -99,3 +99,44 @@ def test_shard_check_plan_covers_owned_rows_at_every_world():
                     assert rows[gi] == a * bh + frames[k]
                 covered += len(pairs)
             assert covered >= 8 * world or world == 1
+
+
+# ---- the watchdog around the ranks of an N > 1 run (the first N > 1 run on hardware is the driver's) ---------------------
+def _record(p):
+    return json.loads([ln for ln in p.stdout.splitlines() if ln.strip()][-1])
+
+
+def test_ranks_of_a_multi_gpu_run_are_supervised():
+    """Every rank process the launcher starts is a supervisor that runs the real rank as a child (bench.py: supervise); the record says so.
+    N = 1 stays a plain process."""
+    p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert _record(p)["launch"] == {"supervised": True, "attempt": 1, "graph_mode": 1, "watchdog_s": 240.0}
+    p = _run("--gpus", "1", "--steps", "2", "--dry-run")
+    assert p.returncode == 0 and _record(p)["launch"]["supervised"] is False
+
+
+def test_watchdog_relaunches_a_stalled_first_attempt_in_the_one_stream_order():
+    """A collective that never completes (rank 1 never issues its first exchange: V2X_BENCH_SIMULATE_HANG) stalls every rank.  Rank 0's supervisor
+    sees no first step within the watchdog time of `ranks-ready`, raises the node-local flag, every supervisor kills its child and starts a
+    FRESH child process with --graph 4 on a new rendezvous; the record comes from attempt 2 and no process is left behind."""
+    p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", env_extra={"V2X_BENCH_SIMULATE_HANG": "1", "V2X_BENCH_WATCHDOG_S": "4"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = _record(p)
+    assert rec["launch"]["attempt"] == 2 and rec["launch"]["graph_mode"] == 4 and rec["exchange_ok"] and rec["ranks_seen"] == 2
+    assert p.stderr.count("attempt 1 stalled") == 2 and "relaunching with --graph 4" in p.stderr
+    assert sum(ln.startswith('{"metric"') for ln in p.stdout.splitlines()) == 1
+    left = subprocess.run(["pgrep", "-f", "bench.py --gpus 2 --steps 2 --warmup 1 --dry-run"], capture_output=True, text=True).stdout.split()
+    assert not left, left
+
+
+@pytest.mark.parametrize("transport", ["allgather", "needed"])
+def test_a_late_rank_delays_but_cannot_deadlock_the_two_stream_host_order(transport):
+    """bench.py's default step issues exchange A and exchange B asynchronously before waiting for either, in the same host order on every rank.
+    With one rank 3 s late for its first exchange the step completes (first attempt, no relaunch) with the right rows -- for the all-gather and
+    for the grouped point-to-point transport."""
+    p = _run("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--transport", transport,
+             env_extra={"V2X_BENCH_DELAY_RANK": "1", "V2X_BENCH_DELAY_S": "3", "V2X_BENCH_WATCHDOG_S": "60"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    rec = _record(p)
+    assert rec["exchange_ok"] and rec["launch"]["attempt"] == 1 and rec["elapsed_s"] >= 2.5
