@@ -561,10 +561,17 @@ class MIMOGeneralDotProductAttention(nn.Module):
 
 class When2com(IntermediateModelBase):
     def __init__(self, layer=3, in_channels=13, num_agent=5, key_size=1024, query_size=32,
-                 image_size=512, warp_flag=1, sparse=False):
+                 image_size=512, warp_flag=1, sparse=False, attn_index="kq", renormalize=False):
         super().__init__(layer, in_channels, num_agent)
         if sparse:
             raise NotImplementedError("sparsemax attention is out of scope (DESIGN.md section 8)")
+        # the two open readings of ASSUMPTIONS.md as switches (defaults = the first reading; the diff against upstream decides):
+        #   row 30  attn_index "kq": fused[q] = sum_k attn[b, k, q] val[k -> q];  "qk": the transposed read attn[b, q, k]
+        #   row 31  renormalize: 'activated' coefficients divided by their sum over the keys (a query whose keys all fell below the
+        #           threshold keeps zeros)
+        if attn_index not in ("kq", "qk"):
+            raise ValueError("attn_index must be 'kq' or 'qk'")
+        self.attn_index, self.renormalize = attn_index, bool(renormalize)
         self.warp_flag = warp_flag
         self.key_size, self.query_size = key_size, query_size
         self.query_key_net = PolicyNet4(in_channels)
@@ -578,6 +585,9 @@ class When2com(IntermediateModelBase):
             coef = prob_action
         elif inference == "activated":      # when2com
             coef = prob_action * (prob_action > thres).float()
+            if getattr(self, "renormalize", False):
+                tot = coef.sum(dim=1, keepdim=True)
+                coef = torch.where(tot > 0, coef / torch.where(tot > 0, tot, torch.ones_like(tot)), coef)
         elif inference == "argmax_test":    # who2com
             coef = F.one_hot(prob_action.max(dim=1)[1], num_classes=prob_action.shape[1]).float().transpose(1, 2)
         else:
@@ -614,7 +624,7 @@ class When2com(IntermediateModelBase):
                         v = lcm[b, k]
                     else:
                         v = feature_transformation(lcm[b, k], trans_matrices[b, q][k], size)
-                    acc = acc + coef[b, k, q] * v
+                    acc = acc + (coef[b, k, q] if self.attn_index == "kq" else coef[b, q, k]) * v
                 fused[b, q] = _q(acc, e)
         x = self.decode_heads(enc, self.agents_to_batch(fused))
         res = self.get_cls_loc_result(x)

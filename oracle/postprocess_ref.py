@@ -43,9 +43,18 @@ def decode_faf(code, anchor):
     return (xa + dx, ya + dy, wa * math.exp(dw), ha * math.exp(dh), math.atan2(sa, ca) + math.atan2(ds, dc))
 
 
-def corners_of(box):
-    """(x, y, w, h, yaw) -> 4 corners, counter-clockwise, first = (+w/2, +h/2) rotated."""
+WH_AXES = ("w_along_heading", "h_along_heading")
+
+
+def corners_of(box, wh_axis="w_along_heading"):
+    """(x, y, w, h, yaw) -> 4 corners, counter-clockwise, first = (+w/2, +h/2) rotated.  wh_axis: which extent runs along the box's local x
+    axis (its heading) before rotation -- ASSUMPTIONS.md row 48, both readings: "w_along_heading" (default) or "h_along_heading" (the
+    rectangle with the two extents exchanged)."""
     x, y, w, h, yaw = box
+    if wh_axis == "h_along_heading":
+        w, h = h, w
+    elif wh_axis != "w_along_heading":
+        raise ValueError("wh_axis must be one of %s" % (WH_AXES,))
     c, s = math.cos(yaw), math.sin(yaw)
     out = []
     for sx, sy in ((0.5, 0.5), (-0.5, 0.5), (-0.5, -0.5), (0.5, -0.5)):
@@ -68,7 +77,7 @@ def aabb_iou(a, b):
     return inter / ((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1]) - inter)
 
 
-def detect(cls, loc, anchors, score_thr=SCORE_THR, nms_thr=NMS_THR, rotated=False):
+def detect(cls, loc, anchors, score_thr=SCORE_THR, nms_thr=NMS_THR, rotated=False, wh_axis="w_along_heading"):
     """One map.  cls [M][2] logits, loc [M][6] codes, anchors [M][6] (any nested sequence / array).
     -> list of dict(index, score, box (x, y, w, h, yaw), corners) in the order the detections are kept:
     score descending, ties by anchor index ascending; a candidate is dropped iff its stand-up box overlaps an
@@ -89,7 +98,7 @@ def detect(cls, loc, anchors, score_thr=SCORE_THR, nms_thr=NMS_THR, rotated=Fals
     kept = []
     for neg_s, i in cand:
         box = decode_faf(loc[i], anchors[i])
-        cor = corners_of(box)
+        cor = corners_of(box, wh_axis)
         sb = standup_of(cor)
         if rotated:
             if any(aabb_iou(sb, k["standup"]) > 0.0 and rotated_iou(cor, k["corners"]) > nms_thr for k in kept):

@@ -71,6 +71,46 @@ def test_training_target_fields_of_the_tuple(tmp_path):
     assert V2XSimDet(dataset_roots=[os.path.join(str(tmp_path), "train", "agent0")], config=cfg, split="train")[0][0][2] is None
 
 
+def test_upstream_style_sample_is_tolerated(tmp_path):
+    """oracle/ASSUMPTIONS.md row 7 (UNVERIFIED key names): a 0.npy written with the keys the author recalls of upstream's create_data_det.py --
+    `num_agent` / `target_agent` spellings, `trans_matrices_no_cross_road`, the sparse training targets (`allocation_mask`, `label_sparse`,
+    `reg_target_sparse`, `reg_loss_mask`, `gt_max_iou`) and extra keys -- loads instead of being refused; the dense targets are upstream's own
+    assignment (not the build's rule), and a dict without the sweep or the poses is refused with the missing key named."""
+    from v2x_sim_amd.datasets.V2XSimDet import normalize_sample, upstream_dense_targets
+    cfg = Config("train")
+    X, Y, Z = cfg.map_dims
+    A = len(cfg.anchor_size)
+    pts = synthetic_points(1, 2000, seed=6)
+    grid, idx = VR.voxelize_occupy(pts[0], return_indices=True)
+    alloc = np.zeros((X, Y, A), bool)
+    alloc[10, 20, 1] = alloc[10, 21, 1] = alloc[200, 7, 4] = True
+    rmask = np.zeros((X, Y, A, 1), bool)
+    rmask[10, 20, 1, 0] = rmask[200, 7, 4, 0] = True            # one allocated anchor is background: in the label, not in the regression mask
+    sparse = np.arange(3 * 6, dtype=np.float32).reshape(3, 1, 6) / 10.0
+    sample = {"voxel_indices_0": idx.astype(np.int32), "trans_matrices": np.eye(4, dtype=np.float32)[None] * 2.0,
+              "trans_matrices_no_cross_road": np.eye(4, dtype=np.float32)[None], "num_agent": 1, "target_agent": 0,
+              "allocation_mask": alloc, "label_sparse": np.array([1, 0, 1]), "reg_target_sparse": sparse, "reg_loss_mask": rmask,
+              "gt_max_iou": np.array([0.7, 0.1, 0.9], np.float32), "current_sample_token": "abc", "3d_dimension": np.zeros(3)}
+    d = os.path.join(str(tmp_path), "train", "agent0", "3_0")
+    os.makedirs(d)
+    np.save(os.path.join(d, "0.npy"), sample, allow_pickle=True)
+    t = V2XSimDet(dataset_roots=[os.path.join(str(tmp_path), "train", "agent0")], config=cfg, split="train", targets=True)[0][0]
+    assert np.array_equal(t[0][0], grid) and t[9] == 0 and t[10] == 1
+    assert np.allclose(t[11], np.eye(4)[None])                  # not a cross-road config: the *_no_cross_road poses
+    label, reg, mask = t[2], t[3], t[4]
+    assert label.shape == (X, Y, A, 2) and reg.shape == (X, Y, A, 1, 6) and mask.shape == (X, Y, A, 1)
+    assert label[10, 20, 1].tolist() == [0.0, 1.0] and label[10, 21, 1].tolist() == [1.0, 0.0] and label[0, 0, 0].tolist() == [1.0, 0.0]
+    assert np.allclose(reg[10, 20, 1, 0], sparse[0, 0]) and np.allclose(reg[200, 7, 4, 0], sparse[2, 0]) and not reg[10, 21, 1].any()
+    assert int(label[..., 1].sum()) == 2 and np.array_equal(t[7], sample["gt_max_iou"])
+    cross = normalize_sample(sample, is_cross_road=True)
+    assert np.allclose(cross["trans_matrices"], 2.0 * np.eye(4)[None])
+    assert upstream_dense_targets({"allocation_mask": alloc}) is None
+    with pytest.raises(KeyError, match="voxel_indices_0"):
+        normalize_sample({"trans_matrices": 0, "num_sensor": 1, "target_agent_id": 0})
+    with pytest.raises(KeyError, match="trans_matrices"):
+        normalize_sample({"voxel_indices_0": idx, "num_sensor": 1, "target_agent_id": 0})
+
+
 def test_errors(tmp_path):
     with pytest.raises(ValueError):
         V2XSimDet(dataset_roots=None, config=Config("test"), split="test")

@@ -258,6 +258,38 @@ def test_when2com(device, inference):
     assert abs(got["num_connect"] - ref["num_connect"]) < 1e-9
 
 
+@pytest.mark.parametrize("attn_index,renormalize", [("qk", False), ("kq", True), ("qk", True)])
+def test_when2com_open_readings_as_switches(device, attn_index, renormalize):
+    """oracle/ASSUMPTIONS.md rows 30 and 31, the second readings behind constructor flags in oracle AND product (as row 25's three readings are):
+    attn_index = "qk" reads the attention matrix transposed in the weighted sum; renormalize divides the 'activated' coefficients by their sum
+    over the keys.  Same end-to-end bars as the default reading; the designed scores make the two attn_index readings select DIFFERENT links
+    for a target (the matrix is not symmetric), so a flag that did nothing would fail."""
+    from v2x_sim_amd.models.det import When2com
+    A, B = 5, 1
+    kw = dict(attn_index=attn_index, renormalize=renormalize)
+    pm, om = build(When2com, R.When2com, device, pkw=kw, okw=kw)
+    _, bev, T = make_inputs(A, B)
+    nat = torch.full((B, A), A)
+    _separate_attention_scores(pm, om, bev, B)
+    om.emulate_bf16 = True
+    with torch.no_grad():
+        got = pm(bev.to(device), T.to(device), nat, training=False, inference="activated", batch_size=B)
+        ref = om(bev, T, nat, training=False, inference="activated", batch_size=B)
+        base = R.When2com().eval()
+        base.load_state_dict(om.state_dict())
+        base.emulate_bf16 = True
+        ref_default = base(bev, T, nat, training=False, inference="activated", batch_size=B)
+    assert torch.equal(got["coef"].cpu() != 0, ref["coef"] != 0)
+    check(got["coef"], ref["coef"], (5e-2, 1e-2), "when2com coef (%s, renorm %s)" % (attn_index, renormalize))
+    if renormalize:
+        tot = got["coef"].sum(1)
+        assert torch.allclose(tot, torch.ones_like(tot), atol=1e-5)
+    check(got["cls"], ref["cls"], TOL_EMU, "when2com cls (%s, renorm %s)" % (attn_index, renormalize))
+    check(got["loc"], ref["loc"], TOL_EMU, "when2com loc (%s, renorm %s)" % (attn_index, renormalize))
+    # the switch is not a no-op: the second reading's logits differ from the first reading's by far more than the tolerance
+    assert float((ref["cls"] - ref_default["cls"]).abs().max()) > 5 * TOL_EMU[0] * float(ref_default["cls"].abs().max()) or renormalize
+
+
 def test_v2vnet_seg(device):
     from v2x_sim_amd import ops
     from v2x_sim_amd.models.seg import V2VNetSeg

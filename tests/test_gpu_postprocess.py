@@ -408,3 +408,40 @@ def test_predict_all_fused_detection_equals_logits_path(device):
     assert "cls" in mod.last_result
     for a, b in zip(small, plain):
         assert np.allclose(a["boxes"], b["boxes"], atol=1e-4) and a["boxes"].shape == b["boxes"].shape
+
+
+def test_box_axis_second_reading_as_a_switch(device):
+    """oracle/ASSUMPTIONS.md row 48, the second reading behind Config.box_wh_axis ("h_along_heading": the extent the codes call h runs along the
+    heading): FaFModule's device path (the first reading's kernels on (w, h)-exchanged anchors and codes, columns swapped back), its host path and
+    the independent oracle (postprocess_ref.detect(..., wh_axis=...)) keep the same anchors and give the same boxes, scores and corners -- for the
+    logits path and for the fused-candidates path -- and the switch is not a no-op: the kept set differs from the first reading's on this fixture."""
+    import os
+    from oracle import postprocess_ref as PR
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.utils import postprocess as P
+    from v2x_sim_amd.utils.CoDetModule import FaFModule
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "postprocess_small.npz"))
+    cls, loc, anc = g["cls"], g["loc"].reshape(-1, 6).copy(), g["anchors"].reshape(-1, 6)
+    rng = np.random.default_rng(5)
+    loc[:, 2] += rng.normal(0, 0.3, loc.shape[0]).astype(np.float32)          # make w and h codes differ, so that exchanging them matters
+    kept = {}
+    for axis in P.WH_AXES:
+        cfg = Config("test")
+        cfg.box_wh_axis = axis
+        cfg.map_dims = [32, 32, 13]
+
+        class _M(torch.nn.Module):
+            pass
+        mod = FaFModule(_M(), None, cfg, None, 0)
+        mod.anchors = g["anchors"]
+        mod.nms_thr = 0.05
+        res = {"cls": torch.from_numpy(cls)[None].to(device), "loc": torch.from_numpy(loc)[None].to(device)}
+        dev = mod.postprocess(res)[0]
+        host = P.apply_nms_det(loc.reshape(32, 32, 6, 6), cls, g["anchors"], mod.score_thr, mod.nms_thr, wh_axis=axis)
+        ref = PR.detect(cls, loc, anc, mod.score_thr, mod.nms_thr, wh_axis=axis)
+        assert len(ref) == dev["boxes"].shape[0] == host["boxes"].shape[0] > 5
+        assert np.allclose(dev["boxes"], np.asarray([d["box"] for d in ref]), atol=1e-4) and np.allclose(dev["boxes"], host["boxes"], atol=1e-4)
+        assert np.allclose(dev["corners"], np.asarray([d["corners"] for d in ref]), atol=1e-4)
+        assert np.allclose(dev["scores"], np.asarray([d["score"] for d in ref]), atol=1e-6)
+        kept[axis] = [d["index"] for d in ref]
+    assert kept["w_along_heading"] != kept["h_along_heading"]

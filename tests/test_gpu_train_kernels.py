@@ -1023,12 +1023,14 @@ def test_repack_plan_equals_the_per_layer_device_packer(device):
     assert not plan.valid()
 
 
+@pytest.mark.parametrize("normalizer", ["positives", "batch"])
 @pytest.mark.parametrize("case", ["scene", "no_positive", "all_masked_in", "soft_and_empty_labels"])
-def test_fused_detection_loss_equals_the_torch_ops(device, tune, case):
+def test_fused_detection_loss_equals_the_torch_ops(device, tune, case, normalizer):
     """csrc/det_loss.hip (v2x_det_loss_forward / _backward behind train/loss.py::detection_loss) against the PyTorch-op specification in the same
     file: the three losses and both gradients, for a synthetic scene's targets, a batch without a positive anchor (n clamps to 1), every anchor
     selected by the regression mask, and label pairs that are not one-hot (0, 0) / (0.3, 0.7) -- the gradient formulas hold for any pair.
-    Also the incoming gradients of the two partial losses (a caller that logs or weights them) and bit-reproducibility."""
+    Also the incoming gradients of the two partial losses (a caller that logs or weights them) and bit-reproducibility.  normalizer = "batch":
+    the second reading of oracle/ASSUMPTIONS.md row 49 (Config.loss_normalizer) -- the kernels' sums rescaled by n_pos / maps on the device."""
     from v2x_sim_amd.train.loss import detection_loss
     g = torch.Generator().manual_seed(7)
     N, X, Y, A = 3, 32, 64, 6
@@ -1056,7 +1058,7 @@ def test_fused_detection_loss_equals_the_torch_ops(device, tune, case):
         tune("TRAIN_HIP", 1)
         tune("TRAIN_LOSS_HIP", flag)
         cls.grad = loc.grad = None
-        out = detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask)
+        out = detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask, normalizer=normalizer)
         (out[0] * w[0] + out[1] * w[1] + out[2] * w[2]).backward()
         return [o.detach().clone() for o in out], cls.grad.clone(), loc.grad.clone()
 
@@ -1072,11 +1074,11 @@ def test_fused_detection_loss_equals_the_torch_ops(device, tune, case):
     assert all(torch.equal(a, b) for a, b in zip(again, got)) and torch.equal(dc, dc2) and torch.equal(dl, dl2), "fixed-order sums: bit-reproducible"
     # only `loss` used (the training loop): the partial losses' gradients arrive as None
     cls.grad = loc.grad = None
-    detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask)[0].backward()
+    detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask, normalizer=normalizer)[0].backward()
     tune("TRAIN_LOSS_HIP", 0)
     g1, g2 = cls.grad.clone(), loc.grad.clone()
     cls.grad = loc.grad = None
-    detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask)[0].backward()
+    detection_loss({"cls": cls, "loc": loc}, lab, tgt, mask, normalizer=normalizer)[0].backward()
     assert float((g1 - cls.grad).abs().max()) <= 2e-6 * float(cls.grad.abs().max()) + 1e-9
     assert float((g2 - loc.grad).abs().max()) <= 2e-6 * max(float(loc.grad.abs().max()), 1e-12) + 1e-9
 

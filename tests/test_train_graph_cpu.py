@@ -93,6 +93,20 @@ def test_detection_loss_known_values():
     beta = 1.0 / SIGMA ** 2
     assert abs(float(l) - (0.5 * 0.05 ** 2 / beta + (1.0 - 0.5 * beta))) < 1e-6
     assert abs(float(loss) - float(c) - float(l)) < 1e-6
+    # oracle/ASSUMPTIONS.md row 49, the second reading (Config.loss_normalizer = "batch"): divided by the number of maps instead of the positives
+    two = {"cls": cls.repeat(2, 1, 1), "loc": loc.repeat(2, 1, 1, 1, 1, 1)}
+    lb, cb, lob = detection_loss(two, labels.repeat(2, 1, 1, 1, 1), reg.repeat(2, 1, 1, 1, 1, 1), mask.repeat(2, 1, 1, 1, 1), normalizer="batch")
+    lp, cp, lop = detection_loss(two, labels.repeat(2, 1, 1, 1, 1), reg.repeat(2, 1, 1, 1, 1, 1), mask.repeat(2, 1, 1, 1, 1))
+    assert abs(float(cb) - float(c)) < 1e-6 and abs(float(lob) - float(l)) < 1e-6          # 2 positives over 2 maps: per-map sums
+    assert abs(float(cp) - float(c)) < 1e-6                                                 # 2 positives: the same number here
+    one_pos = labels.repeat(2, 1, 1, 1, 1).clone()
+    one_pos[1, 1, 1, 0] = torch.tensor([1.0, 0.0])                                          # second map: no positive anchor
+    lb2, cb2, _ = detection_loss(two, one_pos, reg.repeat(2, 1, 1, 1, 1, 1), mask.repeat(2, 1, 1, 1, 1), normalizer="batch")
+    lp2, cp2, _ = detection_loss(two, one_pos, reg.repeat(2, 1, 1, 1, 1, 1), mask.repeat(2, 1, 1, 1, 1))
+    assert abs(float(cp2) - 2.0 * float(cb2)) < 1e-6                                       # 1 positive vs 2 maps
+    import pytest
+    with pytest.raises(ValueError):
+        detection_loss(two, one_pos, reg.repeat(2, 1, 1, 1, 1, 1), mask.repeat(2, 1, 1, 1, 1), normalizer="anchors")
 
 
 def test_step_refuses_cpu():

@@ -31,6 +31,9 @@ class Config(object):
         self.map_dims = [
             int(math.ceil(self.area_extents[i][1] / self.voxel_size[i]) - 1
                 - math.floor(self.area_extents[i][0] / self.voxel_size[i]) + 1) for i in range(3)]
+        # the open readings of oracle/ASSUMPTIONS.md as switches (defaults = the first reading):
+        self.box_wh_axis = "w_along_heading"   # row 48: which box extent runs along the heading ("h_along_heading": the other reading)
+        self.loss_normalizer = "positives"     # row 49: detection loss divided by the positive anchors ("batch": by the number of maps)
         self.category_num = 2
         self.box_code_size = 6  # (x, y, w, h, sin, cos)
         self.category_threshold = [0.4, 0.4, 0.25, 0.25, 0.4]

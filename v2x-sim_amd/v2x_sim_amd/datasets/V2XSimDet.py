@@ -16,6 +16,9 @@ and the reader:
      "target_agent_id":  int,  "num_sensor": int   (number of real agents in the frame),
      "gt_boxes":         float32 (G, 5) optional   [x, y, w, h, yaw] ground truth for test-time mAP}
 
+Samples written by UPSTREAM's create_data_det.py are also accepted as far as the author recalls their keys (normalize_sample /
+upstream_dense_targets below: aliases for the pose, agent-count and agent-id keys, the sparse training targets) -- UNVERIFIED, ASSUMPTIONS.md row 7.
+
 __getitem__ keeps upstream's per-agent tuple order for the fields the inference path consumes
 (padded_voxel_points, trans_matrices, target_agent_id, num_sensor); training targets (label_one_hot,
 reg_target, anchors_map, ...) belong to row f-3 and are returned as None.
@@ -46,6 +49,56 @@ def write_sample(root, split, agent, scene, frame, voxel_indices, trans_matrices
         sample["gt_boxes"] = np.asarray(gt_boxes, dtype=np.float32).reshape(-1, 5)
     np.save(os.path.join(d, "0.npy"), sample, allow_pickle=True)
     return d
+
+
+# ---- a TOLERANT reader for upstream-produced samples (oracle/ASSUMPTIONS.md row 7: key names half-recalled, UNVERIFIED) -------------------------
+# The keys below are what the author recalls of coperception's create_data_det.py::save_data_dict / V2XSimDet.__getitem__; nothing in
+# /root/reference confirms them (README.md:66-79 gives the directory layout only).  A sample that carries them is read instead of refused:
+#   sweep          voxel_indices_0                          (same name as the build's)
+#   poses          trans_matrices | trans_matrices_no_cross_road (cross-road configs)          (A, 4, 4)
+#   agent count    num_sensor | num_agent ;   own index  target_agent_id | target_agent
+#   training       allocation_mask (X, Y, A) bool, label_sparse (n_alloc,) int class ids, reg_target_sparse (n_alloc, 1, 6),
+#                  reg_loss_mask (X, Y, A, 1) bool, gt_max_iou  -> dense label_one_hot / reg_target as upstream's __getitem__ builds them:
+#                  label_one_hot[..., 0] = 1; label_one_hot[allocation_mask] = one_hot(label_sparse); reg_target[allocation_mask] =
+#                  reg_target_sparse; reg_target[~reg_loss_mask] = 0
+# Anything else in the dict is ignored.  The first real upstream file decides which of these survive.
+_ALIASES = {"trans_matrices": ("trans_matrices", "trans_matrices_no_cross_road"), "num_sensor": ("num_sensor", "num_agent"),
+            "target_agent_id": ("target_agent_id", "target_agent")}
+UPSTREAM_TARGET_KEYS = ("allocation_mask", "label_sparse", "reg_target_sparse", "reg_loss_mask")
+
+
+def normalize_sample(gt, is_cross_road=False):
+    """One loaded 0.npy dict -> the build's keys (see the module docstring), from either spelling.  Raises KeyError naming what is missing."""
+    out = dict(gt)
+    for key, names in _ALIASES.items():
+        order = names[::-1] if (key == "trans_matrices" and not is_cross_road and "trans_matrices_no_cross_road" in gt) else names
+        for n in order:
+            if n in gt:
+                out[key] = gt[n]
+                break
+        else:
+            raise KeyError("0.npy holds none of %s (keys present: %s)" % (names, sorted(gt)))
+    if "voxel_indices_0" not in gt:
+        raise KeyError("0.npy holds no 'voxel_indices_0' (keys present: %s)" % sorted(gt))
+    return out
+
+
+def upstream_dense_targets(gt, category_num=2):
+    """The dense training fields from upstream's sparse ones, as recalled of V2XSimDet.__getitem__ (UNVERIFIED, see above).
+    -> (label_one_hot (X, Y, A, category_num) f32, reg_target (X, Y, A, 1, 6) f32, reg_loss_mask (X, Y, A, 1) bool) or None when the sample
+    does not carry all four sparse keys."""
+    if not all(k in gt for k in UPSTREAM_TARGET_KEYS):
+        return None
+    alloc = np.asarray(gt["allocation_mask"]).astype(bool)
+    mask = np.asarray(gt["reg_loss_mask"]).astype(bool).reshape(alloc.shape + (-1,))
+    sparse = np.asarray(gt["reg_target_sparse"], dtype=np.float32).reshape(int(alloc.sum()), mask.shape[-1], -1)
+    reg = np.zeros(alloc.shape + sparse.shape[1:], dtype=np.float32)
+    reg[alloc] = sparse
+    reg[~mask] = 0
+    lab = np.zeros(alloc.shape + (category_num,), dtype=np.float32)
+    lab[..., 0] = 1
+    lab[alloc] = np.eye(category_num, dtype=np.float32)[np.asarray(gt["label_sparse"]).astype(np.int64).reshape(-1)]
+    return lab, reg, mask
 
 
 class V2XSimDet(Dataset):
@@ -88,7 +141,7 @@ class V2XSimDet(Dataset):
         name = self.seq_names[idx]
         res = []
         for root in self.dataset_roots:
-            gt = np.load(os.path.join(root, name, "0.npy"), allow_pickle=True).item()
+            gt = normalize_sample(np.load(os.path.join(root, name, "0.npy"), allow_pickle=True).item(), getattr(self.config, "is_cross_road", False))
             indices = np.asarray(gt["voxel_indices_0"], dtype=np.int32).reshape(-1, 3)
             if self.densify == "cpu":
                 vox = np.zeros(self.dims, dtype=bool)
@@ -103,8 +156,9 @@ class V2XSimDet(Dataset):
                 if self._anchors is None:
                     self._anchors = postprocess.build_anchor_map(self.config)
                 anchors_map = self._anchors
-                label_one_hot, reg_target, reg_loss_mask = synthetic_scene.anchor_targets(boxes, anchors_map)
-            res.append((padded_voxel_points, None, label_one_hot, reg_target, reg_loss_mask, anchors_map, None, None,
+                dense = upstream_dense_targets(gt, getattr(self.config, "category_num", 2))     # an upstream-produced sample carries its own assignment
+                label_one_hot, reg_target, reg_loss_mask = dense if dense is not None else synthetic_scene.anchor_targets(boxes, anchors_map)
+            res.append((padded_voxel_points, None, label_one_hot, reg_target, reg_loss_mask, anchors_map, None, gt.get("gt_max_iou"),
                         os.path.join(root, name), int(gt["target_agent_id"]), int(gt["num_sensor"]),
                         np.asarray(gt["trans_matrices"], dtype=np.float32), boxes))
         return res

@@ -109,13 +109,19 @@ class When2com(IntermediateModelBase):
     def __init__(self, config, n_classes=21, in_channels=13, feat_channel=512, feat_squeezer=-1,
                  attention="additive", has_query=True, sparse=False, layer=3, warp_flag=1, image_size=512,
                  shared_img_encoder="unified", key_size=1024, query_size=32, num_agent=5, compress_level=0,
-                 only_v2i=False):
+                 only_v2i=False, attn_index="kq", renormalize=False):
         super().__init__(config, layer, in_channels, kd_flag=0, num_agent=num_agent,
                          compress_level=compress_level, only_v2i=only_v2i)
         if sparse:
             raise NotImplementedError("sparsemax attention is out of scope (DESIGN.md section 8)")
         if not has_query:
             raise NotImplementedError("has_query=False is out of scope")
+        # the two open readings of oracle/ASSUMPTIONS.md as switches (defaults = the first reading): row 30 attn_index "kq" -- fused[q] =
+        # sum_k attn[b, k, q] val[k -> q] -- or "qk", the transposed read; row 31 renormalize -- 'activated' coefficients divided by their sum
+        # over the keys (a query whose keys all fell below the threshold keeps zeros)
+        if attn_index not in ("kq", "qk"):
+            raise ValueError("attn_index must be 'kq' or 'qk'")
+        self.attn_index, self.renormalize = attn_index, bool(renormalize)
         self.sparse = sparse
         self.warp_flag = warp_flag
         self.key_size, self.query_size = key_size, query_size
@@ -176,8 +182,10 @@ class When2com(IntermediateModelBase):
         else:
             raise ValueError("Incorrect inference mode")
         prob, coef = self.handshake(x0, pk, batch_size, mode)
+        if self.renormalize and mode == "activated":
+            coef = self.renormalized(coef)
         # per output item (q, f): coefficient of every source k, zeroed for padding agents
-        coef_items = coef[plan["f_idx"], :, plan["q_idx"]].contiguous() * plan["mask"]
+        coef_items = (coef[plan["f_idx"], :, plan["q_idx"]] if self.attn_index == "kq" else coef[plan["f_idx"], plan["q_idx"], :]).contiguous() * plan["mask"]
         if self.warp_flag != 1:
             raise NotImplementedError("warp_flag=0 (no spatial alignment) is out of scope")
         feat = feats[self.layer]
@@ -193,6 +201,12 @@ class When2com(IntermediateModelBase):
         res["prob_action"] = prob
         res["coef"] = coef
         return res
+
+    @staticmethod
+    def renormalized(coef):
+        """(B, A_key, A_query) thresholded coefficients -> divided by their sum over the keys where that is non-zero (row 31, second reading)."""
+        tot = coef.sum(dim=1, keepdim=True)
+        return torch.where(tot > 0, coef / torch.where(tot > 0, tot, torch.ones_like(tot)), coef)
 
     @staticmethod
     def num_connect(coef, agent_num):

@@ -340,8 +340,12 @@ class ShardedWhen2com:
         querys = self.exchange(q_loc)                              # (A*Bt, 32)
         mode = "softmax" if (training or inference == "softmax") else inference
         prob, coef = ops.attn_handshake(keys, querys, pk["w_lin"], pk["b_lin"], sh.A, sh.Bt, mode)
-        coef_items = coef[plan["f_idx"], :, plan["q_idx"]].contiguous() * plan["mask"]
-        gathered = self.fetch_maps(feats[m.layer], coef, plan["counts"], mode)
+        if getattr(m, "renormalize", False) and mode == "activated":          # the second readings of ASSUMPTIONS rows 31 / 30, as in When2com.forward_nhwc
+            coef = m.renormalized(coef)
+        transposed = getattr(m, "attn_index", "kq") == "qk"
+        coef_items = (coef[plan["f_idx"], plan["q_idx"], :] if transposed else coef[plan["f_idx"], :, plan["q_idx"]]).contiguous() * plan["mask"]
+        # (the sparse transport plans from coef[f][k][q] = "target q reads source k": hand it that orientation)
+        gathered = self.fetch_maps(feats[m.layer], coef.transpose(1, 2) if transposed else coef, plan["counts"], mode)
         fused_items = ops.warp_fuse(gathered, sh.A, sh.Bt, trans, plan["items"], coef_items, V2X_FUSE_WSUM)
         if plan["local_rows"] is None:
             fused = fused_items

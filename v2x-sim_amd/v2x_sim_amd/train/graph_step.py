@@ -16,7 +16,7 @@ _KEYS = ("bev_seq", "labels", "reg_targets", "reg_loss_mask", "trans_matrices")
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, data, batch_size, warmup=3):
+    def __init__(self, model, optimizer, data, batch_size, warmup=3, normalizer="positives"):
         """model on the MI355X in train mode; optimizer: torch.optim.Adam(..., capturable=True) (lr may be a device tensor, see set_lr) or one without host-side state (plain SGD);
         data: one batch in FaFModule.step's format -- its shapes are the shapes of every later batch."""
         from .graph import train_forward
@@ -26,6 +26,7 @@ class GraphedTrainStep:
             if "capturable" in g and not g["capturable"]:
                 raise ValueError("GraphedTrainStep needs an optimizer created with capturable=True (its step counter lives on the host otherwise)")
         self.model, self.optimizer, self.batch_size = model, optimizer, batch_size
+        self.normalizer = normalizer     # configs.Config.loss_normalizer (oracle/ASSUMPTIONS.md row 49)
         self.static = {k: data[k].clone() for k in _KEYS if data.get(k) is not None}
         self.num_agent = None if data.get("num_agent") is None else data["num_agent"].clone().cpu()
         self._forward = train_forward
@@ -68,7 +69,7 @@ class GraphedTrainStep:
     def _step_body(self):
         s = self.static
         res = self._forward(self.model, s["bev_seq"], s.get("trans_matrices"), self.num_agent, self.batch_size)
-        loss, cls_loss, loc_loss = detection_loss(res, s["labels"], s["reg_targets"], s["reg_loss_mask"])
+        loss, cls_loss, loc_loss = detection_loss(res, s["labels"], s["reg_targets"], s["reg_loss_mask"], normalizer=self.normalizer)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()

@@ -28,6 +28,11 @@ class FaFModule(object):
         self.fused_detection = True       # with device_postprocess: score threshold in the heads' epilogue, logits never stored
         self.cap = 4096                   # candidate capacity per map of the device path
         self._anchors_dev = None
+        # oracle/ASSUMPTIONS.md rows 48 / 49 as switches (configs.Config): which box extent runs along the heading, the loss normaliser
+        self.wh_axis = getattr(config, "box_wh_axis", "w_along_heading")
+        self.loss_normalizer = getattr(config, "loss_normalizer", "positives")
+        if self.wh_axis not in postprocess.WH_AXES:
+            raise ValueError("config.box_wh_axis must be one of %s" % (postprocess.WH_AXES,))
         self._graphed = None              # (batch-shape key, GraphedTrainStep) when V2X_TRAIN_GRAPH=1
 
     def step(self, data, batch_size, num_agent=5):
@@ -51,12 +56,12 @@ class FaFModule(object):
             key = self._graph_key(data, batch_size)
             cache = self.optimizer.__dict__.setdefault("_v2x_graphed_steps", {})
             if key not in cache:
-                cache[key] = GraphedTrainStep(self.model, self.optimizer, data, batch_size)
+                cache[key] = GraphedTrainStep(self.model, self.optimizer, data, batch_size, normalizer=self.loss_normalizer)
             self._graphed = (key, cache[key])
             loss, cls_loss, loc_loss = cache[key](data)
             return loss.item(), cls_loss.item(), loc_loss.item()
         result = train_forward(self.model, bev, data.get("trans_matrices"), data.get("num_agent"), batch_size)
-        loss, cls_loss, loc_loss = detection_loss(result, data["labels"], data["reg_targets"], data["reg_loss_mask"])
+        loss, cls_loss, loc_loss = detection_loss(result, data["labels"], data["reg_targets"], data["reg_loss_mask"], normalizer=self.loss_normalizer)
         self.optimizer.zero_grad(set_to_none=True)
         loss.backward()
         self.optimizer.step()
@@ -64,7 +69,7 @@ class FaFModule(object):
         return loss.item(), cls_loss.item(), loc_loss.item()
 
     def _graph_key(self, data, batch_size):
-        return (id(self.model),) + tuple(tuple(data[k].shape) for k in ("bev_seq", "labels", "reg_targets", "reg_loss_mask")) + (batch_size,)
+        return (id(self.model),) + tuple(tuple(data[k].shape) for k in ("bev_seq", "labels", "reg_targets", "reg_loss_mask")) + (batch_size, self.loss_normalizer)
 
     def _graph_ok(self, data, batch_size):
         from .. import tuning
@@ -88,22 +93,33 @@ class FaFModule(object):
         -> None if a map overflowed `cap` there (the caller re-runs the logits path: no logits exist to fall back on)."""
         from .. import ops
         dev = (result["det"][0] if "det" in result else result["cls"]).device
+        # "h_along_heading": the kernels lay w along the heading; a box with the extents exchanged is what they compute from anchors with
+        # (w, h) exchanged and codes with (dw, dh) exchanged -- w' = a_h exp(dh) = h, h' = a_w exp(dw) = w -- so the second reading costs one
+        # channel permutation of the codes and a column swap of the result, no second kernel (the corners below follow self.wh_axis)
+        swap = self.wh_axis == "h_along_heading"
+        perm = [0, 1, 3, 2, 4, 5]
         if self._anchors_dev is None or self._anchors_dev.device != dev:
-            self._anchors_dev = torch.from_numpy(np.ascontiguousarray(self.anchors.reshape(-1, 6))).to(dev)
+            a = np.ascontiguousarray(self.anchors.reshape(-1, 6))
+            self._anchors_dev = torch.from_numpy(np.ascontiguousarray(a[:, perm]) if swap else a).to(dev)
+
+        def unswap(b):
+            return b[..., [0, 1, 3, 2, 4]] if swap else b
         if "det" in result:
             keys, codes, counts = result["det"]
-            boxes, scores, _, count = ops.det_nms_candidates(keys, codes, counts, self._anchors_dev, self.nms_thr)
+            boxes, scores, _, count = ops.det_nms_candidates(keys, codes[..., perm].contiguous() if swap else codes, counts, self._anchors_dev, self.nms_thr)
+            boxes = unswap(boxes)
             count = count.cpu().numpy()
             if (count < 0).any():
                 return None
             kmax = int(max(1, count.max()))
             boxes, scores = boxes[:, :kmax].cpu().numpy(), scores[:, :kmax].cpu().numpy()
             return [{"boxes": boxes[i, :count[i]], "scores": scores[i, :count[i]],
-                     "corners": postprocess.box_corners(boxes[i, :count[i]]) if count[i] else np.zeros((0, 4, 2), np.float32)}
+                     "corners": postprocess.box_corners(boxes[i, :count[i]], self.wh_axis) if count[i] else np.zeros((0, 4, 2), np.float32)}
                     for i in range(keys.shape[0])]
         cls, loc = result["cls"], result["loc"]
-        boxes, scores, _, count = ops.det_postprocess(cls.contiguous(), loc.contiguous(), self._anchors_dev, self.score_thr,
-                                                      self.nms_thr, self.cap)
+        boxes, scores, _, count = ops.det_postprocess(cls.contiguous(), (loc.reshape(cls.shape[0], -1, 6)[..., perm] if swap else loc).contiguous(), self._anchors_dev,
+                                                      self.score_thr, self.nms_thr, self.cap)
+        boxes = unswap(boxes)
         count = count.cpu().numpy()
         kmax = int(max(1, count.max()))
         boxes, scores = boxes[:, :kmax].cpu().numpy(), scores[:, :kmax].cpu().numpy()
@@ -111,10 +127,10 @@ class FaFModule(object):
         for i in range(cls.shape[0]):
             if count[i] < 0:
                 out.append(postprocess.apply_nms_det(loc[i].float().cpu().numpy(), cls[i].float().cpu().numpy(), self.anchors,
-                                                     self.score_thr, self.nms_thr))
+                                                     self.score_thr, self.nms_thr, wh_axis=self.wh_axis))
                 continue
             b = boxes[i, :count[i]]
-            out.append({"boxes": b, "corners": postprocess.box_corners(b) if count[i] else np.zeros((0, 4, 2), np.float32),
+            out.append({"boxes": b, "corners": postprocess.box_corners(b, self.wh_axis) if count[i] else np.zeros((0, 4, 2), np.float32),
                         "scores": scores[i, :count[i]]})
         return out
 

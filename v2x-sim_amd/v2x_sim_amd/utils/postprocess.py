@@ -54,9 +54,18 @@ def decode_boxes(loc, anchors):
     return np.stack([x, y, w, h, yaw], axis=-1)
 
 
-def box_corners(boxes):
-    """(N, 5) [x, y, w, h, yaw] -> (N, 4, 2) corners, counter-clockwise."""
+WH_AXES = ("w_along_heading", "h_along_heading")
+
+
+def box_corners(boxes, wh_axis="w_along_heading"):
+    """(N, 5) [x, y, w, h, yaw] -> (N, 4, 2) corners, counter-clockwise.  wh_axis (oracle/ASSUMPTIONS.md row 48, both readings): which extent
+    runs along the box's heading -- "w_along_heading" (default) or "h_along_heading" (the rectangle with the extents exchanged);
+    Config.box_wh_axis selects it for FaFModule."""
     x, y, w, h, yaw = (boxes[:, i] for i in range(5))
+    if wh_axis == "h_along_heading":
+        w, h = h, w
+    elif wh_axis != "w_along_heading":
+        raise ValueError("wh_axis must be one of %s" % (WH_AXES,))
     c, s = np.cos(yaw), np.sin(yaw)
     dx = np.stack([w / 2, -w / 2, -w / 2, w / 2], 1)
     dy = np.stack([h / 2, h / 2, -h / 2, -h / 2], 1)
@@ -89,7 +98,7 @@ def nms_standup(boxes_xyxy, scores, iou_thr=0.01, max_out=None):
     return np.asarray(keep, dtype=np.int64)
 
 
-def apply_nms_det(loc, cls, anchors, score_thr=0.7, nms_thr=0.01, max_out=None):
+def apply_nms_det(loc, cls, anchors, score_thr=0.7, nms_thr=0.01, max_out=None, wh_axis="w_along_heading"):
     """One agent.  loc (X, Y, A, 1, 6) or (X, Y, A, 6); cls (X*Y*A, 2); anchors (X, Y, A, 6).
     -> dict(boxes (M, 5), corners (M, 4, 2), scores (M,))."""
     loc = np.asarray(loc, dtype=np.float32).reshape(-1, 6)
@@ -106,7 +115,7 @@ def apply_nms_det(loc, cls, anchors, score_thr=0.7, nms_thr=0.01, max_out=None):
         warnings.warn("apply_nms_det: %d of %d anchors pass the score threshold %.2f; the host NMS will take a long time "
                       "(is the model trained?)" % (sel.size, score.size, score_thr), RuntimeWarning, stacklevel=2)
     boxes = decode_boxes(loc[sel], anchors[sel])
-    corners = box_corners(boxes)
+    corners = box_corners(boxes, wh_axis)
     keep = nms_standup(standup(corners), score[sel], nms_thr, max_out)
     return {"boxes": boxes[keep], "corners": corners[keep], "scores": score[sel][keep]}
 
