@@ -425,10 +425,13 @@ def test_warp_fuse_lds_form_bitwise_and_oracle(device, mode, tune):
     it = torch.tensor(items, dtype=torch.int32, device=device)
     tune("WARP_LDS", 1)
     lds = ops.warp_fuse(x, A, Bt, T.to(device), it, coef.to(device), mode).clone()
+    tune("WARP_LDS", 2)     # (round 5, the default) the rotate set-ups of a window shared through an LDS table: the same arithmetic
+    lds2 = ops.warp_fuse(x, A, Bt, T.to(device), it, coef.to(device), mode).clone()
     tune("WARP_LDS", 0)
     direct = ops.warp_fuse(x, A, Bt, T.to(device), it, coef.to(device), mode).clone()
     tune.reset("WARP_LDS")
     assert torch.equal(lds.view(torch.int16), direct.view(torch.int16))
+    assert torch.equal(lds2.view(torch.int16), direct.view(torch.int16))
     ref = _warp_ref(feat, T, items, coef, A, Bt, mode)
     got = from_nhwc(lds)
     assert torch.allclose(got, bf16r(ref), atol=4e-3, rtol=2 ** -7), float((got - ref).abs().max())

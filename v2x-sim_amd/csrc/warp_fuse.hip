@@ -362,6 +362,221 @@ __global__ __launch_bounds__(256) void warp_fuse_lds_kernel(const uint16_t *__re
     }
 }
 
+// ---- LDS-staged form with SHARED set-ups (round 5) ------------------------------------------------------------------------------------
+// In the kernel above a thread owns 16 channels of a window position (phase 1) or of an output pixel (phase 2), so the coordinate work of a
+// position -- rotation, bilinear set-up, clamps, two IEEE divisions -- is issued once per 16 channels: 648 items per tile and neighbour walk
+// the SAME 81 set-ups eight times each, ~55 of a phase-1 item's ~170 instructions.  Here the 81 rotate set-ups are evaluated ONCE per
+// workgroup and neighbour (threads 0..80, before the barrier phase 1 starts behind anyway) into a 2.5-KiB LDS table {4 clamped source pixel
+// offsets, 4 tap weights}; a phase-1 item reads its entry (two broadcast ds_read_b128) and goes straight to its 8 gathers.  The translate
+// step's per-pixel normalised coordinates (2 w + 1) / W - 1 (two more divisions per phase-2 item) come from a 16-float table built once per
+// workgroup.  Same arithmetic in the same order as rot_sample_cv / the kernel above: BIT-IDENTICAL results (tests compare the three forms).
+// LDS: window 50.5 KiB + tables 2.0 KiB = 53 720 B: still three workgroups per CU (the entry is split into an int2 {clamped source pixel index of
+// the nw tap or -1 = position outside the map / -2 = footprint outside, (dx, dy) steps to the other taps} and a float4 of weights).  MODE is a template parameter (the max / mean / weighted-sum
+// selects and the ego branch's extra code left the inner loops).
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void warp_fuse_lds2_kernel(const uint16_t *__restrict__ feat, int A, int Bt, int H, int W, int C,
+                                                             const float *__restrict__ trans, const int32_t *__restrict__ items,
+                                                             const float *__restrict__ coef, uint16_t *__restrict__ out,
+                                                             const int32_t *__restrict__ order, int order_stride, int n_out_total) {
+    __shared__ float4 win[WL_R * WL_R * WL_POS4 - (WL_POS4 - 4 * WL_G)];   // (the last position needs no padding behind it)
+    __shared__ float4 rwt[WL_R * WL_R];      // tap weights nw, ne, sw, se of a window position, 0 where the tap is zero padding
+    __shared__ int2 roff[WL_R * WL_R];       // x: source pixel index cy0 * W + cx0 (clamped into the map) | -1 | -2;  y: (cx1 - cx0) | (cy1 - cy0) << 1
+    __shared__ float base_xy[2 * WL_T];      // (2 w + 1) / W - 1 for the tile's columns, (2 h + 1) / H - 1 for its rows
+    int m = blockIdx.y, tile = blockIdx.x, cbi = blockIdx.z;
+    if (order) {   // frame-major walk per XCD (see warp_fuse_lds_kernel)
+        const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+        const int tiles = (H / WL_T) * (W / WL_T), cbs = C / WL_CW;
+        const int per_slot = order_stride * tiles * cbs;
+        const int slot = (i / per_slot) * 8 + xcd, rest = i % per_slot;
+        const int e = rest / (tiles * cbs), r2 = rest % (tiles * cbs);
+        if (slot * order_stride + e >= n_out_total) return;
+        m = order[slot * order_stride + e];
+        if (m < 0) return;
+        cbi = r2 / tiles;
+        tile = r2 % tiles;
+    }
+    const int ego = items[2 * m + 0];
+    const int f = items[2 * m + 1];
+    const int tiles_x = W / WL_T;
+    const int h0 = (tile / tiles_x) * WL_T, w0 = (tile % tiles_x) * WL_T;
+    const int cb = cbi * WL_CW;
+    const int tid = threadIdx.x;
+    const size_t map_elems = (size_t)H * W * C;
+    if (tid < 2 * WL_T) {
+        const int k = tid & (WL_T - 1);
+        base_xy[tid] = tid < WL_T ? (float)(2 * (w0 + k) + 1) / (float)W - 1.0f : (float)(2 * (h0 + k) + 1) / (float)H - 1.0f;
+    }
+    constexpr int NI = WL_T * WL_T * WL_G / 256;
+    float acc[NI][2][8];
+#pragma unroll
+    for (int s = 0; s < NI; ++s)
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[s][v][e] = 0.f;
+    int count = 0;
+    for (int j = 0; j < A; ++j) {
+        const float cj = coef[m * A + j];
+        if (cj == 0.0f) continue;  // block-uniform
+        const uint16_t *src = feat + ((size_t)j * Bt + f) * map_elems;
+        ++count;
+        const float wj = (MODE == V2X_FUSE_MEAN) ? 1.0f : cj;
+        if (j == ego) {
+#pragma unroll
+            for (int s = 0; s < NI; ++s) {
+                const int i = tid + 256 * s;
+                const int pixel = i / WL_G, g = i % WL_G;
+                const int pix = (h0 + pixel / WL_T) * W + w0 + pixel % WL_T;
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const uint4 raw = *reinterpret_cast<const uint4 *>(src + (size_t)pix * C + cb + (g + v * WL_G) * 8);
+                    if (MODE == V2X_FUSE_MAX) {
+                        float ev[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) ev[e] = 0.f;
+                        fma8(ev, raw, 1.0f);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) acc[s][v][e] = (count == 1) ? ev[e] : fmaxf(acc[s][v][e], ev[e]);
+                    } else {
+                        fma8(acc[s][v], raw, wj);
+                    }
+                }
+            }
+            continue;
+        }
+        const float *T = trans + (((size_t)f * A + ego) * A + j) * 16;
+        const float r00 = T[0], r01 = T[1], r10 = T[4], r11 = T[5];
+        const float tx = (4.0f * T[3]) / 128.0f;
+        const float ty = -((4.0f * T[7]) / 128.0f);
+        const Bilin b0 = bilin_setup(((float)(2 * w0 + 1) / (float)W - 1.0f) + tx, ((float)(2 * h0 + 1) / (float)H - 1.0f) + ty, W, H);
+        const int qx_lo = b0.x0, qy_lo = b0.y0;
+        // the 81 rotate set-ups of this neighbour, once (rot_sample_cv's coordinate arithmetic, value for value).  The table was last read in the
+        // previous neighbour's phase 1, which every thread left before the barrier that closed it.
+        if (tid < WL_R * WL_R) {
+            const int qx = qx_lo + tid % WL_R, qy = qy_lo + tid / WL_R;
+            int2 eo = make_int2(-1, 0);
+            float4 ew = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)qx < (unsigned)W && (unsigned)qy < (unsigned)H) {   // else never read: the translate tap is zero padding
+                const float xq = (float)(2 * qx + 1) / (float)W - 1.0f;
+                const float yq = (float)(2 * qy + 1) / (float)H - 1.0f;
+                const Bilin b = bilin_setup(__fmaf_rn(r00, xq, __fmul_rn(r01, yq)), __fmaf_rn(r10, xq, __fmul_rn(r11, yq)), W, H);
+                const bool xl = (unsigned)b.x0 < (unsigned)W, xr = (unsigned)(b.x0 + 1) < (unsigned)W;
+                const bool yt = (unsigned)b.y0 < (unsigned)H, yb = (unsigned)(b.y0 + 1) < (unsigned)H;
+                if ((xl || xr) && (yt || yb)) {
+                    const int cx0 = min(max(b.x0, 0), W - 1), cx1 = min(max(b.x0 + 1, 0), W - 1);
+                    const int cy0 = min(max(b.y0, 0), H - 1), cy1 = min(max(b.y0 + 1, 0), H - 1);
+                    eo = make_int2(cy0 * W + cx0, (cx1 - cx0) | ((cy1 - cy0) << 1));
+                    ew = make_float4((yt && xl) ? b.nw : 0.f, (yt && xr) ? b.ne : 0.f, (yb && xl) ? b.sw : 0.f, (yb && xr) ? b.se : 0.f);
+                } else {
+                    eo.x = -2;     // inside the map, whole footprint outside: the rotated sample is exactly zero
+                }
+            }
+            roff[tid] = eo;
+            rwt[tid] = ew;
+        }
+        __syncthreads();   // table written; the previous neighbour's phase 2 is done with the window
+        for (int i = tid; i < WL_R * WL_R * WL_G; i += 256) {
+            const int pos = i / WL_G, g = i % WL_G;
+            const int2 eo = roff[pos];
+            if (eo.x == -1) continue;
+            float r[2][8];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) r[v][q] = 0.f;
+            if (eo.x >= 0) {
+                const float4 ew = rwt[pos];
+                const uint16_t *p00 = src + (size_t)eo.x * C + cb + g * 8;
+                const uint16_t *p10 = p00 + (size_t)((eo.y >> 1) * W) * C;
+                const int dxc = (eo.y & 1) * C;
+                uint4 t[4][2];
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    t[0][v] = *reinterpret_cast<const uint4 *>(p00 + v * (WL_G * 8));
+                    t[1][v] = *reinterpret_cast<const uint4 *>(p00 + dxc + v * (WL_G * 8));
+                    t[2][v] = *reinterpret_cast<const uint4 *>(p10 + v * (WL_G * 8));
+                    t[3][v] = *reinterpret_cast<const uint4 *>(p10 + dxc + v * (WL_G * 8));
+                }
+                const float wt[4] = {ew.x, ew.y, ew.z, ew.w};
+                // (per channel vector the taps are added in the order nw, ne, sw, se, as rot_sample_cv does: the vectors are independent sums)
+#pragma unroll
+                for (int v = 0; v < 2; ++v)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) fma8(r[v], t[k][v], wt[k]);
+            }
+            float4 *dst = win + pos * WL_POS4 + g;
+            dst[0 * WL_G] = make_float4(r[0][0], r[0][1], r[0][2], r[0][3]);
+            dst[1 * WL_G] = make_float4(r[0][4], r[0][5], r[0][6], r[0][7]);
+            dst[2 * WL_G] = make_float4(r[1][0], r[1][1], r[1][2], r[1][3]);
+            dst[3 * WL_G] = make_float4(r[1][4], r[1][5], r[1][6], r[1][7]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NI; ++s) {
+            const int i = tid + 256 * s;
+            const int pixel = i / WL_G, g = i % WL_G;
+            const Bilin b = bilin_setup(base_xy[pixel % WL_T] + tx, base_xy[WL_T + pixel / WL_T] + ty, W, H);
+            float vv[2][8], r[2][8];
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) vv[v][e] = 0.f;
+            const bool xl = (unsigned)b.x0 < (unsigned)W, xr = (unsigned)(b.x0 + 1) < (unsigned)W;
+            const bool yt = (unsigned)b.y0 < (unsigned)H, yb = (unsigned)(b.y0 + 1) < (unsigned)H;
+#define V2X_TAP(COND, QX, QY, WT)                                                                                 \
+    if (COND) {                                                                                                   \
+        const int dx = (QX)-qx_lo, dy = (QY)-qy_lo;                                                               \
+        if ((unsigned)dx < (unsigned)WL_R && (unsigned)dy < (unsigned)WL_R) {                                     \
+            const float4 *p = win + (dy * WL_R + dx) * WL_POS4 + g;                                               \
+            const float4 a0 = p[0], a1 = p[WL_G], a2 = p[2 * WL_G], a3 = p[3 * WL_G];                             \
+            r[0][0] = a0.x; r[0][1] = a0.y; r[0][2] = a0.z; r[0][3] = a0.w;                                       \
+            r[0][4] = a1.x; r[0][5] = a1.y; r[0][6] = a1.z; r[0][7] = a1.w;                                       \
+            r[1][0] = a2.x; r[1][1] = a2.y; r[1][2] = a2.z; r[1][3] = a2.w;                                       \
+            r[1][4] = a3.x; r[1][5] = a3.y; r[1][6] = a3.z; r[1][7] = a3.w;                                       \
+        } else {                                                                                                  \
+            rot_sample_cv<2>(src, H, W, C, cb + g * 8, QX, QY, r00, r01, r10, r11, r, WL_G * 8);                  \
+        }                                                                                                         \
+        _Pragma("unroll") for (int v = 0; v < 2; ++v)                                                             \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) vv[v][e] = __fmaf_rn(r[v][e], WT, vv[v][e]);                               \
+    }
+            V2X_TAP(yt && xl, b.x0, b.y0, b.nw)
+            V2X_TAP(yt && xr, b.x0 + 1, b.y0, b.ne)
+            V2X_TAP(yb && xl, b.x0, b.y0 + 1, b.sw)
+            V2X_TAP(yb && xr, b.x0 + 1, b.y0 + 1, b.se)
+#undef V2X_TAP
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (MODE == V2X_FUSE_MAX) acc[s][v][e] = (count == 1) ? vv[v][e] : fmaxf(acc[s][v][e], vv[v][e]);
+                    else acc[s][v][e] = __fmaf_rn(vv[v][e], wj, acc[s][v][e]);
+                }
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < NI; ++s) {
+        const int i = tid + 256 * s;
+        const int pixel = i / WL_G, g = i % WL_G;
+        const int pix = (h0 + pixel / WL_T) * W + w0 + pixel % WL_T;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            if (MODE == V2X_FUSE_MEAN && count > 0) {
+                const float d = (float)count;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[s][v][e] = acc[s][v][e] / d;
+            }
+            uint4 o;
+            o.x = pack_bf16x2(acc[s][v][0], acc[s][v][1]);
+            o.y = pack_bf16x2(acc[s][v][2], acc[s][v][3]);
+            o.z = pack_bf16x2(acc[s][v][4], acc[s][v][5]);
+            o.w = pack_bf16x2(acc[s][v][6], acc[s][v][7]);
+            *reinterpret_cast<uint4 *>(out + (size_t)m * map_elems + (size_t)pix * C + cb + (g + v * WL_G) * 8) = o;
+            __builtin_amdgcn_sched_barrier(0);   // one vector at a time: eight IEEE divisions' temporaries on top of 32 live accumulators spilled otherwise
+        }
+    }
+}
+
 static int warp_fuse_impl(const uint16_t *feat, int A, int Bt, int H, int W, int C, const float *trans,
                           const int32_t *items, int n_out, const float *coef, int mode, uint16_t *out,
                           const int32_t *order, int order_stride, int order_len, v2x_stream_t stream) {
@@ -371,6 +586,28 @@ static int warp_fuse_impl(const uint16_t *feat, int A, int Bt, int H, int W, int
     V2X_REQUIRE(mode == V2X_FUSE_WSUM || mode == V2X_FUSE_MEAN || mode == V2X_FUSE_MAX, "v2x_warp_fuse: bad mode");
     V2X_REQUIRE(n_out >= 0 && n_out <= 65535, "v2x_warp_fuse: n_out out of range");
     if (n_out == 0) return V2X_OK;
+    if (v2x_tune(V2X_TUNE_WARP_LDS) >= 2 && H % WL_T == 0 && W % WL_T == 0 && C % WL_CW == 0 && (long long)H * W < (1ll << 30)) {
+        // the shared-set-up form (default); WARP_LDS = 1 keeps the per-item set-ups (A/B runs, bitwise test), 0 the direct form
+        dim3 grid((H / WL_T) * (W / WL_T), n_out, C / WL_CW);
+        const int32_t *ord = nullptr;
+        int ostride = 0, olen = 0;
+        if (order && order_stride > 0 && order_len > 0) {
+            const int slots = (order_len + order_stride - 1) / order_stride;
+            const int per_slot = order_stride * (H / WL_T) * (W / WL_T) * (C / WL_CW);
+            const long long blocks = (long long)((slots + 7) / 8) * per_slot * 8;
+            V2X_REQUIRE(blocks < (1ll << 31), "v2x_warp_fuse: grid too large");
+            grid = dim3((unsigned)blocks);
+            ord = order;
+            ostride = order_stride;
+            olen = order_len;
+        }
+        hipStream_t st = (hipStream_t)stream;
+        if (mode == V2X_FUSE_MEAN) hipLaunchKernelGGL(warp_fuse_lds2_kernel<V2X_FUSE_MEAN>, grid, dim3(256), 0, st, feat, A, Bt, H, W, C, trans, items, coef, out, ord, ostride, olen);
+        else if (mode == V2X_FUSE_MAX) hipLaunchKernelGGL(warp_fuse_lds2_kernel<V2X_FUSE_MAX>, grid, dim3(256), 0, st, feat, A, Bt, H, W, C, trans, items, coef, out, ord, ostride, olen);
+        else hipLaunchKernelGGL(warp_fuse_lds2_kernel<V2X_FUSE_WSUM>, grid, dim3(256), 0, st, feat, A, Bt, H, W, C, trans, items, coef, out, ord, ostride, olen);
+        V2X_CHECK_LAUNCH("warp_fuse_lds2_kernel");
+        return V2X_OK;
+    }
     if (v2x_tune(V2X_TUNE_WARP_LDS) != 0 && H % WL_T == 0 && W % WL_T == 0 && C % WL_CW == 0) {
         if (order && order_stride > 0 && order_len > 0) {
             // frame slots of order_stride output maps each (padded with -1); XCD x = linear workgroup id % 8 takes the slots x, x + 8, ...

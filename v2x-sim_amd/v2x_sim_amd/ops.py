@@ -641,7 +641,8 @@ def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
     if out is None:
         out = torch.empty((n_out, H, W, Cc), dtype=torch.bfloat16, device=feat.device)
     lds = H % 8 == 0 and W % 8 == 0 and Cc % 128 == 0 and tuning.get("WARP_LDS") != 0
-    prof = _Prof("warp_fuse_lds_kernel" if lds else "warp_fuse_kernel", 0, (n_out * (A - 1) + n_out) * H * W * Cc * 2)
+    prof = _Prof(("warp_fuse_lds2_kernel<%d>" % mode if tuning.get("WARP_LDS") >= 2 else "warp_fuse_lds_kernel") if lds else "warp_fuse_kernel", 0,
+                 (n_out * (A - 1) + n_out) * H * W * Cc * 2)
     order = _warp_frame_order(items, A, Bt) if (lds and tuning.get("WARP_XCD") != 0) else None
     if order is not None:
         rc = lib.v2x_warp_fuse_ordered(_dev(feat, torch.bfloat16, "feat"), A, Bt, H, W, Cc, _dev(trans, torch.float32, "trans"),
