@@ -175,3 +175,62 @@ def test_parity_class_transpose_detecting(device):
     ref = F.conv2d(torch.cat((F.interpolate(x_up, scale_factor=(2, 2)), x_sk), 1), w, None, 1, 1)
     assert torch.equal(got, bf16r(ref)), float((got - ref).abs().max())
     assert np.count_nonzero(got.numpy()) > 0
+
+
+# ---- the streamed parity-class kernel (conv_stream_pc.hip: conv5_1, conv6_1; w_layout 4) ----------------------------------------------------
+STREAMED = [  # (C0, C1, Cout, N, H, W)
+    (512, 256, 256, 2, 32, 32),     # conv5_1: whole maps = two tiles x two channel tiles
+    (256, 128, 128, 2, 64, 64),     # conv6_1
+    (256, 128, 128, 1, 16, 32),     # a single tile: every border is zero padding
+    (64, 32, 128, 3, 48, 96),       # short K (two up chunks, one skip chunk), ragged persistent walk
+    (512, 256, 256, 40, 32, 32),    # 160 tiles on <= 256 workgroups ... and
+    (256, 128, 128, 80, 64, 64),    # 640 tiles: 2.5 tiles per workgroup (the persistent loop, the next tile's prologue under the stores)
+]
+
+
+@pytest.mark.parametrize("C0,C1,Cout,N,H,W", STREAMED)
+def test_streamed_parity_class_kernel_against_the_same_bf16_operands(device, C0, C1, Cout, N, H, W):
+    """KERNEL test of conv3x3_stream8p_kernel: one bf16 ulp of the output against torch on the pre-summed bf16 weights; repeated launches are
+    bit-identical (no race between the wave groups, the phases and the tiles of the persistent loop)."""
+    from v2x_sim_amd import ops, packing
+    conv, bn = _layer(C0, C1, Cout, seed=C0 + N)
+    x_up, x_sk = _inputs(N, C0, C1, H, W, seed=H + W + N)
+    scale, shift = packing.fold_bn(conv.bias, bn, Cout)
+    pc = packing.pack_conv_stream_parity("conv5_1", conv.weight, scale, shift, C0=C0, C1=C1, device=device)
+    assert ops.conv_kernel_name(pc, H, W) == "conv3x3_stream8p_kernel" and pc.w_kpad == 16 * C0 + 9 * C1
+    xu, xs = to_nhwc_bf16(x_up, device), to_nhwc_bf16(x_sk, device)
+    y = ops.conv2d(pc, xu, xs)
+    again = [ops.conv2d(pc, xu, xs) for _ in range(2)]
+    assert all(torch.equal(y.view(torch.int16), z.view(torch.int16)) for z in again)
+    if N <= 3:
+        ref = _same_operands_ref(packing, conv, bn, x_up, x_sk, C0)
+        got = from_nhwc(y)
+        assert got.shape == ref.shape
+        assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
+    else:   # many maps: every map against the first occurrence of the same input (the inputs repeat with period 2)
+        xu2, xs2 = xu.clone(), xs.clone()
+        xu2[2:] = xu[:2].repeat((N - 2) // 2, 1, 1, 1)
+        xs2[2:] = xs[:2].repeat((N - 2) // 2, 1, 1, 1)
+        y2 = ops.conv2d(pc, xu2, xs2)
+        assert torch.equal(y2[2:].view(torch.int16), y2[:2].repeat((N - 2) // 2, 1, 1, 1).view(torch.int16))   # a map's bits do not depend on its place in the walk
+        assert torch.equal(y2[:2].view(torch.int16), y[:2].view(torch.int16))
+
+
+@pytest.mark.parametrize("C0,C1,Cout,N,H,W", STREAMED[:2])
+def test_streamed_parity_class_layer_against_the_unmodified_fp32_oracle(device, C0, C1, Cout, N, H, W):
+    """PARITY test (same bounds as conv8_1's above): the streamed parity-class kernel and the 9-tap streamed kernel against the oracle's fp32
+    9-tap layer on the nearest-upsampled operand."""
+    from v2x_sim_amd import ops, packing
+    conv, bn = _layer(C0, C1, Cout, seed=5 + H)
+    x_up, x_sk = _inputs(N, C0, C1, H, W, seed=9 + W)
+    ref = _oracle_fp32(conv, bn, x_up, x_sk)
+    scale, shift = packing.fold_bn(conv.bias, bn, Cout)
+    forms = {"parity-class": packing.pack_conv_stream_parity("l", conv.weight, scale, shift, C0=C0, C1=C1, device=device),
+             "9-tap": packing.pack_conv_stream("l", conv.weight, scale, shift, C0=C0, C1=C1, up0=1, device=device)}
+    err = {}
+    for name, pc in forms.items():
+        got = from_nhwc(_run(ops, pc, x_up, x_sk, device))
+        d = got - ref
+        err[name] = (float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), float(d.abs().max() / ref.abs().max()))
+        assert err[name][0] <= 4e-3 and err[name][1] <= 3e-2, (name, err[name])
+    assert abs(err["parity-class"][0] - err["9-tap"][0]) <= 0.25 * err["9-tap"][0], err

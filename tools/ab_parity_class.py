@@ -18,11 +18,15 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    for name, c0, c1, cout, hw in (("conv8_1", 64, 32, 32, 256),):
+    for name, c0, c1, cout, hw in (("conv8_1", 64, 32, 32, 256), ("conv5_1", 512, 256, 256, 32), ("conv6_1", 256, 128, 128, 64)):
         w = torch.randn(cout, c0 + c1, 3, 3, generator=g) * (2.0 / ((c0 + c1) * 9)) ** 0.5
         sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
-        forms = {"9-tap": packing.pack_conv_halo(name, w, sc, sh, C0=c0, C1=c1, device=dev),
-                 "parity": packing.pack_conv_halo_parity(name, w, sc, sh, C0=c0, C1=c1, device=dev)}
+        if cout == 32:
+            forms = {"9-tap": packing.pack_conv_halo(name, w, sc, sh, C0=c0, C1=c1, device=dev),
+                     "parity": packing.pack_conv_halo_parity(name, w, sc, sh, C0=c0, C1=c1, device=dev)}
+        else:
+            forms = {"9-tap": packing.pack_conv_stream(name, w, sc, sh, C0=c0, C1=c1, up0=1, device=dev),
+                     "parity": packing.pack_conv_stream_parity(name, w, sc, sh, C0=c0, C1=c1, device=dev)}
         x0 = torch.relu(torch.randn(maps, hw // 2, hw // 2, c0, generator=g)).to(torch.bfloat16).to(dev)
         x1 = torch.relu(torch.randn(maps, hw, hw, c1, generator=g)).to(torch.bfloat16).to(dev)
         out = torch.empty((maps, hw, hw, cout), dtype=torch.bfloat16, device=dev)

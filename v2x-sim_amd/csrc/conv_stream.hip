@@ -854,6 +854,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (grp == 0) __builtin_amdgcn_s_barrier();   // balance the offset barrier of group 1
 }
 
+int v2x_conv_stream_pc_launch(const StreamArgs &a, hipStream_t s);   // conv_stream_pc.hip
+
 int v2x_num_cus() {   // also used by conv_halo_pair.hip
     // hipDeviceGetAttribute, NOT hipGetDeviceProperties: one call of the latter anywhere in the process made EVERY kernel of
     // the step 4-8 % slower on the MI355X boxes (interleaved A/B, 4 250 vs 4 440 frames/s; a clock/power-state side effect)
@@ -1810,6 +1812,13 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     // 16-byte output stores (stream_epilogue X4): rows of the output view 16-byte aligned, whole 32-channel pairs of tiles
     a.x4 = (v2x_tune(V2X_TUNE_STORE_X4) != 0 && (d->epilogue == V2X_EPI_BF16 || d->epilogue == V2X_EPI_GRU) && (d->Cout2 > 0 ? d->Cout2 : d->Cout) % 32 == 0 &&
             d->out_cstride % 8 == 0 && d->out_coff % 8 == 0 && (reinterpret_cast<uintptr_t>(d->out) & 15) == 0) ? 1 : 0;
+    if (d->w_layout == 4) {   // parity-class form of a decoder `_1` layer (conv_stream_pc.hip): its own kernel, by the packing
+        if (t16 || d->H % 16 != 0 || d->up0 != 1 || d->C0 <= 0 || d->C1 <= 0 || d->Cout % 128 != 0 || d->epilogue != V2X_EPI_BF16 || d->Cout2 > 0 || d->splitk > 1) return 1;
+        a.tiles_y = d->H / 16;
+        a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
+        a.n_co_tiles = d->Cout / 128;
+        return v2x_conv_stream_pc_launch(a, s);
+    }
     const bool chain = d->Cout2 > 0;
     if (d->splitk > 1) {
         // small-batch form: the 4-wave kernel with the chunk range divided over blockIdx.y + the reduce kernel.  Plain and GRU epilogues,

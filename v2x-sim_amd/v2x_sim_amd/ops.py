@@ -114,6 +114,8 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
                 return "conv3x3_stream8g_kernel<%d, %d, %s>" % (rows, epi, "true" if tiled else "false")  # 8 waves, three taps per synchronisation
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
         return "conv3x3_stream_kernel<%d, %d, %d, %d, false>" % (rows, th, tw, epi)
+    if pc.w_layout == 4:
+        return "conv3x3_stream8p_kernel"   # streamed parity-class form (conv5_1, conv6_1)
     if pc.w_layout == 3:
         return "conv3x3_halo_ppc_kernel<%d, %d, %d>" % (pc.C0, pc.C1, pc.Cout)   # parity-class form (pre-summed 2x2-tap weights for the upsampled source)
     if pc.w_layout == 1:
@@ -378,7 +380,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
         nbytes = in0.numel() * (4 if from_bits else 2) + (in1.numel() * 2 if in1 is not None else 0) + pc.weight.numel() * 2 \
             + M * cfin * (4 if pc.epilogue == V2X_EPI_F32 else 2)
         flops = 2.0 * M * (rows_logical * k_logical + (pc.Cout2 or 0) * pc.Cout)
-        if pc.w_layout == 3:   # parity-class form: the FLOPs the kernel EXECUTES (4 taps on the upsampled source); the reference's 9-tap count is
+        if pc.w_layout in (3, 4):   # parity-class forms: the FLOPs the kernel EXECUTES (4 taps on the upsampled source); the reference's 9-tap count is
             flops = 2.0 * M * pc.Cout * (4 * pc.C0 + 9 * pc.C1)   # reported separately (bench.py: reference_flops)
         prof = _Prof(conv_kernel_name(pc, H, W, from_bits, N) if splitk <= 1 else
                      "conv3x3_%sstream_kernel<%d, split-K %d> + splitk_reduce" % ("s2_" if pc.stride == 2 else "", lib.v2x_conv_stream_tile_rows(pc.Cout, pc.epilogue), splitk),
@@ -904,6 +906,8 @@ def halo_eligible(H, W, w_layout=1, cmax=0):
     in 20 bits (conv_halo.hip: (10 W + 34) cmax < 2^20, i.e. W < 1 635 at 64 channels); wider maps take the layer's fallback."""
     if w_layout in (1, 3) and (10 * W + 34) * cmax >= (1 << 20):
         return False
+    if w_layout == 4:
+        return H % 16 == 0 and W % 32 == 0      # the streamed parity-class kernel: 16 x 32 tiles only
     if H % 8 == 0 and W % 32 == 0:
         return True
     return w_layout == 2 and H % 16 == 0 and W % 16 == 0  # the streamed kernel also has 16x16 tiles
@@ -928,7 +932,7 @@ def run_layer(layer, in0, in1=None, zbits=0):
             return conv2d(h, in0, in1, split=layer.split, splitk=small_batch_splitk(h, in0.shape[0], H, W))
     elif h is not None and halo_eligible(H, W, h.w_layout, max(h.C0, h.C1 or 0)):
         use = True
-        if h.w_layout == 2:
+        if h.w_layout in (2, 4):
             # streamed kernel = one 256-pixel x <=128-channel tile per workgroup.  The choice looks at the map extent
             # only, never at the batch: kernel selection must not change with the number of items a rank owns, or
             # R-rank results would stop being bitwise equal to 1-rank results.  16x16 maps give Cout/128 workgroups

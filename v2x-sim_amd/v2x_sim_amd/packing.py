@@ -516,6 +516,26 @@ def pack_conv_halo_parity(name, weight, scale, shift, *, C0, C1, relu=True, devi
                       w_kpad=16 * C0 + 9 * C1, w_layout=3, Cout2=0)
 
 
+def pack_conv_stream_parity(name, weight, scale, shift, *, C0, C1, relu=True, device="cuda"):
+    """Decoder layer cat(up(in0) [C0], in1 [C1]) -> 3x3 with Cout % 128 == 0 in the parity-class form of the STREAMED kernel (w_layout 4,
+    conv_stream_pc.hip: conv5_1, conv6_1).  Per 128-row channel tile: [C0 / 32][class tap 2a + b][class 2py + px][4 k-slots][128][8] with the
+    pre-summed weights of parity_class_weights, then [C1 / 32][kx][ky][4 k-slots][128][8]; + 64 B of zeros (the kernel's zero page) at the end."""
+    w = _home(weight)
+    cout, cin, k, _ = w.shape
+    if k != 3 or C0 + C1 != cin or C0 % 32 or C1 % 32 or not C0 or not C1 or cout % 128:
+        raise ValueError("%s: the streamed parity-class form needs a 3x3 layer on cat(up(C0), C1), C0 and C1 multiples of 32, Cout of 128" % name)
+    nt, n_up, n_sk = cout // 128, C0 // 32, C1 // 32
+    up = parity_class_weights(w[:, :C0])                                                   # [cls][tap][cout][C0]
+    up = up.view(4, 4, nt, 128, n_up, 4, 8).permute(2, 4, 1, 0, 5, 3, 6).contiguous()      # [tile][chunk][tap][cls][k-slot][row][8]
+    sk = w[:, C0:].reshape(nt, 128, n_sk, 4, 8, 3, 3).permute(0, 2, 6, 5, 3, 1, 4).contiguous()   # [tile][chunk][kx][ky][k-slot][row][8]
+    flat = torch.cat([up.view(nt, -1), sk.view(nt, -1)], 1).reshape(-1)
+    flat = torch.cat([flat, torch.zeros(32, dtype=flat.dtype, device=flat.device)])
+    return PackedConv(name=name, weight=flat.to(torch.bfloat16).to(device).contiguous(),
+                      scale=scale.detach().float().to(device).contiguous(), shift=shift.detach().float().to(device).contiguous(),
+                      C0=C0, C1=C1, Cout=cout, ksize=3, stride=1, pad=1, up0=1, epilogue=V2X_EPI_BF16, relu=relu, w_rows=cout,
+                      w_kpad=16 * C0 + 9 * C1, w_layout=4, Cout2=0)
+
+
 def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
     """conv+BN(+ReLU) as an ops.Layer: gather-kernel packing always, plus the packing of the patch-based kernel that
     covers the layer -- halo (3x3 stride 1, <= 96 input channels), streamed (3x3 stride 1, >= 128 input channels),
@@ -534,6 +554,9 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         elif key in ((0, 32, 32), (64, 32, 32), (0, 64, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):   # (0, 64, 32): no model layer; the data gradient of conv1_1 (train_layout)
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
+        elif (fb.C1 and fb.up0 == 1 and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 128 == 0 and STREAM_KERNEL
+              and tuning.get("PARITY_CLASS") >= 2):   # conv5_1, conv6_1: streamed parity-class form (PARITY_CLASS = 2: also the streamed layers)
+            h = pack_conv_stream_parity(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, relu=relu, device=device)
         elif (cin_p >= (64 if STREAM_64 else 128) and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
               and STREAM_KERNEL):
             h = pack_conv_stream(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, up0=fb.up0, relu=relu,
