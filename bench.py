@@ -50,8 +50,10 @@ TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffi
 # algorithmic FLOPs of one 5-agent frame, points -> logits: encoder + decoder + heads, + one ConvGRU pass per GNN round
 # (h0 = 0: W_hh is never multiplied and not counted)
 GFLOP_PER_FRAME_BASE, GFLOP_PER_GNN_ROUND = 155.8, 36.2
-# FLOPs the parity-class form of conv8_1 does NOT execute: (9 - 4) taps x 64 upsampled channels x 32 outputs x 256^2 pixels x 2 x 5 agents
-GFLOP_PARITY_CLASS_SAVED = 2 * AGENTS * (9 - 4) * 64 * 32 * 256 * 256 / 1e9
+# FLOPs the parity-class forms do NOT execute, per frame: (9 - 4) taps x upsampled channels x outputs x pixels x 2 x 5 agents -- conv8_1 (PARITY_CLASS >= 1),
+# conv5_1 and conv6_1 (PARITY_CLASS >= 2); each 6.71 GFLOP
+GFLOP_PARITY_CLASS_SAVED = {0: 0.0, 1: 2 * AGENTS * 5 * 64 * 32 * 256 * 256 / 1e9,
+                            2: 2 * AGENTS * 5 * (64 * 32 * 256 * 256 + 512 * 256 * 32 * 32 + 256 * 128 * 64 * 64) / 1e9}
 
 
 def parse(argv=None):
@@ -843,7 +845,7 @@ def main():
         cpu = cpu_baseline(state, args.gnn_iters)
 
     from v2x_sim_amd import tuning as _tuning
-    parity_saved = GFLOP_PARITY_CLASS_SAVED if _tuning.get("PARITY_CLASS") != 0 else 0.0
+    parity_saved = GFLOP_PARITY_CLASS_SAVED[max(0, min(2, _tuning.get("PARITY_CLASS")))]
     if rank == 0:
         rec = {
             "metric": "BEV frames/sec, V2VNet 5-agent detection (256x256 BEV)", "value": fps, "unit": "frames/s",
@@ -860,8 +862,8 @@ def main():
                                     % ("all-gather" if args.transport == "allgather" else "grouped send/recv of the needed rows"))
                                    if world > 1 else "single GPU, no collective",
                        "exec_mode": exec_mode, "hip_graph": bool(mode)},
-            # fraction of the bf16 MFMA peak from the FLOPs the kernels EXECUTE: conv8_1 runs in the parity-class form (4 instead of 9 taps on its
-            # x2-upsampled source, -6.7 GFLOP per frame; tuning switch PARITY_CLASS); the reference's 9-tap count is quoted beside it, never mixed in
+            # fraction of the bf16 MFMA peak from the FLOPs the kernels EXECUTE: conv8_1, conv5_1 and conv6_1 run in the parity-class form (4 instead of
+            # 9 taps on their x2-upsampled source, -6.7 GFLOP per frame each; tuning switch PARITY_CLASS); the reference's 9-tap count is quoted beside it
             "whole_step_frac": (GFLOP_PER_FRAME_BASE + GFLOP_PER_GNN_ROUND * args.gnn_iters - parity_saved) * 1e9 * fps / world / (PEAK_MFMA_TFLOPS * 1e12),
             "executed_gflop_per_frame": GFLOP_PER_FRAME_BASE + GFLOP_PER_GNN_ROUND * args.gnn_iters - parity_saved,
             "reference_gflop_per_frame": GFLOP_PER_FRAME_BASE + GFLOP_PER_GNN_ROUND * args.gnn_iters,

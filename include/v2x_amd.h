@@ -145,7 +145,9 @@ typedef struct v2x_conv_desc {
     int32_t split;       /* multiple of 4; 0 = no split (out2 ignored)                           */
     int32_t out2_cstride;
     /* --- halo-tile kernel (conv_halo.hip): 3x3 stride-1 layers with <= 96 input channels ------ */
-    int32_t w_layout;    /* 3: parity-class form of a decoder layer cat(up(in0), in1) -> 3x3 (conv_halo.hip, conv8_1's shape   */
+    int32_t w_layout;    /* 4: the same for the STREAMED layers (conv_stream_pc.hip: conv5_1, conv6_1; Cout % 128 == 0, H % 16 == 0,    */
+                         /*    W % 32 == 0); w_kpad = 16*C0 + 9*C1                                                                */
+                         /* 3: parity-class form of a decoder layer cat(up(in0), in1) -> 3x3 (conv_halo.hip, conv8_1's shape   */
                          /*    C0 = 64, C1 = 32, Cout = 32; H%8==0, W%32==0): see "weight layouts"; w_kpad = 16*C0 + 9*C1     */
                          /* 0: row-major [w_rows][w_kpad] (gather kernel)                          */
                          /* 1: k-slot-major [9*Cin/8][Cout][8] (halo kernel; H%8==0, W%32==0)      */
@@ -175,7 +177,7 @@ typedef struct v2x_conv_desc {
 
 /* ---------------------------------------------------------------- weight layouts and their packers (HOST side)
  * A checkpoint holds conv weights as fp32 OIHW [Cout][Cin][k][k] (the ConvGRU: weight_ih [3*hidden][Cin][3][3], gates in
- * (r, z, n) order).  Every kernel reads bf16 (round-to-nearest-even) in one of four layouts, selected by
+ * (r, z, n) order).  Every kernel reads bf16 (round-to-nearest-even) in one of five layouts, selected by
  * v2x_conv_desc.w_layout.  With Cin' = Cin zero-padded to `cin_pad`, K = k*k*Cin' and the reduction index
  * kk = (ky*k + kx)*Cin' + c  (tap-major, channels fastest, matching NHWC activations):
  *
@@ -199,6 +201,10 @@ typedef struct v2x_conv_desc {
  *       [class 2*py+px][tap 2*a+b][c_up/8][Cout][8] followed by the skip half [tap 3*ky+kx][C1/8][Cout][8];  w_rows = Cout,
  *       w_kpad = 16*c_up + 9*C1.  (No upstream counterpart: an exact identity in real arithmetic; the tests hold the kernel to the
  *       unmodified fp32 9-tap layer at the tolerance of the 9-tap kernel.)
+ *   w_layout 4 (streamed parity-class kernel; the same identity for Cout % 128 == 0): per 128-row channel tile
+ *       [c_up/32 chunks][class tap 2*a+b][class 2*py+px][4 k-slots][128 rows][8] with the pre-summed weights of layout 3, then
+ *       [C1/32 chunks][kx][ky][4 k-slots][128 rows][8]; after the last tile 64 B of zeros (the kernel's zero page).  w_rows = Cout,
+ *       w_kpad = 16*c_up + 9*C1.
  *   chained layers (Cout2 > 0; layouts 1 and 2): the rows of the FIRST layer are stored in "chain order": packed row
  *       rho = 16*i + 4*q + r holds output channel kappa = 32*(i>>1) + 8*q + 4*(i&1) + r (a lane's accumulators of the first
  *       GEMM are then exactly its B fragment of the second); its scale / shift stay in natural channel order.  The chained
@@ -213,7 +219,7 @@ typedef struct v2x_pack_spec {
     int32_t w_layout; /* 0, 1 or 2 (above)                                                               */
     int32_t epilogue; /* V2X_EPI_*: selects the row tile; V2X_EPI_GRU = (r, z, n) row regrouping           */
     int32_t chain;    /* 1: the layer is followed by a chained 1x1 (Cout2 > 0): rows in chain order       */
-    int32_t c_up;     /* w_layout 3 only: the first c_up input channels are the x2-upsampled source (v2x_conv_desc.C0); else 0 */
+    int32_t c_up;     /* w_layout 3 and 4 only: the first c_up input channels are the x2-upsampled source (v2x_conv_desc.C0); else 0 */
 } v2x_pack_spec;
 
 /* Bytes of the packed bf16 buffer (0 = unsupported spec, see v2x_last_error) and the w_rows / w_kpad to put in the descriptor. */

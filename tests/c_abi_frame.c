@@ -2,7 +2,7 @@
  *
  *   points --v2x_voxelize_bits--> bit grid --v2x_conv2d_pair / v2x_conv2d x N (encoder)--> pyramid
  *          --v2x_warp_fuse (mean over neighbours) --v2x_conv2d (ConvGRU)--> fused level
- *          --v2x_conv2d x 8 (decoder; conv8_1 in the parity-class layout)--> v2x_conv2d (det heads) --> cls / loc logits
+ *          --v2x_conv2d x 8 (decoder; conv5_1, conv6_1, conv8_1 in the parity-class layouts)--> v2x_conv2d (det heads) --> cls / loc logits
  *          --v2x_det_postprocess--> boxes, scores, anchor indices, counts
  *
  * driven from raw fp32 CHECKPOINT tensors (OIHW weights, BN statistics, biases) through the C packers only (v2x_fold_bn, v2x_pack_conv,
@@ -216,6 +216,8 @@ static packed pack_patch(const ckpt_conv *c, int cin_pad, int C0, int C1, int up
             p = pack(c->w, c->cout, c->cin, 3, 0, 3, V2X_EPI_BF16, 0, C0, sc, sh, c->cout, C0, C1, 1, 1, relu);
         else if ((k0 == 0 && k1 == 32 && c->cout == 32) || (k0 == 0 && k1 == 64 && (c->cout == 32 || c->cout == 64)))
             p = pack(c->w, c->cout, c->cin, 3, cin_h != c->cin ? cin_h : 0, 1, V2X_EPI_BF16, 0, 0, sc, sh, c->cout, cin_h, 0, 0, 1, relu);
+        else if (C1 && up0 == 1 && C0 % 32 == 0 && C1 % 32 == 0 && c->cout % 128 == 0)   /* conv5_1, conv6_1: streamed parity-class form (w_layout 4) */
+            p = pack(c->w, c->cout, c->cin, 3, 0, 4, V2X_EPI_BF16, 0, C0, sc, sh, c->cout, C0, C1, 1, 1, relu);
         else if (cinp >= 64 && (C1 ? C0 : cinp) % 32 == 0 && C1 % 32 == 0 && c->cout % 64 == 0)
             p = pack(c->w, c->cout, c->cin, 3, 0, 2, V2X_EPI_BF16, 0, 0, sc, sh, c->cout, C1 ? C0 : cinp, C1, up0, 1, relu);
     } else if (stride == 2 && !C1 && cinp % 32 == 0 && c->cout % 64 == 0) {
@@ -274,6 +276,7 @@ static void conv(const packed *p, const void *in0, const void *in1, int N, int H
     V2XOK(v2x_conv2d(&d, NULL));
 }
 static int halo_eligible(int H, int W, int layout, int cmax) {
+    if (layout == 4) return H % 16 == 0 && W % 32 == 0;
     if ((layout == 1 || layout == 3) && (long long)(10 * W + 34) * cmax >= (1 << 20)) return 0;
     if (H % 8 == 0 && W % 32 == 0) return 1;
     return layout == 2 && H % 16 == 0 && W % 16 == 0;
@@ -290,7 +293,7 @@ static uint16_t *run_layer(const packed *patch, const packed *fb, const packed *
         if (patch->stride == 2) use = (H % 8 == 0 && W % 64 == 0) || (H % 16 == 0 && W % 32 == 0);
         else {
             const int cmax = patch->C0 > patch->C1 ? patch->C0 : patch->C1;
-            use = halo_eligible(H, W, patch->w_layout, cmax) && (patch->w_layout != 2 || H * W >= 256);
+            use = halo_eligible(H, W, patch->w_layout, cmax) && ((patch->w_layout != 2 && patch->w_layout != 4) || H * W >= 256);
         }
     }
     if (use) {

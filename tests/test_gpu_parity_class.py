@@ -135,6 +135,13 @@ def test_parity_class_packing_is_selected_by_shape_and_switch(device, tune):
     tune.reset("PARITY_CLASS")
     conv7, bn7 = _layer(128, 64, 64, seed=4)
     assert packing.layer_conv_bn("conv7_1", conv7, bn7, device=device, C0=128, C1=64, up0=1).halo.w_layout == 2
+    # conv6_1's shape: the streamed parity-class kernel at PARITY_CLASS = 2 (default), with a 9-tap streamed packing for declared latency launches
+    conv6, bn6 = _layer(256, 128, 128, seed=5)
+    lay = packing.layer_conv_bn("conv6_1", conv6, bn6, device=device, C0=256, C1=128, up0=1)
+    assert lay.halo.w_layout == 4 and lay.latency is not None and lay.latency.w_layout == 2
+    tune("PARITY_CLASS", 1)
+    lay = packing.layer_conv_bn("conv6_1", conv6, bn6, device=device, C0=256, C1=128, up0=1)
+    assert lay.halo.w_layout == 2 and lay.latency is None
 
 
 def test_parity_class_store_forms_walks_and_repeats_are_bit_identical(device, tune):

@@ -102,6 +102,20 @@ def test_layout3_parity_class(cout, c_up, c1):
     assert lib.v2x_pack_conv_size(C.byref(bad), None, None) == 0 and b"layout 3" in lib.v2x_last_error()
 
 
+@pytest.mark.parametrize("cout,c_up,c1", [(256, 512, 256), (128, 256, 128), (128, 64, 32)])
+def test_layout4_streamed_parity_class(cout, c_up, c1):
+    """The streamed parity-class layout (conv_stream_pc.hip): C packer == torch packer bit for bit, zero page included."""
+    w = rnd(cout, c_up + c1, 3, 3, seed=cout + c_up + 1)
+    pc = packing.pack_conv_stream_parity("t", w, torch.ones(cout), torch.zeros(cout), C0=c_up, C1=c1, device="cpu")
+    got, rows, kpad = c_pack(w, layout=4, c_up=c_up)
+    assert (rows, kpad) == (pc.w_rows, pc.w_kpad) == (cout, 16 * c_up + 9 * c1)
+    assert got.size == cout * kpad + 32 and not got[-32:].any()
+    assert np.array_equal(got, bits(pc.weight))
+    lib = _lib.load()
+    bad = PackSpec(Cout=64, Cin=96, ksize=3, cin_pad=0, w_layout=4, epilogue=V2X_EPI_BF16, chain=0, c_up=64)
+    assert lib.v2x_pack_conv_size(C.byref(bad), None, None) == 0 and b"layout 4" in lib.v2x_last_error()
+
+
 def test_gru_layouts_and_bias():
     hid, cin = 256, 512
     w = rnd(3 * hid, cin, 3, 3, seed=1)

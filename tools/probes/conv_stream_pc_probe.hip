@@ -18,12 +18,6 @@
 //   * the two wave groups run half a step apart (one computes while the other loads: stream8g's ping-pong); the LDS holds either phase's
 //     ring + patches in the same 151 KiB.  Each phase has its own prologue; the NEXT tile's up prologue is issued BEFORE this tile's output
 //     stores (vmcnt is in order: the wait then covers the DMAs and leaves the stores in flight).
-// What bounds it (profiles/r05_stream8p_probe.txt, phase-removal builds of tools/probes/conv_stream_pc_probe.hip): the up phase's MFMAs are hidden
-// entirely (removing them: -1 %); its time is the 32 + 3 one-KiB LDS-DMA pieces per step -- 0.9 us per step = ~22 B/clk per CU, the LDS-DMA rate
-// these kernels see everywhere -- so the class decomposition's 4x weight bytes per MFMA, not its MFMA count, sets the layer's time: -19 % against
-// the 9-tap kernel where the MFMA count alone says -37 %.  Variants measured and dropped: four up slots (above), the weight pieces split over
-// both groups (no change), a drain-free up -> skip transition with per-phase waits in group 0 (-8 % instead of -19 %: group 0 then stalls on its
-// own patch piece every step).
 // K order: (up chunk, class tap), then (skip chunk, kx, ky) -- results differ from the 9-tap kernels in the weights (pre-summed, rounded once)
 // and in fp32 summation order; tests/test_gpu_parity_class.py holds this kernel to the unmodified fp32 9-tap oracle layer at the 9-tap
 // kernel's tolerance, and to a torch evaluation of the same bf16 operands.
@@ -41,12 +35,21 @@ constexpr int USTEP = 4 * SLICE, SSTEP = 3 * SLICE;    // bytes a step streams
 constexpr int UP_PIECES = (PH0 * PW0 * 4 + 63) / 64;   // 12 one-KiB pieces
 constexpr int SP_PIECES = (2 * PHF * PWH * 4 + 63) / 64;   // 39
 #ifndef V2X_PCS_USLOTS_BUILD
-#define V2X_PCS_USLOTS_BUILD 3
+#define V2X_PCS_USLOTS_BUILD 4
 #endif
-// up-phase ring: NU slots, the image of step s + NU - 1 streams in while step s computes.  Measured (tools/ab_pcs.sh, profiles/r05_stream8p_probe.txt):
-// four slots are no faster than three (2-4 % slower): the up phase is bound by the CU's LDS-DMA throughput (35 KiB per 32-MFMA step at ~22 B/clk),
-// not by the time a piece has to land.
+// up-phase ring: NU slots, the image of step s + NU - 1 streams in while step s computes.  With three slots a piece has ~1.25 steps to land and the
+// 32-MFMA steps run at the L2 -> LDS latency (~1.0 us per step); with four, 2.25 steps (measured: tools/ab_pcs.sh).
 constexpr int NU = V2X_PCS_USLOTS_BUILD;
+// TIMING EXPERIMENTS ONLY (tools/ab_pcs.sh "-DV2X_PCS_DBG_BUILD=n"; results are garbage): 1 no up-phase weight DMAs, 2 no up-phase MFMAs, 4 no up-phase
+// fragment reads, 8 skip phase left out, 16 up phase left out, 32 no up-phase patch DMAs
+#ifndef V2X_PCS_DBG_BUILD
+#define V2X_PCS_DBG_BUILD 0
+#endif
+constexpr int PDBG = V2X_PCS_DBG_BUILD;
+#ifndef V2X_PCS_SPLITW_BUILD
+#define V2X_PCS_SPLITW_BUILD 0
+#endif
+constexpr int SPLITW = V2X_PCS_SPLITW_BUILD;   // up phase: 1 = every wave streams 4 of a step's 32 weight pieces (every fragment of an up step is read in the load phases, so group 0's load phase also lies behind the last reader of the slot); 0 = group 1's waves 8 each
 constexpr int OFF_P0 = 3 * SSTEP, OFF_P1 = OFF_P0 + SP_PIECES * 1024;
 constexpr int OFF_UPA = NU * USTEP, OFF_UPB = OFF_UPA + UP_PIECES * 1024;
 constexpr int OFF_SS = (OFF_UPB + UP_PIECES * 1024 > OFF_P1 + SP_PIECES * 1024) ? OFF_UPB + UP_PIECES * 1024 : OFF_P1 + SP_PIECES * 1024;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // =============================================== UP PHASE ================================================
         __builtin_amdgcn_s_barrier();                     // the prologue's pieces of every wave have landed
         if (grp == 1) __builtin_amdgcn_s_barrier();       // half-step offset
-        for (int kc = 0; kc < n_up; ++kc) {
+        for (int kc = 0; kc < ((PDBG & 16) ? 0 : n_up); ++kc) {
             const char *pb = smem + up_buf(kc);
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -184,13 +187,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int fjl = ln & 15, fql = ln >> 4;
                 // ---- L: group 1 streams the slot of step st + 2, group 0 the next chunk's patch; the step's 12 fragments
                 [[maybe_unused]] int nw = 0;
-                if (grp == 1) {
+                constexpr int PW_ = SPLITW ? 4 : 8;      // weight pieces a streaming wave issues per step
+                if (grp == 1 || SPLITW) {
                     if (st + NU - 1 < S_up) {
-                        issue_up_weights(st + NU - 1, wv * 8, 8);
-                        nw = 8;
+                        if constexpr ((PDBG & 1) == 0) issue_up_weights(st + NU - 1, SPLITW ? grp * 16 + wv * 4 : wv * 8, PW_);
+                        nw = PW_;
                     }
-                } else if (t < 3 && kc + 1 < n_up) {
-                    issue_up_patch_piece(n, y0, x0, kc + 1, wv + 4 * t, up_buf(kc + 1));
+                }
+                if (grp == 0 && t < 3 && kc + 1 < n_up) {
+                    if constexpr ((PDBG & 32) == 0) issue_up_patch_piece(n, y0, x0, kc + 1, wv + 4 * t, up_buf(kc + 1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 bf16x8_t B[4], A[TCO];
@@ -198,21 +203,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int pc = fjl + tb + px;
                     const char *p = pb + ((4 * grp + py + ta) * PW0 * 4 + pc * 4 + (fql ^ PCS_SWZ(pc))) * 16;
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) B[y] = *reinterpret_cast<const bf16x8_t *>(p + y * (PW0 * 64));
+                    for (int y = 0; y < 4; ++y) {
+                        if constexpr ((PDBG & 4) == 0) B[y] = *reinterpret_cast<const bf16x8_t *>(p + y * (PW0 * 64));
+                        else B[y] = __builtin_bit_cast(bf16x8_t, make_uint4(st, y, fjl, pc));
+                    }
                     const char *ws = smem + (st % NU) * USTEP + wv * SLICE + (fql * BCO + fjl) * 16;
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i) A[i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+                    for (int i = 0; i < TCO; ++i) {
+                        if constexpr ((PDBG & 4) == 0) A[i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+                        else A[i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, fql, 1));
+                    }
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-                if (grp == 1) {
+                if (grp == 1 || SPLITW) {
+                    // the image of step st + 1 has landed: of the pieces this wave streams, only those of the NU - 2 newest steps (PW_ pieces each;
+                    // fewer near the end of the phase) may stay in flight -- for group 0 (SPLITW) plus the patch pieces younger than them (at most
+                    // NU - 2: one per step; at t == 3 none is allowed, the next chunk's patch must be there).  vmcnt is in order and the previous tile's
+                    // output stores sit between the prologue's pieces and this phase's: in the tile's first steps they may stay in flight too
                     int keep = 0;
-                    for (int d = 2; d <= NU - 1; ++d) keep += (st + d < S_up) ? 8 : 0;
+                    for (int d = 2; d <= NU - 1; ++d) keep += (st + d < S_up) ? PW_ : 0;
                     const int stores = (st < NU - 2) ? (a.x4 ? 16 : 32) : 0;
+                    if (grp == 0 && t == 3) keep = 0;
                     switch (keep + stores) {
+                        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
                         case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
                         case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                        case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
                         case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
                         case 32: asm volatile("s_waitcnt vmcnt(32)" ::: "memory"); break;
+                        case 36: asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); break;
                         case 40: asm volatile("s_waitcnt vmcnt(40)" ::: "memory"); break;
                         case 48: asm volatile("s_waitcnt vmcnt(48)" ::: "memory"); break;
                         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
@@ -227,7 +246,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int i = 0; i < TCO; ++i)
 #pragma unroll
-                    for (int y = 0; y < 4; ++y) acc[i][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], B[y], acc[i][y], 0, 0, 0);
+                    for (int y = 0; y < 4; ++y) {
+                        if constexpr ((PDBG & 2) == 0) acc[i][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], B[y], acc[i][y], 0, 0, 0);
+                        else if (y == 0) acc[i][0] += __builtin_bit_cast(f32x4_t, A[i]) + __builtin_bit_cast(f32x4_t, B[i & 3]);
+                    }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();
-        for (int kc = 0; kc < n_sk; ++kc) {
+        for (int kc = 0; kc < ((PDBG & 8) ? 0 : n_sk); ++kc) {
             const char *pb = smem + sk_buf(kc);
 #pragma unroll 1
             for (int kx = 0; kx < 3; ++kx) {

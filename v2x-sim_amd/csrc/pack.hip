@@ -82,6 +82,16 @@ static int pack_geometry(const v2x_pack_spec *p, PackGeom *g) {
         g->elems = (size_t)g->w_kpad * p->Cout;
         return V2X_OK;
     }
+    case 4: {
+        const int c_up = p->c_up, c1 = g->cin_p - c_up;
+        V2X_REQUIRE(p->ksize == 3 && !gru && !p->chain && g->cin_p == p->Cin && c_up > 0 && c1 > 0 && c_up % 32 == 0 && c1 % 32 == 0 && p->Cout % 128 == 0,
+                    "v2x_pack_conv: layout 4 (streamed parity-class kernel) needs 3x3, no padding, c_up and Cin - c_up multiples of 32 (both > 0), Cout %% 128 == 0");
+        g->w_rows = p->Cout;
+        g->w_kpad = 16 * c_up + 9 * c1;
+        g->tile = 128;
+        g->elems = (size_t)g->w_kpad * p->Cout + 32;   // + 64 B of zeros: the kernel's zero page
+        return V2X_OK;
+    }
     default:
         v2x_set_error("v2x_pack_conv: w_layout=%d unknown", p->w_layout);
         return V2X_EINVAL;
@@ -103,6 +113,41 @@ extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16
     V2X_REQUIRE(w_oihw && dst, "v2x_pack_conv: null pointer");
     const int ks = p->ksize, taps = ks * ks, cin = p->Cin, cin_p = g.cin_p, K = g.K;
     const bool gru = p->epilogue == V2X_EPI_GRU;
+    if (p->w_layout == 4) {   // streamed parity-class form: per 128-row tile [up chunk][class tap][class][k-slot][row][8], then [skip chunk][kx][ky][k-slot][row][8]
+#pragma clang fp contract(off)
+        static const int G[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};
+        const int c_up = p->c_up, c1 = cin - c_up, cout = p->Cout;
+        size_t o = 0;
+        for (int tl = 0; tl < cout / 128; ++tl) {
+            for (int kc = 0; kc < c_up / 32; ++kc)
+                for (int t = 0; t < 4; ++t)
+                    for (int cls = 0; cls < 4; ++cls) {
+                        const int py = cls >> 1, px = cls & 1, a = t >> 1, b = t & 1;
+                        for (int slot = 0; slot < 4; ++slot)
+                            for (int r = 0; r < 128; ++r)
+                                for (int j = 0; j < 8; ++j, ++o) {
+                                    const float *ws = w_oihw + ((size_t)(tl * 128 + r) * cin + kc * 32 + slot * 8 + j) * 9;
+                                    float acc = 0.0f;
+                                    bool first = true;
+                                    for (int ky = G[py][a][0]; ky <= G[py][a][1]; ++ky)
+                                        for (int kx = G[px][b][0]; kx <= G[px][b][1]; ++kx) {
+                                            acc = first ? ws[ky * 3 + kx] : acc + ws[ky * 3 + kx];
+                                            first = false;
+                                        }
+                                    dst[o] = host_bf16_rne(acc);
+                                }
+                    }
+            for (int kc = 0; kc < c1 / 32; ++kc)
+                for (int kx = 0; kx < 3; ++kx)
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int slot = 0; slot < 4; ++slot)
+                            for (int r = 0; r < 128; ++r)
+                                for (int j = 0; j < 8; ++j, ++o)
+                                    dst[o] = host_bf16_rne(w_oihw[((size_t)(tl * 128 + r) * cin + c_up + kc * 32 + slot * 8 + j) * 9 + ky * 3 + kx]);
+        }
+        for (int j = 0; j < 32; ++j) dst[o + j] = 0;
+        return V2X_OK;
+    }
     if (p->w_layout == 3) {   // parity-class form: pre-summed 2x2-tap weights for the upsampled source (fp32 sums, (ky, kx) ascending, ONE rounding)
 #pragma clang fp contract(off)
         static const int G[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};   // [parity][class tap] -> first and last 3x3 tap
@@ -244,7 +289,7 @@ static int fill_pack_job(const v2x_pack_spec *p, const float *w_oihw_dev, int tr
     const int rc = pack_geometry(p, &g);
     if (rc != V2X_OK) return rc;
     V2X_REQUIRE(w_oihw_dev && dst_dev, "%s: null pointer", who);
-    V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain && p->w_layout != 3, "%s: plain layers only (no GRU regrouping, no chain order, no parity-class sums)", who);
+    V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain && p->w_layout != 3 && p->w_layout != 4, "%s: plain layers only (no GRU regrouping, no chain order, no parity-class sums)", who);
     V2X_REQUIRE(transform == 0 || transform == 1, "%s: transform must be 0 or 1", who);
     V2X_REQUIRE(g.elems % 8 == 0, "%s: internal: destination not a whole number of 16-byte groups", who);
     d.w = w_oihw_dev;

@@ -849,10 +849,11 @@ class Layer:
     conv_halo.hip (3x3 stride 1, H % 8 == 0, W % 32 == 0); `fallback` is the list of gather-kernel
     convs computing the same thing for any other extent.  `split` > 0: two output tensors."""
 
-    __slots__ = ("halo", "fallback", "split", "name", "det")
+    __slots__ = ("halo", "fallback", "split", "name", "det", "latency")
 
-    def __init__(self, fallback, halo=None, split=0, name=None):
+    def __init__(self, fallback, halo=None, split=0, name=None, latency=None):
         self.fallback, self.halo, self.split = list(fallback), halo, split
+        self.latency = latency   # a 9-tap streamed packing for DECLARED latency launches when `halo` is a form without split-K (the streamed parity-class kernel)
         self.det = None      # det heads only: the packing with the score threshold in the epilogue (packing.pack_heads_det)
         self.name = name or self.fallback[0].name
 
@@ -926,6 +927,10 @@ def run_layer(layer, in0, in1=None, zbits=0):
     else:
         H, W = in0.shape[1], in0.shape[2]
     h = layer.halo
+    if layer.latency is not None and latency_launches():
+        sk = small_batch_splitk(layer.latency, in0.shape[0], H, W)
+        if sk > 1:
+            return conv2d(layer.latency, in0, in1, split=layer.split, splitk=sk)
     if h is not None and h.stride == 2:
         # stride-2 streamed kernel: 4x32 output tiles, or 8x16 ones for narrow maps (conv4_1: 16x16 outputs)
         if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and tuning.get("S2_T16") != 0):

@@ -557,6 +557,10 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         elif (fb.C1 and fb.up0 == 1 and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 128 == 0 and STREAM_KERNEL
               and tuning.get("PARITY_CLASS") >= 2):   # conv5_1, conv6_1: streamed parity-class form (PARITY_CLASS = 2: also the streamed layers)
             h = pack_conv_stream_parity(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, relu=relu, device=device)
+            # declared latency launches (a handful of maps) split K over several workgroups per tile (ops.small_batch_splitk): that form exists for
+            # the 9-tap streamed layout only, so the layer carries it as well
+            lat = pack_conv_stream(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, up0=fb.up0, relu=relu, device=device)
+            return Layer([fb], h, name=name, latency=lat)
         elif (cin_p >= (64 if STREAM_64 else 128) and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 64 == 0
               and STREAM_KERNEL):
             h = pack_conv_stream(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, up0=fb.up0, relu=relu,
