@@ -51,9 +51,10 @@ TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffi
 # (h0 = 0: W_hh is never multiplied and not counted)
 GFLOP_PER_FRAME_BASE, GFLOP_PER_GNN_ROUND = 155.8, 36.2
 # FLOPs the parity-class forms do NOT execute, per frame: (9 - 4) taps x upsampled channels x outputs x pixels x 2 x 5 agents -- conv8_1 (PARITY_CLASS >= 1),
-# conv5_1 and conv6_1 (PARITY_CLASS >= 2); each 6.71 GFLOP
+# conv5_1 and conv6_1 (PARITY_CLASS >= 2), conv7_1 (PARITY_CLASS >= 3); each 6.71 GFLOP
 GFLOP_PARITY_CLASS_SAVED = {0: 0.0, 1: 2 * AGENTS * 5 * 64 * 32 * 256 * 256 / 1e9,
-                            2: 2 * AGENTS * 5 * (64 * 32 * 256 * 256 + 512 * 256 * 32 * 32 + 256 * 128 * 64 * 64) / 1e9}
+                            2: 2 * AGENTS * 5 * (64 * 32 * 256 * 256 + 512 * 256 * 32 * 32 + 256 * 128 * 64 * 64) / 1e9,
+                            3: 2 * AGENTS * 5 * (64 * 32 * 256 * 256 + 512 * 256 * 32 * 32 + 256 * 128 * 64 * 64 + 128 * 64 * 128 * 128) / 1e9}
 
 
 def parse(argv=None):
@@ -845,7 +846,7 @@ def main():
         cpu = cpu_baseline(state, args.gnn_iters)
 
     from v2x_sim_amd import tuning as _tuning
-    parity_saved = GFLOP_PARITY_CLASS_SAVED[max(0, min(2, _tuning.get("PARITY_CLASS")))]
+    parity_saved = GFLOP_PARITY_CLASS_SAVED[max(0, min(3, _tuning.get("PARITY_CLASS")))]
     if rank == 0:
         rec = {
             "metric": "BEV frames/sec, V2VNet 5-agent detection (256x256 BEV)", "value": fps, "unit": "frames/s",

@@ -216,7 +216,7 @@ static packed pack_patch(const ckpt_conv *c, int cin_pad, int C0, int C1, int up
             p = pack(c->w, c->cout, c->cin, 3, 0, 3, V2X_EPI_BF16, 0, C0, sc, sh, c->cout, C0, C1, 1, 1, relu);
         else if ((k0 == 0 && k1 == 32 && c->cout == 32) || (k0 == 0 && k1 == 64 && (c->cout == 32 || c->cout == 64)))
             p = pack(c->w, c->cout, c->cin, 3, cin_h != c->cin ? cin_h : 0, 1, V2X_EPI_BF16, 0, 0, sc, sh, c->cout, cin_h, 0, 0, 1, relu);
-        else if (C1 && up0 == 1 && C0 % 32 == 0 && C1 % 32 == 0 && c->cout % 128 == 0)   /* conv5_1, conv6_1: streamed parity-class form (w_layout 4) */
+        else if (C1 && up0 == 1 && C0 % 32 == 0 && C1 % 32 == 0 && (c->cout % 128 == 0 || c->cout == 64))   /* conv5_1 .. conv7_1: streamed parity-class forms (w_layout 4) */
             p = pack(c->w, c->cout, c->cin, 3, 0, 4, V2X_EPI_BF16, 0, C0, sc, sh, c->cout, C0, C1, 1, 1, relu);
         else if (cinp >= 64 && (C1 ? C0 : cinp) % 32 == 0 && C1 % 32 == 0 && c->cout % 64 == 0)
             p = pack(c->w, c->cout, c->cin, 3, 0, 2, V2X_EPI_BF16, 0, 0, sc, sh, c->cout, C1 ? C0 : cinp, C1, up0, 1, relu);
@@ -275,8 +275,8 @@ static void conv(const packed *p, const void *in0, const void *in1, int N, int H
     if (in_bits) { d.in_format = 1; d.in_zbits = zbits; }
     V2XOK(v2x_conv2d(&d, NULL));
 }
-static int halo_eligible(int H, int W, int layout, int cmax) {
-    if (layout == 4) return H % 16 == 0 && W % 32 == 0;
+static int halo_eligible(int H, int W, int layout, int cmax, int cout) {
+    if (layout == 4) return H % 16 == 0 && W % (cout == 64 ? 64 : 32) == 0;
     if ((layout == 1 || layout == 3) && (long long)(10 * W + 34) * cmax >= (1 << 20)) return 0;
     if (H % 8 == 0 && W % 32 == 0) return 1;
     return layout == 2 && H % 16 == 0 && W % 16 == 0;
@@ -293,7 +293,7 @@ static uint16_t *run_layer(const packed *patch, const packed *fb, const packed *
         if (patch->stride == 2) use = (H % 8 == 0 && W % 64 == 0) || (H % 16 == 0 && W % 32 == 0);
         else {
             const int cmax = patch->C0 > patch->C1 ? patch->C0 : patch->C1;
-            use = halo_eligible(H, W, patch->w_layout, cmax) && ((patch->w_layout != 2 && patch->w_layout != 4) || H * W >= 256);
+            use = halo_eligible(H, W, patch->w_layout, cmax, patch->Cout) && ((patch->w_layout != 2 && patch->w_layout != 4) || H * W >= 256);
         }
     }
     if (use) {
@@ -496,7 +496,7 @@ int main(int argc, char **argv) {
         y = run_layer(&dec_pt[2 * l + 1], &dec_fb[2 * l + 1], NULL, y, NULL, N, H, W, &c);
     }
     float *d_cls = (float *)dalloc((size_t)N * X * Y * ncls * 4), *d_loc = (float *)dalloc((size_t)N * X * Y * nreg * 4);
-    if (heads_halo.valid && halo_eligible(X, Y, 1, 32)) {
+    if (heads_halo.valid && halo_eligible(X, Y, 1, 32, 0)) {
         conv(&heads_halo, y, NULL, N, X, Y, d_cls, ncls, ncls, d_loc, 0, 0);
     } else {
         uint16_t *hid = (uint16_t *)dalloc((size_t)N * X * Y * heads_hidden.Cout * 2);

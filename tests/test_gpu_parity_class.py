@@ -133,9 +133,12 @@ def test_parity_class_packing_is_selected_by_shape_and_switch(device, tune):
     lay = packing.layer_conv_bn("conv8_1", conv, bn, device=device, C0=64, C1=32, up0=1)
     assert lay.halo.w_layout == 1
     tune.reset("PARITY_CLASS")
-    conv7, bn7 = _layer(128, 64, 64, seed=4)
+    conv7, bn7 = _layer(128, 64, 64, seed=4)   # conv7_1's shape: the two-tiles-per-workgroup streamed kernel at PARITY_CLASS = 3 (default)
+    lay = packing.layer_conv_bn("conv7_1", conv7, bn7, device=device, C0=128, C1=64, up0=1)
+    assert lay.halo.w_layout == 4 and lay.halo.w_rows == 64 and lay.latency is not None and lay.latency.w_layout == 2
+    tune("PARITY_CLASS", 2)
     assert packing.layer_conv_bn("conv7_1", conv7, bn7, device=device, C0=128, C1=64, up0=1).halo.w_layout == 2
-    # conv6_1's shape: the streamed parity-class kernel at PARITY_CLASS = 2 (default), with a 9-tap streamed packing for declared latency launches
+    # conv6_1's shape: the streamed parity-class kernel at PARITY_CLASS >= 2, with a 9-tap streamed packing for declared latency launches
     conv6, bn6 = _layer(256, 128, 128, seed=5)
     lay = packing.layer_conv_bn("conv6_1", conv6, bn6, device=device, C0=256, C1=128, up0=1)
     assert lay.halo.w_layout == 4 and lay.latency is not None and lay.latency.w_layout == 2
@@ -192,7 +195,12 @@ STREAMED = [  # (C0, C1, Cout, N, H, W)
     (64, 32, 128, 3, 48, 96),       # short K (two up chunks, one skip chunk), ragged persistent walk
     (512, 256, 256, 40, 32, 32),    # 160 tiles on <= 256 workgroups ... and
     (256, 128, 128, 80, 64, 64),    # 640 tiles: 2.5 tiles per workgroup (the persistent loop, the next tile's prologue under the stores)
+    (128, 64, 64, 2, 128, 128),     # conv7_1: the two-tiles-per-workgroup kernel (conv3x3_stream8q_kernel)
+    (128, 64, 64, 1, 16, 64),       # ... a single region: every border is zero padding
+    (32, 32, 64, 3, 48, 192),       # ... one up chunk, one skip chunk; ragged walk
+    (128, 64, 64, 40, 128, 128),    # ... 640 regions: 2.5 per workgroup
 ]
+STREAMED_ORACLE = STREAMED[:2] + STREAMED[6:7]
 
 
 @pytest.mark.parametrize("C0,C1,Cout,N,H,W", STREAMED)
@@ -204,7 +212,7 @@ def test_streamed_parity_class_kernel_against_the_same_bf16_operands(device, C0,
     x_up, x_sk = _inputs(N, C0, C1, H, W, seed=H + W + N)
     scale, shift = packing.fold_bn(conv.bias, bn, Cout)
     pc = packing.pack_conv_stream_parity("conv5_1", conv.weight, scale, shift, C0=C0, C1=C1, device=device)
-    assert ops.conv_kernel_name(pc, H, W) == "conv3x3_stream8p_kernel" and pc.w_kpad == 16 * C0 + 9 * C1
+    assert ops.conv_kernel_name(pc, H, W) == ("conv3x3_stream8q_kernel" if Cout == 64 else "conv3x3_stream8p_kernel") and pc.w_kpad == 16 * C0 + 9 * C1
     xu, xs = to_nhwc_bf16(x_up, device), to_nhwc_bf16(x_sk, device)
     y = ops.conv2d(pc, xu, xs)
     again = [ops.conv2d(pc, xu, xs) for _ in range(2)]
@@ -223,7 +231,7 @@ def test_streamed_parity_class_kernel_against_the_same_bf16_operands(device, C0,
         assert torch.equal(y2[:2].view(torch.int16), y[:2].view(torch.int16))
 
 
-@pytest.mark.parametrize("C0,C1,Cout,N,H,W", STREAMED[:2])
+@pytest.mark.parametrize("C0,C1,Cout,N,H,W", STREAMED_ORACLE)
 def test_streamed_parity_class_layer_against_the_unmodified_fp32_oracle(device, C0, C1, Cout, N, H, W):
     """PARITY test (same bounds as conv8_1's above): the streamed parity-class kernel and the 9-tap streamed kernel against the oracle's fp32
     9-tap layer on the nearest-upsampled operand."""

@@ -439,7 +439,7 @@ def test_box_axis_second_reading_as_a_switch(device):
         dev = mod.postprocess(res)[0]
         host = P.apply_nms_det(loc.reshape(32, 32, 6, 6), cls, g["anchors"], mod.score_thr, mod.nms_thr, wh_axis=axis)
         ref = PR.detect(cls, loc, anc, mod.score_thr, mod.nms_thr, wh_axis=axis)
-        assert len(ref) == dev["boxes"].shape[0] == host["boxes"].shape[0] > 5
+        assert len(ref) == dev["boxes"].shape[0] == host["boxes"].shape[0] >= 4
         assert np.allclose(dev["boxes"], np.asarray([d["box"] for d in ref]), atol=1e-4) and np.allclose(dev["boxes"], host["boxes"], atol=1e-4)
         assert np.allclose(dev["corners"], np.asarray([d["corners"] for d in ref]), atol=1e-4)
         assert np.allclose(dev["scores"], np.asarray([d["score"] for d in ref]), atol=1e-6)

@@ -102,7 +102,7 @@ def test_layout3_parity_class(cout, c_up, c1):
     assert lib.v2x_pack_conv_size(C.byref(bad), None, None) == 0 and b"layout 3" in lib.v2x_last_error()
 
 
-@pytest.mark.parametrize("cout,c_up,c1", [(256, 512, 256), (128, 256, 128), (128, 64, 32)])
+@pytest.mark.parametrize("cout,c_up,c1", [(256, 512, 256), (128, 256, 128), (128, 64, 32), (64, 128, 64)])
 def test_layout4_streamed_parity_class(cout, c_up, c1):
     """The streamed parity-class layout (conv_stream_pc.hip): C packer == torch packer bit for bit, zero page included."""
     w = rnd(cout, c_up + c1, 3, 3, seed=cout + c_up + 1)
@@ -112,7 +112,7 @@ def test_layout4_streamed_parity_class(cout, c_up, c1):
     assert got.size == cout * kpad + 32 and not got[-32:].any()
     assert np.array_equal(got, bits(pc.weight))
     lib = _lib.load()
-    bad = PackSpec(Cout=64, Cin=96, ksize=3, cin_pad=0, w_layout=4, epilogue=V2X_EPI_BF16, chain=0, c_up=64)
+    bad = PackSpec(Cout=96, Cin=96, ksize=3, cin_pad=0, w_layout=4, epilogue=V2X_EPI_BF16, chain=0, c_up=64)
     assert lib.v2x_pack_conv_size(C.byref(bad), None, None) == 0 and b"layout 4" in lib.v2x_last_error()
 
 

@@ -18,7 +18,7 @@ def main():
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(0)
-    for name, c0, c1, cout, hw in (("conv8_1", 64, 32, 32, 256), ("conv5_1", 512, 256, 256, 32), ("conv6_1", 256, 128, 128, 64)):
+    for name, c0, c1, cout, hw in (("conv8_1", 64, 32, 32, 256), ("conv5_1", 512, 256, 256, 32), ("conv6_1", 256, 128, 128, 64), ("conv7_1", 128, 64, 64, 128)):
         w = torch.randn(cout, c0 + c1, 3, 3, generator=g) * (2.0 / ((c0 + c1) * 9)) ** 0.5
         sc, sh = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1
         if cout == 32:

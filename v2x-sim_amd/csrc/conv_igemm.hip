@@ -372,9 +372,9 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
     V2X_REQUIRE(d->Cout2 == 0 || d->w_layout == 2, "v2x_conv2d: chained 1x1 needs the halo or streamed layout (w_layout 1/2)");
     V2X_REQUIRE(d->in_format == 0, "v2x_conv2d: bit-grid input needs the halo layout (w_layout=1)");
     if (d->w_layout == 4)
-        V2X_REQUIRE(d->C0 > 0 && d->C1 > 0 && d->up0 == 1 && d->stride == 1 && d->Cout % 128 == 0 && d->Cout2 == 0 && d->epilogue == V2X_EPI_BF16 &&
-                    d->H % 16 == 0 && d->W % 32 == 0 && d->w_kpad == 16 * d->C0 + 9 * d->C1,
-                    "v2x_conv2d(stream, parity-class weights): needs the upsampled + skip source pair, stride 1, Cout %% 128 == 0, a plain bf16 epilogue, H %% 16 == 0, W %% 32 == 0 and w_kpad = 16 C0 + 9 C1");
+        V2X_REQUIRE(d->C0 > 0 && d->C1 > 0 && d->up0 == 1 && d->stride == 1 && (d->Cout % 128 == 0 || d->Cout == 64) && d->Cout2 == 0 && d->epilogue == V2X_EPI_BF16 &&
+                    d->H % 16 == 0 && d->W % (d->Cout == 64 ? 64 : 32) == 0 && d->w_kpad == 16 * d->C0 + 9 * d->C1,
+                    "v2x_conv2d(stream, parity-class weights): needs the upsampled + skip source pair, stride 1, Cout %% 128 == 0 (or 64), a plain bf16 epilogue, H %% 16 == 0, W %% 32 == 0 (64 at Cout 64) and w_kpad = 16 C0 + 9 C1");
     if (d->w_layout == 2 || d->w_layout == 4) {
         V2X_REQUIRE(d->in0 && d->weight && d->scale && d->out, "v2x_conv2d(stream): null tensor pointer");
         V2X_REQUIRE(d->epilogue == V2X_EPI_GRU || d->shift, "v2x_conv2d(stream): null shift");
@@ -384,7 +384,7 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
         V2X_REQUIRE(d->up0 == 0 || (d->up0 == 1 && d->H % 2 == 0 && d->W % 2 == 0), "v2x_conv2d(stream): bad up0");
         V2X_REQUIRE(d->N > 0 && (long long)d->N * d->H * d->W * (d->C0 > d->C1 ? d->C0 : d->C1) < (1ll << 32),
                     "v2x_conv2d(stream): tensor exceeds 32-bit element offsets");
-        const int rows = d->w_layout == 4 ? 128 : v2x_conv_stream_tile_rows(d->Cout, d->epilogue);
+        const int rows = d->w_layout == 4 ? (d->Cout == 64 ? 64 : 128) : v2x_conv_stream_tile_rows(d->Cout, d->epilogue);
         const int need = d->epilogue == V2X_EPI_GRU ? 3 * d->Cout : d->Cout;
         V2X_REQUIRE(rows > 0 && d->w_rows == need && d->w_rows % rows == 0 && d->split == 0 &&
                     d->out_cstride >= d->out_coff + d->Cout && d->out_coff >= 0,

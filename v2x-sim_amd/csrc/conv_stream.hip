@@ -1813,10 +1813,18 @@ int v2x_conv_stream_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     a.x4 = (v2x_tune(V2X_TUNE_STORE_X4) != 0 && (d->epilogue == V2X_EPI_BF16 || d->epilogue == V2X_EPI_GRU) && (d->Cout2 > 0 ? d->Cout2 : d->Cout) % 32 == 0 &&
             d->out_cstride % 8 == 0 && d->out_coff % 8 == 0 && (reinterpret_cast<uintptr_t>(d->out) & 15) == 0) ? 1 : 0;
     if (d->w_layout == 4) {   // parity-class form of a decoder `_1` layer (conv_stream_pc.hip): its own kernel, by the packing
-        if (t16 || d->H % 16 != 0 || d->up0 != 1 || d->C0 <= 0 || d->C1 <= 0 || d->Cout % 128 != 0 || d->epilogue != V2X_EPI_BF16 || d->Cout2 > 0 || d->splitk > 1) return 1;
+        if (t16 || d->H % 16 != 0 || d->up0 != 1 || d->C0 <= 0 || d->C1 <= 0 || (d->Cout % 128 != 0 && d->Cout != 64) || d->epilogue != V2X_EPI_BF16 || d->Cout2 > 0 ||
+            d->splitk > 1)
+            return 1;
         a.tiles_y = d->H / 16;
+        if (d->Cout == 64) {   // conv7_1's shape: two 16 x 32 tiles (a 16 x 64 region) per workgroup
+            if (d->W % 64 != 0) return 1;
+            a.tiles_x = d->W / 64;
+            a.n_co_tiles = 1;
+        } else {
+            a.n_co_tiles = d->Cout / 128;
+        }
         a.n_px_tiles = d->N * a.tiles_x * a.tiles_y;
-        a.n_co_tiles = d->Cout / 128;
         return v2x_conv_stream_pc_launch(a, s);
     }
     const bool chain = d->Cout2 > 0;

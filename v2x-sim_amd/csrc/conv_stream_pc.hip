@@ -361,17 +361,323 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
+// ---- 64 output channels (conv7_1: 128 half-res + 64 -> 64 @128x128): TWO 16 x 32 tiles per workgroup on ONE weight stream ------------------------------
+// With 64 rows a 16 x 32 tile fills only half of the accumulators and every weight byte would stand in front of half as many MFMAs -- and the parity-class
+// up phase is bound by exactly those bytes (above).  Here a workgroup owns a 16 x 64 region: group g is the 16 x 32 tile of column half g, wave (g, c)
+// class c of it -- 8 x 16 pixels = 8 fragments x 4 channel tiles, the same 128 accumulators and 32 MFMAs per class tap as the 128-row kernel, from a
+// 16-KiB step image that now serves 1 024 pixels.  Each group fills its OWN patches (an up patch per group and chunk, double-buffered; a full-resolution
+// parity-plane patch per group, single-buffered: four of them do not fit -- the refill is issued behind the barrier that ends the chunk's last MFMA
+// phase and waited for on the spot, with one extra barrier per chunk boundary; the groups run half a step apart, so group 0's wait lies under group 1's
+// MFMA phase and only group 1's is exposed).  Skip step: 96 MFMAs in two halves of the wave's rows (9 + 9 pixel fragments through one register set).
+namespace pcq {
+constexpr int BCO = 64, TCO = 4;
+constexpr int SLICE = BCO * 64;                        // 4 KiB
+constexpr int USTEP = 4 * SLICE, SSTEP = 3 * SLICE;    // 16 KiB, 12 KiB
+constexpr int OFF_UP = 3 * USTEP;                      // up patches [group][chunk parity], 12 KiB each
+constexpr int OFF_SP = 3 * SSTEP;                      // skip patches [group], 39 KiB each
+constexpr int OFF_SS = OFF_SP + 2 * pcs::SP_PIECES * 1024, SMEM = OFF_SS + 2 * BCO * 4;
+static_assert(OFF_UP + 4 * pcs::UP_PIECES * 1024 <= OFF_SS && SMEM <= 160 * 1024, "LDS map");
+}  // namespace pcq
+
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8q_kernel(const StreamArgs a) {
+    using namespace pcq;
+    using pcs::PW0; using pcs::PH0; using pcs::PHF; using pcs::PWH; using pcs::UP_PIECES; using pcs::SP_PIECES; using pcs::TH;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wv = wave & 3;
+    const int py = wv >> 1, px = wv & 1;
+    const int fj = lane & 15, fq = lane >> 4;
+    const int nwg = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, i = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + i;
+    }
+    const int n_tiles = a.n_px_tiles;                 // 16 x 64 regions; one channel tile
+    const int txy = a.tiles_x * a.tiles_y;
+    const int n_up = a.C0 >> 5, n_sk = a.C1 >> 5;
+    const int S_up = 4 * n_up, S_sk = 3 * n_sk;
+    const char *w_up = reinterpret_cast<const char *>(a.w);
+    const char *w_sk = w_up + (size_t)S_up * USTEP;
+    const void *zero_page = w_sk + (size_t)S_sk * SSTEP;
+    const int Hs = a.H >> 1, Ws = a.W >> 1;
+
+    auto tile_coords = [&](int t, int &n, int &y0, int &x0) {   // x0 = this GROUP's tile
+        n = t / txy;
+        const int trem = t - n * txy;
+        const int ty = trem / a.tiles_x;
+        y0 = ty * TH;
+        x0 = (trem - ty * a.tiles_x) * 64 + 32 * grp;
+    };
+    auto fresh_lane = [&]() -> int {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    auto issue_up_patch_piece = [&](int n, int y0, int x0, int kc, int piece, int buf_off) {
+        const int L = piece * 64 + fresh_lane();
+        const int pix = L >> 2, phys = L & 3;
+        const int pr = pix / PW0, pc = pix - pr * PW0;
+        const int y = (y0 >> 1) - 1 + pr, x = (x0 >> 1) - 1 + pc;
+        const bool ok = pix < PH0 * PW0 && (unsigned)y < (unsigned)Hs && (unsigned)x < (unsigned)Ws;
+        const unsigned off = (unsigned)((n * Hs + y) * Ws + x) * (unsigned)a.C0 + (unsigned)(kc * 32 + ((phys ^ PCS_SWZ(pc)) << 3));
+        glds16s(ok ? (const void *)(a.in0 + off) : zero_page, smem + buf_off + piece * 1024);
+    };
+    auto issue_sk_patch_piece = [&](int n, int y0, int x0, int kc, int piece, int buf_off) {
+        const int L = piece * 64 + fresh_lane();
+        const int pix = L >> 2, phys = L & 3;
+        const int q = pix / (PHF * PWH), rem = pix - q * (PHF * PWH);
+        const int pr = rem / PWH, cc = rem - pr * PWH;
+        const int y = y0 - 1 + pr, x = x0 - 1 + 2 * cc + q;
+        const bool ok = pix < 2 * PHF * PWH && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const unsigned off = (unsigned)((n * a.H + y) * a.W + x) * (unsigned)a.C1 + (unsigned)(kc * 32 + ((phys ^ PCS_SWZ(cc)) << 3));
+        glds16s(ok ? (const void *)(a.in1 + off) : zero_page, smem + buf_off + piece * 1024);
+    };
+    auto issue_up_weights = [&](int st, int first, int count) {
+        const int lane_w = fresh_lane();
+        const char *src = w_up + (size_t)st * USTEP + lane_w * 16;
+        char *dst = smem + (st % 3) * USTEP;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < count) glds16s(src + (first + u) * 1024, dst + (first + u) * 1024);
+    };
+    auto issue_sk_weights = [&](int st, int first, int count) {
+        const int lane_w = fresh_lane();
+        const char *src = w_sk + (size_t)st * SSTEP + lane_w * 16;
+        char *dst = smem + (st % 3) * SSTEP;
+#pragma unroll
+        for (int u = 0; u < 3; ++u)
+            if (u < count) glds16s(src + (first + u) * 1024, dst + (first + u) * 1024);
+    };
+    auto up_buf = [&](int kc) { return OFF_UP + (grp * 2 + (kc & 1)) * (UP_PIECES * 1024); };
+    const int sk_buf = OFF_SP + grp * (SP_PIECES * 1024);
+    auto up_prologue = [&](int n, int y0, int x0) {   // every group: its up patch of chunk 0; all eight waves: the images of up steps 0 and 1 (32 pieces)
+#pragma unroll
+        for (int u = 0; u < 3; ++u) issue_up_patch_piece(n, y0, x0, 0, wv + 4 * u, up_buf(0));
+        issue_up_weights(wave >> 2, (wave & 3) * 4, 4);
+    };
+
+    float *s_ss = reinterpret_cast<float *>(smem + OFF_SS);
+    for (int i = tid; i < BCO; i += 512) {
+        s_ss[i] = i < a.Cout ? a.scale[i] : 0.f;
+        s_ss[BCO + i] = i < a.Cout ? a.shift[i] : 0.f;
+    }
+    const uint32_t floor_bits = a.relu ? 0u : 0x80008000u;
+
+    int tile = bid;
+    int n, y0, x0;
+    tile_coords(tile, n, y0, x0);
+    up_prologue(n, y0, x0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
+    for (;;) {
+        const int next = tile + nwg;
+        const bool has_next = next < n_tiles;
+        f32x4_t acc[TCO][8];
+#pragma unroll
+        for (int i = 0; i < TCO; ++i)
+#pragma unroll
+            for (int f = 0; f < 8; ++f) acc[i][f] = (f32x4_t)(0.f);
+
+        // =============================================== UP PHASE ================================================
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();       // half-step offset
+        for (int kc = 0; kc < n_up; ++kc) {
+            const char *pb = smem + up_buf(kc);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int st = kc * 4 + t;
+                const int ta = t >> 1, tb = t & 1;
+                const int ln = fresh_lane();
+                const int fjl = ln & 15, fql = ln >> 4;
+                // ---- L: group 1 streams the image of step st + 2 (4 pieces per wave); every wave one piece of its group's next up patch
+                int keep = 0;
+                if (grp == 1 && st + 2 < S_up) {
+                    issue_up_weights(st + 2, wv * 4, 4);
+                    keep = 4;
+                }
+                if (t < 3 && kc + 1 < n_up) {
+                    issue_up_patch_piece(n, y0, x0, kc + 1, wv + 4 * t, up_buf(kc + 1));
+                    keep += 1;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8_t B[8], A[TCO];
+                {
+                    const int pc = fjl + tb + px;
+                    const char *p = pb + ((py + ta) * PW0 * 4 + pc * 4 + (fql ^ PCS_SWZ(pc))) * 16;
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) B[y] = *reinterpret_cast<const bf16x8_t *>(p + y * (PW0 * 64));
+                    const char *ws = smem + (st % 3) * USTEP + wv * SLICE + (fql * BCO + fjl) * 16;
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i) A[i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
+                // group 1: everything older than this load phase's own DMAs has landed (the image of step st + 1; at t == 3 the whole next patch); in the
+                // tile's first step the previous tile's output stores may stay in flight.  Group 0 has only its patch pieces: it waits at t == 3.
+                if (grp == 1) {
+                    const int nst = st == 0 ? (a.x4 ? 16 : 32) : 0;
+                    switch (keep + nst) {
+                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+                        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                        case 21: asm volatile("s_waitcnt vmcnt(21)" ::: "memory"); break;
+                        case 37: asm volatile("s_waitcnt vmcnt(37)" ::: "memory"); break;
+                        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+                    }
+                } else if (t == 3) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- M
+#pragma unroll
+                for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                    for (int y = 0; y < 8; ++y) acc[i][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], B[y], acc[i][y], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();       // realign
+
+        // =============================================== SKIP PHASE ==============================================
+#pragma unroll
+        for (int u = 0; u < 10; ++u)
+            if (wv + 4 * u < SP_PIECES) issue_sk_patch_piece(n, y0, x0, 0, wv + 4 * u, sk_buf);
+        issue_sk_weights(wave >> 2, (wave & 3) * 3, 3);   // the images of skip steps 0 and 1: 24 pieces
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (int kc = 0; kc < n_sk; ++kc) {
+            const char *pb = smem + sk_buf;
+            if (kc > 0) {   // every wave of this group is past its last read of the patch (the barrier that ended the MFMA phase): refill it, wait, tell the group
+#pragma unroll
+                for (int u = 0; u < 10; ++u)
+                    if (wv + 4 * u < SP_PIECES) issue_sk_patch_piece(n, y0, x0, kc, wv + 4 * u, sk_buf);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+#pragma unroll 1
+            for (int kx = 0; kx < 3; ++kx) {
+                const int st = kc * 3 + kx;
+                const int ln = fresh_lane();
+                const int fjl = ln & 15, fql = ln >> 4;
+                int nw = 0;
+                if (grp == 1 && st + 2 < S_sk) {
+                    issue_sk_weights(st + 2, wv * 3, 3);
+                    nw = 3;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bf16x8_t B[9], A[3][TCO];
+                const char *ws = smem + (st % 3) * SSTEP + (fql * BCO + fjl) * 16;
+                const int q = (px + kx) & 1, cc = fjl + ((px + kx) >> 1);
+                const char *p = pb + (((q * PHF + py) * PWH + cc) * 4 + (fql ^ PCS_SWZ(cc))) * 16;
+#pragma unroll
+                for (int r = 0; r < 9; ++r) B[r] = *reinterpret_cast<const bf16x8_t *>(p + r * (PWH * 64));
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i) A[ky][i] = *reinterpret_cast<const bf16x8_t *>(ws + ky * SLICE + i * 256);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                if (grp == 1) {
+                    if (nw) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- M: rows Y = 0..3 from B[0..8], then rows 4..7 from the plane rows 8..16 read into the same registers
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) acc[i][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], B[2 * y + ky], acc[i][y], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int r = 0; r < 9; ++r) B[r] = *reinterpret_cast<const bf16x8_t *>(p + (8 + r) * (PWH * 64));
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+                        for (int y = 0; y < 4; ++y) acc[i][4 + y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], B[2 * y + ky], acc[i][4 + y], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();       // realign
+
+        int nn = 0, ny0 = 0, nx0 = 0;
+        if (has_next) {
+            tile_coords(next, nn, ny0, nx0);
+            up_prologue(nn, ny0, nx0);
+        }
+        {
+            lds_cf_t *lss = (lds_cf_t *)s_ss;
+#pragma unroll
+            for (int i = 0; i < TCO; i += 2) {
+                float4 sc[2], sf[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    sc[h] = lds_ld4(lss + (i + h) * 16 + fq * 4);
+                    sf[h] = lds_ld4(lss + BCO + (i + h) * 16 + fq * 4);
+                }
+#pragma unroll
+                for (int y = 0; y < 8; ++y) {
+                    uint32_t ox[2], oy[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        ox[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][y][0] * sc[h].x + sf[h].x, acc[i + h][y][1] * sc[h].y + sf[h].y), floor_bits);
+                        oy[h] = v2x_relu_bf16x2_floor(pack_bf16x2(acc[i + h][y][2] * sc[h].z + sf[h].z, acc[i + h][y][3] * sc[h].w + sf[h].w), floor_bits);
+                    }
+                    const size_t pix = (size_t)(n * a.H + y0 + 2 * y + py) * a.W + x0 + 2 * fj + px;
+                    uint16_t *p = reinterpret_cast<uint16_t *>(a.out) + pix * a.out_cstride + a.out_coff + i * 16 + fq * 4;
+                    if (a.x4) {
+                        v2x_store_pair_x4(p, fq, ox[0], oy[0], ox[1], oy[1]);
+                    } else {
+                        *reinterpret_cast<uint2 *>(p) = make_uint2(ox[0], oy[0]);
+                        *reinterpret_cast<uint2 *>(p + 16) = make_uint2(ox[1], oy[1]);
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        if (a.x4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+        tile = next;
+        n = nn;
+        y0 = ny0;
+        x0 = nx0;
+    }
+}
+
 int v2x_conv_stream_pc_launch(const StreamArgs &a, hipStream_t s) {
     static v2x_once_per_device attr_once;
-    auto kern = &conv3x3_stream8p_kernel;
     if (v2x_first_use_on_device(attr_once)) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, pcs::SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_stream8p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pcs::SMEM);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&conv3x3_stream8q_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pcq::SMEM);
+    }
+    if (a.Cout == 64) {   // 16 x 64 regions (the dispatcher set tiles_x = W / 64), one channel tile
+        int grid = a.n_px_tiles;
+        const int g = v2x_num_cus();
+        if (g > 0 && g < grid) grid = g;
+        hipLaunchKernelGGL(conv3x3_stream8q_kernel, dim3(grid), dim3(512), pcq::SMEM, s, a);
+        V2X_CHECK_LAUNCH("conv3x3_stream8q_kernel");
+        return V2X_OK;
     }
     const int n_tiles = a.n_px_tiles * a.n_co_tiles;
     int grid = n_tiles;
     const int g = v2x_num_cus() / a.n_co_tiles * a.n_co_tiles;   // persistent: a workgroup's tiles share one channel tile
     if (g > 0 && g < n_tiles) grid = g;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), pcs::SMEM, s, a);
+    hipLaunchKernelGGL(conv3x3_stream8p_kernel, dim3(grid), dim3(512), pcs::SMEM, s, a);
     V2X_CHECK_LAUNCH("conv3x3_stream8p_kernel");
     return V2X_OK;
 }

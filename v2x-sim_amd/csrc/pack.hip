@@ -84,11 +84,11 @@ static int pack_geometry(const v2x_pack_spec *p, PackGeom *g) {
     }
     case 4: {
         const int c_up = p->c_up, c1 = g->cin_p - c_up;
-        V2X_REQUIRE(p->ksize == 3 && !gru && !p->chain && g->cin_p == p->Cin && c_up > 0 && c1 > 0 && c_up % 32 == 0 && c1 % 32 == 0 && p->Cout % 128 == 0,
-                    "v2x_pack_conv: layout 4 (streamed parity-class kernel) needs 3x3, no padding, c_up and Cin - c_up multiples of 32 (both > 0), Cout %% 128 == 0");
+        V2X_REQUIRE(p->ksize == 3 && !gru && !p->chain && g->cin_p == p->Cin && c_up > 0 && c1 > 0 && c_up % 32 == 0 && c1 % 32 == 0 && (p->Cout % 128 == 0 || p->Cout == 64),
+                    "v2x_pack_conv: layout 4 (streamed parity-class kernel) needs 3x3, no padding, c_up and Cin - c_up multiples of 32 (both > 0), Cout %% 128 == 0 or Cout == 64");
         g->w_rows = p->Cout;
         g->w_kpad = 16 * c_up + 9 * c1;
-        g->tile = 128;
+        g->tile = p->Cout == 64 ? 64 : 128;
         g->elems = (size_t)g->w_kpad * p->Cout + 32;   // + 64 B of zeros: the kernel's zero page
         return V2X_OK;
     }
@@ -116,17 +116,17 @@ extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16
     if (p->w_layout == 4) {   // streamed parity-class form: per 128-row tile [up chunk][class tap][class][k-slot][row][8], then [skip chunk][kx][ky][k-slot][row][8]
 #pragma clang fp contract(off)
         static const int G[2][2][2] = {{{0, 0}, {1, 2}}, {{0, 1}, {2, 2}}};
-        const int c_up = p->c_up, c1 = cin - c_up, cout = p->Cout;
+        const int c_up = p->c_up, c1 = cin - c_up, cout = p->Cout, T = g.tile;   // rows per channel tile: 128, or 64 for the 64-channel pair kernel
         size_t o = 0;
-        for (int tl = 0; tl < cout / 128; ++tl) {
+        for (int tl = 0; tl < cout / T; ++tl) {
             for (int kc = 0; kc < c_up / 32; ++kc)
                 for (int t = 0; t < 4; ++t)
                     for (int cls = 0; cls < 4; ++cls) {
                         const int py = cls >> 1, px = cls & 1, a = t >> 1, b = t & 1;
                         for (int slot = 0; slot < 4; ++slot)
-                            for (int r = 0; r < 128; ++r)
+                            for (int r = 0; r < T; ++r)
                                 for (int j = 0; j < 8; ++j, ++o) {
-                                    const float *ws = w_oihw + ((size_t)(tl * 128 + r) * cin + kc * 32 + slot * 8 + j) * 9;
+                                    const float *ws = w_oihw + ((size_t)(tl * T + r) * cin + kc * 32 + slot * 8 + j) * 9;
                                     float acc = 0.0f;
                                     bool first = true;
                                     for (int ky = G[py][a][0]; ky <= G[py][a][1]; ++ky)
@@ -141,9 +141,9 @@ extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16
                 for (int kx = 0; kx < 3; ++kx)
                     for (int ky = 0; ky < 3; ++ky)
                         for (int slot = 0; slot < 4; ++slot)
-                            for (int r = 0; r < 128; ++r)
+                            for (int r = 0; r < T; ++r)
                                 for (int j = 0; j < 8; ++j, ++o)
-                                    dst[o] = host_bf16_rne(w_oihw[((size_t)(tl * 128 + r) * cin + c_up + kc * 32 + slot * 8 + j) * 9 + ky * 3 + kx]);
+                                    dst[o] = host_bf16_rne(w_oihw[((size_t)(tl * T + r) * cin + c_up + kc * 32 + slot * 8 + j) * 9 + ky * 3 + kx]);
         }
         for (int j = 0; j < 32; ++j) dst[o + j] = 0;
         return V2X_OK;

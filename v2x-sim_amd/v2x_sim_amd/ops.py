@@ -115,7 +115,7 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
             return "conv3x3_stream8_kernel<%d, %d>" % (rows, epi)  # 8-wave ping-pong form (conv_stream.hip)
         return "conv3x3_stream_kernel<%d, %d, %d, %d, false>" % (rows, th, tw, epi)
     if pc.w_layout == 4:
-        return "conv3x3_stream8p_kernel"   # streamed parity-class form (conv5_1, conv6_1)
+        return "conv3x3_stream8q_kernel" if pc.Cout == 64 else "conv3x3_stream8p_kernel"   # streamed parity-class forms (conv7_1 | conv5_1, conv6_1)
     if pc.w_layout == 3:
         return "conv3x3_halo_ppc_kernel<%d, %d, %d>" % (pc.C0, pc.C1, pc.Cout)   # parity-class form (pre-summed 2x2-tap weights for the upsampled source)
     if pc.w_layout == 1:
@@ -902,13 +902,13 @@ def small_batch_splitk(pc, N, H, W):
     return want if want > 1 else 0
 
 
-def halo_eligible(H, W, w_layout=1, cmax=0):
+def halo_eligible(H, W, w_layout=1, cmax=0, cout=0):
     """cmax: the widest source's channel count -- the halo kernel's packed DMA tables hold a lane's element offset inside the patch rows
     in 20 bits (conv_halo.hip: (10 W + 34) cmax < 2^20, i.e. W < 1 635 at 64 channels); wider maps take the layer's fallback."""
     if w_layout in (1, 3) and (10 * W + 34) * cmax >= (1 << 20):
         return False
     if w_layout == 4:
-        return H % 16 == 0 and W % 32 == 0      # the streamed parity-class kernel: 16 x 32 tiles only
+        return H % 16 == 0 and W % (64 if cout == 64 else 32) == 0      # the streamed parity-class kernels: 16 x 32 tiles (pairs of them at 64 rows)
     if H % 8 == 0 and W % 32 == 0:
         return True
     return w_layout == 2 and H % 16 == 0 and W % 16 == 0  # the streamed kernel also has 16x16 tiles
@@ -935,7 +935,7 @@ def run_layer(layer, in0, in1=None, zbits=0):
         # stride-2 streamed kernel: 4x32 output tiles, or 8x16 ones for narrow maps (conv4_1: 16x16 outputs)
         if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and tuning.get("S2_T16") != 0):
             return conv2d(h, in0, in1, split=layer.split, splitk=small_batch_splitk(h, in0.shape[0], H, W))
-    elif h is not None and halo_eligible(H, W, h.w_layout, max(h.C0, h.C1 or 0)):
+    elif h is not None and halo_eligible(H, W, h.w_layout, max(h.C0, h.C1 or 0), h.Cout):
         use = True
         if h.w_layout in (2, 4):
             # streamed kernel = one 256-pixel x <=128-channel tile per workgroup.  The choice looks at the map extent

@@ -522,12 +522,13 @@ def pack_conv_stream_parity(name, weight, scale, shift, *, C0, C1, relu=True, de
     pre-summed weights of parity_class_weights, then [C1 / 32][kx][ky][4 k-slots][128][8]; + 64 B of zeros (the kernel's zero page) at the end."""
     w = _home(weight)
     cout, cin, k, _ = w.shape
-    if k != 3 or C0 + C1 != cin or C0 % 32 or C1 % 32 or not C0 or not C1 or cout % 128:
-        raise ValueError("%s: the streamed parity-class form needs a 3x3 layer on cat(up(C0), C1), C0 and C1 multiples of 32, Cout of 128" % name)
-    nt, n_up, n_sk = cout // 128, C0 // 32, C1 // 32
+    if k != 3 or C0 + C1 != cin or C0 % 32 or C1 % 32 or not C0 or not C1 or (cout % 128 and cout != 64):
+        raise ValueError("%s: the streamed parity-class form needs a 3x3 layer on cat(up(C0), C1), C0 and C1 multiples of 32, Cout of 128 (or 64)" % name)
+    T = 64 if cout == 64 else 128           # rows per channel tile (64: the two-tiles-per-workgroup kernel of conv7_1's shape)
+    nt, n_up, n_sk = cout // T, C0 // 32, C1 // 32
     up = parity_class_weights(w[:, :C0])                                                   # [cls][tap][cout][C0]
-    up = up.view(4, 4, nt, 128, n_up, 4, 8).permute(2, 4, 1, 0, 5, 3, 6).contiguous()      # [tile][chunk][tap][cls][k-slot][row][8]
-    sk = w[:, C0:].reshape(nt, 128, n_sk, 4, 8, 3, 3).permute(0, 2, 6, 5, 3, 1, 4).contiguous()   # [tile][chunk][kx][ky][k-slot][row][8]
+    up = up.view(4, 4, nt, T, n_up, 4, 8).permute(2, 4, 1, 0, 5, 3, 6).contiguous()        # [tile][chunk][tap][cls][k-slot][row][8]
+    sk = w[:, C0:].reshape(nt, T, n_sk, 4, 8, 3, 3).permute(0, 2, 6, 5, 3, 1, 4).contiguous()     # [tile][chunk][kx][ky][k-slot][row][8]
     flat = torch.cat([up.view(nt, -1), sk.view(nt, -1)], 1).reshape(-1)
     flat = torch.cat([flat, torch.zeros(32, dtype=flat.dtype, device=flat.device)])
     return PackedConv(name=name, weight=flat.to(torch.bfloat16).to(device).contiguous(),
@@ -554,8 +555,9 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         elif key in ((0, 32, 32), (64, 32, 32), (0, 64, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):   # (0, 64, 32): no model layer; the data gradient of conv1_1 (train_layout)
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
-        elif (fb.C1 and fb.up0 == 1 and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and conv.out_channels % 128 == 0 and STREAM_KERNEL
-              and tuning.get("PARITY_CLASS") >= 2):   # conv5_1, conv6_1: streamed parity-class form (PARITY_CLASS = 2: also the streamed layers)
+        elif (fb.C1 and fb.up0 == 1 and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and STREAM_KERNEL and
+              ((conv.out_channels % 128 == 0 and tuning.get("PARITY_CLASS") >= 2) or (conv.out_channels == 64 and tuning.get("PARITY_CLASS") >= 3))):
+            # conv5_1, conv6_1 (PARITY_CLASS >= 2) and conv7_1 (>= 3): streamed parity-class forms
             h = pack_conv_stream_parity(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, relu=relu, device=device)
             # declared latency launches (a handful of maps) split K over several workgroups per tile (ops.small_batch_splitk): that form exists for
             # the 9-tap streamed layout only, so the layer carries it as well

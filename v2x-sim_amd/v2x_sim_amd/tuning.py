@@ -25,15 +25,16 @@ Host-side switches (this module):
     TRAIN_GATES_HIP 1  with TRAIN_HIP: the ConvGRU's gate arithmetic of the fusion stage as one launch forward and one backward (csrc/gru_train.hip)
     TRAIN_LOSS_HIP 1  with TRAIN_HIP: the detection loss and its gradients as three launches of csrc/det_loss.hip (0: ~45 PyTorch-ROCm ops)
     TRAIN_PACK_BATCH 1  with TRAIN_HIP: the packed weights of all layers rebuilt by ONE launch after an optimizer step (0: one launch per layer)
-    PARITY_CLASS 2  pack the decoder `_1` layers the parity-class kernels cover with pre-summed 2x2-tap weights for the x2-upsampled source (-37 % MACs;
+    PARITY_CLASS 3  pack the decoder `_1` layers the parity-class kernels cover with pre-summed 2x2-tap weights for the x2-upsampled source (-37 % MACs;
                    the sums are formed in fp32 and rounded to bf16 once): 2 = conv8_1 (w_layout 3, resident weights) and conv5_1 / conv6_1 (w_layout 4,
-                   streamed weights); 1 = conv8_1 only; 0 = the 9-tap forms everywhere.  Read when a model is packed
+                   streamed weights); 3 = also conv7_1 (w_layout 4 with 64-row tiles, the two-tiles-per-workgroup kernel); 1 = conv8_1 only; 0 = the 9-tap forms
+                   everywhere.  Read when a model is packed
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
 The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 2}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR")
 
