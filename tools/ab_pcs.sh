@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (GPU box): tools/ab_pcs.sh "<flags A>" "<flags B>" ...   -- rebuilds conv_stream_pc.o with each flag set and times the streamed parity-class layers
+# usage (GPU box): tools/ab_pcs.sh "<flags A>" "<flags B>" ...   -- rebuilds conv_stream_pc.o from tools/probes/conv_stream_pc_probe.hip with each flag set and times the streamed parity-class layers
 cd "$(dirname "$0")/.."
 for X in "$@"; do
     rm -f v2x-sim_amd/csrc/build/conv_stream_pc.o
-    make -s -C v2x-sim_amd/csrc FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $X" > /dev/null 2>&1
+    make -s -C v2x-sim_amd/csrc PROBE=conv_stream_pc FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $X" > /dev/null 2>&1
     echo "== flags: $X"
     python3 tools/ab_parity_class.py 320 20 2>&1 | grep -E "conv5_1|conv6_1"
 done

@@ -22,8 +22,14 @@
 
 
 
-// The timing experiments on these kernels (phase-removal builds, per-phase time stamps: tools/stream8_phase_probe.sh, tools/stream8g_timeline.sh) are built
-// from an instrumented COPY of this file, tools/probes/conv_stream_probe.hip (`make PROBE=conv_stream`); this file carries none of that scaffolding.
+// TIMING EXPERIMENTS ONLY (tools/stream8_phase_probe.sh builds the library with -DV2X_STREAM_DBG_BUILD=n): which part of the
+// 8-wave kernel's step is the long pole?  1 = no weight DMAs, 2 = no patch DMAs, 4 = no fragment reads, 8 = no MFMAs, 16 = per-phase time stamps
+// (tools/stream8g_timeline.sh), 64 = stream8g's epilogue replaced by a sum of the accumulators (what does a tile's epilogue cost in all?).  Results are
+// garbage in those builds; the default build (0) compiles every branch away.
+#ifndef V2X_STREAM_DBG_BUILD
+#define V2X_STREAM_DBG_BUILD 0
+#endif
+constexpr int SDBG = V2X_STREAM_DBG_BUILD;
 // Patch swizzle: pixel pc's channel slot s (16 bytes) lives at physical slot s ^ PSWZ(pc) of its 64 bytes.  A pixel-fragment read is
 // lane (fj, fq) -> pixel pc0 + fj (full resolution) or ((c + fj) >> 1) + 1 (half resolution), slot fq.  tools/lds_conflict_probe.hip times
 // candidate swizzles with eight reads in flight: (pc >> 2) & 3 serves every alignment of both forms at 17.5 ns per read, the round-1 choice
@@ -35,6 +41,17 @@
 #define V2X_STREAM_PSWZ_BUILD 1
 #endif
 #define PSWZ(pc) (((pc) >> V2X_STREAM_PSWZ_BUILD) & 3)
+// bit 16: TIMESTAMPS.  Lane 0 of waves 0 and 4 (one wave per group) of workgroup 0 records s_memrealtime (100 MHz) at four points of
+// each of its first 128 steps into 4 KiB of extra LDS, dumped to this buffer when the workgroup ends: [group][step][point], points =
+// top of the load phase, before the first barrier (loads issued, waits done), after it (MFMA phase begins), end of the MFMA phase.
+// tools/stream8g_timeline.py fetches it through v2x_debug_stream_timeline (exported by these builds only).
+constexpr int SDBG_T_STEPS = 128;
+#if (V2X_STREAM_DBG_BUILD & 16)
+__device__ unsigned v2x_stream_timeline[2 * SDBG_T_STEPS * 4];
+extern "C" int v2x_debug_stream_timeline(unsigned *dst) {   // exists in the timestamp builds only; the default library exports no debug entry
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(v2x_stream_timeline), sizeof(unsigned) * 2 * SDBG_T_STEPS * 4);
+}
+#endif
 // Variants of stream8g that were built, measured and REMOVED from this file in round 4 (HISTORY.md "Round 3 -- measured and rejected" holds the
 // numbers, the code is in the git history up to commit 7e0187e): the 32x32x16-MFMA form (M32: bit-identical, 9-20 % slower), weight fragments
 // read two blocks ahead (PF = 2: +2.8-3.7 %), s_setprio in the load / MFMA phase (LPRIO, PRIO: no effect), the prefetch point inside a block
@@ -691,6 +708,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const uint16_t *wsrc = wbase + lane * 8 + wave * 512;
     auto issue_dummy = [&]() { glds16s(zero_page, s_dummy); };
     auto issue_slice = [&](int slice, int slot, bool real) {  // exactly one DMA
+        if constexpr ((SDBG & 1) != 0) return;
         if (has_w && real) glds16s(wsrc + (size_t)slice * (BCO * 32), s_ring + slot * SLICE_BYTES + wave * 1024);
         else issue_dummy();
     };
@@ -772,7 +790,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const int s3 = s + 3;
                         issue_slice(s3 < S ? s3 : s3 - S, (g + 3) & (RING - 1), s3 < S || has_next);
                     }
-                    if (tap < 5 && fill) {
+                    if constexpr ((SDBG & 2) != 0) {
+                    } else if (tap < 5 && fill) {
                         int d = pd[0];
 #pragma unroll
                         for (int u = 1; u < 5; ++u) d = (tap == u) ? pd[u] : d;
@@ -782,12 +801,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     const char *ws = s_ring + (g & (RING - 1)) * SLICE_BYTES;
                     bf16x8_t fa[TCO], fb[4];
+                    if constexpr ((SDBG & 4) == 0) {
 #pragma unroll
-                    for (int f = 0; f < 4; ++f)
-                        fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + ct[f][kx]);
+                        for (int f = 0; f < 4; ++f)
+                            fb[f] = *reinterpret_cast<const bf16x8_t *>(pb + rowoff[f] + ct[f][kx]);
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i)
-                        fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+                        for (int i = 0; i < TCO; ++i)
+                            fa[i] = *reinterpret_cast<const bf16x8_t *>(ws + (fq * BCO + i * 16 + fj) * 16);
+                    } else {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) fb[f] = __builtin_bit_cast(bf16x8_t, make_uint4(s, s, s, s));
+#pragma unroll
+                        for (int i = 0; i < TCO; ++i) fa[i] = __builtin_bit_cast(bf16x8_t, make_uint4(g, g, g, g));
+                    }
                     // own pieces of slice s+1 (and older) have landed; right after an epilogue its stores are younger
                     // than that group and may stay in flight
                     if (relaxed > 0) {
@@ -801,11 +827,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
                     // ---- M(s)
+                    if constexpr ((SDBG & 8) == 0) {
 #pragma unroll
-                    for (int i = 0; i < TCO; ++i)
+                        for (int i = 0; i < TCO; ++i)
 #pragma unroll
-                        for (int f = 0; f < 4; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                            for (int f = 0; f < 4; ++f)
+                                acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[f], acc[i][f], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < TCO; ++i) acc[i][0] += __builtin_bit_cast(f32x4_t, fa[i]) + __builtin_bit_cast(f32x4_t, fb[i & 3]);
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
                     __builtin_amdgcn_sched_barrier(0);
@@ -873,7 +904,7 @@ _Pragma("unroll") \
                         int d = pd[0]; \
 _Pragma("unroll") \
                         for (int u = 1; u < 10; ++u) d = (tt == u) ? pd[u] : d; \
-                        issue_piece(d, kcn, tt, (gc + 1) & 1); \
+                        if constexpr ((SDBG & 2) == 0) issue_piece(d, kcn, tt, (gc + 1) & 1); \
                     } \
                 }
 //   WT (wave tiling): false -- a wave owns ALL BCO channels x 64 pixels (2 rows) of its group's 8x32 pixels: 24 weight + 8 pixel fragment
@@ -979,6 +1010,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int p = wq + NQ * u;
             if (p >= 3 * W_PIECES) break;                  // wave-uniform (96-row tiles: 18 pieces)
             ++cnt;
+            if constexpr ((SDBG & 1) != 0) continue;
             const int ky = p / W_PIECES, pis = p - ky * W_PIECES;
             glds16s(wbase + (size_t)(kc * 9 + ky * 3 + kx) * (BCO * 32) + pis * 512 + lane_w * 8,
                     s_ring + slot * STEP_BYTES + ky * SLICE_BYTES + pis * 1024);
@@ -1040,7 +1072,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     // epilogue parameters of this workgroup's channel tile -> LDS (1 KiB behind the patches): see stream_epilogue
-    float *s_ss = reinterpret_cast<float *>(smem + 3 * STEP_BYTES + 2 * PATCH8_BYTES);
+    float *s_ss = reinterpret_cast<float *>(smem + 3 * STEP_BYTES + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0));
     // (paired A/B: plain layers -0.7 ... -3.4 %, most on the 12-step layers; the ConvGRU +0.7 % -- its table stays in global memory)
     if constexpr (V2X_STREAM_LSS_BUILD != 0 && EPI != SEPI_GRU) {
         if constexpr (EPI == SEPI_GRU) {
@@ -1064,6 +1096,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int g = 0;     // global step counter
     bool relaxed = false;
     int slot = 0;  // ring slot of the current step = g % 3
+    int dbg_n = 0; // (SDBG & 16) steps stamped so far
     int gc = 0;    // global chunk counter: patch buffer = gc & 1
     for (;;) {
         const int next = tile + nwg;
@@ -1104,6 +1137,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int kx = 0; kx < 3; ++kx, ++g, slot = (slot == 2 ? 0 : slot + 1)) {
                 const int st = kc * 3 + kx;
                 const int ln = fresh_lane();
+                auto stamp = [&](int point) __attribute__((always_inline)) {
+                    if constexpr ((SDBG & 16) != 0) {
+                        if (blockIdx.x == 0 && (wave & 3) == 0 && dbg_n < SDBG_T_STEPS) {
+                            const unsigned t = (unsigned)__builtin_amdgcn_s_memrealtime();
+                            if (fresh_lane() == 0) *reinterpret_cast<unsigned *>(smem + 3 * STEP_BYTES + 2 * PATCH8_BYTES + ((grp * SDBG_T_STEPS + dbg_n) * 4 + point) * 4) = t;
+                        }
+                    }
+                };
+                stamp(0);
                 const int fjl = ln & 15, fql = ln >> 4;
                 // ---- L: group 1 streams the weights of step st+2 (wrapping into the next tile), group 0 the next chunk's patch
                 int nw = 0;   // weight DMAs this wave issues in this phase
@@ -1118,13 +1160,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int coff = ((pc << 2) + (fql ^ ((pc >> PSH) & 3))) * 16;
 #pragma unroll
                     for (int q = 0; q < NB / 2; ++q) {
-                        B[q * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + row0 + (((q - sh) >> sh) + sh) * row_bytes + coff);
+                        if constexpr ((SDBG & 4) == 0) B[q * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(pb + row0 + (((q - sh) >> sh) + sh) * row_bytes + coff);
+                        else B[q * 2 + ch] = __builtin_bit_cast(bf16x8_t, make_uint4(coff, q, st, ch));
                     }
                 }
                 const char *ws = s_ring + slot * STEP_BYTES + (fql * BCO + fjl) * 16 + coh * (HCO * 256);   // + compile-time offsets below
                 bf16x8_t A[2][WT ? BT : HCO];                    // two alternating sets: the next block's fragments land under this block's MFMAs
 #pragma unroll
-                for (int i = 0; i < (WT ? BT : HCO); ++i) A[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+                for (int i = 0; i < (WT ? BT : HCO); ++i) {
+                    if constexpr ((SDBG & 4) == 0) A[0][i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
+                    else A[0][i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, slot, ln));
+                }
                 __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): fragments in registers before the patch / ring may be overwritten
                 // drain: group 1 -- the weights issued one step ago (everything but this phase's own NWD DMAs; right after an epilogue
                 // the tile's output stores are younger than those and may stay in flight); group 0 -- at kx = 2, the patch it issued
@@ -1135,9 +1181,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 } else if (kx == 2) {
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 }
+                stamp(1);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                stamp(2);
                 // ---- M: six half taps.  The weight fragments of half h+1 are read in the MIDDLE of half h's MFMA block: the compiler
                 // waits for them with lgkmcnt(0) before their first use (it does not count LDS reads individually here), so reads
                 // issued right before a block would be waited for at once -- six exposed LDS latencies per step (the first form:
@@ -1154,8 +1202,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                             for (int j = j0; j < j1; ++j)
 #pragma unroll
-                                for (int f = 0; f < 8; ++f)
-                                    acc[i0 + j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b & 1][j], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i0 + j][f], 0, 0, 0);
+                                for (int f = 0; f < 8; ++f) {
+                                    if constexpr ((SDBG & 8) == 0)
+                                        acc[i0 + j][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[b & 1][j], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i0 + j][f], 0, 0, 0);
+                                    else if (f == 0)
+                                        acc[i0 + j][0] += __builtin_bit_cast(f32x4_t, A[b & 1][j]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
+                                }
                         };
                         __builtin_amdgcn_sched_barrier(0);
                         mma_tiles(0, 1);
@@ -1163,7 +1215,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         if (b + 1 < NBLK) {
                             const int ky1 = ((b + 1) * BT) / HCO, j1 = ((b + 1) * BT) % HCO;
 #pragma unroll
-                            for (int j = 0; j < BT; ++j) A[(b + 1) & 1][j] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (j1 + j) * 256);
+                            for (int j = 0; j < BT; ++j) {
+                                if constexpr ((SDBG & 4) == 0) {
+                                    A[(b + 1) & 1][j] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (j1 + j) * 256);
+                                } else {
+                                    A[(b + 1) & 1][j] = __builtin_bit_cast(bf16x8_t, make_uint4(st, j, b, ln));
+                                }
+                            }
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         mma_tiles(1, BT);
@@ -1178,8 +1236,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                         for (int i = i0; i < i1; ++i)
 #pragma unroll
-                            for (int f = 0; f < 4; ++f)
-                                acc[hh * HCO + i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[h & 1][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[hh * HCO + i][f], 0, 0, 0);
+                            for (int f = 0; f < 4; ++f) {
+                                if constexpr ((SDBG & 8) == 0)
+                                    acc[hh * HCO + i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[h & 1][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[hh * HCO + i][f], 0, 0, 0);
+                                else if (f == 0)
+                                    acc[hh * HCO + i][0] += __builtin_bit_cast(f32x4_t, A[h & 1][i]) + __builtin_bit_cast(f32x4_t, B[ky * 2]);
+                            }
                     };
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(0, H1);
@@ -1187,13 +1249,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     if (h + 1 < 6) {
                         const int ky1 = (h + 1) >> 1, hh1 = (h + 1) & 1;
 #pragma unroll
-                        for (int i = 0; i < HCO; ++i) A[(h + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (hh1 * HCO + i) * 256);
+                        for (int i = 0; i < HCO; ++i) {
+                            if constexpr ((SDBG & 4) == 0) A[(h + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(ws + ky1 * SLICE_BYTES + (hh1 * HCO + i) * 256);
+                            else A[(h + 1) & 1][i] = __builtin_bit_cast(bf16x8_t, make_uint4(st, i, h, ln));
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     mma_part(H1, HCO);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 }
+                stamp(3);
+                if constexpr ((SDBG & 16) != 0) ++dbg_n;
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -1201,7 +1268,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         constexpr bool LSS = V2X_STREAM_LSS_BUILD != 0 && EPI != SEPI_GRU;
         // (the GRU's table is float4 per hidden channel: a channel half of the tile starts BCO / 6 channels = 4 * BCO / 6 floats in)
-        if constexpr (WT)
+        if constexpr ((SDBG & 64) != 0) {   // timing experiment: the epilogue replaced by a sum of the accumulators (128 adds) and a store that never happens
+            f32x4_t sum = (f32x4_t)(0.f);
+#pragma unroll
+            for (int i = 0; i < AT; ++i)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) sum += acc[i][f];
+            if (sum[0] + sum[1] + sum[2] + sum[3] == 12345.678f) reinterpret_cast<uint16_t *>(a.out)[(size_t)tile * 64 + lane] = 1;
+        } else if constexpr (WT)
             stream_epilogue<BCO / 2, TW, EPI, 8, false, true, true>(a, acc, co_tile * 2 + coh, n, y0, x0, frow, fj, fq, nullptr,
                                                                     LSS ? (lds_cf_t *)s_ss + coh * (EPI == SEPI_GRU ? 4 * (BCO / 6) : BCO / 2) : (lds_cf_t *)nullptr, BCO, a.x4 != 0);
         else stream_epilogue<BCO, TW, EPI, 4, false, true, true>(a, acc, co_tile, n, y0, x0, frow, fj, fq, nullptr, LSS ? (lds_cf_t *)s_ss : (lds_cf_t *)nullptr, BCO, a.x4 != 0);
@@ -1213,11 +1287,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         relaxed = true;   // the stores just issued are younger than the weight DMAs the next load phase waits for
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();            // balance the offset barrier of group 1
+#if (V2X_STREAM_DBG_BUILD & 16)
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < 2 * SDBG_T_STEPS * 4; i += 512)
+            v2x_stream_timeline[i] = *reinterpret_cast<const unsigned *>(smem + 3 * STEP_BYTES + 2 * PATCH8_BYTES + i * 4);
+#endif
 }
 
 template <int BCO, int EPI, bool WT = false>
 static int launch_stream8g(const StreamArgs &a, hipStream_t s) {
-    constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES + 1024;   // 153 KiB at 128 rows, 135 KiB at 96 (+1 KiB: epilogue parameters)
+    constexpr int smem = 3 * 3 * BCO * 64 + 2 * PATCH8_BYTES + ((SDBG & 16) ? 2 * SDBG_T_STEPS * 16 : 0) + 1024;   // 153 KiB at 128 rows, 135 KiB at 96 (+1 KiB: epilogue parameters)
     static_assert(smem <= 160 * 1024, "LDS budget");
     static v2x_once_per_device attr_once;
     auto kern = &conv3x3_stream8g_kernel<BCO, EPI, WT>;
