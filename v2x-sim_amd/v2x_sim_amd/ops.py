@@ -12,30 +12,8 @@ from . import _lib, tuning
 from ._lib import ConvDesc, V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_FUSE_MAX, V2X_FUSE_MEAN, V2X_FUSE_WSUM  # noqa: F401
 
 
-def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-# Optional per-launch instrumentation used by bench.py's roofline pass: when PROFILE is a list,
-# every wrapper appends (kernel_name, algorithmic_flops, algorithmic_bytes, start_event, end_event, layer_name)
-# with HIP events recorded on the stream the kernel is launched on.
-PROFILE = None
-
-
-class _Prof:
-    __slots__ = ("rec",)
-
-    def __init__(self, name, flops, nbytes, layer=None):
-        self.rec = None
-        if PROFILE is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            self.rec = (name, float(flops), float(nbytes), e0, e1, layer or name)
-            e0.record(torch.cuda.current_stream())
-
-    def done(self):
-        if self.rec is not None:
-            self.rec[4].record(torch.cuda.current_stream())
-            PROFILE.append(self.rec)
+from . import _launch
+from ._launch import _Prof, _dev, _dev_opt, _stream  # noqa: F401
 
 
 # Latency dispatch.  Kernel forms whose choice depends on the NUMBER of maps in a launch (split-K of the streamed layers, the 1-tap stride-2
@@ -131,21 +109,6 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
         return "conv3x3_halo_kernel<%d, %d, %d, %d, %d>" % (c0, c1, pc.Cout, co2, e2)
     rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
     return "conv_igemm_kernel<%d, %d, %d, %d, %d>" % (_CONV_TILES[rows] + (pc.epilogue,))
-
-
-def _dev(t, dtype, name):
-    if not isinstance(t, torch.Tensor) or not t.is_cuda:
-        raise RuntimeError("%s must be a tensor on the MI355X (cuda) device; the v2x_sim_amd hot path has no CPU "
-                           "fallback" % name)
-    if t.dtype != dtype:
-        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
-    if not t.is_contiguous():
-        raise ValueError("%s must be contiguous" % name)
-    return C.c_void_p(t.data_ptr())
-
-
-def _dev_opt(t, dtype, name):
-    return None if t is None else _dev(t, dtype, name)
 
 
 # ------------------------------------------------------------------ a1
@@ -373,7 +336,7 @@ def conv2d(pc, in0, in1=None, out=None, out_coff=0, split=0, zbits=0, splitk=0):
         d.splitk, d.splitk_ws = splitk, ws.data_ptr()
     d.small_batch = 1 if latency_launches() else 0
     prof = None
-    if PROFILE is not None:
+    if _launch.PROFILE is not None:
         rows_logical = 3 * pc.Cout if pc.epilogue == V2X_EPI_GRU else pc.Cout
         k_logical = pc.ksize * pc.ksize * (zbits if from_bits else pc.C0 + pc.C1)   # bit-grid input: zbits real channels, the rest padding
         M = N * Ho * Wo
@@ -424,7 +387,7 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
     db.out = _dev(out, torch.bfloat16, "out").value
     db.out_cstride, db.out_coff = out.shape[3], 0
     prof = None
-    if PROFILE is not None:
+    if _launch.PROFILE is not None:
         M = N * H * W
         # algorithmic FLOPs: the first layer has `zbits` (13) real input channels -- the 32 of the packed layout are zero padding
         prof = _Prof("conv3x3_pair_bits_kernel<%s>" % ("true" if tuning.get("STORE_X4") != 0 else "false"), 2.0 * M * 9 * (pa.Cout * zbits + pb.Cout * pb.C0),
@@ -434,199 +397,6 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
         prof.done()
     _lib.check(rc, "v2x_conv2d_pair(%s, %s)" % (pa.name, pb.name))
     return out
-
-
-def conv3x3_wgrad(x, dy, cin_out=None):
-    """Weight gradient of a 3x3 stride-1 pad-1 conv.  x (N, H, W, Cin), dy (N, H, W, Cout) bf16 NHWC -> dW (Cout, cin_out or Cin, 3, 3) fp32
-    (the parameter's own layout; cin_out < Cin: the input was stored zero-padded).  MFMA kernel contracting over pixels + a fixed-order
-    sum of the per-block partials written straight in OIHW order (v2x_conv3x3_wgrad_reduce)."""
-    lib = _lib.load()
-    N, H, W, Cin = x.shape
-    Cout = dy.shape[3]
-    if tuple(dy.shape[:3]) != (N, H, W):
-        raise ValueError("x %s and dy %s disagree" % (tuple(x.shape), tuple(dy.shape)))
-    ns = lib.v2x_conv3x3_wgrad_splits(N, H, W, Cin, Cout)
-    if ns == 0:
-        raise ValueError("v2x_conv3x3_wgrad needs H % 8 == 0, W % 32 == 0, Cin % 32 == 0 and Cout % 32 == 0")
-    ws = torch.empty((ns, Cout, 3, 3, Cin), dtype=torch.float32, device=x.device)
-    prof = _Prof("conv3x3_wgrad_kernel", 2.0 * N * H * W * Cout * 9 * Cin, (x.numel() + dy.numel()) * 2 + ws.numel() * 4)
-    rc = lib.v2x_conv3x3_wgrad(_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"), N, H, W, Cin, Cout,
-                               _dev(ws, torch.float32, "workspace"), ns, _stream())
-    prof.done()
-    _lib.check(rc, "v2x_conv3x3_wgrad")
-    cin_out = Cin if cin_out is None else cin_out
-    dw = torch.empty((Cout, cin_out, 3, 3), dtype=torch.float32, device=x.device)
-    _lib.check(lib.v2x_conv3x3_wgrad_reduce(_dev(ws, torch.float32, "workspace"), ns, Cout, Cin, cin_out, _dev(dw, torch.float32, "dw"), _stream()),
-               "v2x_conv3x3_wgrad_reduce")
-    return dw
-
-
-def gru_gates(gi, bias_hh):
-    """v2x_gru_gates_f32: gi (P, 3C, H, W) fp32 contiguous, bias_hh (3C,) fp32 -> h (P, C, H, W) fp32 (h0 = 0: h = n - z n)."""
-    lib = _lib.load()
-    P, C3, H, W = gi.shape
-    h = torch.empty((P, C3 // 3, H, W), dtype=torch.float32, device=gi.device)
-    _lib.check(lib.v2x_gru_gates_f32(_dev(gi, torch.float32, "gi"), _dev(bias_hh, torch.float32, "bias_hh"), P, C3 // 3, H * W,
-                                     _dev(h, torch.float32, "h"), _stream()), "v2x_gru_gates_f32")
-    return h
-
-
-def gru_gates_backward(gi, bias_hh, dh):
-    """v2x_gru_gates_bwd_f32: -> (dgi like gi, dn_r (P, C, H, W)): d bias_hh = cat(dgi[:, :2C].sum((0, 2, 3)), dn_r.sum((0, 2, 3)))."""
-    lib = _lib.load()
-    P, C3, H, W = gi.shape
-    dgi = torch.empty_like(gi)
-    dn_r = torch.empty((P, C3 // 3, H, W), dtype=torch.float32, device=gi.device)
-    _lib.check(lib.v2x_gru_gates_bwd_f32(_dev(gi, torch.float32, "gi"), _dev(bias_hh, torch.float32, "bias_hh"), _dev(dh, torch.float32, "dh"),
-                                         P, C3 // 3, H * W, _dev(dgi, torch.float32, "dgi"), _dev(dn_r, torch.float32, "dn_r"), _stream()),
-               "v2x_gru_gates_bwd_f32")
-    return dgi, dn_r
-
-
-def det_loss_forward(cls, labels, loc, targets, mask, alpha, beta):
-    """v2x_det_loss_forward: fp32 contiguous device tensors cls / labels (n, 2), loc / targets (n, 6), mask (n,) bool or uint8 ->
-    out4 (4,) fp32 = (loss, cls_loss, loc_loss, n_pos clamped to >= 1)."""
-    lib = _lib.load()
-    n = cls.numel() // 2
-    ws = torch.empty((lib.v2x_det_loss_workspace_size(n) // 4,), dtype=torch.float32, device=cls.device)
-    out = torch.empty((4,), dtype=torch.float32, device=cls.device)
-    m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
-    _lib.check(lib.v2x_det_loss_forward(_dev(cls, torch.float32, "cls"), _dev(labels, torch.float32, "labels"), _dev(loc, torch.float32, "loc"),
-                                        _dev(targets, torch.float32, "targets"), _dev(m8, torch.uint8, "mask"), n, alpha, beta,
-                                        _dev(out, torch.float32, "out4"), _dev(ws, torch.float32, "workspace"), _stream()), "v2x_det_loss_forward")
-    return out
-
-
-def det_loss_backward(cls, labels, loc, targets, mask, alpha, beta, out4, g_loss, g_cls, g_loc):
-    """v2x_det_loss_backward: -> (dcls like cls, dloc like loc) for the incoming gradients of (loss, cls_loss, loc_loss) (fp32 device scalars or None)."""
-    lib = _lib.load()
-    n = cls.numel() // 2
-    dcls, dloc = torch.empty_like(cls), torch.empty_like(loc)
-    m8 = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
-    gs = [None if g is None else _dev(g, torch.float32, "grad") for g in (g_loss, g_cls, g_loc)]
-    _lib.check(lib.v2x_det_loss_backward(_dev(cls, torch.float32, "cls"), _dev(labels, torch.float32, "labels"), _dev(loc, torch.float32, "loc"),
-                                         _dev(targets, torch.float32, "targets"), _dev(m8, torch.uint8, "mask"), n, alpha, beta,
-                                         _dev(out4, torch.float32, "out4"), gs[0], gs[1], gs[2], _dev(dcls, torch.float32, "dcls"),
-                                         _dev(dloc, torch.float32, "dloc"), _stream()), "v2x_det_loss_backward")
-    return dcls, dloc
-
-
-def channel_sum(x):
-    """x (..., C) bf16 NHWC -> (C,) fp32 = the sum over every other axis, in a fixed order (the bias gradient of a convolution)."""
-    lib = _lib.load()
-    Cc = x.shape[-1]
-    M = x.numel() // Cc
-    nbytes = lib.v2x_channel_sum_workspace_size(M, Cc)
-    if nbytes == 0:
-        return x.float().reshape(M, Cc).sum(0)          # channel counts the kernel does not tile (C / 8 must divide 256)
-    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
-    out = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-    _lib.check(lib.v2x_channel_sum_bf16(_dev(x, torch.bfloat16, "x"), M, Cc, _dev(out, torch.float32, "out"), _dev(ws, torch.float32, "workspace"),
-                                        _stream()), "v2x_channel_sum_bf16")
-    return out
-
-
-def warp_affine(x, theta, backward=False):
-    """F.grid_sample(x, F.affine_grid(theta, x.shape, align_corners=False), "bilinear", "zeros", align_corners=False) on the HIP kernel
-    (warp_train.hip), or -- backward=True -- its exact transpose applied to an output gradient x (deterministic gather).
-    x (P, C, H, W) fp32 contiguous, theta (P, 2, 3) fp32 on the same device -> (P, C, H, W) fp32."""
-    lib = _lib.load()
-    P, Cc, H, W = x.shape
-    if theta.shape != (P, 2, 3):
-        raise ValueError("warp_affine: theta must be (%d, 2, 3), got %s" % (P, tuple(theta.shape)))
-    theta = theta.contiguous()
-    out = torch.empty_like(x)
-    fn = lib.v2x_warp_affine_bwd_f32 if backward else lib.v2x_warp_affine_f32
-    _lib.check(fn(_dev(x, torch.float32, "x"), _dev(theta, torch.float32, "theta"), P, Cc, H, W, _dev(out, torch.float32, "out"), _stream()),
-               "v2x_warp_affine_bwd_f32" if backward else "v2x_warp_affine_f32")
-    return out
-
-
-def upcat(lo, skip):
-    """cat(nearest x2 upsample of lo, skip) along the channels: lo (N, H, W, C0), skip (N, 2H, 2W, C1) bf16 NHWC -> (N, 2H, 2W, C0 + C1)."""
-    lib = _lib.load()
-    N, H, W, C0 = lo.shape
-    if skip.shape[:3] != (N, 2 * H, 2 * W):
-        raise ValueError("upcat: skip %s does not match twice the extent of lo %s" % (tuple(skip.shape), tuple(lo.shape)))
-    C1 = skip.shape[3]
-    out = torch.empty((N, 2 * H, 2 * W, C0 + C1), dtype=torch.bfloat16, device=lo.device)
-    _lib.check(lib.v2x_upcat_bf16(_dev(lo, torch.bfloat16, "lo"), _dev(skip, torch.bfloat16, "skip"), N, H, W, C0, C1, _dev(out, torch.bfloat16, "out"),
-                                  _stream()), "v2x_upcat_bf16")
-    return out
-
-
-def upcat_backward(dcat, C0):
-    """Backward of upcat: dcat (N, 2H, 2W, C0 + C1) bf16 -> (d_lo (N, H, W, C0) = the 2x2 sums, d_skip (N, 2H, 2W, C1))."""
-    lib = _lib.load()
-    N, H2, W2, Ct = dcat.shape
-    H, W, C1 = H2 // 2, W2 // 2, Ct - C0
-    d_lo = torch.empty((N, H, W, C0), dtype=torch.bfloat16, device=dcat.device)
-    d_skip = torch.empty((N, H2, W2, C1), dtype=torch.bfloat16, device=dcat.device)
-    _lib.check(lib.v2x_upcat_bwd_bf16(_dev(dcat, torch.bfloat16, "dcat"), N, H, W, C0, C1, _dev(d_lo, torch.bfloat16, "d_lo"),
-                                      _dev(d_skip, torch.bfloat16, "d_skip"), _stream()), "v2x_upcat_bwd_bf16")
-    return d_lo, d_skip
-
-
-def zero_insert(dy):
-    """dy (N, Ho, Wo, C) bf16 of a stride-2 layer -> (N, 2Ho, 2Wo, C) with dy at the even positions, zeros elsewhere (one launch)."""
-    lib = _lib.load()
-    N, Ho, Wo, Cc = dy.shape
-    out = torch.empty((N, 2 * Ho, 2 * Wo, Cc), dtype=torch.bfloat16, device=dy.device)
-    _lib.check(lib.v2x_zero_insert_bf16(_dev(dy, torch.bfloat16, "dy"), N, Ho, Wo, Cc, _dev(out, torch.bfloat16, "out"), _stream()), "v2x_zero_insert_bf16")
-    return out
-
-
-def bn_train_forward(x, gamma, beta, running_mean, running_var, eps, momentum, relu=True):
-    """Batch-statistics BN (+ ReLU) of a bf16 NHWC map on the HIP kernels (bn_train.hip).  x (..., C) bf16; gamma / beta (C,) fp32;
-    running_mean / running_var fp32 (updated in place) or None.  -> (y bf16 like x, save_mean, save_invstd)."""
-    lib = _lib.load()
-    C = x.shape[-1]
-    M = x.numel() // C
-    nbytes = lib.v2x_bn_train_workspace_size(M, C)
-    if nbytes == 0:
-        raise ValueError("v2x_bn_train_forward: unsupported shape M=%d C=%d (C / 8 must divide 256)" % (M, C))
-    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    y = torch.empty_like(x)
-    mean = torch.empty(C, dtype=torch.float32, device=x.device)
-    invstd = torch.empty(C, dtype=torch.float32, device=x.device)
-    prof = _Prof("bn_train_forward", 0.0, x.numel() * 2 * 3)
-    rc = lib.v2x_bn_train_forward(_dev(x, torch.bfloat16, "x"), M, C, _dev(gamma, torch.float32, "gamma"), _dev(beta, torch.float32, "beta"),
-                                  float(eps), float(momentum), _dev_opt(running_mean, torch.float32, "running_mean"),
-                                  _dev_opt(running_var, torch.float32, "running_var"), 1 if relu else 0, _dev(y, torch.bfloat16, "y"),
-                                  _dev(mean, torch.float32, "save_mean"), _dev(invstd, torch.float32, "save_invstd"),
-                                  _dev(ws, torch.float32, "workspace"), _stream())
-    prof.done()
-    _lib.check(rc, "v2x_bn_train_forward")
-    return y, mean, invstd
-
-
-def bn_train_backward(x, dy, gamma, beta, mean, invstd, relu=True, dx_sum=False):
-    """Backward of bn_train_forward: -> (dx bf16 like x, dgamma (C,), dbeta (C,)) fp32; dx_sum=True: also the per-channel sum of dx as stored
-    (fp32 (C,): the bias gradient of the convolution that produced x), accumulated by the kernel that writes dx."""
-    lib = _lib.load()
-    C = x.shape[-1]
-    M = x.numel() // C
-    nbytes = lib.v2x_bn_train_workspace_size(M, C)
-    if nbytes == 0:
-        raise ValueError("v2x_bn_train_backward: unsupported shape M=%d C=%d" % (M, C))
-    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    dx = torch.empty_like(x)
-    dgamma = torch.empty(C, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(C, dtype=torch.float32, device=x.device)
-    prof = _Prof("bn_train_backward", 0.0, x.numel() * 2 * 5)
-    args = [_dev(x, torch.bfloat16, "x"), _dev(dy, torch.bfloat16, "dy"), M, C, _dev(gamma, torch.float32, "gamma"),
-            _dev(beta, torch.float32, "beta"), _dev(mean, torch.float32, "save_mean"), _dev(invstd, torch.float32, "save_invstd"),
-            1 if relu else 0, _dev(dx, torch.bfloat16, "dx"), _dev(dgamma, torch.float32, "dgamma"), _dev(dbeta, torch.float32, "dbeta")]
-    if dx_sum:
-        ws2 = torch.empty(lib.v2x_bn_dxsum_workspace_size(M, C) // 4, dtype=torch.float32, device=x.device)
-        dsum = torch.empty(C, dtype=torch.float32, device=x.device)
-        rc = lib.v2x_bn_train_backward_dxsum(*args, _dev(dsum, torch.float32, "dx_sum"), _dev(ws, torch.float32, "workspace"),
-                                             _dev(ws2, torch.float32, "sum_workspace"), _stream())
-    else:
-        rc = lib.v2x_bn_train_backward(*args, _dev(ws, torch.float32, "workspace"), _stream())
-    prof.done()
-    _lib.check(rc, "v2x_bn_train_backward")
-    return (dx, dgamma, dbeta, dsum) if dx_sum else (dx, dgamma, dbeta)
 
 
 def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
@@ -718,115 +488,6 @@ def pixel_weighted_fuse(scores, valid, maps):
                                            _dev(valid, torch.float32, "valid"), _dev(maps, torch.bfloat16, "maps"), n, A, H, W,
                                            Cc, _dev(out, torch.bfloat16, "out"), _stream()), "v2x_pixel_weighted_fuse")
     return out
-
-
-# ------------------------------------------------------------------ f-1
-def det_postprocess(cls, loc, anchors, score_thr=0.7, nms_thr=0.01, cap=4096, rotated=False):
-    """cls (n, M, 2) fp32, loc (n, ..., 6) fp32 with M anchors per map, anchors (M, 6) fp32 on the device ->
-    (boxes (n, cap, 5), scores (n, cap), index (n, cap) int32, count (n,) int32); count < 0: more than `cap` candidates.
-    rotated=True: suppression on the rotated boxes' polygon IoU instead of upstream's stand-up boxes."""
-    lib = _lib.load()
-    n, M = cls.shape[0], cls.shape[1]
-    loc = loc.reshape(n, M, 6)
-    anchors = anchors.reshape(M, 6)
-    dev = cls.device
-    boxes = torch.empty((n, cap, 5), dtype=torch.float32, device=dev)
-    scores = torch.empty((n, cap), dtype=torch.float32, device=dev)
-    index = torch.empty((n, cap), dtype=torch.int32, device=dev)
-    count = torch.empty((n,), dtype=torch.int32, device=dev)
-    keys = torch.empty((n, cap), dtype=torch.int64, device=dev)
-    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
-    fn = lib.v2x_det_postprocess_rotated if rotated else lib.v2x_det_postprocess
-    _lib.check(fn(_dev(cls, torch.float32, "cls"), _dev(loc, torch.float32, "loc"),
-                                       _dev(anchors, torch.float32, "anchors"), n, M, C.c_float(score_thr),
-                                       C.c_float(nms_thr), cap, _dev(boxes, torch.float32, "boxes"),
-                                       _dev(scores, torch.float32, "scores"), _dev(index, torch.int32, "index"),
-                                       _dev(count, torch.int32, "count"), _dev(keys, torch.int64, "keys"),
-                                       _dev(cnt, torch.int32, "cnt"), _stream()), "v2x_det_postprocess")
-    return boxes, scores, index, count
-
-
-def conv2d_det(pc, x, score_thr, cap=4096):
-    """The fused detection heads (packing.pack_heads_det; conv_halo.hip V2X_EPI_DET) on the decoder's output x (N, H, W, 32) bf16:
-    softmax(cls)[1] >= score_thr is evaluated in the epilogue, only the candidates leave the kernel.
-    -> keys (N, cap) int64, codes (N, cap, 6) fp32, counts (N,) int32 (the true count even when > cap) for det_nms_candidates."""
-    lib = _lib.load()
-    N, H, W, Cx = x.shape
-    if Cx != pc.C0 or pc.epilogue != _lib.V2X_EPI_DET:
-        raise ValueError("conv2d_det needs the det-heads packing and a %d-channel input" % pc.C0)
-    keys = torch.empty((N, cap), dtype=torch.int64, device=x.device)
-    codes = torch.empty((N, cap, 6), dtype=torch.float32, device=x.device)
-    counts = torch.zeros((N,), dtype=torch.int32, device=x.device)
-    d = ConvDesc()
-    d.in0, d.in1 = _dev(x, torch.bfloat16, "x").value, None
-    d.C0, d.C1, d.up0 = pc.C0, 0, 0
-    d.N, d.H, d.W = N, H, W
-    d.ksize, d.stride, d.pad = 3, 1, 1
-    d.Cout, d.w_rows, d.w_kpad = pc.Cout, pc.w_rows, pc.w_kpad
-    d.weight, d.scale, d.shift = pc.weight.data_ptr(), pc.scale.data_ptr(), pc.shift.data_ptr()
-    d.epilogue, d.relu = _lib.V2X_EPI_DET, int(bool(pc.relu))
-    d.out, d.out_cstride, d.out_coff = keys.data_ptr(), cap, 0
-    d.out2, d.split, d.out2_cstride = codes.data_ptr(), 0, 6
-    d.w_layout = 1
-    d.Cout2, d.relu2 = pc.Cout2, 0
-    d.weight2, d.scale2, d.shift2 = pc.weight2.data_ptr(), pc.scale2.data_ptr(), pc.shift2.data_ptr()
-    d.det_counts, d.det_thr, d.det_cap = counts.data_ptr(), float(score_thr), cap
-    prof = None
-    if PROFILE is not None:
-        M = N * H * W
-        prof = _Prof("conv3x3_halo_kernel<0, 32, 64, 64, 3>", 2.0 * M * (64 * 9 * 32 + 48 * 64), x.numel() * 2 + pc.weight.numel() * 2, pc.name)
-    rc = lib.v2x_conv2d(C.byref(d), _stream())
-    if prof is not None:
-        prof.done()
-    _lib.check(rc, "v2x_conv2d(%s, det)" % pc.name)
-    return keys, codes, counts
-
-
-def det_nms_candidates(keys, codes, counts, anchors, nms_thr=0.01, rotated=False):
-    """Second half of det_postprocess for the candidates conv2d_det selected: sort, 'faf' decode, greedy NMS.
-    -> (boxes (n, cap, 5), scores (n, cap), index (n, cap) int32, count (n,) int32), identical to det_postprocess on the logits."""
-    lib = _lib.load()
-    n, cap = keys.shape
-    anchors = anchors.reshape(-1, 6)
-    M = anchors.shape[0]
-    dev = keys.device
-    boxes = torch.empty((n, cap, 5), dtype=torch.float32, device=dev)
-    scores = torch.empty((n, cap), dtype=torch.float32, device=dev)
-    index = torch.empty((n, cap), dtype=torch.int32, device=dev)
-    count = torch.empty((n,), dtype=torch.int32, device=dev)
-    _lib.check(lib.v2x_det_nms_candidates(_dev(keys, torch.int64, "keys"), _dev(codes, torch.float32, "codes"), _dev(counts, torch.int32, "counts"),
-                                          _dev(anchors, torch.float32, "anchors"), n, M, cap, C.c_float(nms_thr), int(bool(rotated)),
-                                          _dev(boxes, torch.float32, "boxes"), _dev(scores, torch.float32, "scores"),
-                                          _dev(index, torch.int32, "index"), _dev(count, torch.int32, "count"), _stream()),
-               "v2x_det_nms_candidates")
-    return boxes, scores, index, count
-
-
-def rotated_iou(boxes_a, boxes_b):
-    """boxes (na, 5), (nb, 5) fp32 (x, y, w, h, yaw) on the device -> (na, nb) fp32 IoU of the rotated rectangles."""
-    lib = _lib.load()
-    na, nb = boxes_a.shape[0], boxes_b.shape[0]
-    out = torch.zeros((na, nb), dtype=torch.float32, device=boxes_a.device)
-    if na and nb:
-        _lib.check(lib.v2x_rotated_iou(_dev(boxes_a, torch.float32, "boxes_a"), na, _dev(boxes_b, torch.float32, "boxes_b"), nb,
-                                       _dev(out, torch.float32, "iou"), _stream()), "v2x_rotated_iou")
-    return out
-
-
-def match_detections(det_boxes, det_count, gt_boxes, gt_count, iou_thr, want_iou=False):
-    """eval_map's matching on the device.  det_boxes (n, det_cap, 5) fp32 in descending-score order, det_count (n,) int32,
-    gt_boxes (n, gt_cap, 5) fp32, gt_count (n,) int32 -> tp (n, det_cap) int32 [, best_iou (n, det_cap) fp32]."""
-    lib = _lib.load()
-    n, det_cap, _ = det_boxes.shape
-    gt_cap = gt_boxes.shape[1]
-    tp = torch.zeros((n, det_cap), dtype=torch.int32, device=det_boxes.device)
-    best = torch.zeros((n, det_cap), dtype=torch.float32, device=det_boxes.device) if want_iou else None
-    _lib.check(lib.v2x_match_detections(_dev(det_boxes, torch.float32, "det_boxes"), _dev(det_count, torch.int32, "det_count"), det_cap,
-                                        _dev(gt_boxes, torch.float32, "gt_boxes"), _dev(gt_count, torch.int32, "gt_count"), gt_cap, n,
-                                        C.c_float(iou_thr), _dev(tp, torch.int32, "tp"),
-                                        _dev(best, torch.float32, "best_iou") if best is not None else None, _stream()),
-               "v2x_match_detections")
-    return (tp, best) if want_iou else tp
 
 
 # ------------------------------------------------------------------ a8
@@ -949,3 +610,27 @@ def run_layer(layer, in0, in1=None, zbits=0):
     for i, pc in enumerate(layer.fallback[1:], 1):
         y = conv2d(pc, y, split=layer.split if i == len(layer.fallback) - 1 else 0)
     return y
+
+
+# ------------------------------------------------------------------ rows f-1 and f-3 live in their own modules; `ops.<name>` keeps working
+from .ops_post import conv2d_det, det_nms_candidates, det_postprocess, match_detections, rotated_iou  # noqa: E402,F401
+from .ops_train import (bn_train_backward, bn_train_forward, channel_sum, conv3x3_wgrad, det_loss_backward, det_loss_forward,  # noqa: E402,F401
+                        gru_gates, gru_gates_backward, upcat, upcat_backward, warp_affine, zero_insert)
+
+
+# `ops.PROFILE = []` / `ops.PROFILE` (bench.py, tools/): one list for every wrapper module, kept in _launch
+import sys as _sys  # noqa: E402
+import types as _types  # noqa: E402
+
+
+class _OpsModule(_types.ModuleType):
+    @property
+    def PROFILE(self):
+        return _launch.PROFILE
+
+    @PROFILE.setter
+    def PROFILE(self, value):
+        _launch.PROFILE = value
+
+
+_sys.modules[__name__].__class__ = _OpsModule
