@@ -46,7 +46,7 @@ PEAK_MFMA_TFLOPS = 2500.0
 AGENTS = 5
 POINTS_PER_SWEEP = 65536
 # committed PMC traffic summaries, newest first (tools/profile_round.sh -> tools/pmc_traffic.py)
-TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 # algorithmic FLOPs of one 5-agent frame, points -> logits: encoder + decoder + heads, + one ConvGRU pass per GNN round
 # (h0 = 0: W_hh is never multiplied and not counted)
 GFLOP_PER_FRAME_BASE, GFLOP_PER_GNN_ROUND = 155.8, 36.2
