@@ -1,0 +1,113 @@
+"""The detection tail as one launch (csrc/conv_tail.hip through v2x_conv2d_pair's second form): conv8_2 followed by the fused detection heads,
+conv8_2's output never written.  The bar is BIT equality with the two stand-alone launches (which are held to the oracle by test_gpu_stages.py /
+test_gpu_models.py): same K order, same epilogue arithmetic, zero padding of BOTH layers at the image border."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(device, seed=0):
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    torch.manual_seed(seed)
+    m = FaFNet(Config("test"))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():   # non-trivial BN statistics and biases: every scale / shift entry of the three layers matters
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.num_features, generator=g) * 0.2)
+                mod.running_var.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+                mod.weight.copy_(torch.rand(mod.num_features, generator=g) + 0.5)
+                mod.bias.copy_(torch.randn(mod.num_features, generator=g) * 0.2)
+    return m.to(device).eval()
+
+
+def _x(N, H, W, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    return torch.relu(torch.randn(N, H, W, 32, generator=g)).to(torch.bfloat16).to(device)   # conv8_1's output is post-ReLU
+
+
+def _two_launches(ops, pk, x):
+    y = ops.run_layer(pk["dec"][-1], x)
+    return ops.run_layer(pk["heads"], y)
+
+
+# one tile (group 1 idle); three tiles in a column (odd count: the last pair is half empty); ragged persistent walk; every border case of a 2 x 2 tile
+# map; the full 256 x 256 extent with more pairs than workgroups
+CASES = [(1, 8, 32), (1, 24, 32), (3, 64, 96), (2, 16, 64), (5, 256, 256)]
+
+
+@pytest.mark.parametrize("N,H,W", CASES)
+def test_tail_equals_two_launches_bitwise(device, N, H, W):
+    from v2x_sim_amd import ops
+    m = _model(device, seed=N + H)
+    pk = m.packed(device)
+    last, heads = pk["dec"][-1], pk["heads"]
+    x = _x(N, H, W, seed=W + N, device=device)
+    assert ops.tail_eligible(last.halo, heads.halo, x)
+    cls0, loc0 = _two_launches(ops, pk, x)
+    cls1, loc1 = ops.conv2d_tail(last.halo, heads.halo, x, heads.split)
+    assert cls1.shape == cls0.shape == (N, H, W, 12) and loc1.shape == loc0.shape == (N, H, W, 36)
+    assert torch.equal(cls1.view(torch.int32), cls0.view(torch.int32)), float((cls1 - cls0).abs().max())
+    assert torch.equal(loc1.view(torch.int32), loc0.view(torch.int32)), float((loc1 - loc0).abs().max())
+    again = ops.conv2d_tail(last.halo, heads.halo, x, heads.split)
+    assert torch.equal(again[0].view(torch.int32), cls1.view(torch.int32)) and torch.equal(again[1].view(torch.int32), loc1.view(torch.int32))
+
+
+def test_tail_without_relu_and_border_padding(device):
+    """conv8_2 WITHOUT its ReLU leaves negative values in the patch -- the zero padding of the heads must then still be zeros (not conv8_2 evaluated
+    outside the image), and the bf16 'floor' form of the ReLU must be the identity."""
+    from v2x_sim_amd import ops
+    m = _model(device, seed=7)
+    pk = m.packed(device)
+    last, heads = pk["dec"][-1], pk["heads"]
+    x = _x(2, 24, 64, seed=3, device=device)
+    prev = last.halo.relu
+    try:
+        last.halo.relu = False
+        for pc in last.fallback:
+            pc.relu = False
+        cls0, loc0 = _two_launches(ops, pk, x)
+        cls1, loc1 = ops.conv2d_tail(last.halo, heads.halo, x, heads.split)
+    finally:
+        last.halo.relu = prev
+        for pc in last.fallback:
+            pc.relu = prev
+    assert torch.equal(cls1.view(torch.int32), cls0.view(torch.int32)) and torch.equal(loc1.view(torch.int32), loc0.view(torch.int32))
+
+
+def test_model_forward_takes_the_tail_kernel_and_the_switch_restores_two_launches(device, tune):
+    """decode_heads launches the fused tail by default; TAIL_FUSE = 0 gives the two launches; the logits are the same bits either way.  The
+    instrumented pass (ops.PROFILE) names the kernels that ran."""
+    from v2x_sim_amd import ops
+    m = _model(device, seed=11)
+    g = torch.Generator().manual_seed(5)
+    bev = (torch.rand(2, 1, 256, 256, 13, generator=g) < 0.05).float().to(device)
+    with torch.no_grad():
+        ops.PROFILE = []
+        a = m(bev)
+        torch.cuda.synchronize()
+        names_a, ops.PROFILE = [r[0] for r in ops.PROFILE], None
+        tune("TAIL_FUSE", 0)
+        ops.PROFILE = []
+        b = m(bev)
+        torch.cuda.synchronize()
+        names_b, ops.PROFILE = [r[0] for r in ops.PROFILE], None
+    assert "conv3x3_tail_kernel" in names_a and "conv3x3_tail_kernel" not in names_b and len(names_b) == len(names_a) + 1
+    assert torch.equal(a["cls"].view(torch.int32), b["cls"].view(torch.int32)) and torch.equal(a["loc"].view(torch.int32), b["loc"].view(torch.int32))
+
+
+def test_tail_argument_validation(device):
+    from v2x_sim_amd import ops
+    m = _model(device, seed=1)
+    pk = m.packed(device)
+    last, heads = pk["dec"][-1], pk["heads"]
+    x = _x(1, 12, 32, seed=1, device=device)          # H % 8 != 0
+    assert not ops.tail_eligible(last.halo, heads.halo, x)
+    with pytest.raises(Exception) as e:
+        ops.conv2d_tail(last.halo, heads.halo, x, heads.split)
+    assert "tail form" in str(e.value)
+    with pytest.raises(RuntimeError):
+        ops.conv2d_tail(last.halo, heads.halo, x.cpu(), heads.split)   # no CPU fallback

@@ -337,8 +337,11 @@ int v2x_num_cus();   // conv_stream.hip
 
 // first: 3x3 s1 p1, bit-grid input (in_format 1), 32 (padded) -> 32, w_layout 1, bf16 epilogue; second: 32 -> 32 likewise.
 // The intermediate map is never stored: first->out is ignored.
+int v2x_conv_tail_dispatch(const v2x_conv_desc *first, const v2x_conv_desc *second, hipStream_t stream);   // conv_tail.hip
+
 extern "C" int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream) {
     V2X_REQUIRE(first && second, "v2x_conv2d_pair: null descriptor");
+    if (second->Cout2 > 0 && first->in_format == 0) return v2x_conv_tail_dispatch(first, second, (hipStream_t)stream);   // conv8_2 o detection heads
     const v2x_conv_desc *ds[2] = {first, second};
     for (int k = 0; k < 2; ++k) {
         const v2x_conv_desc *d = ds[k];

@@ -261,8 +261,17 @@ class DetModelBase(nn.Module):
         """Decoder + heads on the (possibly fused) pyramid `feats` -> {'loc', 'cls'}; inside `with model.detections(thr, cap)` and when
         the extent allows -> {'det': (keys, codes, counts)}: the candidates of apply_nms_det's threshold step straight from the heads'
         epilogue (ops.conv2d_det), the logits never written."""
-        x = LidarDecoder.run(pk["dec"], *feats)
         req = getattr(self, "_det_request", None)
+        heads, last = pk["heads"], pk["dec"][-1]
+        if req is None and heads.halo is not None and last.halo is not None:
+            # logits: conv8_2 and the heads as ONE launch when the extent allows (conv_tail.hip; bit-identical to the two launches)
+            x = LidarDecoder.run(pk["dec"], *feats, last=False)
+            if ops.tail_eligible(last.halo, heads.halo, x):
+                cls, loc = ops.conv2d_tail(last.halo, heads.halo, x, heads.split)
+                return self._shape_cls_loc(cls, loc)
+            x = ops.run_layer(last, x)
+        else:
+            x = LidarDecoder.run(pk["dec"], *feats)
         det = getattr(pk["heads"], "det", None)
         if (req is not None and det is not None and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0 and x.shape[1] * x.shape[2] * 6 < (1 << 20)
                 and (self.anchor_num_per_loc, self.category_num, self.box_code_size, self.out_seq_len) == (6, 2, 6, 1)):

@@ -399,6 +399,40 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
     return out
 
 
+def tail_eligible(pa, pb, x):
+    """conv_tail.hip covers: conv8_2 as a halo-packed 3x3 s1 32 -> 32 bf16 layer, the fused heads (halo-packed 3x3 32 -> 64 chained with the
+    1x1 -> 12 + 36, fp32), a bf16 NHWC input with H % 8 == 0, W % 32 == 0 and N H W < 2^27."""
+    return (pa is not None and pb is not None and pa.w_layout == 1 and pa.ksize == 3 and pa.stride == 1 and pa.C0 == 32 and not pa.C1 and pa.Cout == 32
+            and not pa.Cout2 and pa.epilogue == V2X_EPI_BF16 and pb.w_layout == 1 and pb.ksize == 3 and pb.stride == 1 and pb.C0 == 32 and not pb.C1
+            and pb.Cout == 64 and pb.Cout2 == 48 and pb.epilogue == V2X_EPI_F32 and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 32
+            and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0 and x.shape[0] * x.shape[1] * x.shape[2] < (1 << 27) and tuning.get("TAIL_FUSE") != 0)
+
+
+def conv2d_tail(pa, pb, x, split):
+    """heads(conv8_2(x)) in one launch (conv_tail.hip through v2x_conv2d_pair's second form): x (N, H, W, 32) bf16 = conv8_1's output ->
+    (cls (N, H, W, split), loc (N, H, W, 48 - split)) fp32, bit-identical to conv2d(pa) followed by conv2d(pb, split=split)."""
+    lib = _lib.load()
+    N, H, W, _ = x.shape
+    out = torch.empty((N, H, W, split), dtype=torch.float32, device=x.device)
+    out2 = torch.empty((N, H, W, pb.Cout2 - split), dtype=torch.float32, device=x.device)
+    da, db = _pair_desc(pa, N, H, W), _pair_desc(pb, N, H, W)
+    da.in0 = _dev(x, torch.bfloat16, "x").value
+    db.Cout2, db.relu2 = pb.Cout2, int(bool(pb.relu2))
+    db.weight2, db.scale2, db.shift2 = pb.weight2.data_ptr(), pb.scale2.data_ptr(), pb.shift2.data_ptr()
+    db.out, db.out_cstride, db.out_coff = out.data_ptr(), split, 0
+    db.out2, db.split, db.out2_cstride = out2.data_ptr(), split, out2.shape[3]
+    prof = None
+    if _launch.PROFILE is not None:
+        M = N * H * W
+        prof = _Prof("conv3x3_tail_kernel", 2.0 * M * (9 * 32 * 32 + 9 * 32 * 64 + 64 * 48), x.numel() * 2 + (out.numel() + out2.numel()) * 4 +
+                     (pa.weight.numel() + pb.weight.numel() + pb.weight2.numel()) * 2, pa.name + "+" + pb.name)
+    rc = lib.v2x_conv2d_pair(C.byref(da), C.byref(db), _stream())
+    if prof is not None:
+        prof.done()
+    _lib.check(rc, "v2x_conv2d_pair(%s, %s)" % (pa.name, pb.name))
+    return out, out2
+
+
 def warp_fuse(feat, A, Bt, trans, items, coef, mode, out=None):
     """feat (A*Bt, H, W, C) bf16; trans (Bt, A, A, 4, 4) fp32; items (n_out, 2) int32; coef (n_out, A) fp32."""
     lib = _lib.load()

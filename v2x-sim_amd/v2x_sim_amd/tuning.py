@@ -29,12 +29,14 @@ Host-side switches (this module):
                    the sums are formed in fp32 and rounded to bf16 once): 2 = conv8_1 (w_layout 3, resident weights) and conv5_1 / conv6_1 (w_layout 4,
                    streamed weights); 3 = also conv7_1 (w_layout 4 with 64-row tiles, the two-tiles-per-workgroup kernel); 1 = conv8_1 only; 0 = the 9-tap forms
                    everywhere.  Read when a model is packed
+    TAIL_FUSE 1  conv8_2 and the detection heads as ONE launch (conv_tail.hip: conv8_2's output never leaves the CU; bit-identical to the two launches);
+                   0 = two launches.  Read at every forward
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
 The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR")
 
