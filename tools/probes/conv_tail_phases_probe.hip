@@ -14,17 +14,6 @@
 // one stage apart (raw s_barrier, group 1 starts one barrier late): while one group's waves multiply stage A of their next tile, the other's
 // are in stage B and its 12 logit stores per wave -- one workgroup per CU, 152 KiB of LDS.  The next tile's window is requested right after the
 // barrier that ends stage A and waited for with a COUNTED vmcnt that leaves the tile's own stores in flight.
-// What bounds it (profiles/r05_tail_probe.txt; phase-removal builds of tools/probes/conv_tail_probe.hip): not HBM (no logit stores: -1 %) and not the
-// MFMAs alone (none at all: -27 %) but the LDS -- a wave reads 156 fragments per tile (54 of them weights, 18 the scale / shift vectors), 1.2 MiB per pair
-// of tiles at the ~85 B/clk the CU delivers for this mix.  Measured and dropped (same probe file; all bit-identical):
-//   * the stages cut into 14 barrier-separated load / MFMA phases with the groups an odd number of phases apart (stream8g's scheme;
-//     tools/probes/conv_tail_phases_probe.hip): 1 841 us against 1 577 -- a phase is then one tap column, its 24 KiB per wave of reads take as long as the
-//     other group's MFMAs (~1 700 cycles), and 14 barriers per tile add their skew;
-//   * a WAVE-PRIVATE form (tools/probes/conv_tail_wave_probe.hip): one wave per SIMD with 512 registers, its own 8 x 16 tile, window and patch, conv8_2's and the
-//     1x1's weights in registers, 8 fragments per hidden-layer weight fragment, no workgroup barrier in the loop -- 174 instead of 312 fragment reads per 128
-//     pixels, and 1 735 us against 1 511: with one wave per SIMD its ~1 600 VALU instructions per tile (364 of them AGPR -> VGPR copies for the epilogues) run
-//     in series with its 552 MFMAs;
-//   * the other patch swizzle ((x >> 2) & 3, the faster one in isolation): +3 %;  no scheduling fences inside the stages, no stage offset between the groups: +-1 %.
 // K order and epilogue arithmetic are those of the stand-alone kernels: the logits are bit-identical to v2x_conv2d(conv8_2) followed by
 // v2x_conv2d(heads) (tests/test_gpu_tail.py).  The recompute of conv8_2 on the halo ring costs 22/16 of its MFMAs.
 #include "conv_stream.h"   // lds_ld4: LDS table reads through an explicit address-space pointer
@@ -58,13 +47,16 @@ struct TailArgs {
     int xcd_walk;
 };
 
-#ifndef V2X_TAIL_FENCE_BUILD
-#define V2X_TAIL_FENCE_BUILD 1
-#endif
-#if V2X_TAIL_FENCE_BUILD
-#define TAIL_FENCE __builtin_amdgcn_sched_barrier(0)
-#else
-#define TAIL_FENCE
+// a phase ends: the fragments it read are in registers (the windows / patches may be rewritten behind the barrier), nothing moves across the barrier
+#define TAIL_PHASE_END()                                   \
+    do {                                                   \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        __builtin_amdgcn_s_barrier();                      \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    } while (0)
+#ifndef V2X_TAIL_PHASE_OFFSET_BUILD
+#define V2X_TAIL_PHASE_OFFSET_BUILD 7
 #endif
 namespace tail {
 constexpr int TH = 8, TW = 32;
@@ -83,12 +75,11 @@ constexpr int GRP_BYTES = IN_BYTES + MID_BYTES;
 constexpr int OFF_GRP = WA_BYTES + WB_BYTES;
 constexpr int OFF_DUMMY = OFF_GRP + 2 * GRP_BYTES;
 constexpr int OFF_TAB = OFF_DUMMY + 1024;
-constexpr int SMEM = OFF_TAB + 288 * 4;     // (12 fp32 dwordx4 stores per wave and tile: 3 channel tiles x 4 fragments -- the counted wait below)
-static_assert(IN_BYTES % 1024 == 0 && SMEM <= 160 * 1024, "LDS map");
-#ifndef V2X_TAIL_PSWZ_BUILD
-#define V2X_TAIL_PSWZ_BUILD 1
-#endif
-__device__ __forceinline__ int swz4(int slot, int x) { return slot ^ ((x >> V2X_TAIL_PSWZ_BUILD) & 3); }
+constexpr int OFF_W2 = OFF_TAB + 288 * 4;   // the 1x1's weights [48][64] bf16, row-major as the caller holds them (6 KiB)
+constexpr int SMEM = OFF_W2 + 48 * 64 * 2;     // (12 fp32 dwordx4 stores per wave and tile: 3 channel tiles x 4 fragments -- the counted wait below)
+constexpr int PHASE_OFFSET = V2X_TAIL_PHASE_OFFSET_BUILD;   // group 1 runs this many phases behind group 0 (odd: L opposite M; 7 = half a tile: the groups' store bursts alternate)
+static_assert(IN_BYTES % 1024 == 0 && SMEM <= 160 * 1024 && (PHASE_OFFSET & 1) == 1, "LDS map; odd phase offset");
+__device__ __forceinline__ int swz4(int slot, int x) { return slot ^ ((x >> 1) & 3); }
 }  // namespace tail
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tail_kernel(const TailArgs a) {
@@ -98,20 +89,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int lane = tid & 63;
     const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave8 >> 2, wave = wave8 & 3;
-    const int fj = lane & 15, fq = lane >> 4;
+    const int fj = lane & 15;
     char *s_wA = smem, *s_wB = smem + WA_BYTES;
     char *s_in = smem + OFF_GRP + grp * GRP_BYTES, *s_mid = s_in + IN_BYTES;
 
-    // the three weight sets: wA and wB by LDS-DMA (resident), the 1x1's fragments in registers
+    // the three weight sets by LDS-DMA, resident for the whole kernel
     for (int off = wave8 * 1024; off < WA_BYTES + WB_BYTES; off += 8192) {
         const char *src = off < WA_BYTES ? reinterpret_cast<const char *>(a.wA) + off : reinterpret_cast<const char *>(a.wB) + (off - WA_BYTES);
         __builtin_amdgcn_global_load_lds((gptr_tl_t)(src + lane * 16), (lptr_tl_t)(smem + off), 16, 0, 0);
     }
-    bf16x8_t w2f[3][2];
-#pragma unroll
-    for (int i2 = 0; i2 < 3; ++i2)
-#pragma unroll
-        for (int s = 0; s < 2; ++s) w2f[i2][s] = *reinterpret_cast<const bf16x8_t *>(a.w2 + (size_t)(i2 * 16 + fj) * 64 + s * 32 + fq * 8);
+    for (int off = wave8 * 1024; off < 48 * 64 * 2; off += 8192)
+        __builtin_amdgcn_global_load_lds((gptr_tl_t)(reinterpret_cast<const char *>(a.w2) + off + lane * 16), (lptr_tl_t)(smem + OFF_W2 + off), 16, 0, 0);
     // scale / shift vectors of the three layers: a 1.1-KiB LDS table [scA 32 | shA 32 | scB 64 | shB 64 | sc2 48 | sh2 48] (in registers they are 72 VGPRs
     // the two stages cannot spare; read from global memory per tile they would be waited for together with the previous tile's stores)
     float *s_tab = reinterpret_cast<float *>(smem + OFF_TAB);
@@ -126,22 +114,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         s_tab[i] = v;
     }
     const uint32_t floorA = a.reluA ? 0u : 0x80008000u, floorB = a.reluB ? 0u : 0x80008000u;
-    // everything loaded once is CONSUMED before the loop: vmcnt is in-order, and a load the compiler still has to wait for inside the loop would
-    // be waited for together with the previous tile's stores (conv_halo_pair.hip)
-#pragma unroll
-    for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(w2f[i][0]), "v"(w2f[i][1]));
-
-    // tile-invariant lane geometry.  Stage A: the lane's pixel of each of its fragments, its window offsets per tap column (the swizzle follows
-    // the column).
-    int in_off[FPW][3], rc[FPW];
+    // tile-invariant lane geometry of stage A: the lane's pixel of each of its fragments
+    int rc[FPW];   // region row | column << 8 | valid << 16 | window pixel index (r IW + c) << 20
 #pragma unroll
     for (int t = 0; t < FPW; ++t) {
         const int p = (wave + 4 * t) * 16 + fj;
         const int pc = p < NMID ? p : NMID - 1;
         const int r = pc / MW, c = pc - r * MW;
-        rc[t] = r | (c << 8) | ((p < NMID ? 1 : 0) << 16);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) in_off[t][kx] = ((r * IW + c + kx) * 4 + swz4(fq, c + kx)) * 16;
+        rc[t] = r | (c << 8) | ((p < NMID ? 1 : 0) << 16) | ((r * IW + c) << 20);
     }
     const int txy = a.tiles_x * a.tiles_y;
     auto tile_coords = [&](int tile, int &n, int &ty, int &tx) {
@@ -184,121 +164,45 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // weights and both first windows have landed
-#ifndef V2X_TAIL_OFFSET_BUILD
-#define V2X_TAIL_OFFSET_BUILD 1
-#endif
-    if (V2X_TAIL_OFFSET_BUILD && grp == 1) __builtin_amdgcn_s_barrier();   // one stage behind group 0
+    if (grp == 1)
+        for (int i = 0; i < PHASE_OFFSET; ++i) __builtin_amdgcn_s_barrier();   // an odd number of phases behind group 0: its load phases meet the other's MFMA phases
 
-    for (; pair_i < walk.end; pair_i += walk.step) {
+    // ---- the phases of a tile (every one ends with a workgroup barrier; L = LDS / VALU work, M = MFMAs from registers) ----------------------------------
+    //   0 L  the PREVIOUS tile's stage-B epilogue (hidden -> 1x1 -> 12 logit stores), then the fragments of stage-A tap column 0
+    //   1 M  its 36 MFMAs          2 L / 3 M  tap column 1          4 L / 5 M  tap column 2
+    //   6 L  the next window's DMAs (every wave of the group is past its last window read), stage A's epilogue -> patch
+    //   7 M  (nothing)             8 L / 9 M, 10 L / 11 M, 12 L / 13 M  stage B's three tap columns, 48 MFMAs each; phase 13 ends with the wait for the window
+    // One extra pass of phase 0 after the last tile writes its logits.
+    f32x4_t accB[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int f = 0; f < 4; ++f) accB[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    bool have_prev = false;
+    int pn = 0, pty = 0, ptx = 0;
+    for (;; pair_i += walk.step) {
+        const bool live = pair_i < walk.end;
         const int tile = 2 * pair_i + grp;
-        const bool has = tile < a.n_tiles;
+        const bool has = live && tile < a.n_tiles;
         const int next_pair = pair_i + walk.step;
         const int next = 2 * next_pair + grp;
-        const bool has_next = next_pair < walk.end && next < a.n_tiles;
+        const bool has_next = live && next_pair < walk.end && next < a.n_tiles;
         int n = 0, ty = 0, tx = 0;
         tile_coords(has ? tile : 0, n, ty, tx);
+        // lane coordinates recomputed per tile (opaque to the compiler): with the 14 phases unrolled it otherwise hoists >100 registers of tile-invariant
+        // addresses out of this loop and spills them -- and scratch reloads are vector-memory operations (in-order vmcnt behind the logit stores)
+        const int ln_t = fresh_lane();
+        const int fj = ln_t & 15, fq = ln_t >> 4;
 
-        // ================= STAGE A: conv8_2 on the 10 x 34 region =================
-        if (has) {
-            f32x4_t acc[FPW][2];
-#pragma unroll
-            for (int t = 0; t < FPW; ++t)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) acc[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                // per tap: 2 weight + 6 pixel fragments in front of 12 MFMAs; the next tap's fragments are read under them (two alternating sets)
-                bf16x8_t A[2][2], B[2][FPW];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) A[0][i] = *reinterpret_cast<const bf16x8_t *>(s_wA + ((kx * 4 + fq) * 32 + i * 16 + fj) * 16);
-#pragma unroll
-                for (int t = 0; t < FPW; ++t) B[0][t] = *reinterpret_cast<const bf16x8_t *>(s_in + in_off[t][kx]);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    TAIL_FENCE;
-                    if (ky < 2) {
-#pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            A[(ky + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(s_wA + ((((ky + 1) * 3 + kx) * 4 + fq) * 32 + i * 16 + fj) * 16);
-#pragma unroll
-                        for (int t = 0; t < FPW; ++t) B[(ky + 1) & 1][t] = *reinterpret_cast<const bf16x8_t *>(s_in + in_off[t][kx] + (ky + 1) * (IW * 64));
-                    }
-                    TAIL_FENCE;
-#pragma unroll
-                    for (int t = 0; t < FPW; ++t)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky & 1][i], B[ky & 1][t], acc[t][i], 0, 0, 0);
-                }
-                TAIL_FENCE;
-            }
-            float4 scA[2], shA[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                scA[i] = lds_ld4((lds_cf_t *)s_tab + i * 16 + fq * 4);
-                shA[i] = lds_ld4((lds_cf_t *)s_tab + 32 + i * 16 + fq * 4);
-            }
-#pragma unroll
-            for (int t = 0; t < FPW; ++t) {
-                const int r = rc[t] & 0xff, c = (rc[t] >> 8) & 0xff;
-                const int y = ty * TH - 1 + r, x = tx * TW - 1 + c;
-                const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                if (!(rc[t] >> 16)) continue;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    uint2 o;
-                    o.x = v2x_relu_bf16x2_floor(pack_bf16x2(acc[t][i][0] * scA[i].x + shA[i].x, acc[t][i][1] * scA[i].y + shA[i].y), floorA);
-                    o.y = v2x_relu_bf16x2_floor(pack_bf16x2(acc[t][i][2] * scA[i].z + shA[i].z, acc[t][i][3] * scA[i].w + shA[i].w), floorA);
-                    o.x = inside ? o.x : 0u;
-                    o.y = inside ? o.y : 0u;
-                    *(lds_u2_t *)(s_mid + ((r * MW + c) * 4 + swz4(i * 2 + (fq >> 1), c)) * 16 + (fq & 1) * 8) = (u32x2_tl_t){o.x, o.y};
-                }
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();   // (X) this group's patch is complete; every wave of the group is done reading its window
-        __builtin_amdgcn_sched_barrier(0);
-        if (has_next) load_window(next);   // lands under stage B
-
-        // ================= STAGE B: heads hidden 3x3 32 -> 64, chained 1x1, fp32 logits =================
-        if (has) {
-            f32x4_t acc[4][4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                // the tap column's 8 pixel fragments (4 patch rows x 2 column halves) serve its three taps; the weight fragments of tap ky + 1 are read
-                // under the 16 MFMAs of tap ky (two alternating sets: 32 registers instead of 48)
-                bf16x8_t A[2][4], B[8];
-#pragma unroll
-                for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                    for (int ch = 0; ch < 2; ++ch) {
-                        const int pr = 2 * wave + rr, pc = ch * 16 + fj + kx;
-                        B[rr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(s_mid + ((pr * MW + pc) * 4 + swz4(fq, pc)) * 16);
-                    }
-#pragma unroll
-                for (int i = 0; i < 4; ++i) A[0][i] = *reinterpret_cast<const bf16x8_t *>(s_wB + ((kx * 4 + fq) * 64 + i * 16 + fj) * 16);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    TAIL_FENCE;
-                    if (ky < 2) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            A[(ky + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(s_wB + ((((ky + 1) * 3 + kx) * 4 + fq) * 64 + i * 16 + fj) * 16);
-                    }
-                    TAIL_FENCE;
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int f = 0; f < 4; ++f)
-                            acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky & 1][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
-                }
-                TAIL_FENCE;
-            }
+        // ================= phase 0: stage B's epilogue of the previous tile =================
+        {   // (straight-line even without a previous tile: only the stores are predicated -- conditional regions around the phases cost the allocator
+            //  ~140 registers of copies, i.e. spills)
             float4 scB[4], shB[4], s2v[3], t2v[3];
+            bf16x8_t w2f[3][2];
+#pragma unroll
+            for (int i2 = 0; i2 < 3; ++i2)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) w2f[i2][s] = *reinterpret_cast<const bf16x8_t *>(smem + OFF_W2 + ((i2 * 16 + fj) * 64 + s * 32 + fq * 8) * 2);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {   // packed row 16 i + 4 q + r computes hidden channel kappa = 32 (i >> 1) + 8 q + 4 (i & 1) + r
                 const int kappa = 32 * (i >> 1) + 8 * fq + 4 * (i & 1);
@@ -319,10 +223,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
                         const int i = 2 * s + half;
-                        h[half * 4 + 0] = acc[i][f][0] * scB[i].x + shB[i].x;
-                        h[half * 4 + 1] = acc[i][f][1] * scB[i].y + shB[i].y;
-                        h[half * 4 + 2] = acc[i][f][2] * scB[i].z + shB[i].z;
-                        h[half * 4 + 3] = acc[i][f][3] * scB[i].w + shB[i].w;
+                        h[half * 4 + 0] = accB[i][f][0] * scB[i].x + shB[i].x;
+                        h[half * 4 + 1] = accB[i][f][1] * scB[i].y + shB[i].y;
+                        h[half * 4 + 2] = accB[i][f][2] * scB[i].z + shB[i].z;
+                        h[half * 4 + 3] = accB[i][f][3] * scB[i].w + shB[i].w;
                     }
                     uint4 p;
                     p.x = v2x_relu_bf16x2_floor(pack_bf16x2(h[0], h[1]), floorB);
@@ -331,8 +235,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     p.w = v2x_relu_bf16x2_floor(pack_bf16x2(h[6], h[7]), floorB);
                     hb[s] = __builtin_bit_cast(bf16x8_t, p);
                 }
-                const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
-                const size_t pix = (size_t)(n * a.H + y) * a.W + x;
+                const int y = pty * TH + 2 * wave + (f >> 1), x = ptx * TW + (f & 1) * 16 + fj;
+                const size_t pix = (size_t)(pn * a.H + y) * a.W + x;
 #pragma unroll
                 for (int i2 = 0; i2 < 3; ++i2) {
                     f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
@@ -349,18 +253,107 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     const bool second = co >= a.split;
                     float *dst = second ? a.out2 + pix * a.out2_cstride + (co - a.split) : a.out + pix * a.out_cstride + a.out_coff + co;
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
+                    if (have_prev) *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
                 }
             }
         }
-        // the next window's pieces are OLDER than this tile's stores (in-order vmcnt): they have landed, the stores stay in flight
-        if (has) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();   // (Y) the patch may be rewritten; the next window is visible to the whole group
-        __builtin_amdgcn_sched_barrier(0);
+        if (!live) break;
+        have_prev = has;
+        pn = n;
+        pty = ty;
+        ptx = tx;
+
+        // ================= phases 0 .. 5: stage A, conv8_2 on the 10 x 34 region, one tap column per L / M pair =================
+        f32x4_t accA[FPW][2];
+#pragma unroll
+        for (int t = 0; t < FPW; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) accA[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            bf16x8_t A[3][2], B[3][FPW];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_wA + (((ky * 3 + kx) * 4 + fq) * 32 + i * 16 + fj) * 16);
+#pragma unroll
+                for (int t = 0; t < FPW; ++t) {
+                    const int col = ((rc[t] >> 8) & 0xff) + kx;
+                    B[ky][t] = *reinterpret_cast<const bf16x8_t *>(s_in + (((rc[t] >> 20) + kx) * 4 + swz4(fq, col)) * 16 + ky * (IW * 64));
+                }
+            }
+            TAIL_PHASE_END();   // L
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int t = 0; t < FPW; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) accA[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], B[ky][t], accA[t][i], 0, 0, 0);
+            TAIL_PHASE_END();   // M
+        }
+
+        // ================= phase 6: the next window's DMAs; stage A's epilogue -> the patch =================
+        if (has_next) load_window(next);
+        {
+            float4 scA[2], shA[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                scA[i] = lds_ld4((lds_cf_t *)s_tab + i * 16 + fq * 4);
+                shA[i] = lds_ld4((lds_cf_t *)s_tab + 32 + i * 16 + fq * 4);
+            }
+#pragma unroll
+            for (int t = 0; t < FPW; ++t) {
+                const int r = rc[t] & 0xff, c = (rc[t] >> 8) & 0xff;
+                const int y = ty * TH - 1 + r, x = tx * TW - 1 + c;
+                const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+                if (!(rc[t] >> 16)) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    uint2 o;
+                    o.x = v2x_relu_bf16x2_floor(pack_bf16x2(accA[t][i][0] * scA[i].x + shA[i].x, accA[t][i][1] * scA[i].y + shA[i].y), floorA);
+                    o.y = v2x_relu_bf16x2_floor(pack_bf16x2(accA[t][i][2] * scA[i].z + shA[i].z, accA[t][i][3] * scA[i].w + shA[i].w), floorA);
+                    o.x = inside ? o.x : 0u;
+                    o.y = inside ? o.y : 0u;
+                    *(lds_u2_t *)(s_mid + ((r * MW + c) * 4 + swz4(i * 2 + (fq >> 1), c)) * 16 + (fq & 1) * 8) = (u32x2_tl_t){o.x, o.y};
+                }
+            }
+        }
+        TAIL_PHASE_END();   // L: the group's patch is complete
+        TAIL_PHASE_END();   // M: (nothing -- keeps this group's load phases opposite the other group's MFMA phases)
+
+        // ================= phases 8 .. 13: stage B, the heads' hidden 3x3 32 -> 64 =================
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int f = 0; f < 4; ++f) accB[i][f] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            bf16x8_t A[3][4], B[8];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int ch = 0; ch < 2; ++ch) {
+                    const int pr = 2 * wave + rr, pc = ch * 16 + fj + kx;
+                    B[rr * 2 + ch] = *reinterpret_cast<const bf16x8_t *>(s_mid + ((pr * MW + pc) * 4 + swz4(fq, pc)) * 16);
+                }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_wB + (((ky * 3 + kx) * 4 + fq) * 64 + i * 16 + fj) * 16);
+            TAIL_PHASE_END();   // L
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        accB[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], B[((f >> 1) + ky) * 2 + (f & 1)], accB[i][f], 0, 0, 0);
+            if (kx == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next window (requested 7 phases ago) and the previous tile's stores (13 phases ago)
+            TAIL_PHASE_END();   // M
+        }
     }
-    if (V2X_TAIL_OFFSET_BUILD && grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's offset barrier
+    if (grp == 0)
+        for (int i = 0; i < PHASE_OFFSET; ++i) __builtin_amdgcn_s_barrier();   // balance group 1's offset
 }
 
 int v2x_num_cus();   // conv_stream.hip
