@@ -2,7 +2,7 @@
  *
  *   points --v2x_voxelize_bits--> bit grid --v2x_conv2d_pair / v2x_conv2d x N (encoder)--> pyramid
  *          --v2x_warp_fuse (mean over neighbours) --v2x_conv2d (ConvGRU)--> fused level
- *          --v2x_conv2d x 8 (decoder; conv5_1, conv6_1, conv8_1 in the parity-class layouts)--> v2x_conv2d (det heads) --> cls / loc logits
+ *          --v2x_conv2d x 7 (decoder; the four _1 layers in the parity-class layouts)--> v2x_conv2d_pair (conv8_2 + det heads, one launch) --> cls / loc logits
  *          --v2x_det_postprocess--> boxes, scores, anchor indices, counts
  *
  * driven from raw fp32 CHECKPOINT tensors (OIHW weights, BN statistics, biases) through the C packers only (v2x_fold_bn, v2x_pack_conv,
@@ -248,8 +248,8 @@ static packed pack_chain(const ckpt_conv *c, const ckpt_conv *c3, int layout) {
 }
 
 /* ---------------------------------------------------------------- launches */
-static void conv(const packed *p, const void *in0, const void *in1, int N, int H, int W, void *out, int out_cstride, int split, void *out2,
-                 int in_bits, int zbits) {
+static v2x_conv_desc desc_of(const packed *p, const void *in0, const void *in1, int N, int H, int W, void *out, int out_cstride, int split, void *out2,
+                             int in_bits, int zbits) {
     v2x_conv_desc d;
     memset(&d, 0, sizeof d);
     d.in0 = (const uint16_t *)in0;
@@ -273,6 +273,11 @@ static void conv(const packed *p, const void *in0, const void *in1, int N, int H
         d.weight2 = p->weight2; d.scale2 = p->scale2; d.shift2 = p->shift2;
     }
     if (in_bits) { d.in_format = 1; d.in_zbits = zbits; }
+    return d;
+}
+static void conv(const packed *p, const void *in0, const void *in1, int N, int H, int W, void *out, int out_cstride, int split, void *out2,
+                 int in_bits, int zbits) {
+    const v2x_conv_desc d = desc_of(p, in0, in1, N, H, W, out, out_cstride, split, out2, in_bits, zbits);
     V2XOK(v2x_conv2d(&d, NULL));
 }
 static int halo_eligible(int H, int W, int layout, int cmax, int cout) {
@@ -490,13 +495,22 @@ int main(int argc, char **argv) {
     /* ---- a6: decoder, a7: heads ------------------------------------------------------------------------------------------------------ */
     uint16_t *y = feat[4];
     int c = 0;
+    /* conv8_2 and the heads go out as ONE launch when both have their halo packings and the extent allows (v2x_conv2d_pair's second form,
+     * conv_tail.hip: conv8_2's output is never stored; bit-identical to the two launches) */
+    const int tail = heads_halo.valid && dec_pt[7].valid && dec_pt[7].w_layout == 1 && dec_pt[7].C0 == 32 && dec_pt[7].Cout == 32 && halo_eligible(X, Y, 1, 32, 0) &&
+                     (long long)N * X * Y < (1ll << 27);
     for (int l = 0; l < 4; ++l) {
         const int H = fh[3 - l], W = fw[3 - l];
         y = run_layer(&dec_pt[2 * l], &dec_fb[2 * l], NULL, y, feat[3 - l], N, H, W, &c);
+        if (l == 3 && tail) break;
         y = run_layer(&dec_pt[2 * l + 1], &dec_fb[2 * l + 1], NULL, y, NULL, N, H, W, &c);
     }
     float *d_cls = (float *)dalloc((size_t)N * X * Y * ncls * 4), *d_loc = (float *)dalloc((size_t)N * X * Y * nreg * 4);
-    if (heads_halo.valid && halo_eligible(X, Y, 1, 32, 0)) {
+    if (tail) {
+        const v2x_conv_desc d8 = desc_of(&dec_pt[7], y, NULL, N, X, Y, NULL, 32, 0, NULL, 0, 0);
+        const v2x_conv_desc dh = desc_of(&heads_halo, NULL, NULL, N, X, Y, d_cls, ncls, ncls, d_loc, 0, 0);
+        V2XOK(v2x_conv2d_pair(&d8, &dh, NULL));
+    } else if (heads_halo.valid && halo_eligible(X, Y, 1, 32, 0)) {
         conv(&heads_halo, y, NULL, N, X, Y, d_cls, ncls, ncls, d_loc, 0, 0);
     } else {
         uint16_t *hid = (uint16_t *)dalloc((size_t)N * X * Y * heads_hidden.Cout * 2);
