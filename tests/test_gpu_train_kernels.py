@@ -980,6 +980,44 @@ def test_batched_repack_changes_no_bit(device, tune, family):
         assert torch.equal(p[k], ref_p[k]), k
 
 
+def test_discarded_models_leave_no_packings_behind(device, tune):
+    """ the training-graph cache holds its packed buffers strongly and the parameters weakly: when a model is dropped, the next
+    train_forward prunes its cache entries and every re-pack plan that names them -- the device memory of a discarded model is released."""
+    import gc
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.train import detection_loss, train_forward, hip_graph
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    tune("TRAIN_HIP", 1)
+    tune("TRAIN_PACK_BATCH", 1)
+    cfg = Config("train")
+    hip_graph._CACHE.clear()
+    hip_graph._PLANS.clear()
+    d = synthetic_batch_on_device(cfg, 1, 2, seed=31, device=device)
+
+    def steps(m, n):
+        opt = torch.optim.SGD(m.parameters(), lr=1e-3)
+        for _ in range(n):
+            res = train_forward(m, d["bev_seq"], d["trans_matrices"], d["num_agent"], 1)
+            loss = detection_loss(res, d["labels"], d["reg_targets"], d["reg_loss_mask"])[0]
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+
+    first = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=1).to(device).train()
+    steps(first, 3)
+    n_first, plans_first = len(hip_graph._CACHE), len(hip_graph._PLANS)
+    assert n_first > 20 and plans_first >= 1
+    del first
+    gc.collect()
+    second = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=2).to(device).train()
+    steps(second, 3)
+    torch.cuda.synchronize()
+    alive = [k for k, ent in hip_graph._CACHE.items() if ent[2]() is not None]
+    assert len(hip_graph._CACHE) == len(alive) == n_first, (len(hip_graph._CACHE), len(alive), n_first)    # the first model's entries are gone
+    assert all(set(pk) <= set(hip_graph._CACHE) for pk in hip_graph._PLANS) and len(hip_graph._PLANS) <= plans_first + 1
+
+
 def test_repack_plan_equals_the_per_layer_device_packer(device):
     """packing.RepackPlan (v2x_pack_conv_device_job / _batch): every layout the training graph packs (gather, halo, streamed; forward and
     data-gradient; 3x3 and 1x1; a padded bias), rebuilt in place after the parameters changed == a fresh per-layer packing, bit for bit."""

@@ -79,15 +79,24 @@ def _entry_packs(obj):
 def _repack_stale():
     if tuning.get("TRAIN_PACK_BATCH") == 0 or not _CACHE:
         return
-    stale = []
+    stale, dead = [], []
     for key, ent in _CACHE.items():
         w = ent[2]()
         b = None if ent[3] is None else ent[3]()
         if w is None or (ent[3] is not None and b is None):
+            dead.append(key)                           # the parameter is gone (a discarded model): its packed buffers go with it
             continue
         ver = _versions(w, b)
         if ver != ent[0]:
             stale.append((key, ent, ver))
+    if dead:
+        #  only the weights are weakly referenced: without this the packings and the job tables of discarded models stayed resident
+        # until the 512-entry / 16-plan overflow clears.  A plan is keyed by the cache keys it re-packs: drop those that name a dead entry.
+        gone = set(dead)
+        for key in dead:
+            del _CACHE[key]
+        for pkey in [k for k in _PLANS if gone.intersection(k) or not _PLANS[k].valid()]:
+            del _PLANS[pkey]
     if len(stale) < 2:
         return
     pkey = tuple(k for k, _, _ in stale)
