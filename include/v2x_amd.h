@@ -272,7 +272,7 @@ int v2x_conv2d(const v2x_conv_desc *desc, v2x_stream_t stream);
  * Backbone.py::LidarDecoder's conv8_2 + bn + relu followed by DetModelBase.py's ClassificationHead and SingleRegressionHead.
  * first = conv8_2 (3x3, stride 1, pad 1, w_layout 1, C0 = 32, C1 = 0, Cout = 32, bf16 epilogue, in0 = conv8_1's output, bf16 NHWC [N][H][W][32]);
  * second = the fused heads exactly as v2x_conv2d takes them (w_layout 1, C0 = 32, Cout = 64 hidden rows in chain order, Cout2 = 48, weight2 / scale2 /
- * shift2, epilogue V2X_EPI_F32, split = the classification channels, out / out2 16-byte aligned).  H % 8 == 0, W % 32 == 0, N H W < 2^27.  conv8_2's
+ * shift2, relu2 = 0, epilogue V2X_EPI_F32, split = the classification channels (4, 8 or 12), out / out2 16-byte aligned).  H % 8 == 0, W % 32 == 0, N H W < 2^27.  conv8_2's
  * output is never stored (first->out ignored); the logits are bit-identical to v2x_conv2d(first) followed by v2x_conv2d(second). */
 int v2x_conv2d_pair(const v2x_conv_desc *first, const v2x_conv_desc *second, v2x_stream_t stream);
 

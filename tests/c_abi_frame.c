@@ -498,7 +498,7 @@ int main(int argc, char **argv) {
     /* conv8_2 and the heads go out as ONE launch when both have their halo packings and the extent allows (v2x_conv2d_pair's second form,
      * conv_tail.hip: conv8_2's output is never stored; bit-identical to the two launches) */
     const int tail = heads_halo.valid && dec_pt[7].valid && dec_pt[7].w_layout == 1 && dec_pt[7].C0 == 32 && dec_pt[7].Cout == 32 && halo_eligible(X, Y, 1, 32, 0) &&
-                     (long long)N * X * Y < (1ll << 27);
+                     (long long)N * X * Y < (1ll << 27) && (ncls == 4 || ncls == 8 || ncls == 12);
     for (int l = 0; l < 4; ++l) {
         const int H = fh[3 - l], W = fw[3 - l];
         y = run_layer(&dec_pt[2 * l], &dec_fb[2 * l], NULL, y, feat[3 - l], N, H, W, &c);

@@ -5,8 +5,8 @@
 // Why: both launches are HBM-bound (conv8_2 reads 1.5 GB and writes 1.34 GB per 320 maps, the heads read those 1.34 GB back 0.5 ms later and
 // write 4.03 GB of logits: 530 + 1 100 us).  Here conv8_2's output never leaves the CU: per 8 x 32 output tile
 //   * the 12 x 36-pixel window of conv8_1's output is moved into LDS by LDS-DMA (pixel-major, swizzled: conv_halo.hip's patch layout);
-//   * STAGE A evaluates conv8_2 on the 10 x 34 region the heads need -- 340 pixels walked as 22 linear 16-pixel fragments (conv_halo_pair.hip's
-//     scheme), scale / shift / ReLU, rounded to bf16 exactly as the stand-alone layer stores it, ZERO where the pixel lies outside the image
+//   * STAGE A evaluates conv8_2 on the 10 x 34 region the heads need -- 20 row-segment fragments of the tile's own columns + 2 fragments for the two
+//     halo columns (22 fragments for 340 pixels; row segments share their window reads across the tap rows), scale / shift / ReLU, rounded to bf16 exactly as the stand-alone layer stores it, ZERO where the pixel lies outside the image
 //     (= the heads' zero padding) -- into a second LDS patch;
 //   * STAGE B is conv_halo.hip's heads form on that patch: tap-column groups, the hidden rows in kappa order so that a lane's accumulators are
 //     its B fragment of the 1x1, whose weights live in registers; fp32 split stores (cls | loc).
@@ -14,17 +14,19 @@
 // one stage apart (raw s_barrier, group 1 starts one barrier late): while one group's waves multiply stage A of their next tile, the other's
 // are in stage B and its 12 logit stores per wave -- one workgroup per CU, 152 KiB of LDS.  The next tile's window is requested right after the
 // barrier that ends stage A and waited for with a COUNTED vmcnt that leaves the tile's own stores in flight.
-// What bounds it (profiles/r05_tail_probe.txt; phase-removal builds of tools/probes/conv_tail_probe.hip): not HBM (no logit stores: -1 %) and not the
-// MFMAs alone (none at all: -27 %) but the LDS -- a wave reads 156 fragments per tile (54 of them weights, 18 the scale / shift vectors), 1.2 MiB per pair
-// of tiles at the ~85 B/clk the CU delivers for this mix.  Measured and dropped (same probe file; all bit-identical):
+// What bounds it (profiles/r05_tail_probe.txt; phase-removal and time-stamp builds of tools/probes/conv_tail_probe.hip, tools/tail_timeline.sh): not HBM (no
+// logit stores: -1 %) and not one pipe -- a SIMD's two waves (one per group) issue ~480 VALU, ~130 LDS and 276 MFMA instructions per tile each, and the
+// stage times are close to the SUM of those three (stage A ~5 us for 0.8 us of MFMAs).  What helped: fewer instructions -- one output address per tensor and
+// pixel with the channel tiles at immediate offsets instead of a `co >= split` select per store, no second ReLU, a window fill without bounds tests for tiles
+// away from the image border (lane offsets precomputed), stage A on row segments (wave-uniform border tests, a third fewer pixel reads): 1 555 -> 1 422 us.
+// Measured and dropped (same probe file; all bit-identical):
 //   * the stages cut into 14 barrier-separated load / MFMA phases with the groups an odd number of phases apart (stream8g's scheme;
-//     tools/probes/conv_tail_phases_probe.hip): 1 841 us against 1 577 -- a phase is then one tap column, its 24 KiB per wave of reads take as long as the
-//     other group's MFMAs (~1 700 cycles), and 14 barriers per tile add their skew;
+//     tools/probes/conv_tail_phases_probe.hip): 1 841 us against 1 577 -- a phase is then one tap column, and 14 barriers per tile add their skew;
 //   * a WAVE-PRIVATE form (tools/probes/conv_tail_wave_probe.hip): one wave per SIMD with 512 registers, its own 8 x 16 tile, window and patch, conv8_2's and the
 //     1x1's weights in registers, 8 fragments per hidden-layer weight fragment, no workgroup barrier in the loop -- 174 instead of 312 fragment reads per 128
 //     pixels, and 1 735 us against 1 511: with one wave per SIMD its ~1 600 VALU instructions per tile (364 of them AGPR -> VGPR copies for the epilogues) run
 //     in series with its 552 MFMAs;
-//   * the other patch swizzle ((x >> 2) & 3, the faster one in isolation): +3 %;  no scheduling fences inside the stages, no stage offset between the groups: +-1 %.
+//   * the other patch swizzle ((x >> 2) & 3, the faster one in isolation): +3 %;  no scheduling fences inside the stages: +-1 %;  no stage offset between the groups: +2.5 %.
 // K order and epilogue arithmetic are those of the stand-alone kernels: the logits are bit-identical to v2x_conv2d(conv8_2) followed by
 // v2x_conv2d(heads) (tests/test_gpu_tail.py).  The recompute of conv8_2 on the halo ring costs 22/16 of its MFMAs.
 #include "conv_stream.h"   // lds_ld4: LDS table reads through an explicit address-space pointer
@@ -51,7 +53,7 @@ struct TailArgs {
     int reluB;
     const uint16_t *w2;                 // chained 1x1: row-major [48][64] bf16, K in kappa order
     const float *sc2, *sh2;             // [48]
-    int relu2, split;                   // rows < split -> out, the others -> out2
+    int split;                          // rows < split (4, 8 or 12) -> out, the others -> out2; no ReLU on the logits
     float *out, *out2;
     int out_cstride, out_coff, out2_cstride;
     int tiles_x, tiles_y, n_tiles;
@@ -71,8 +73,6 @@ constexpr int TH = 8, TW = 32;
 constexpr int MH = TH + 2, MW = TW + 2;     // stage-A region = stage B's patch
 constexpr int IH = TH + 4, IW = TW + 4;     // input window
 constexpr int NMID = MH * MW;               // 340
-constexpr int NFRAG = (NMID + 15) / 16;     // 22
-constexpr int FPW = (NFRAG + 3) / 4;        // 6 (waves 2, 3 of a group own 5)
 constexpr int WA_BYTES = 36 * 32 * 16;      // 18 432
 constexpr int WB_BYTES = 36 * 64 * 16;      // 36 864
 constexpr int IN_BYTES = IH * IW * 64;      // 27 648 = 27 one-KiB pieces
@@ -131,17 +131,28 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < 3; ++i) asm volatile("" ::"v"(w2f[i][0]), "v"(w2f[i][1]));
 
-    // tile-invariant lane geometry.  Stage A: the lane's pixel of each of its fragments, its window offsets per tap column (the swizzle follows
-    // the column).
-    int in_off[FPW][3], rc[FPW];
+    // Stage A's fragments.  The 10 x 34 region = BODY (columns 1 .. 32 = the tile's own 32 columns: two 16-pixel segments per row, 20 fragments) +
+    // the two halo COLUMNS 0 and 33 (20 pixels: two more fragments).  A body fragment of region row r and tap (ky, kx) reads window row r + ky at
+    // columns seg + kx .. + 15 -- the same read for every (r, ky) with the same sum, so a wave that owns consecutive rows reads each window row once
+    // per tap column (the linear walk of conv_halo_pair.hip read one fragment per MFMA pair: 54 instead of 30-33 pixel reads per wave and tile).
+    // Waves 0, 1 own three body rows (6 fragments), waves 2, 3 two body rows and one halo-column fragment (5): rows 3w.. resp. 6 + 2 (w - 2)..
+    const int r0 = wave < 2 ? 3 * wave : 6 + 2 * (wave - 2);                       // wave-uniform
+    int body_off[2][3];                                                             // lane offset of (segment, kx) inside a window row, swizzled
 #pragma unroll
-    for (int t = 0; t < FPW; ++t) {
-        const int p = (wave + 4 * t) * 16 + fj;
-        const int pc = p < NMID ? p : NMID - 1;
-        const int r = pc / MW, c = pc - r * MW;
-        rc[t] = r | (c << 8) | ((p < NMID ? 1 : 0) << 16);
+    for (int sg = 0; sg < 2; ++sg)
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) in_off[t][kx] = ((r * IW + c + kx) * 4 + swz4(fq, c + kx)) * 16;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int col = 1 + 16 * sg + fj + kx;
+            body_off[sg][kx] = (col * 4 + swz4(fq, col)) * 16;
+        }
+    // halo fragment: wave 2 -- lanes 0 .. 9 = column 0 rows 0 .. 9, lanes 10 .. 15 = column 33 rows 0 .. 5;  wave 3 -- lanes 0 .. 3 = column 33 rows 6 .. 9
+    int hr, hc, hvalid;
+    {
+        const int q = (wave == 3 ? 16 : 0) + fj;                                    // 0 .. 19: column 0 rows 0..9, then column 33 rows 0..9
+        const int qc = q < 20 ? q : 19;
+        hc = qc < 10 ? 0 : MW - 1;
+        hr = qc < 10 ? qc : qc - 10;
+        hvalid = (wave >= 2 && q < 20) ? 1 : 0;
     }
     const int txy = a.tiles_x * a.tiles_y;
     auto tile_coords = [&](int tile, int &n, int &ty, int &tx) {
@@ -155,9 +166,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
         return l;
     };
+    // window fill: the lane's element offset from the window's first pixel per piece (tile-invariant: 7 registers); a tile away from the image border
+    // (70 % of them at 256 x 256) needs no bounds test -- 3 VALU instructions per piece instead of ~15
+    unsigned woff[PPW];
+#pragma unroll
+    for (int u = 0; u < PPW; ++u) {
+        const int sidx = (wave + 4 * u) * 64 + lane;
+        const int pix = sidx >> 2, phys = sidx & 3;
+        const int pr = pix / IW, pcx = pix - pr * IW;
+        woff[u] = (unsigned)(pr * a.W + pcx) * (unsigned)a.in_cstride + (unsigned)(swz4(phys, pcx) * 8);
+    }
     auto load_window = [&](int tile) {   // exactly PPW DMAs per wave (the fourth wave's 7th goes to a dummy page)
         int n, ty, tx;
         tile_coords(tile, n, ty, tx);
+        const bool interior = ty > 0 && ty + 1 < a.tiles_y && tx > 0 && tx + 1 < a.tiles_x;   // wave-uniform
+        if (interior) {
+            const uint16_t *base = a.in + (size_t)((n * a.H + ty * TH - 2) * a.W + tx * TW - 2) * a.in_cstride + a.in_coff;
+#pragma unroll
+            for (int u = 0; u < PPW; ++u) {
+                const int piece = wave + 4 * u;
+                char *dst = piece < IN_PIECES ? s_in + piece * 1024 : smem + OFF_DUMMY;   // wave-uniform
+                __builtin_amdgcn_global_load_lds((gptr_tl_t)(piece < IN_PIECES ? (const void *)(base + woff[u]) : (const void *)g_zero_page_tail), (lptr_tl_t)dst, 16, 0, 0);
+            }
+            return;
+        }
         const int ln = fresh_lane();
 #pragma unroll
         for (int u = 0; u < PPW; ++u) {
@@ -200,34 +232,53 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
         // ================= STAGE A: conv8_2 on the 10 x 34 region =================
         if (has) {
-            f32x4_t acc[FPW][2];
+            f32x4_t acc[6][2];   // [2 j + segment] for the wave's body rows j = 0, 1 (and 2: waves 0, 1);  waves 2, 3: [4] = the halo-column fragment
 #pragma unroll
-            for (int t = 0; t < FPW; ++t)
+            for (int t = 0; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[t][i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            const char *wrow = s_in + r0 * (IW * 64);
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                // per tap: 2 weight + 6 pixel fragments in front of 12 MFMAs; the next tap's fragments are read under them (two alternating sets)
-                bf16x8_t A[2][2], B[2][FPW];
+            for (int kx = 0; kx < 3; ++kx) {   // K order of the stand-alone layer: tap column outer, tap row inner
+                // X: waves 0, 1 -- the fifth window row's two segments (their third body row's last tap row);  waves 2, 3 -- the halo fragment's three tap rows
+                bf16x8_t A[3][2], Bb[4][2], X[3];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) A[0][i] = *reinterpret_cast<const bf16x8_t *>(s_wA + ((kx * 4 + fq) * 32 + i * 16 + fj) * 16);
+                for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int t = 0; t < FPW; ++t) B[0][t] = *reinterpret_cast<const bf16x8_t *>(s_in + in_off[t][kx]);
+                    for (int i = 0; i < 2; ++i) A[ky][i] = *reinterpret_cast<const bf16x8_t *>(s_wA + (((ky * 3 + kx) * 4 + fq) * 32 + i * 16 + fj) * 16);
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                    for (int sg = 0; sg < 2; ++sg) Bb[rr][sg] = *reinterpret_cast<const bf16x8_t *>(wrow + rr * (IW * 64) + body_off[sg][kx]);
+                if (wave < 2) {
+#pragma unroll
+                    for (int sg = 0; sg < 2; ++sg) X[sg] = *reinterpret_cast<const bf16x8_t *>(wrow + 4 * (IW * 64) + body_off[sg][kx]);
+                    X[2] = X[1];
+                } else {
+                    const int col = hc + kx;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) X[ky] = *reinterpret_cast<const bf16x8_t *>(s_in + (((hr + ky) * IW + col) * 4 + swz4(fq, col)) * 16);
+                }
+                TAIL_FENCE;
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    TAIL_FENCE;
-                    if (ky < 2) {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            A[(ky + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(s_wA + ((((ky + 1) * 3 + kx) * 4 + fq) * 32 + i * 16 + fj) * 16);
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                        for (int t = 0; t < FPW; ++t) B[(ky + 1) & 1][t] = *reinterpret_cast<const bf16x8_t *>(s_in + in_off[t][kx] + (ky + 1) * (IW * 64));
+                        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+                                acc[2 * j + sg][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], Bb[j + ky][sg], acc[2 * j + sg][i], 0, 0, 0);
+                    if (wave < 2) {
+#pragma unroll
+                        for (int sg = 0; sg < 2; ++sg)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i)
+                                acc[4 + sg][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], ky == 2 ? X[sg] : Bb[2 + ky][sg], acc[4 + sg][i], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) acc[4][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], X[ky], acc[4][i], 0, 0, 0);
                     }
-                    TAIL_FENCE;
-#pragma unroll
-                    for (int t = 0; t < FPW; ++t)
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky & 1][i], B[ky & 1][t], acc[t][i], 0, 0, 0);
                 }
                 TAIL_FENCE;
             }
@@ -237,21 +288,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 scA[i] = lds_ld4((lds_cf_t *)s_tab + i * 16 + fq * 4);
                 shA[i] = lds_ld4((lds_cf_t *)s_tab + 32 + i * 16 + fq * 4);
             }
-#pragma unroll
-            for (int t = 0; t < FPW; ++t) {
-                const int r = rc[t] & 0xff, c = (rc[t] >> 8) & 0xff;
-                const int y = ty * TH - 1 + r, x = tx * TW - 1 + c;
-                const bool inside = (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-                if (!(rc[t] >> 16)) continue;
+            auto emit = [&](const f32x4_t (&v)[2], int r, int c, bool keep, bool inside) __attribute__((always_inline)) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     uint2 o;
-                    o.x = v2x_relu_bf16x2_floor(pack_bf16x2(acc[t][i][0] * scA[i].x + shA[i].x, acc[t][i][1] * scA[i].y + shA[i].y), floorA);
-                    o.y = v2x_relu_bf16x2_floor(pack_bf16x2(acc[t][i][2] * scA[i].z + shA[i].z, acc[t][i][3] * scA[i].w + shA[i].w), floorA);
+                    o.x = v2x_relu_bf16x2_floor(pack_bf16x2(v[i][0] * scA[i].x + shA[i].x, v[i][1] * scA[i].y + shA[i].y), floorA);
+                    o.y = v2x_relu_bf16x2_floor(pack_bf16x2(v[i][2] * scA[i].z + shA[i].z, v[i][3] * scA[i].w + shA[i].w), floorA);
                     o.x = inside ? o.x : 0u;
                     o.y = inside ? o.y : 0u;
-                    *(lds_u2_t *)(s_mid + ((r * MW + c) * 4 + swz4(i * 2 + (fq >> 1), c)) * 16 + (fq & 1) * 8) = (u32x2_tl_t){o.x, o.y};
+                    if (keep) *(lds_u2_t *)(s_mid + ((r * MW + c) * 4 + swz4(i * 2 + (fq >> 1), c)) * 16 + (fq & 1) * 8) = (u32x2_tl_t){o.x, o.y};
                 }
+            };
+            // body fragments: their columns are the tile's own (always inside the image); a row is outside only for the first / last tile row (wave-uniform)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                if (j == 2 && wave >= 2) break;
+                const int r = r0 + j;
+                const int y = ty * TH - 1 + r;
+                const bool inside = (unsigned)y < (unsigned)a.H;
+#pragma unroll
+                for (int sg = 0; sg < 2; ++sg) emit(acc[2 * j + sg], r, 1 + 16 * sg + fj, true, inside);
+            }
+            if (wave >= 2) {
+                const int y = ty * TH - 1 + hr, x = tx * TW - 1 + hc;
+                emit(acc[4], hr, hc, hvalid != 0, (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -332,24 +392,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     hb[s] = __builtin_bit_cast(bf16x8_t, p);
                 }
                 const int y = ty * TH + 2 * wave + (f >> 1), x = tx * TW + (f & 1) * 16 + fj;
-                const size_t pix = (size_t)(n * a.H + y) * a.W + x;
+                const uint32_t pix = (uint32_t)((n * a.H + y) * a.W + x);
+                // channel tile 0 straddles the split (its lanes with 4 fq >= split belong to out2), tiles 1 and 2 lie behind it: ONE address per output
+                // tensor and pixel, the tiles at immediate offsets (the general `co >= split` select per store cost 8 VALU instructions each)
+                float *p1 = a.out + (size_t)pix * a.out_cstride + a.out_coff + fq * 4;
+                float *p2 = a.out2 + (size_t)pix * a.out2_cstride + fq * 4 - a.split;
+                float *p0 = (fq * 4 >= a.split) ? p2 : p1;
 #pragma unroll
                 for (int i2 = 0; i2 < 3; ++i2) {
                     f32x4_t d = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[i2][s], hb[s], d, 0, 0, 0);
-                    const int co = i2 * 16 + fq * 4;
                     const float4 s2 = s2v[i2], t2 = t2v[i2];
-                    float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;
-                    if (a.relu2) {
-                        v0 = fmaxf(v0, 0.f);
-                        v1 = fmaxf(v1, 0.f);
-                        v2 = fmaxf(v2, 0.f);
-                        v3 = fmaxf(v3, 0.f);
-                    }
-                    const bool second = co >= a.split;
-                    float *dst = second ? a.out2 + pix * a.out2_cstride + (co - a.split) : a.out + pix * a.out_cstride + a.out_coff + co;
-                    *reinterpret_cast<float4 *>(dst) = make_float4(v0, v1, v2, v3);
+                    const float v0 = d[0] * s2.x + t2.x, v1 = d[1] * s2.y + t2.y, v2 = d[2] * s2.z + t2.z, v3 = d[3] * s2.w + t2.w;   // (no second ReLU: the dispatch requires relu2 == 0)
+                    *reinterpret_cast<float4 *>(i2 == 0 ? p0 : p2 + i2 * 16) = make_float4(v0, v1, v2, v3);
                 }
             }
         }
@@ -385,8 +441,8 @@ int v2x_conv_tail_dispatch(const v2x_conv_desc *first, const v2x_conv_desc *seco
                 "v2x_conv2d_pair (tail form): the first layer must be a halo-packed 3x3 stride-1 32 -> 32 bf16 layer on a bf16 NHWC input");
     V2X_REQUIRE(second->ksize == 3 && second->stride == 1 && second->pad == 1 && second->w_layout == 1 && second->C0 == 32 && second->C1 == 0 &&
                     second->Cout == 64 && second->Cout2 == 48 && second->epilogue == V2X_EPI_F32 && second->up0 == 0 && second->split > 0 &&
-                    second->split % 4 == 0 && second->split < 48,
-                "v2x_conv2d_pair (tail form): the second layer must be the fused heads (3x3 32 -> 64 chained with a 1x1 -> 48, fp32 split outputs)");
+                    second->split % 4 == 0 && second->split <= 12 && second->relu2 == 0,
+                "v2x_conv2d_pair (tail form): the second layer must be the fused heads (3x3 32 -> 64 chained with a 1x1 -> 48 without ReLU, fp32 outputs split at 4, 8 or 12 channels)");
     V2X_REQUIRE(first->in0 && first->weight && first->scale && first->shift && second->weight && second->scale && second->shift && second->weight2 &&
                     second->scale2 && second->shift2 && second->out && second->out2,
                 "v2x_conv2d_pair (tail form): null pointer");
@@ -417,7 +473,6 @@ int v2x_conv_tail_dispatch(const v2x_conv_desc *first, const v2x_conv_desc *seco
     a.w2 = second->weight2;
     a.sc2 = second->scale2;
     a.sh2 = second->shift2;
-    a.relu2 = second->relu2;
     a.split = second->split;
     a.out = reinterpret_cast<float *>(second->out);
     a.out2 = reinterpret_cast<float *>(second->out2);

@@ -266,7 +266,7 @@ class DetModelBase(nn.Module):
         if req is None and heads.halo is not None and last.halo is not None:
             # logits: conv8_2 and the heads as ONE launch when the extent allows (conv_tail.hip; bit-identical to the two launches)
             x = LidarDecoder.run(pk["dec"], *feats, last=False)
-            if ops.tail_eligible(last.halo, heads.halo, x):
+            if ops.tail_eligible(last.halo, heads.halo, x, heads.split):
                 cls, loc = ops.conv2d_tail(last.halo, heads.halo, x, heads.split)
                 return self._shape_cls_loc(cls, loc)
             x = ops.run_layer(last, x)

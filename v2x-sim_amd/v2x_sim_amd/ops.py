@@ -399,12 +399,12 @@ def conv2d_pair(pa, pb, bits, zbits, out=None):
     return out
 
 
-def tail_eligible(pa, pb, x):
+def tail_eligible(pa, pb, x, split=12):
     """conv_tail.hip covers: conv8_2 as a halo-packed 3x3 s1 32 -> 32 bf16 layer, the fused heads (halo-packed 3x3 32 -> 64 chained with the
-    1x1 -> 12 + 36, fp32), a bf16 NHWC input with H % 8 == 0, W % 32 == 0 and N H W < 2^27."""
-    return (pa is not None and pb is not None and pa.w_layout == 1 and pa.ksize == 3 and pa.stride == 1 and pa.C0 == 32 and not pa.C1 and pa.Cout == 32
+    1x1 -> split + (48 - split) without ReLU, fp32, split in {4, 8, 12}), a bf16 NHWC input with H % 8 == 0, W % 32 == 0 and N H W < 2^27."""
+    return (pa is not None and pb is not None and split in (4, 8, 12) and pa.w_layout == 1 and pa.ksize == 3 and pa.stride == 1 and pa.C0 == 32 and not pa.C1 and pa.Cout == 32
             and not pa.Cout2 and pa.epilogue == V2X_EPI_BF16 and pb.w_layout == 1 and pb.ksize == 3 and pb.stride == 1 and pb.C0 == 32 and not pb.C1
-            and pb.Cout == 64 and pb.Cout2 == 48 and pb.epilogue == V2X_EPI_F32 and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 32
+            and pb.Cout == 64 and pb.Cout2 == 48 and not pb.relu2 and pb.epilogue == V2X_EPI_F32 and x.dtype == torch.bfloat16 and x.dim() == 4 and x.shape[3] == 32
             and x.shape[1] % 8 == 0 and x.shape[2] % 32 == 0 and x.shape[0] * x.shape[1] * x.shape[2] < (1 << 27) and tuning.get("TAIL_FUSE") != 0)
 
 
