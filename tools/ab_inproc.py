@@ -57,6 +57,8 @@ def main():
              ("conv2_2 -> conv3d_2 chain: 128 -> 128 -> 128 @64", 128, 0, 128, 64, 0, "chain"),
              ("halo conv8_2: 32 -> 32 @256", 32, 0, 32, 256, 0, "halo"), ("halo conv7_2: 64 -> 64 @128", 64, 0, 64, 128, 0, "halo"),
              ("halo conv8_1: (64 half-res + 32) -> 32 @256", 64, 32, 32, 256, 1, "halo"),
+             ("halo conv8_1 parity-class: (64 half-res + 32) -> 32 @256", 64, 32, 32, 256, 1, "ppc"),
+             ("halo conv1_2 -> conv3d_1 chain: 64 -> 64 -> 64 @256... at 128", 64, 0, 64, 128, 0, "halochain"),
              ("halo heads: 32 -> 64 -> 12 | 36 fp32 @256", 32, 0, 64, 256, 0, "heads"),
              ("s2 conv2_1: 64 -> 128 @128 -> 64", 64, 0, 128, 128, 0, "s2"), ("s2 conv3_1: 128 -> 256 @64 -> 32", 128, 0, 256, 64, 0, "s2"),
              ("s2 conv4_1: 256 -> 512 @32 -> 16", 256, 0, 512, 32, 0, "s2"), ("pair conv_pre_1 -> conv_pre_2 from the bit grid @256", 32, 0, 32, 256, 0, "pair")]
@@ -105,6 +107,13 @@ def main():
             w = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
             pc = packing.pack_conv_halo(name, w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, C0=c0 if c1 else c0 + c1, C1=c1, relu=True,
                                         device=dev)
+        elif gru == "ppc":
+            w = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
+            pc = packing.pack_conv_halo_parity(name, w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, C0=c0, C1=c1, relu=True, device=dev)
+        elif gru == "halochain":
+            w = torch.randn(cout, c0, 3, 3, generator=g) * 0.05
+            ch = (torch.randn(cout, cout, 1, 1, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, True)
+            pc = packing.pack_conv_halo(name, w, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, relu=True, chain=ch, device=dev)
         elif gru == "chain":
             w = torch.randn(cout, c0, 3, 3, generator=g) * 0.05
             ch = (torch.randn(cout, cout, 1, 1, generator=g) * 0.1, torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.1, True)
