@@ -249,3 +249,44 @@ def test_streamed_parity_class_layer_against_the_unmodified_fp32_oracle(device, 
         err[name] = (float(d.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()), float(d.abs().max() / ref.abs().max()))
         assert err[name][0] <= 4e-3 and err[name][1] <= 3e-2, (name, err[name])
     assert abs(err["parity-class"][0] - err["9-tap"][0]) <= 0.25 * err["9-tap"][0], err
+
+
+# ---- seeded random-shape sweeps (every eligible combination the dispatch accepts, not only the network's shapes) ---------------------------------------
+def _sweep_cases(seed, n):
+    rng = np.random.default_rng(seed)
+    cases = []
+    while len(cases) < n:
+        kind = int(rng.integers(0, 3))
+        if kind == 0:      # resident parity-class kernel: the one compiled shape, any extent
+            C0, C1, Cout = 64, 32, 32
+            H, W = 8 * int(rng.integers(1, 7)), 32 * int(rng.integers(1, 4))
+        elif kind == 1:    # streamed, 128-row tiles
+            C0, C1, Cout = 32 * int(rng.integers(1, 5)), 32 * int(rng.integers(1, 4)), 128 * int(rng.integers(1, 3))
+            H, W = 16 * int(rng.integers(1, 4)), 32 * int(rng.integers(1, 3))
+        else:              # streamed, 64 rows: two tiles per workgroup
+            C0, C1, Cout = 32 * int(rng.integers(1, 5)), 32 * int(rng.integers(1, 3)), 64
+            H, W = 16 * int(rng.integers(1, 4)), 64 * int(rng.integers(1, 3))
+        cases.append((C0, C1, Cout, int(rng.integers(1, 4)), H, W))
+    return cases
+
+
+@pytest.mark.parametrize("C0,C1,Cout,N,H,W", _sweep_cases(2025, 18))
+def test_parity_class_kernels_random_shapes(device, C0, C1, Cout, N, H, W):
+    """One bf16 ulp against torch on the same pre-summed operands, for shapes drawn at random from what the dispatch accepts (channel counts, tile
+    counts, odd numbers of tiles, extents of a single tile); and the layer stays inside the fp32 oracle's bounds."""
+    from v2x_sim_amd import ops, packing
+    conv, bn = _layer(C0, C1, Cout, seed=C0 + 3 * C1 + Cout + N)
+    x_up, x_sk = _inputs(N, C0, C1, H, W, seed=H * 7 + W + N)
+    scale, shift = packing.fold_bn(conv.bias, bn, Cout)
+    if (C0, C1, Cout) == (64, 32, 32):
+        pc = packing.pack_conv_halo_parity("sweep", conv.weight, scale, shift, C0=C0, C1=C1, device=device)
+    else:
+        pc = packing.pack_conv_stream_parity("sweep", conv.weight, scale, shift, C0=C0, C1=C1, device=device)
+    assert pc.w_layout in (3, 4) and ops.halo_eligible(H, W, pc.w_layout, max(C0, C1), Cout)
+    got = from_nhwc(_run(ops, pc, x_up, x_sk, device))
+    ref = _same_operands_ref(packing, conv, bn, x_up, x_sk, C0)
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, atol=2e-3, rtol=2 ** -7), float((got - ref).abs().max())
+    orc = _oracle_fp32(conv, bn, x_up, x_sk)
+    d = got - orc
+    assert float(d.pow(2).mean().sqrt() / orc.pow(2).mean().sqrt()) <= 4e-3 and float(d.abs().max() / orc.abs().max()) <= 3e-2

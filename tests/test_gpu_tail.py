@@ -111,3 +111,22 @@ def test_tail_argument_validation(device):
     assert "tail form" in str(e.value)
     with pytest.raises(RuntimeError):
         ops.conv2d_tail(last.halo, heads.halo, x.cpu(), heads.split)   # no CPU fallback
+
+
+def _tail_sweep(seed, n):
+    rng = np.random.default_rng(seed)
+    return [(int(rng.integers(1, 5)), 8 * int(rng.integers(1, 9)), 32 * int(rng.integers(1, 5))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("N,H,W", _tail_sweep(77, 12))
+def test_tail_random_extents_bitwise(device, N, H, W):
+    """Random extents the dispatch accepts (single tiles, odd tile counts, one-tile-high and one-tile-wide maps -- every border combination of the
+    window fill's interior / border paths): bit equality with the two launches."""
+    from v2x_sim_amd import ops
+    m = _model(device, seed=H + W)
+    pk = m.packed(device)
+    last, heads = pk["dec"][-1], pk["heads"]
+    x = _x(N, H, W, seed=N * 1000 + H + W, device=device)
+    cls0, loc0 = _two_launches(ops, pk, x)
+    cls1, loc1 = ops.conv2d_tail(last.halo, heads.halo, x, heads.split)
+    assert torch.equal(cls1.view(torch.int32), cls0.view(torch.int32)) and torch.equal(loc1.view(torch.int32), loc0.view(torch.int32))
