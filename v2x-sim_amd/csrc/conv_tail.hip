@@ -60,14 +60,7 @@ struct TailArgs {
     int xcd_walk;
 };
 
-#ifndef V2X_TAIL_FENCE_BUILD
-#define V2X_TAIL_FENCE_BUILD 1
-#endif
-#if V2X_TAIL_FENCE_BUILD
-#define TAIL_FENCE __builtin_amdgcn_sched_barrier(0)
-#else
-#define TAIL_FENCE
-#endif
+// (the build-time experiment switches of this kernel -- scheduling fences, group offset, phase removal, time stamps -- live in tools/probes/conv_tail_probe.hip)
 namespace tail {
 constexpr int TH = 8, TW = 32;
 constexpr int MH = TH + 2, MW = TW + 2;     // stage-A region = stage B's patch
@@ -85,10 +78,7 @@ constexpr int OFF_DUMMY = OFF_GRP + 2 * GRP_BYTES;
 constexpr int OFF_TAB = OFF_DUMMY + 1024;
 constexpr int SMEM = OFF_TAB + 288 * 4;     // (12 fp32 dwordx4 stores per wave and tile: 3 channel tiles x 4 fragments -- the counted wait below)
 static_assert(IN_BYTES % 1024 == 0 && SMEM <= 160 * 1024, "LDS map");
-#ifndef V2X_TAIL_PSWZ_BUILD
-#define V2X_TAIL_PSWZ_BUILD 1
-#endif
-__device__ __forceinline__ int swz4(int slot, int x) { return slot ^ ((x >> V2X_TAIL_PSWZ_BUILD) & 3); }
+__device__ __forceinline__ int swz4(int slot, int x) { return slot ^ ((x >> 1) & 3); }
 }  // namespace tail
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_tail_kernel(const TailArgs a) {
@@ -216,10 +206,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // weights and both first windows have landed
-#ifndef V2X_TAIL_OFFSET_BUILD
-#define V2X_TAIL_OFFSET_BUILD 1
-#endif
-    if (V2X_TAIL_OFFSET_BUILD && grp == 1) __builtin_amdgcn_s_barrier();   // one stage behind group 0
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // one stage behind group 0
 
     for (; pair_i < walk.end; pair_i += walk.step) {
         const int tile = 2 * pair_i + grp;
@@ -259,7 +246,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) X[ky] = *reinterpret_cast<const bf16x8_t *>(s_in + (((hr + ky) * IW + col) * 4 + swz4(fq, col)) * 16);
                 }
-                TAIL_FENCE;
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
@@ -280,7 +267,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         for (int i = 0; i < 2; ++i) acc[4][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky][i], X[ky], acc[4][i], 0, 0, 0);
                     }
                 }
-                TAIL_FENCE;
+                __builtin_amdgcn_sched_barrier(0);
             }
             float4 scA[2], shA[2];
 #pragma unroll
@@ -343,20 +330,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int i = 0; i < 4; ++i) A[0][i] = *reinterpret_cast<const bf16x8_t *>(s_wB + ((kx * 4 + fq) * 64 + i * 16 + fj) * 16);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
-                    TAIL_FENCE;
+                    __builtin_amdgcn_sched_barrier(0);
                     if (ky < 2) {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
                             A[(ky + 1) & 1][i] = *reinterpret_cast<const bf16x8_t *>(s_wB + ((((ky + 1) * 3 + kx) * 4 + fq) * 64 + i * 16 + fj) * 16);
                     }
-                    TAIL_FENCE;
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int f = 0; f < 4; ++f)
                             acc[i][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[ky & 1][i], B[((f >> 1) + ky) * 2 + (f & 1)], acc[i][f], 0, 0, 0);
                 }
-                TAIL_FENCE;
+                __builtin_amdgcn_sched_barrier(0);
             }
             float4 scB[4], shB[4], s2v[3], t2v[3];
 #pragma unroll
@@ -416,7 +403,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_s_barrier();   // (Y) the patch may be rewritten; the next window is visible to the whole group
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (V2X_TAIL_OFFSET_BUILD && grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's offset barrier
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance group 1's offset barrier
 }
 
 int v2x_num_cus();   // conv_stream.hip
