@@ -23,7 +23,8 @@
 // these kernels see everywhere -- so the class decomposition's 4x weight bytes per MFMA, not its MFMA count, sets the layer's time: -19 % against
 // the 9-tap kernel where the MFMA count alone says -37 %.  Variants measured and dropped: four up slots (above), the weight pieces split over
 // both groups (no change), a drain-free up -> skip transition with per-phase waits in group 0 (-8 % instead of -19 %: group 0 then stalls on its
-// own patch piece every step).
+// own patch piece every step), a LOCKSTEP up phase (one barrier per step, all eight waves issuing the DMAs of step s + 2, reading, multiplying and then
+// waiting under their MFMAs: -13 % instead of -19 % -- the two groups' alternation is worth more than the second barrier costs).
 // K order: (up chunk, class tap), then (skip chunk, kx, ky) -- results differ from the 9-tap kernels in the weights (pre-summed, rounded once)
 // and in fp32 summation order; tests/test_gpu_parity_class.py holds this kernel to the unmodified fp32 9-tap oracle layer at the 9-tap
 // kernel's tolerance, and to a torch evaluation of the same bf16 operands.
@@ -53,9 +54,7 @@ constexpr int OFF_SS = (OFF_UPB + UP_PIECES * 1024 > OFF_P1 + SP_PIECES * 1024) 
 constexpr int SMEM = OFF_SS + 2 * BCO * 4;
 static_assert(SMEM <= 160 * 1024 && (NU == 3 || NU == 4), "LDS map");
 #define PCS_SWZ(pc) (((pc) >> 1) & 3)
-#ifndef V2X_PCS_UPLOCK_BUILD
-#define V2X_PCS_UPLOCK_BUILD 0
-#endif
+
 }  // namespace pcs
 
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_stream8p_kernel(const StreamArgs a) {
@@ -175,61 +174,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int f = 0; f < 4; ++f) acc[i][f] = (f32x4_t)(0.f);
 
         // =============================================== UP PHASE ================================================
-#if V2X_PCS_UPLOCK_BUILD
-        // LOCKSTEP form: ONE barrier per step.  All eight waves issue the DMAs of step st + 2 (4 weight pieces each; a wave of group 0 one piece of the next
-        // chunk's patch), read the step's 12 fragments, issue its 32 MFMAs and then wait -- under those MFMAs -- for everything older than this step's own
-        // DMAs (i.e. for step st + 1's pieces); the barrier that ends the step also says that every wave is done reading the slot step st + 3 will overwrite.
-        __builtin_amdgcn_s_barrier();                     // the prologue's pieces of every wave have landed
-        for (int kc = 0; kc < n_up; ++kc) {
-            const char *pb = smem + up_buf(kc);
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int st = kc * 4 + t;
-                const int ta = t >> 1, tb = t & 1;
-                const int ln = fresh_lane();
-                const int fjl = ln & 15, fql = ln >> 4;
-                int keep = 0;
-                if (st + 2 < S_up) {
-                    issue_up_weights(st + 2, wave * 4, 4);
-                    keep = 4;
-                }
-                if (grp == 0 && t < 3 && kc + 1 < n_up) {
-                    issue_up_patch_piece(n, y0, x0, kc + 1, wv + 4 * t, up_buf(kc + 1));
-                    keep += 1;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                bf16x8_t B[4], A[TCO];
-                {
-                    const int pc = fjl + tb + px;
-                    const char *p = pb + ((4 * grp + py + ta) * PW0 * 4 + pc * 4 + (fql ^ PCS_SWZ(pc))) * 16;
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) B[y] = *reinterpret_cast<const bf16x8_t *>(p + y * (PW0 * 64));
-                    const char *ws = smem + (st % NU) * USTEP + wv * SLICE + (fql * BCO + fjl) * 16;
-#pragma unroll
-                    for (int i = 0; i < TCO; ++i) A[i] = *reinterpret_cast<const bf16x8_t *>(ws + i * 256);
-                }
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0)
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < TCO; ++i)
-#pragma unroll
-                    for (int y = 0; y < 4; ++y) acc[i][y] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[i], B[y], acc[i][y], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                // (step 0: what it needs next -- step 1's image -- was waited for before the previous tile's stores were left in flight; keep them there)
-                if (st > 0) {
-                    switch (keep) {
-                        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-                        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-#else
         __builtin_amdgcn_s_barrier();                     // the prologue's pieces of every wave have landed
         if (grp == 1) __builtin_amdgcn_s_barrier();       // half-step offset
         for (int kc = 0; kc < n_up; ++kc) {
@@ -292,8 +236,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();       // realign: group 1's last MFMA phase
-
-#endif
 
         // =============================================== SKIP PHASE ==============================================
         // prologue: patch of skip chunk 0 (group 0), slot images of skip steps 0 and 1 (all eight waves: 48 pieces)
