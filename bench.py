@@ -660,6 +660,12 @@ def main():
     argv = sys.argv[1:]
     args = parse(argv)
     launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not args.dry_run:
+        # a clear answer instead of "HIP error: invalid device ordinal" out of rank N-1 (device_count does not initialise the GPU on this image)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print("bench.py: --gpus %d requested, this node exposes %d GPU%s" % (args.gpus, have, "" if have == 1 else "s"), file=sys.stderr)
+            sys.exit(2)
     if args.gpus > 1 and not launched:
         sys.exit(launch_ranks(args, argv))
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -61,15 +61,17 @@ def test_n1_dry_run_needs_no_launcher():
 
 
 def test_ranks_fail_loudly_without_a_gpu():
-    """Without --dry-run on a box without GPUs every rank stops at the 'needs the MI355X' check; the parent relays
-    a non-zero exit code and no record (never a CPU fallback number)."""
+    """Without --dry-run on a box without (enough) GPUs nothing runs: --gpus N > device_count() is refused by the parent with the two numbers, a single
+    rank stops at the 'needs the MI355X' check; a non-zero exit code and no record either way (never a CPU fallback number)."""
     import torch
     if torch.cuda.is_available():
         pytest.skip("GPU box: the real run is the driver's")
     p = _run("--gpus", "2", "--steps", "2", "--warmup", "1")
     assert p.returncode != 0
-    assert "needs the MI355X" in p.stderr
+    assert "--gpus 2 requested, this node exposes 0 GPUs" in p.stderr          # (round 5) the parent answers before it starts any rank
     assert not any(ln.startswith('{"metric"') for ln in p.stdout.splitlines())
+    p = _run("--gpus", "1", "--steps", "2", "--warmup", "1")
+    assert p.returncode != 0 and "needs the MI355X" in p.stderr and not any(ln.startswith('{"metric"') for ln in p.stdout.splitlines())
 
 
 def test_world_size_mismatch_is_refused():
