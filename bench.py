@@ -46,6 +46,7 @@ PEAK_MFMA_TFLOPS = 2500.0
 AGENTS = 5
 POINTS_PER_SWEEP = 65536
 # committed PMC traffic summaries, newest first (tools/profile_round.sh -> tools/pmc_traffic.py)
+LIVE_TRAFFIC = (None, "not attempted")     # ({kernel: (read, write, launches)} | None, note): live_traffic_table, filled by main() before the GPU is touched
 TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 # algorithmic FLOPs of one 5-agent frame, points -> logits: encoder + decoder + heads, + one ConvGRU pass per GNN round
 # (h0 = 0: W_hh is never multiplied and not counted)
@@ -55,6 +56,61 @@ GFLOP_PER_FRAME_BASE, GFLOP_PER_GNN_ROUND = 155.8, 36.2
 GFLOP_PARITY_CLASS_SAVED = {0: 0.0, 1: 2 * AGENTS * 5 * 64 * 32 * 256 * 256 / 1e9,
                             2: 2 * AGENTS * 5 * (64 * 32 * 256 * 256 + 512 * 256 * 32 * 32 + 256 * 128 * 64 * 64) / 1e9,
                             3: 2 * AGENTS * 5 * (64 * 32 * 256 * 256 + 512 * 256 * 32 * 32 + 256 * 128 * 64 * 64 + 128 * 64 * 128 * 128) / 1e9}
+
+
+def live_traffic_table(args):
+    """HBM bytes per launch of EVERY kernel of the step, MEASURED in this run: two child passes of this script under `rocprofv3 --pmc FETCH_SIZE` /
+    `--pmc WRITE_SIZE` (separate passes, counters only -- no trace domain beside them; /opt/skills/guides/MI355X_MICROARCH.md, HBM section), 2 eager steps
+    each, corrected as tools/pmc_traffic.py does (KiB -> bytes; FETCH_SIZE x 2 on gfx950).  Called BEFORE this process touches the GPU (a process that
+    has initialised the GPU must not fork + exec on this pool).  Returns ({kernel: (read, write, launches)}, note) or (None, why not): any failure falls
+    back to the committed profiles/ file.  Never under a profiler itself, never at N > 1, never from a rank child."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if args.no_live_traffic or args.no_roofline or os.environ.get("V2X_BENCH_LIVE_TRAFFIC", "1") == "0":
+        return None, "switched off"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprofiler" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    table = {}
+    for counter, factor in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+        out = tempfile.mkdtemp(prefix="v2x_pmc_", dir="/tmp")
+        cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "2", "--warmup", "1", "--graph", "0", "--frames-per-gpu", str(args.frames_per_gpu), "--gnn-iters", str(args.gnn_iters),
+               "--no-cpu-baseline", "--no-extras", "--no-calibration", "--no-shard-check", "--no-roofline"]
+        env = dict(os.environ, TMPDIR="/tmp", V2X_BENCH_LIVE_TRAFFIC="0")
+        try:
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = proc.wait(timeout=float(os.environ.get("V2X_BENCH_PMC_TIMEOUT_S", "300")))
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, 9)
+                proc.wait()
+                return None, "the %s pass timed out" % counter
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None, "the %s pass failed (exit code %s)" % (counter, rc)
+            acc = {}
+            with open(files[0]) as fh:
+                for r in csv.DictReader(fh):
+                    if r["Counter_Name"] != counter:
+                        continue
+                    name = r["Kernel_Name"].replace("void ", "")
+                    name = name[:name.index("(")] if "(" in name else name
+                    e = acc.setdefault(name, [0, 0.0])
+                    e[0] += 1
+                    e[1] += float(r["Counter_Value"])
+            for name, (n, total) in acc.items():
+                table.setdefault(name, {})[counter] = (factor * total / n, n)
+        except Exception as e:      # noqa: BLE001 -- a measurement aid must never take the bench line down
+            return None, "%s: %s" % (type(e).__name__, e)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    full = {k: (v["FETCH_SIZE"][0], v["WRITE_SIZE"][0], v["FETCH_SIZE"][1]) for k, v in table.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    return (full, "measured in this run") if full else (None, "no kernel in both passes")
 
 
 def parse(argv=None):
@@ -68,6 +124,8 @@ def parse(argv=None):
     ap.add_argument("--gnn-iters", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not re-measure the dominant kernel's HBM traffic with two rocprofv3 --pmc child passes (the committed profiles/ file is quoted instead)")
     ap.add_argument("--no-calibration", action="store_true", help="skip the streaming / MFMA calibration probes (the `calibration` sub-record)")
     ap.add_argument("--graph", type=int, default=1,
                     help="1: four hipGraph segments with the exchange between them, the two half-batches on two streams (every N); "
@@ -689,6 +747,9 @@ def main():
             pass
     if args.dry_run:
         sys.exit(dry_run(args, world, rank))
+    global LIVE_TRAFFIC
+    if world == 1 and args.scaling == "weak" and torch.cuda.device_count() > 0:
+        LIVE_TRAFFIC = live_traffic_table(args)       # two short child runs under rocprofv3 --pmc, BEFORE this process initialises the GPU
     if not torch.cuda.is_available():
         print("bench.py needs the MI355X: the product path has no CPU fallback (use --dry-run for the launcher walk)",
               file=sys.stderr)
@@ -792,6 +853,15 @@ def main():
                     roofline["traffic"] = tk["hbm_bytes_per_launch"]
                     roofline["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc passes of this workload; not re-measured in this run)" % tname
                     break
+        if LIVE_TRAFFIC[0] is not None and dom in LIVE_TRAFFIC[0]:   # (round 5) re-measured in THIS run; the committed value stays beside it
+            rd, wr, nl = LIVE_TRAFFIC[0][dom]
+            roofline["traffic_committed"] = roofline["traffic"]
+            roofline["traffic"] = rd + wr
+            roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this script before the timed run "
+                                          "(separate, counters only; 2 eager steps each, %d launches of the kernel averaged; KiB -> bytes, FETCH_SIZE x 2 on gfx950): "
+                                          "read %.1f MB + write %.1f MB per launch" % (nl, rd / 1e6, wr / 1e6))
+        else:
+            roofline["traffic_live"] = "not re-measured: " + (LIVE_TRAFFIC[1] if LIVE_TRAFFIC[0] is None else "kernel not in the counter passes")
         roofline.update({"kernel": dom, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                          "launches_per_step": d["launches"] // n_inst,
                          "share_of_kernel_time": d["ms"] / total_ms,

@@ -142,3 +142,47 @@ def test_a_late_rank_delays_but_cannot_deadlock_the_two_stream_host_order(transp
     assert p.returncode == 0, p.stderr[-2000:]
     rec = _record(p)
     assert rec["exchange_ok"] and rec["launch"]["attempt"] == 1 and rec["elapsed_s"] >= 2.5
+
+
+def test_live_traffic_measurement_is_optional_and_fails_soft(monkeypatch, tmp_path):
+    """bench.py re-measures the dominant kernel's HBM traffic with two `rocprofv3 --pmc` child passes BEFORE it touches the GPU; switched off, under a
+    profiler, without rocprofv3 or when a pass fails it says why and the committed profiles/ value is quoted -- it never raises."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    args = bench.parse(["--no-live-traffic"])
+    assert bench.live_traffic_table(args) == (None, "switched off")
+    args = bench.parse([])
+    monkeypatch.setenv("V2X_BENCH_LIVE_TRAFFIC", "0")
+    assert bench.live_traffic_table(args)[0] is None
+    monkeypatch.delenv("V2X_BENCH_LIVE_TRAFFIC")
+    monkeypatch.setenv("ROCPROFILER_FAKE", "1")
+    assert bench.live_traffic_table(args) == (None, "this run is itself under a profiler")
+    monkeypatch.delenv("ROCPROFILER_FAKE")
+    # a "rocprofv3" that fails at once: the pass is reported as failed, nothing is raised, no temporary directory is left behind
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\nexit 7\n")
+    fake.chmod(0o755)
+    monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
+    before = set(os.listdir("/tmp"))
+    table, note = bench.live_traffic_table(args)
+    assert table is None and "FETCH_SIZE pass failed (exit code 7)" in note
+    assert not [d for d in set(os.listdir("/tmp")) - before if d.startswith("v2x_pmc_")]
+    # ... and one that writes the csv rocprofv3 writes: parsed per kernel, KiB -> bytes, FETCH_SIZE doubled
+    fake.write_text("""#!/bin/sh
+out=""; c=""
+while [ $# -gt 0 ]; do
+    case "$1" in --pmc) c=$2; shift;; -d) out=$2; shift;; --) break;; esac
+    shift
+done
+if [ "$c" = FETCH_SIZE ]; then v=1000; else v=300; fi
+mkdir -p "$out/host"; f="$out/host/p_counter_collection.csv"
+echo '"Kernel_Name","Counter_Name","Counter_Value"' > "$f"
+echo "\\"void conv3x3_stream8g_kernel<96, 2, false>(StreamArgs)\\",\\"$c\\",$v" >> "$f"
+echo "\\"void conv3x3_stream8g_kernel<96, 2, false>(StreamArgs)\\",\\"$c\\",$v" >> "$f"
+""")
+    table, note = bench.live_traffic_table(args)
+    assert note == "measured in this run" and table == {"conv3x3_stream8g_kernel<96, 2, false>": (2.0 * 1024.0 * 1000, 1024.0 * 300, 2)}
