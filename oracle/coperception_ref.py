@@ -33,8 +33,10 @@ HIP path (bf16 weights and activations, fp32 accumulation, BN folded to an fp32
 scale/shift applied after the accumulation); it is the tight comparator for the
 kernels, while the plain fp32 graph is the spec the tolerance is stated against.
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
-this module.
+Only tests/, __graft_entry__.smoke() and bench.py's baseline legs (`cpu_baseline`,
+and since round 6 `gpu_stock_baseline`: this same graph moved to cuda:0 as the
+same-node stock-PyTorch comparator, outside the timed region) may import this
+module.
 """
 import math
 
@@ -236,9 +238,11 @@ def feature_transformation(feat, nb_warp, size):
     y_trans = -(4 * nb_warp[1, 3]) / 128
     theta_rot = torch.tensor([[nb_warp[0, 0], nb_warp[0, 1], 0.0],
                               [nb_warp[1, 0], nb_warp[1, 1], 0.0]]).type(dtype=torch.float).unsqueeze(0)
-    grid_rot = F.affine_grid(theta_rot, size=torch.Size(size), align_corners=False)
+    # (.to(feat.device): a no-op on the CPU, where this oracle is the checker; bench.py's `gpu_stock_baseline` times the same graph on cuda:0, with
+    # the pose matrices kept on the host exactly so that these scalar reads do not synchronise the device)
+    grid_rot = F.affine_grid(theta_rot.to(feat.device), size=torch.Size(size), align_corners=False)
     theta_trans = torch.tensor([[1.0, 0.0, x_trans], [0.0, 1.0, y_trans]]).type(dtype=torch.float).unsqueeze(0)
-    grid_trans = F.affine_grid(theta_trans, size=torch.Size(size), align_corners=False)
+    grid_trans = F.affine_grid(theta_trans.to(feat.device), size=torch.Size(size), align_corners=False)
     warp_rot = F.grid_sample(nb, grid_rot, mode="bilinear", padding_mode="zeros", align_corners=False)
     warp_trans = F.grid_sample(warp_rot, grid_trans, mode="bilinear", padding_mode="zeros", align_corners=False)
     return warp_trans.squeeze(0)
@@ -329,7 +333,7 @@ class Conv2dGRUCell(nn.Module):
     def forward(self, x, hx=None, emulate=False):
         # x: (N, Cin, H, W); hx: (N, hidden, H, W) or None (-> zeros)
         if hx is None:
-            hx = torch.zeros(x.shape[0], self.hidden, x.shape[2], x.shape[3], dtype=x.dtype)
+            hx = torch.zeros(x.shape[0], self.hidden, x.shape[2], x.shape[3], dtype=x.dtype, device=x.device)
         if emulate:
             gi = F.conv2d(_q(x, True), _q(self.weight_ih_l0, True), None, 1, self.pad) + self.bias_ih_l0.view(1, -1, 1, 1)
             gh = F.conv2d(_q(hx, True), _q(self.weight_hh_l0, True), None, 1, self.pad) + self.bias_hh_l0.view(1, -1, 1, 1)

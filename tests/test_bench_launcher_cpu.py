@@ -145,8 +145,9 @@ def test_a_late_rank_delays_but_cannot_deadlock_the_two_stream_host_order(transp
 
 
 def test_live_traffic_measurement_is_optional_and_fails_soft(monkeypatch, tmp_path):
-    """bench.py re-measures the dominant kernel's HBM traffic with two `rocprofv3 --pmc` child passes BEFORE it touches the GPU; switched off, under a
-    profiler, without rocprofv3 or when a pass fails it says why and the committed profiles/ value is quoted -- it never raises."""
+    """bench.py re-measures the dominant kernel's HBM traffic with two `rocprofv3 --pmc` child passes from a process that never touches the GPU (round 6:
+    the N = 1 orchestrator, AFTER the timed run's child); switched off, under a profiler, without rocprofv3 or when a pass fails it says why and the
+    committed profiles/ value is quoted -- it never raises."""
     import importlib.util
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -154,13 +155,13 @@ def test_live_traffic_measurement_is_optional_and_fails_soft(monkeypatch, tmp_pa
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     args = bench.parse(["--no-live-traffic"])
-    assert bench.live_traffic_table(args) == (None, "switched off")
+    assert bench.live_traffic_table(args) == (None, "switched off", 0.0) and bench.live_traffic_wanted(args) == (False, "switched off")
     args = bench.parse([])
     monkeypatch.setenv("V2X_BENCH_LIVE_TRAFFIC", "0")
     assert bench.live_traffic_table(args)[0] is None
     monkeypatch.delenv("V2X_BENCH_LIVE_TRAFFIC")
     monkeypatch.setenv("ROCPROFILER_FAKE", "1")
-    assert bench.live_traffic_table(args) == (None, "this run is itself under a profiler")
+    assert bench.live_traffic_table(args) == (None, "this run is itself under a profiler", 0.0)
     monkeypatch.delenv("ROCPROFILER_FAKE")
     # a "rocprofv3" that fails at once: the pass is reported as failed, nothing is raised, no temporary directory is left behind
     fake = tmp_path / "rocprofv3"
@@ -168,8 +169,8 @@ def test_live_traffic_measurement_is_optional_and_fails_soft(monkeypatch, tmp_pa
     fake.chmod(0o755)
     monkeypatch.setenv("PATH", str(tmp_path) + os.pathsep + os.environ["PATH"])
     before = set(os.listdir("/tmp"))
-    table, note = bench.live_traffic_table(args)
-    assert table is None and "FETCH_SIZE pass failed (exit code 7)" in note
+    table, note, seconds = bench.live_traffic_table(args)
+    assert table is None and "FETCH_SIZE pass failed (exit code 7)" in note and seconds >= 0.0
     assert not [d for d in set(os.listdir("/tmp")) - before if d.startswith("v2x_pmc_")]
     # ... and one that writes the csv rocprofv3 writes: parsed per kernel, KiB -> bytes, FETCH_SIZE doubled
     fake.write_text("""#!/bin/sh
@@ -183,6 +184,48 @@ mkdir -p "$out/host"; f="$out/host/p_counter_collection.csv"
 echo '"Kernel_Name","Counter_Name","Counter_Value"' > "$f"
 echo "\\"void conv3x3_stream8g_kernel<96, 2, false>(StreamArgs)\\",\\"$c\\",$v" >> "$f"
 echo "\\"void conv3x3_stream8g_kernel<96, 2, false>(StreamArgs)\\",\\"$c\\",$v" >> "$f"
+mkdir -p "$out/helper"; echo '"Kernel_Name","Counter_Name","Counter_Value"' > "$out/helper/q_counter_collection.csv"
 """)
-    table, note = bench.live_traffic_table(args)
+    table, note, seconds = bench.live_traffic_table(args)     # (the LARGEST csv is the bench child's: the header-only one of a helper process is ignored)
     assert note == "measured in this run" and table == {"conv3x3_stream8g_kernel<96, 2, false>": (2.0 * 1024.0 * 1000, 1024.0 * 300, 2)}
+    # the merge into a roofline record: measured value in, committed value kept beside it, the passes' duration recorded
+    roof = bench.apply_live_traffic({"kernel": "conv3x3_stream8g_kernel<96, 2, false>", "traffic": 7.0, "traffic_live": "x"}, (table, note, 12.34), "AFTER the timed run")
+    assert roof["traffic"] == 2.0 * 1024.0 * 1000 + 1024.0 * 300 and roof["traffic_committed"] == 7.0 and roof["pmc_passes_s"] == 12.3
+    assert "AFTER the timed run" in roof["traffic_source"] and "traffic_live" not in roof
+    roof = bench.apply_live_traffic({"kernel": "other", "traffic": 7.0}, (table, note, 1.0), "after")
+    assert roof["traffic"] == 7.0 and "kernel not in the counter passes" in roof["traffic_live"]
+    # kernel names: the ARGUMENT list is cut, not the first parenthesis
+    assert bench.strip_kernel_args("void (anonymous namespace)::k<1, 2>(Args, (anonymous namespace)::T)") == "(anonymous namespace)::k<1, 2>"
+    assert bench.strip_kernel_args("conv3x3_tail_kernel(TailArgs) [clone .kd]") == "conv3x3_tail_kernel(TailArgs) [clone .kd]"
+
+
+def test_n1_orchestrator_runs_the_bench_child_first_and_merges_the_counter_passes(tmp_path):
+    """Round 6: at N = 1 the process the driver starts stays off the GPU; it runs the benchmark as a child FIRST and the two
+    rocprofv3 --pmc passes AFTER it, then merges.  Here with a stand-in child (V2X_BENCH_INNER=1 makes bench.py the child: on a CPU box it exits 3
+    "needs the MI355X") -- the orchestrator must relay that exit code and print no record."""
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("#!/bin/sh\necho pmc-pass-ran >> %s\nexit 7\n" % (tmp_path / "calls"))
+    fake.chmod(0o755)
+    env = {"V2X_BENCH_LIVE_TRAFFIC": "1", "V2X_BENCH_FORCE_ORCHESTRATE": "1", "PATH": str(tmp_path) + os.pathsep + os.environ["PATH"]}
+    p = _run("--steps", "1", "--warmup", "0", env_extra=env)
+    assert p.returncode == 3 and "needs the MI355X" in p.stderr and '{"metric"' not in p.stdout
+    assert not (tmp_path / "calls").exists()        # no record from the child -> no counter pass is started
+
+
+def test_summary_and_training_fractions():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    tr = {"maps_per_step": 10, "FaFNet": {"fp32 PyTorch-ROCm graph (MIOpen) ms": 48.5, "bf16 NHWC graph on the HIP kernels ms": 5.8, "the same as one replayed hipGraph ms": 5.17},
+          "maps_40": {"FaFNet bf16 NHWC graph on the HIP kernels ms": 12.8}}
+    fr = bench.training_fractions(tr)
+    assert abs(fr["FaFNet_10_maps"] - 3 * 31.16 * 10 / 5.17 / 2500.0) < 1e-6 and abs(fr["FaFNet_40_maps"] - 3 * 31.16 * 40 / 12.8 / 2500.0) < 1e-6
+    tr["frac_of_mfma_peak"] = fr
+    sm = bench.build_summary(6400.0, 20.0, {"b1_ms": 0.5, "b1_frames_per_s": 2000.0, "b8_ms": 1.5, "b8_frames_per_s": 5300.0, "b32_ms": 5.0, "b32_frames_per_s": 6400.0},
+                             {"configs": {"0n lowerbound network": {"frames_per_s": 7000.0}, "4 V2VNet segmentation": {"frames_per_s": 6900.0}}}, tr,
+                             {"fp32_frames_per_s": 100.0, "bf16_autocast_channels_last_frames_per_s": 200.0, "value": 200.0}, {"value": 2.0}, {"frac": 0.58}, 165.2, 1)
+    assert sm["latency_b8_frames_per_s"] == 5300.0 and sm["config4_v2vnet_seg_frames_per_s"] == 6900.0 and sm["speedup_vs_gpu_stock"] == 32.0
+    assert sm["speedup_vs_cpu_baseline"] == 3200.0 and all(not isinstance(v, (dict, list)) for v in sm.values())
+    assert abs(sm["whole_step_frac"] - 165.2e9 * 6400.0 / 2.5e15) < 1e-9

@@ -71,7 +71,12 @@ def test_points_path_equals_dense_bev_path(device, tune):
         rn = ShardedV2VNet(pm, shard).forward_points(ptd, cnt, T, shard.fusion_plan(nat, device))
     assert torch.equal(plain["cls"], outs[1]["cls"]) and torch.equal(rn["cls"], outs[0]["cls"])
     d = (outs[1]["cls"] - outs[0]["cls"]).abs().max() / outs[0]["cls"].abs().max()
-    assert float(d) < 2e-2          # the two dispatches differ by fp32 summation order only (one bf16 rounding per split layer)
+    # The two dispatches differ by fp32 summation order (split-K) AND, for conv5_1 / conv6_1, by the weight form: the split launch multiplies the layer's
+    # 9-tap bf16 weights, the throughput launch the pre-summed parity-class weights (ops.py header).  Both are within TOL of the oracle
+    # (test_gpu_models.py); against each other they are held to 2e-2 of max|ref| for cls AND loc here.
+    assert float(d) < 2e-2
+    dl = (outs[1]["loc"] - outs[0]["loc"]).abs().max() / outs[0]["loc"].abs().max()
+    assert float(dl) < 2e-2
 
 
 @pytest.mark.parametrize("shape", [(3, 256, 256), (2, 8, 32), (5, 40, 96), (1, 64, 32)])

@@ -1,0 +1,96 @@
+"""DIRECT oracle contact for the two fused kernels that move the most bytes: until round 6 `conv3x3_tail_kernel` (conv8_2 + det heads)
+and `conv3x3_pair_bits_kernel` (conv_pre_1 + conv_pre_2 from the bit grid) were compared only with the launches they replace (tests/test_gpu_tail.py,
+tests/test_gpu_bits_input.py) -- which are held to the oracle elsewhere -- i.e. through one hop.  Here each fused launch is compared with the oracle's own
+modules (oracle/coperception_ref.py: LidarEncoder.conv_pre_1 / conv_pre_2; LidarDecoder.conv8_2 -> ClassificationHead / SingleRegressionHead; upstream
+coperception/models/det/backbone/Backbone.py and base/DetModelBase.py, /root/reference/README.md:101) in its bf16-EMULATING mode: the same bf16 weights and
+activations, fp32 accumulation, BN as an fp32 scale / shift after the accumulation.
+
+Tolerances.  A bf16 OUTPUT (the pair) is held to one bf16 ulp (rtol 2^-7, atol 2e-3: tests/test_gpu_stages.py::test_conv_vs_torch's bound): a hidden value
+that rounds differently (different fp32 summation order) moves an output by ~|w| ulp(hidden), a fraction of the output's own ulp.  fp32 LOGITS (the tail) are
+not rounded, so the same rare event shows undiluted: a conv8_2 value or a head's hidden value one bf16 ulp apart (2^-8 relative) times a 1x1 weight (~0.1).
+The bound therefore has two parts, both asserted: (a) the BULK -- at least 97 % of the logits within atol 2e-4 + rtol 1e-4 (the single-layer fp32 bound of
+test_conv_vs_torch: what VERDICT r5 item 4 names); (b) EVERY logit within 5e-3 absolute and the mean error below 1e-4 (the chained-layer mechanism above,
+an order of magnitude inside the end-to-end bound of tests/test_gpu_models.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import coperception_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(device, seed):
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.utils.synthetic import init_synthetic_weights
+    pm = init_synthetic_weights(FaFNet(Config("test")), seed=seed)
+    om = R.FaFNet().eval()
+    om.load_state_dict(pm.state_dict())
+    om.emulate_bf16 = True
+    return pm.to(device), om
+
+
+@pytest.mark.parametrize("N,H,W,seed", [(5, 256, 256, 0), (3, 64, 96, 1), (1, 8, 32, 2)])
+def test_tail_vs_oracle(device, N, H, W, seed):
+    """conv3x3_tail_kernel against R.LidarDecoder.conv8_2 -> R.ClassificationHead / R.SingleRegressionHead (emulating oracle, same bf16 operands), at the
+    bench extent (5 maps of 256 x 256), a ragged extent and a single tile."""
+    from v2x_sim_amd import ops
+    pm, om = _models(device, seed)
+    pk = pm.packed(device)
+    last, heads = pk["dec"][-1], pk["heads"]
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.relu(torch.randn(N, H, W, 32, generator=g)).to(torch.bfloat16)          # conv8_1's output: post-ReLU bf16, NHWC
+    assert ops.tail_eligible(last.halo, heads.halo, x.to(device))
+    cls, loc = ops.conv2d_tail(last.halo, heads.halo, x.to(device), heads.split)      # (N, H, W, 12) | (N, H, W, 36), fp32
+    with torch.no_grad():
+        dec = om.stpn.decoder
+        y = R.cbr(x.float().permute(0, 3, 1, 2), dec.conv8_2, dec.bn8_2, emulate=True)
+        ref = om.get_cls_loc_result(y)
+    got_cls = cls.cpu().reshape(N, H * W * 6, 2)                                        # the oracle's own output views
+    got_loc = loc.cpu().reshape(N, H, W, 6, 1, 6)
+    for name, got, want in (("cls", got_cls, ref["cls"]), ("loc", got_loc, ref["loc"])):
+        d = (got - want).abs()
+        bulk = float((d <= 2e-4 + 1e-4 * want.abs()).float().mean())
+        print("tail vs oracle %s (%d,%d,%d): within 2e-4: %.4f %%  max %.3e  mean %.3e  (max|ref| %.2f)" % (name, N, H, W, 100 * bulk, float(d.max()), float(d.mean()),
+                                                                                                            float(want.abs().max())))
+        assert bulk >= 0.97 and float(d.max()) <= 5e-3 and float(d.mean()) <= 1e-4, (name, bulk, float(d.max()), float(d.mean()))
+
+
+def _bits(shape, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    dens = torch.rand((shape[0], 1, 1), generator=g) * 0.5
+    dens[0] = 0.02                                                                      # one map at a sweep's sparsity
+    bits = torch.zeros(shape, dtype=torch.int32)
+    for z in range(13):
+        bits |= ((torch.rand(shape, generator=g) < dens).to(torch.int32) << z)
+    return bits.to(device)
+
+
+@pytest.mark.parametrize("N,H,W,seed", [(5, 256, 256, 0), (2, 40, 96, 1), (1, 8, 32, 2)])
+def test_pair_bits_vs_oracle(device, N, H, W, seed):
+    """conv3x3_pair_bits_kernel (bit grid -> conv_pre_1 -> conv_pre_2, one launch, the intermediate map in LDS) against R.LidarEncoder's first two layers
+    (emulating oracle) at one bf16 ulp.  Round 6: with the stride-2 third layer (conv1_1) the same launch chain is held to R.LidarEncoder's first THREE layers."""
+    from v2x_sim_amd import ops
+    pm, om = _models(device, seed)
+    stage = pm.packed(device)["enc"][0]
+    bits = _bits((N, H, W), 200 + seed, device)
+    assert ops.pair_eligible(stage[0].halo, stage[1].halo, bits, 13)
+    got = ops.conv2d_pair(stage[0].halo, stage[1].halo, bits, 13)                      # (N, H, W, 32) bf16
+    dense = ops.bits_to_dense(bits, 13).cpu().float().permute(0, 3, 1, 2).contiguous()  # (N, H, W, Z) {0,1} -> NCHW: the oracle's input
+    with torch.no_grad():
+        enc = om.stpn.encoder
+        mid = R.cbr(dense, enc.conv_pre_1, enc.bn_pre_1, emulate=True)
+        ref = R.cbr(mid, enc.conv_pre_2, enc.bn_pre_2, emulate=True)
+    g32 = got.float().cpu().permute(0, 3, 1, 2)
+    d = (g32 - ref).abs()
+    print("pair_bits vs oracle (%d,%d,%d): max %.3e  differing %.4f %%" % (N, H, W, float(d.max()), 100 * float((g32 != ref).float().mean())))
+    assert torch.allclose(g32, ref, atol=2e-3, rtol=2 ** -7), float(d.max())
+    assert float((g32 != ref).float().mean()) < 0.02          # the rest: accumulation-order flips of a bf16 rounding
+    # ... and the layer after them on the product's own kernel (conv1_1, stride 2), fed by the pair's output: the first THREE layers against the oracle
+    x1 = ops.run_layer(pm.packed(device)["enc"][1][0], got)
+    with torch.no_grad():
+        ref1 = R.cbr(ref, enc.conv1_1, enc.bn1_1, emulate=True)
+    g1 = x1.float().cpu().permute(0, 3, 1, 2)
+    assert g1.shape == ref1.shape == (N, 64, H // 2, W // 2)
+    assert torch.allclose(g1, ref1, atol=4e-3, rtol=2 ** -6), float((g1 - ref1).abs().max())      # (two bf16 roundings deep: two ulp)

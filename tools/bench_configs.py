@@ -131,6 +131,13 @@ def run_configs(frames=64, reps=5, dev=None):
         return e0.elapsed_time(e1) / reps
 
     out = {}
+    # a1 alone, on the uniform synthetic sweeps of the bench and on 32-beam ring sweeps (near-range duplicates)
+    from v2x_sim_amd.utils.synthetic import synthetic_ring_sweep
+    out["a1 voxeliser alone, uniform synthetic sweeps (%d clouds)" % (A * B)] = timed(lambda: ops.voxelize_bits(cs.pts, cs.n_pts, cs.grid))
+    ring = torch.from_numpy(np.concatenate([synthetic_ring_sweep(1, 65536, seed=7000 + r) for r in range(16)])).to(dev)
+    ring = ring.repeat((A * B + 15) // 16, 1, 1)[:A * B].contiguous()
+    out["a1 voxeliser alone, 32-beam ring sweeps with near-range duplicates (%d clouds)" % (A * B)] = timed(lambda: ops.voxelize_bits(ring, cs.n_pts, cs.grid))
+    del ring
     out["0n lowerbound network (no fusion), HIP path"] = timed(cs.build("lowerbound"))
     out["1 upperbound (early fusion: 5x the points per ego grid)"] = timed(cs.build("upperbound"))
     out["2 V2VNet (warp + ConvGRU, gnn_iter=1)"] = timed(cs.build("v2vnet"))

@@ -18,7 +18,7 @@
 //   * the two wave groups run half a step apart (one computes while the other loads: stream8g's ping-pong); the LDS holds either phase's
 //     ring + patches in the same 151 KiB.  Each phase has its own prologue; the NEXT tile's up prologue is issued BEFORE this tile's output
 //     stores (vmcnt is in order: the wait then covers the DMAs and leaves the stores in flight).
-// What bounds it (profiles/r05_stream8p_probe.txt, phase-removal builds of tools/probes/conv_stream_pc_probe.hip): the up phase's MFMAs are hidden
+// What bounds it (profiles/r05_stream8p_probe.txt, phase-removal builds of an instrumented copy, retired in round 6: git show c68e3aa:tools/probes/conv_stream_pc_probe.hip): the up phase's MFMAs are hidden
 // entirely (removing them: -1 %); its time is the 32 + 3 one-KiB LDS-DMA pieces per step -- 0.9 us per step = ~22 B/clk per CU, the LDS-DMA rate
 // these kernels see everywhere -- so the class decomposition's 4x weight bytes per MFMA, not its MFMA count, sets the layer's time: -19 % against
 // the 9-tap kernel where the MFMA count alone says -37 %.  Variants measured and dropped: four up slots (above), the weight pieces split over
@@ -44,7 +44,7 @@ constexpr int SP_PIECES = (2 * PHF * PWH * 4 + 63) / 64;   // 39
 #ifndef V2X_PCS_USLOTS_BUILD
 #define V2X_PCS_USLOTS_BUILD 3
 #endif
-// up-phase ring: NU slots, the image of step s + NU - 1 streams in while step s computes.  Measured (tools/ab_pcs.sh, profiles/r05_stream8p_probe.txt):
+// up-phase ring: NU slots, the image of step s + NU - 1 streams in while step s computes.  Measured (profiles/r05_stream8p_probe.txt):
 // four slots are no faster than three (2-4 % slower): the up phase is bound by the CU's LDS-DMA throughput (35 KiB per 32-MFMA step at ~22 B/clk),
 // not by the time a piece has to land.
 constexpr int NU = V2X_PCS_USLOTS_BUILD;

@@ -21,8 +21,8 @@
 // away from the image border (lane offsets precomputed), stage A on row segments (wave-uniform border tests, a third fewer pixel reads): 1 555 -> 1 422 us.
 // Measured and dropped (same probe file; all bit-identical):
 //   * the stages cut into 14 barrier-separated load / MFMA phases with the groups an odd number of phases apart (stream8g's scheme;
-//     tools/probes/conv_tail_phases_probe.hip): 1 841 us against 1 577 -- a phase is then one tap column, and 14 barriers per tile add their skew;
-//   * a WAVE-PRIVATE form (tools/probes/conv_tail_wave_probe.hip): one wave per SIMD with 512 registers, its own 8 x 16 tile, window and patch, conv8_2's and the
+//     git show c68e3aa:tools/probes/conv_tail_phases_probe.hip): 1 841 us against 1 577 -- a phase is then one tap column, and 14 barriers per tile add their skew;
+//   * a WAVE-PRIVATE form (git show c68e3aa:tools/probes/conv_tail_wave_probe.hip): one wave per SIMD with 512 registers, its own 8 x 16 tile, window and patch, conv8_2's and the
 //     1x1's weights in registers, 8 fragments per hidden-layer weight fragment, no workgroup barrier in the loop -- 174 instead of 312 fragment reads per 128
 //     pixels, and 1 735 us against 1 511: with one wave per SIMD its ~1 600 VALU instructions per tile (364 of them AGPR -> VGPR copies for the epilogues) run
 //     in series with its 552 MFMAs;

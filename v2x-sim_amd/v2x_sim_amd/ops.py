@@ -21,6 +21,12 @@ from ._launch import _Prof, _dev, _dev_opt, _stream  # noqa: F401
 # tuning SMALL_BATCH: 0 never; 1 every launch of the process (the explicit pin, also for the sharded runners); 2 (default) only inside a
 # `with ops.latency_dispatch():` block -- the plain single-GPU model classes enter one in forward_nhwc() (@ops.latency_entry: the common entry
 # of forward(), forward_points() and the Seg / Det modules), the sharded runners (R-rank == 1-rank bitwise) never do.
+# NOT only a summation order: the streamed parity-class kernel (conv5_1, conv6_1: w_layout 4) has no split-K form, so a declared latency
+# launch that splits takes `Layer.latency` -- the layer's 9-TAP bf16 weights -- while a throughput launch of the same model multiplies the PRE-SUMMED
+# parity-class weights (fp32 sums of 1, 2 or 4 taps rounded to bf16 once).  The two forms agree with the fp32 oracle layer to the same bound
+# (tests/test_gpu_parity_class.py) but differ from each other by that weight rounding, not just by summation order; one-frame inference mixes them
+# (conv7_1 / conv8_1 parity-class, conv5_1 / conv6_1 9-tap).  Bounded end to end: tests/test_gpu_bits_input.py (latency vs throughput logits of one frame
+# within 2e-2 of max|ref|) and tests/test_gpu_models.py (either dispatch within TOL of the oracle).
 import threading as _threading
 
 _latency = _threading.local()   # per THREAD: a latency forward in one thread must not switch a sharded runner or a training step in another

@@ -10,7 +10,9 @@ Host-side switches (this module):
     CONV_PAIR   1  conv_pre_1 -> conv_pre_2 as one launch from the bit grid; 0: two launches
     PP_64       1  pack the 64 -> 64 full-resolution layers for the ping-pong halo kernel (read when a model is packed)
     SMALL_BATCH 2  latency dispatch: split-K for the streamed layers when a launch has fewer tiles than CUs (ops.small_batch_splitk) and the 1-tap
-                   stride-2 kernel below four tiles per CU; results differ from the default kernels by fp32 summation order.  0: never; 1: every
+                   stride-2 kernel below four tiles per CU; results differ from the default kernels by fp32 summation order -- and, for conv5_1 / conv6_1,
+                   by the weight form: a split launch multiplies the 9-tap bf16 weights, the throughput launch the pre-summed parity-class weights
+                   (ops.py header; bounded in tests/test_gpu_bits_input.py).  0: never; 1: every
                    launch of the process (explicit pin, also for the sharded runners); 2: only inside `with ops.latency_dispatch():`, which the
                    plain single-GPU model classes enter in forward() -- the sharded runners never do (R-rank == 1-rank bitwise)
     TRAIN_HIP   1  training graph on the hand-written kernels (train/hip_graph.py: bf16 NHWC activations, fp32 master weights); 0: the fp32

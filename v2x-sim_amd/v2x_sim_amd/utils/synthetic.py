@@ -45,6 +45,46 @@ def synthetic_points(n_clouds, n_pts, seed=0):
     return pts
 
 
+def synthetic_ring_sweep(n_clouds, n_pts=65536, seed=0, beams=32, sensor_height=1.8):
+    """A 32-beam spinning-LiDAR sweep as V2X-Sim's sensors produce them (nuScenes-style LIDAR_TOP, /root/reference/README.md:50-64), in the sensor
+    frame: `beams` elevation angles from -30.7 to +10.7 degrees, n_pts / beams azimuth steps per ring.  Downward beams hit the ground plane
+    (z = -sensor_height) at r = h / tan(-elevation) unless one of ~40 random boxes (vehicles, walls) stands in the way; upward beams hit a box /
+    facade or return nothing (such points are parked far outside the BEV extents, as a driver's max-range returns are).  2 cm range noise.  What
+    the uniform generator lacks and this has: the steep inner rings put their 2 048 returns on circles of a few metres radius -- tens of points
+    per 0.25 m voxel (duplicates that collide in one LDS word), empty space between the rings, and a dense / sparse mix across the map."""
+    rng = np.random.default_rng(seed)
+    per = n_pts // beams
+    elev = np.deg2rad(np.linspace(-30.67, 10.67, beams))
+    out = np.empty((n_clouds, per * beams, 4), dtype=np.float32)
+    for c in range(n_clouds):
+        az = (np.arange(per) + rng.uniform(0, 1)) * (2 * math.pi / per)
+        azg, elg = np.meshgrid(az, elev)                         # (beams, per)
+        dx, dy, dz = np.cos(elg) * np.cos(azg), np.cos(elg) * np.sin(azg), np.sin(elg)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            r = np.where(dz < -1e-3, -sensor_height / dz, np.inf)
+        # boxes: axis-aligned in the sensor frame for simplicity (centre, half extents, top); a ray stops at the nearest box face it enters
+        nb = 40
+        bc = rng.uniform(-45, 45, (nb, 2))
+        bh = np.stack([rng.uniform(0.8, 6.0, nb), rng.uniform(0.8, 3.0, nb)], 1)
+        top = rng.uniform(-0.3, 4.0, nb)
+        for k in range(nb):
+            if (np.abs(bc[k]) - bh[k]).max() < 2.5:
+                continue                                         # nothing within 2.5 m of the sensor (the vehicle itself is there)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                tx0, tx1 = (bc[k, 0] - bh[k, 0]) / dx, (bc[k, 0] + bh[k, 0]) / dx
+                ty0, ty1 = (bc[k, 1] - bh[k, 1]) / dy, (bc[k, 1] + bh[k, 1]) / dy
+            tn = np.maximum(np.minimum(tx0, tx1), np.minimum(ty0, ty1))
+            tf = np.minimum(np.maximum(tx0, tx1), np.maximum(ty0, ty1))
+            hit = (tn < tf) & (tn > 0) & (-sensor_height + 0 * tn <= top[k]) & (dz * tn <= top[k]) & (tn < r)
+            r = np.where(hit, tn, r)
+        r = r + rng.normal(0, 0.02, r.shape)
+        lost = ~np.isfinite(r) | (r > 70.0)
+        r = np.where(lost, 200.0, r)                             # no return: far outside the extents
+        pts = np.stack([r * dx, r * dy, r * dz, rng.uniform(0, 1, r.shape)], -1).reshape(-1, 4)
+        out[c] = pts[rng.permutation(pts.shape[0])].astype(np.float32)      # packets do not arrive ring by ring
+    return out
+
+
 def synthetic_poses(batch, agents, seed=0):
     """Random SE(2) poses; trans[b, i, j] = inv(P_i) @ P_j maps agent j's frame into agent i's
     (the matrix upstream stores as trans_matrices[b, i, j] and feeds to feature_transformation)."""
