@@ -105,12 +105,12 @@ def live_traffic_table(args):
         return None, why, 0.0
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     table = {}
-    timeout_s = float(os.environ.get("V2X_BENCH_PMC_TIMEOUT_S", "90"))
+    timeout_s = float(os.environ.get("V2X_BENCH_PMC_TIMEOUT_S", "120"))
     for counter, factor in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
         out = tempfile.mkdtemp(prefix="v2x_pmc_", dir="/tmp")
         cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                "--steps", "2", "--warmup", "1", "--graph", "0", "--frames-per-gpu", str(args.frames_per_gpu), "--gnn-iters", str(args.gnn_iters),
-               "--no-cpu-baseline", "--no-extras", "--no-calibration", "--no-shard-check", "--no-roofline"]
+               "--no-cpu-baseline", "--no-gpu-baseline", "--no-extras", "--no-calibration", "--no-shard-check", "--no-roofline"]
         env = dict(os.environ, TMPDIR="/tmp", V2X_BENCH_LIVE_TRAFFIC="0", V2X_BENCH_INNER="1")
         try:
             proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)

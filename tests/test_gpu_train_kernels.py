@@ -1163,3 +1163,74 @@ def test_fused_gru_gates_equal_the_torch_ops(device, tune, shape):
         assert torch.isfinite(a).all(), name
         scale = max(float(b.abs().max()), 1e-6)
         assert float((a - b).abs().max()) <= 3e-6 * scale + 1e-7, (name, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("M_shape,Cin,Cout,f32_out,relu", [((2, 64, 64), 64, 64, False, True), ((1, 64, 64), 32, 12, True, False), ((2, 32, 32), 32, 36, True, False),
+                                                             ((1, 32, 64), 128, 128, False, True), ((3, 24, 40), 64, 32, False, False), ((1, 5, 7), 32, 32, False, True),
+                                                             ((10, 256, 256), 32, 12, True, False), ((4, 128, 128), 64, 64, False, True), ((2, 16, 16), 128, 64, False, False)])
+def test_streaming_conv1x1_equals_the_gather_kernel_bitwise(device, tune, M_shape, Cin, Cout, f32_out, relu):
+    """conv1x1.hip (round 6: 1x1 layers as a register-resident-weights stream, no LDS) against the gather kernel it replaces for these shapes (switch CONV1X1 = 0):
+    the same K order, one MFMA per 32-channel chunk, the same epilogue arithmetic -> the same bits, for bf16 and fp32 outputs, Cout not a multiple of 16 (12, 36: the
+    heads), pixel counts that are not a multiple of 16, and against torch fp32 on the same bf16 operands."""
+    from v2x_sim_amd import ops, packing
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + M_shape[1])
+    N, H, W = M_shape
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) * 0.2
+    b = torch.randn(Cout, generator=g)
+    pc = packing.pack_conv1x1_device("t", w.to(device), b.to(device), f32_out=f32_out)
+    pc.relu = relu
+    xd = x.to(device)
+    ops.PROFILE = []
+    new = ops.conv2d(pc, xd)
+    torch.cuda.synchronize()
+    ops.PROFILE = None
+    tune("CONV1X1", 0)
+    old = ops.conv2d(pc, xd)
+    tune.reset("CONV1X1")
+    assert new.dtype == old.dtype == (torch.float32 if f32_out else torch.bfloat16) and new.shape == (N, H, W, Cout)
+    assert torch.equal(new, old), float((new.float() - old.float()).abs().max())
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), b).permute(0, 2, 3, 1)
+    if relu:
+        ref = torch.relu(ref)
+    tol = 2e-4 if f32_out else 2.0 ** -7
+    assert torch.allclose(new.float().cpu(), ref, atol=2e-3 if not f32_out else 2e-4, rtol=tol), float((new.float().cpu() - ref).abs().max())
+    assert torch.equal(ops.conv2d(pc, xd), new)
+
+
+@pytest.mark.parametrize("shape,cp", [((2, 64, 64, 12), 32), ((1, 32, 32, 36), 64), ((10, 256, 256, 12), 32), ((3, 8, 32, 36), 64), ((1, 5, 3, 32), 32)])
+def test_cast_pad_chsum_equals_the_torch_ops(device, shape, cp):
+    """v2x_cast_pad_chsum_f32 (round 6: a 1x1 head's fp32 logit gradients -> bf16, channels zero-padded for the gradient kernels, bias gradient on the side) against
+    F.pad + .to(bfloat16) (bit-equal) and an fp64 sum (fp32-accumulation error only); bit-reproducible."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(sum(shape) + cp)
+    x = (torch.randn(shape, generator=g) * 0.1 + 0.01).to(device)
+    out, sums = ops.cast_pad_chsum(x, cp)
+    ref = F.pad(x, (0, cp - shape[-1])).to(torch.bfloat16)
+    assert out.shape == ref.shape and torch.equal(out, ref)
+    ref_s = x.double().reshape(-1, shape[-1]).sum(0)
+    scale = float(x.double().abs().reshape(-1, shape[-1]).sum(0).max())
+    assert sums.shape == (shape[-1],) and float((sums.double() - ref_s).abs().max()) <= 2e-6 * scale
+    out2, sums2 = ops.cast_pad_chsum(x, cp)
+    assert torch.equal(out2, out) and torch.equal(sums2, sums)
+    assert ops.cast_pad_chsum(x[..., :shape[-1] - 1].contiguous(), cp) is None if (shape[-1] - 1) % 4 else True      # C % 4 != 0: the caller's torch path
+
+
+def test_head_gradient_pack_changes_the_step_only_in_the_last_bits(device, tune):
+    """The heads' 1x1 backward with TRAIN_HEAD_PACK = 1 (one pass) and 0 (pad / cast / sum): same data gradient and weight gradient bits (the bf16 values are
+    bit-equal), bias gradients equal to fp32 summation order."""
+    from v2x_sim_amd.train import hip_graph
+    g = torch.Generator().manual_seed(5)
+    N, H, W, Cin, Cout = 2, 64, 64, 32, 36
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(device)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) * 0.2).to(device)
+    b = torch.randn(Cout, generator=g).to(device)
+    dy = (torch.randn(N, H, W, Cout, generator=g) * 0.05).to(device)
+    grads = {}
+    for flag in (1, 0):
+        tune("TRAIN_HEAD_PACK", flag)
+        xd, wd, bd = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        hip_graph.conv1x1(xd, wd, bd, f32_out=True).backward(dy)
+        grads[flag] = (xd.grad.clone(), wd.grad.clone(), bd.grad.clone())
+    assert torch.equal(grads[1][0], grads[0][0]) and torch.equal(grads[1][1], grads[0][1])
+    assert torch.allclose(grads[1][2], grads[0][2], rtol=1e-5, atol=1e-5)

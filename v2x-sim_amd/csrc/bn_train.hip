@@ -457,6 +457,42 @@ __global__ __launch_bounds__(256) void channel_sum_finish_kernel(const float *__
     if (lane == 0) out[c] = (float)s;
 }
 
+// fp32 [M][C] -> bf16 [M][Cp] (zero-padded channels) + per-workgroup partial channel sums of the fp32 values: the logit gradients of a 1x1 head on their way
+// into the data- / weight-gradient kernels (include/v2x_amd.h: v2x_cast_pad_chsum_f32).  A thread owns one 8-channel group of the padded row (one 16-B store).
+__global__ __launch_bounds__(256) void cast_pad_chsum_kernel(const float *__restrict__ x, long long M, int C, int Cp, uint16_t *__restrict__ out, float *__restrict__ part) {
+    __shared__ float red[256][8];
+    const int groups = Cp / 8, rpp = 256 / groups;
+    const int cg = threadIdx.x % groups, r0 = threadIdx.x / groups;
+    const long long per = (M + gridDim.x - 1) / gridDim.x;
+    const long long lo = (long long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
+    const bool q0 = cg * 8 + 4 <= C, q1 = cg * 8 + 8 <= C;      // which of the group's two float4 exist (C % 4 == 0)
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (long long r = lo + r0; r < hi; r += rpp) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        if (q0) a = *reinterpret_cast<const float4 *>(x + r * C + cg * 8);
+        if (q1) b = *reinterpret_cast<const float4 *>(x + r * C + cg * 8 + 4);
+        acc[0] += a.x; acc[1] += a.y; acc[2] += a.z; acc[3] += a.w;
+        acc[4] += b.x; acc[5] += b.y; acc[6] += b.z; acc[7] += b.w;
+        uint4 v;
+        v.x = pack_bf16x2(a.x, a.y);
+        v.y = pack_bf16x2(a.z, a.w);
+        v.z = pack_bf16x2(b.x, b.y);
+        v.w = pack_bf16x2(b.z, b.w);
+        *reinterpret_cast<uint4 *>(out + r * Cp + cg * 8) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x][j] = acc[j];
+    __syncthreads();
+    if (r0 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float s = 0.f;
+            for (int k = 0; k < rpp; ++k) s += red[k * groups + cg][j];
+            part[(size_t)blockIdx.x * Cp + cg * 8 + j] = s;
+        }
+    }
+}
+
 extern "C" long long v2x_channel_sum_workspace_size(long long M, int C) {
     if (!bn_shape_ok(M, C)) return 0;
     return (long long)cs_blocks(M, C) * C * (long long)sizeof(float);
@@ -469,5 +505,18 @@ extern "C" int v2x_channel_sum_bf16(const uint16_t *x, long long M, int C, float
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, M, C, workspace);
     hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, C, out);
     V2X_CHECK_LAUNCH("channel_sum kernels");
+    return V2X_OK;
+}
+
+extern "C" long long v2x_cast_pad_chsum_workspace_size(long long M, int Cp) { return v2x_channel_sum_workspace_size(M, Cp); }
+
+extern "C" int v2x_cast_pad_chsum_f32(const float *x, long long M, int C, int Cp, uint16_t *out, float *sums, float *workspace, v2x_stream_t stream) {
+    V2X_REQUIRE(x && out && sums && workspace, "v2x_cast_pad_chsum_f32: null pointer");
+    V2X_REQUIRE(bn_shape_ok(M, Cp) && C > 0 && C % 4 == 0 && C <= Cp, "v2x_cast_pad_chsum_f32: needs M > 0, C %% 4 == 0, C <= Cp, Cp in {8, 16, 32, ...} (Cp / 8 divides 256), got M=%lld C=%d Cp=%d", M, C, Cp);
+    V2X_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0, "v2x_cast_pad_chsum_f32: x and out must be 16-byte aligned");
+    const int nblk = cs_blocks(M, Cp);
+    hipLaunchKernelGGL(cast_pad_chsum_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, M, C, Cp, out, workspace);
+    hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((Cp + 3) / 4), dim3(256), 0, (hipStream_t)stream, workspace, nblk, Cp, sums);
+    V2X_CHECK_LAUNCH("cast_pad_chsum kernels");
     return V2X_OK;
 }

@@ -287,6 +287,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 // ---- host side -------------------------------------------------------------------------
+int v2x_conv1x1_dispatch(const v2x_conv_desc *d, hipStream_t s);   // conv1x1.hip: V2X_OK / error, or 1 = not a shape of the streaming 1x1 kernel
 extern "C" int v2x_conv_tile_rows(int Cout, int epilogue) {
     if (epilogue == V2X_EPI_GRU) return 96;
     if (Cout <= 32) return 32;
@@ -425,6 +426,10 @@ extern "C" int v2x_conv2d(const v2x_conv_desc *d, v2x_stream_t stream) {
         V2X_REQUIRE(d->out_cstride >= d->out_coff + d->Cout && d->out_coff >= 0, "v2x_conv2d: bad output channel window");
     }
 
+    if (d->ksize == 1 && v2x_tune(V2X_TUNE_CONV1X1) != 0) {     // 1x1 layers with <= 128 channels either side: the streaming kernel (conv1x1.hip), same bits
+        const int rc1 = v2x_conv1x1_dispatch(d, (hipStream_t)stream);
+        if (rc1 != 1) return rc1;
+    }
     ConvArgs a;
     a.in0 = d->in0;
     a.in1 = d->in1;

@@ -113,6 +113,10 @@ def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
         if (c0, c1, pc.Cout, co2) in ((64, 32, 32, 0), (0, 64, 64, 0)) and tuning.get("HALO_PP") != 0:
             return "conv3x3_halo_pp_kernel<%d, %d, %d, 0>" % (c0, c1, pc.Cout)   # conv8_1 / conv7_2: 8-wave ping-pong form
         return "conv3x3_halo_kernel<%d, %d, %d, %d, %d>" % (c0, c1, pc.Cout, co2, e2)
+    if (pc.ksize == 1 and pc.stride == 1 and not pc.C1 and not pc.Cout2 and pc.epilogue in (V2X_EPI_BF16, V2X_EPI_F32) and pc.C0 % 32 == 0 and pc.C0 <= 128
+            and pc.C0 // 32 != 3 and 4 <= pc.Cout <= 128 and pc.Cout % 4 == 0 and (pc.Cout + 15) // 16 in (1, 2, 3, 4, 6, 8) and tuning.get("CONV1X1") != 0):
+        ks, ct = pc.C0 // 32, (pc.Cout + 15) // 16      # conv1x1.hip: the streaming 1x1 kernel (round 6; same bits as the gather kernel)
+        return "conv1x1_stream_kernel<%d, %d, %s, %d>" % (ks, ct, "true" if pc.epilogue == V2X_EPI_F32 else "false", 2 if ks * ct >= 16 else 4)
     rows = _lib.load().v2x_conv_tile_rows(pc.Cout, pc.epilogue)
     return "conv_igemm_kernel<%d, %d, %d, %d, %d>" % (_CONV_TILES[rows] + (pc.epilogue,))
 
@@ -654,7 +658,7 @@ def run_layer(layer, in0, in1=None, zbits=0):
 
 # ------------------------------------------------------------------ rows f-1 and f-3 live in their own modules; `ops.<name>` keeps working
 from .ops_post import conv2d_det, det_nms_candidates, det_postprocess, match_detections, rotated_iou  # noqa: E402,F401
-from .ops_train import (bn_train_backward, bn_train_forward, channel_sum, conv3x3_wgrad, det_loss_backward, det_loss_forward,  # noqa: E402,F401
+from .ops_train import (bn_train_backward, bn_train_forward, cast_pad_chsum, channel_sum, conv3x3_wgrad, det_loss_backward, det_loss_forward,  # noqa: E402,F401
                         gru_gates, gru_gates_backward, upcat, upcat_backward, warp_affine, zero_insert)
 
 

@@ -96,6 +96,26 @@ def channel_sum(x):
     return out
 
 
+def cast_pad_chsum(x, c_pad):
+    """x (..., C) fp32 -> (bf16 (..., c_pad) with channels C.. zero, (C,) fp32 per-channel sums of x) in ONE pass + a finish launch (v2x_cast_pad_chsum_f32):
+    the logit gradients of a 1x1 head made ready for its data- and weight-gradient kernels, with the bias gradient on the side.  None when the shape is not
+    one the kernel takes (the caller falls back to pad / cast / sum)."""
+    lib = _lib.load()
+    Cc = x.shape[-1]
+    M = x.numel() // Cc
+    if x.dtype != torch.float32 or not x.is_cuda or not x.is_contiguous() or Cc % 4 or c_pad < Cc:
+        return None
+    nbytes = lib.v2x_cast_pad_chsum_workspace_size(M, c_pad)
+    if nbytes == 0:
+        return None
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    out = torch.empty(x.shape[:-1] + (c_pad,), dtype=torch.bfloat16, device=x.device)
+    sums = torch.empty((c_pad,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.v2x_cast_pad_chsum_f32(_dev(x, torch.float32, "x"), M, Cc, c_pad, _dev(out, torch.bfloat16, "out"), _dev(sums, torch.float32, "sums"),
+                                          _dev(ws, torch.float32, "workspace"), _stream()), "v2x_cast_pad_chsum_f32")
+    return out, sums[:Cc]
+
+
 def warp_affine(x, theta, backward=False):
     """F.grid_sample(x, F.affine_grid(theta, x.shape, align_corners=False), "bilinear", "zeros", align_corners=False) on the HIP kernel
     (warp_train.hip), or -- backward=True -- its exact transpose applied to an output gradient x (deterministic gather).

@@ -285,12 +285,21 @@ class _Conv1x1(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         cout = weight.shape[0]
         cp = (cout + 31) // 32 * 32
-        db = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = _attached_channel_sum(dy)
-            if db is None:
-                db = dy.float().sum((0, 1, 2))
-        dyp = F.pad(dy, (0, cp - cout)).to(BF16).contiguous() if (cp != cout or dy.dtype != BF16) else dy.contiguous()
+        db = dyp = None
+        if dy.dtype == torch.float32 and tuning.get("TRAIN_HEAD_PACK") != 0:
+            # the heads' logit gradients arrive fp32 from the loss: bf16 + channel padding + the bias gradient in one pass (v2x_cast_pad_chsum_f32, round 6)
+            # instead of pad (fill + copy), cast, and a separate fp32 reduction -- six launches and four passes over the gradients per head
+            packed = ops.cast_pad_chsum(dy.contiguous(), cp)
+            if packed is not None:
+                dyp, db = packed
+        if dyp is None:
+            if ctx.has_bias and ctx.needs_input_grad[2]:
+                db = _attached_channel_sum(dy)
+                if db is None:
+                    db = dy.float().sum((0, 1, 2))
+            dyp = F.pad(dy, (0, cp - cout)).to(BF16).contiguous() if (cp != cout or dy.dtype != BF16) else dy.contiguous()
+        if not (ctx.has_bias and ctx.needs_input_grad[2]):
+            db = None
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d(_layer_1x1("dgrad", weight, None, False, cp), dyp)

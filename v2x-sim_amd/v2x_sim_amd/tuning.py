@@ -2,7 +2,7 @@
 libv2x_amd.so for the kernel-selection ones) and changed afterwards only through set() -- nothing on the hot path calls os.environ.
 
 Kernel-selection switches live in the library (include/v2x_amd.h: v2x_tuning_set / v2x_tuning_get; defaults = the measured-fastest forms):
-    STREAM_WAVES STREAM_G STREAM_WT STORE_X4 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP S2_RESIDENT VOXELIZE_LDS WARP_LDS S2_G GRU_XCD_WALK HALO_XCD WGRAD_TR
+    STREAM_WAVES STREAM_G STREAM_WT STORE_X4 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP S2_RESIDENT VOXELIZE_LDS WARP_LDS S2_G GRU_XCD_WALK HALO_XCD WGRAD_TR CONV1X1
     (STORE_X4 1: 16-byte output stores -- two channel tiles exchanged between the k-slot quarters with v_permlane16_swap_b32 -- in every bf16 epilogue
      that has the form; 0: 8-byte stores, same bytes and values)
 Host-side switches (this module):
@@ -33,14 +33,15 @@ Host-side switches (this module):
                    everywhere.  Read when a model is packed
     TAIL_FUSE 1  conv8_2 and the detection heads as ONE launch (conv_tail.hip: conv8_2's output never leaves the CU; bit-identical to the two launches);
                    0 = two launches.  Read at every forward
+    TRAIN_HEAD_PACK 1  with TRAIN_HIP: the heads' fp32 logit gradients -> bf16, channel padding and bias gradient in one pass (v2x_cast_pad_chsum_f32); 0: torch ops
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
 The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
-                    "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR")
+                    "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "CONV1X1")
 
 
 def _env_int(name, default):
