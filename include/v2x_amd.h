@@ -220,6 +220,11 @@ typedef struct v2x_pack_spec {
     int32_t epilogue; /* V2X_EPI_*: selects the row tile; V2X_EPI_GRU = (r, z, n) row regrouping           */
     int32_t chain;    /* 1: the layer is followed by a chained 1x1 (Cout2 > 0): rows in chain order       */
     int32_t c_up;     /* w_layout 3 and 4 only: the first c_up input channels are the x2-upsampled source (v2x_conv_desc.C0); else 0 */
+    /* ABI 17, v2x_pack_conv_device / _job with transform = 1 only (0, 0 everywhere else): the data-gradient layer of a SLICE of a convolution's input
+     * channels -- rows src_row0 .. src_row0 + Cout - 1 of the src_rows rows the full data-gradient layer has (src_rows = the convolution's Cin; the
+     * weights are read from its whole tensor W [Cin = this spec's][src_rows][k][k]).  Lets a data gradient be computed as several launches that each
+     * fit a kernel (conv8_1 of the decoder: 32 -> 96 channels as 32 -> 64 and 32 -> 32 into one 96-channel map). */
+    int32_t src_rows, src_row0;
 } v2x_pack_spec;
 
 /* Bytes of the packed bf16 buffer (0 = unsupported spec, see v2x_last_error) and the w_rows / w_kpad to put in the descriptor. */
@@ -241,6 +246,7 @@ typedef struct v2x_pack_job {
     const float *w;       /* DEVICE fp32 parameter            */
     uint16_t *dst;        /* DEVICE packed bf16 destination   */
     int32_t rows_src, cin, cin_p, taps, K, w_kpad, tile, cout, layout, transform;
+    int32_t src_stride, reserved0; /* transform = 1: rows of the source tensor per input channel (= rows_src unless the job packs a row slice)  */
     int64_t groups, data_groups;   /* 16-byte groups of the destination; of them real rows */
     int64_t block_begin;  /* first workgroup of this job in the batched launch */
 } v2x_pack_job;

@@ -820,6 +820,7 @@ def test_conv_bias_gradients_come_from_the_bn_backward_kernel(device, tune, monk
     from v2x_sim_amd.train import detection_loss, hip_graph, train_forward
     from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
     tune("TRAIN_HIP", 1)
+    tune("TRAIN_BN_BIAS_ZERO", 0)       # (round 6's default returns these gradients as exact zeros: test_bias_gradient_in_front_of_a_batchnorm_is_zero)
     cfg = Config("train", binary=True, only_det=True)
     model = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=4).to(device).train()
     data = synthetic_batch_on_device(cfg, 1, 2, seed=6, device=device)
@@ -1234,3 +1235,93 @@ def test_head_gradient_pack_changes_the_step_only_in_the_last_bits(device, tune)
         grads[flag] = (xd.grad.clone(), wd.grad.clone(), bd.grad.clone())
     assert torch.equal(grads[1][0], grads[0][0]) and torch.equal(grads[1][1], grads[0][1])
     assert torch.allclose(grads[1][2], grads[0][2], rtol=1e-5, atol=1e-5)
+
+
+def test_bias_gradient_in_front_of_a_batchnorm_is_zero(device, tune):
+    """Round 6 (TRAIN_BN_BIAS_ZERO = 1, the default): a conv + batch-statistics BN pair returns its bias gradient as the exact value, zero.  Checked on a
+    FaFNet step: (a) the COMPUTED values (switch 0: what autograd's sum gives up to order) are rounding residue -- below 5 % of a live bias gradient of the same
+    step (the heads' last layers), although they sum 1e5-1e6 terms each; (b) the logits do not depend on those biases beyond the bf16 noise floor (shifting them all by 0.02 -- the BN subtracts the batch mean, whatever
+    the bias added to it); (c) with the switch on those gradients are exact zeros and every OTHER gradient of the step is bit-identical."""
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    tune("TRAIN_HIP", 1)
+    cfg = Config("train", binary=True, only_det=True)
+    model = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=4).to(device).train()
+    data = synthetic_batch_on_device(cfg, 1, 2, seed=6, device=device)
+
+    def step():
+        model.zero_grad(set_to_none=True)
+        res = train_forward(model, data["bev_seq"], None, None, 1)
+        loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+        loss.backward()
+        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    tune("TRAIN_BN_BIAS_ZERO", 0)
+    l0, g0 = step()
+    tune("TRAIN_BN_BIAS_ZERO", 1)
+    l1, g1 = step()
+    assert l0 == l1 and set(g0) == set(g1)
+    bn_biases = [n for n in g1 if n.endswith("bias") and float(g1[n].abs().max()) == 0.0 and "bn" not in n]
+    assert len(bn_biases) >= 20, bn_biases                      # every 3x3 / 1x1x1 convolution in front of a BatchNorm (22 in FaFNet, minus the width-padded layer)
+    residue = max(float(g0[n].abs().max()) for n in bn_biases)
+    signal = max(float(g0[n].abs().max()) for n in g0 if n.endswith("bias") and n not in bn_biases and "bn" not in n)     # the heads' last layers: real gradients
+    print("bias gradients in front of a BatchNorm: computed residue <= %.3e; a live bias gradient of the same step: %.3e" % (residue, signal))
+    assert residue <= 0.05 * signal, (residue, signal)
+    for n in g0:
+        if n not in bn_biases:
+            assert torch.equal(g0[n], g1[n]), n
+    # the biases are dead parameters in train mode: the BN subtracts whatever they add
+    with torch.no_grad():
+        ref = train_forward(model, data["bev_seq"], None, None, 1)
+        for n, p in model.named_parameters():
+            if n in bn_biases:
+                p.add_(0.02)     # (small: the convolution's output is STORED in bf16 before the BN, so a large bias costs the map precision -- exact arithmetic only is bias-blind)
+        got = train_forward(model, data["bev_seq"], None, None, 1)
+    for k in ("cls", "loc"):
+        # (the shifted maps are rounded to bf16 at other points: the two passes are two draws of the storage noise -- compared in the mean)
+        d, scale = (got[k] - ref[k]).abs(), float(ref[k].abs().max())
+        print("logits after shifting every such bias by 0.02: %s mean |diff| %.2e, max %.2e of max|ref|" % (k, float(d.mean()) / scale, float(d.max()) / scale))
+        assert float(d.mean()) <= 5e-3 * scale, k
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 32), (1, 128, 128), (3, 8, 16)])
+def test_upcat_conv8_on_the_halo_kernels_vs_autograd_and_the_gather_path(device, tune, N, H, W):
+    """Round 6 (TRAIN_UPCAT_CONV): conv8_1 = conv3x3(cat(up(lo 64 ch), skip 32 ch)) -> 32 -- forward on the two-source halo kernel, the data gradient as two
+    halo launches (32 -> 64 | 32 -> 32, packed from row slices of the transposed weights: v2x_pack_spec.src_rows / src_row0) into one 96-channel map, then
+    the upsample / concat backward.  Against fp32 autograd on the same bf16 operands (1 bf16 ulp of the largest value, as the other layers of the graph are
+    held) and against the gather-kernel path it replaces (same operands, different K walk: 1 ulp); the weight gradient is the same launch either way: bit-equal."""
+    from v2x_sim_amd.train import hip_graph
+    g = torch.Generator().manual_seed(N * 100 + H)
+    lo = torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16)
+    skip = torch.randn(N, 2 * H, 2 * W, 32, generator=g).to(torch.bfloat16)
+    conv = torch.nn.Conv2d(96, 32, 3, 1, 1)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(32, 96, 3, 3, generator=g) * (2.0 / (96 * 9)) ** 0.5)
+        conv.bias.copy_(torch.randn(32, generator=g) * 0.1)
+    dy = torch.randn(N, 2 * H, 2 * W, 32, generator=g).to(torch.bfloat16)
+    # fp32 autograd reference on the bf16-rounded operands
+    lor, skr = lo.float().requires_grad_(True), skip.float().requires_grad_(True)
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    up = F.interpolate(lor.permute(0, 3, 1, 2), scale_factor=2)
+    yr = F.conv2d(torch.cat((up, skr.permute(0, 3, 1, 2)), 1), wr, conv.bias.detach(), 1, 1)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    res = {}
+    convd = conv.to(device)
+    for flag in (1, 0):
+        tune("TRAIN_UPCAT_CONV", flag)
+        hip_graph._CACHE.clear()
+        lod, skd = lo.to(device).requires_grad_(True), skip.to(device).requires_grad_(True)
+        convd.zero_grad(set_to_none=True)
+        y = hip_graph.upcat_conv3x3(lod, skd, convd)
+        y.backward(dy.to(device))
+        res[flag] = (y.detach().float().cpu(), lod.grad.float().cpu(), skd.grad.float().cpu(), convd.weight.grad.detach().cpu().clone(), convd.bias.grad.detach().cpu().clone())
+    ulp = 2.0 ** -7
+    refs = (yr.detach().permute(0, 2, 3, 1), lor.grad, skr.grad)
+    for k, name in enumerate(("y", "d_lo", "d_skip")):
+        scale = float(refs[k].abs().max())
+        for flag in (1, 0):
+            assert float((res[flag][k] - refs[k]).abs().max()) <= ulp * scale, (name, flag, float((res[flag][k] - refs[k]).abs().max()), scale)
+        assert float((res[1][k] - res[0][k]).abs().max()) <= ulp * scale, name
+    assert torch.equal(res[1][3], res[0][3]) and torch.equal(res[1][4], res[0][4])
+    assert float((res[1][3] - wr.grad).abs().max()) <= 2e-3 * float(wr.grad.abs().max())

@@ -1468,6 +1468,9 @@ int v2x_conv_halo_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     // there, conv8_1 on the concatenated 96-channel map and conv8_1's data gradient 32 -> 96, do not fit: <0, 32, 96> spills 232 bytes beside 24
     // accumulator tiles, the single-buffer <0, 96, 32> 192 bytes under its 128-register budget -- and a spill breaks the counted waits.)
     HALO_CASE(0, 64, 32, 0, 0)
+    // round 6: conv8_1's data gradient in TWO launches into one 96-channel map -- 32 -> 64 (the x2-upsampled source's channels; this case) and 32 -> 32 (the skip's;
+    // the single-buffer form above) -- from row slices of the transposed weights (v2x_pack_spec.src_rows / src_row0) instead of the gather kernel's 32 -> 96
+    HALO_CASE(0, 32, 64, 0, 0)
     HALO_CASE(0, 32, 64, 48, 2)   // det heads: (cls | reg) hidden -> 12 + 36 logits
     HALO_CASE(0, 32, 32, 16, 2)   // seg: conv8_2 chained with the 1x1 class head (<= 16 classes, fp32 logits)
     if (e2 == 3) {                // det heads with the score threshold in the epilogue: candidates instead of logits

@@ -111,6 +111,7 @@ extern "C" int v2x_pack_conv(const v2x_pack_spec *p, const float *w_oihw, uint16
     const int rc = pack_geometry(p, &g);
     if (rc != V2X_OK) return rc;
     V2X_REQUIRE(w_oihw && dst, "v2x_pack_conv: null pointer");
+    V2X_REQUIRE(p->src_rows == 0 && p->src_row0 == 0, "v2x_pack_conv: row slices (src_rows / src_row0) exist for the device packer's transform = 1 only");
     const int ks = p->ksize, taps = ks * ks, cin = p->Cin, cin_p = g.cin_p, K = g.K;
     const bool gru = p->epilogue == V2X_EPI_GRU;
     if (p->w_layout == 4) {   // streamed parity-class form: per 128-row tile [up chunk][class tap][class][k-slot][row][8], then [skip chunk][kx][ky][k-slot][row][8]
@@ -255,7 +256,7 @@ __device__ __forceinline__ void pack_group(const float *__restrict__ w, uint16_t
             const int c = c0 + j;
             float x = 0.0f;
             if (c < g.cin)
-                x = g.transform ? w[((size_t)c * g.rows_src + row) * g.taps + (g.taps - 1 - tap)] : w[((size_t)row * g.cin + c) * g.taps + tap];
+                x = g.transform ? w[((size_t)c * g.src_stride + row) * g.taps + (g.taps - 1 - tap)] : w[((size_t)row * g.cin + c) * g.taps + tap];
             f[j] = x;
         }
         v = make_uint4(pack_bf16x2(f[0], f[1]), pack_bf16x2(f[2], f[3]), pack_bf16x2(f[4], f[5]), pack_bf16x2(f[6], f[7]));
@@ -292,8 +293,12 @@ static int fill_pack_job(const v2x_pack_spec *p, const float *w_oihw_dev, int tr
     V2X_REQUIRE(p->epilogue != V2X_EPI_GRU && !p->chain && p->w_layout != 3 && p->w_layout != 4, "%s: plain layers only (no GRU regrouping, no chain order, no parity-class sums)", who);
     V2X_REQUIRE(transform == 0 || transform == 1, "%s: transform must be 0 or 1", who);
     V2X_REQUIRE(g.elems % 8 == 0, "%s: internal: destination not a whole number of 16-byte groups", who);
-    d.w = w_oihw_dev;
+    V2X_REQUIRE(p->src_rows == 0 || (transform == 1 && p->src_row0 >= 0 && p->src_row0 + g.rows_src <= p->src_rows),
+                "%s: a row slice (src_rows = %d, src_row0 = %d) needs transform = 1 and src_row0 + %d <= src_rows", who, p->src_rows, p->src_row0, g.rows_src);
+    d.w = w_oihw_dev + (p->src_rows ? (size_t)p->src_row0 * (p->ksize * p->ksize) : 0);
     d.dst = dst_dev;
+    d.src_stride = p->src_rows ? p->src_rows : g.rows_src;
+    d.reserved0 = 0;
     d.rows_src = g.rows_src;
     d.cin = p->Cin;
     d.cin_p = g.cin_p;
@@ -315,7 +320,7 @@ extern "C" int v2x_pack_conv_device(const v2x_pack_spec *p, const float *w_oihw_
     const int rc = fill_pack_job(p, w_oihw_dev, transform, dst_dev, d, "v2x_pack_conv_device");
     if (rc != V2X_OK) return rc;
     const long long blocks = (d.groups + 255) / 256;
-    hipLaunchKernelGGL(pack_conv_device_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, w_oihw_dev, dst_dev, d);
+    hipLaunchKernelGGL(pack_conv_device_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, (hipStream_t)stream, d.w, d.dst, d);   // (d.w: the source with a row slice's offset applied)
     V2X_CHECK_LAUNCH("pack_conv_device_kernel");
     return V2X_OK;
 }

@@ -40,13 +40,15 @@ class PackJob(C.Structure):
     _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p),
                 ("rows_src", C.c_int32), ("cin", C.c_int32), ("cin_p", C.c_int32), ("taps", C.c_int32), ("K", C.c_int32), ("w_kpad", C.c_int32),
                 ("tile", C.c_int32), ("cout", C.c_int32), ("layout", C.c_int32), ("transform", C.c_int32),
+                ("src_stride", C.c_int32), ("reserved0", C.c_int32),
                 ("groups", C.c_int64), ("data_groups", C.c_int64), ("block_begin", C.c_int64)]
 
 
 class PackSpec(C.Structure):
     """Mirror of `struct v2x_pack_spec` (include/v2x_amd.h)."""
     _fields_ = [("Cout", C.c_int32), ("Cin", C.c_int32), ("ksize", C.c_int32), ("cin_pad", C.c_int32),
-                ("w_layout", C.c_int32), ("epilogue", C.c_int32), ("chain", C.c_int32), ("c_up", C.c_int32)]
+                ("w_layout", C.c_int32), ("epilogue", C.c_int32), ("chain", C.c_int32), ("c_up", C.c_int32),
+                ("src_rows", C.c_int32), ("src_row0", C.c_int32)]
 
 
 # name -> (restype, argtypes); every symbol include/v2x_amd.h declares

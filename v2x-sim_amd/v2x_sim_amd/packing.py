@@ -317,6 +317,52 @@ def pack_conv_device(name, weight, bias, *, stride=1, cin_pad=None, dgrad=False)
     return Layer([pc], None, name=name) if layout == 0 else Layer([], pc, name=name)
 
 
+def pack_conv_device_halo(name, weight, bias, *, c_up=0, dgrad_rows=None):
+    """Round 6, the decoder's full-resolution `_1` layer (conv8_1) of the training graph on the resident-weights halo kernels (w_layout 1), one launch per
+    packing like pack_conv_device.  weight = the fp32 parameter ON THE DEVICE, [Cout, Cin, 3, 3].
+      * dgrad_rows=None: the FORWARD layer on cat(up(lo), skip) with the two sources read in place -- C0 = c_up channels of the half-resolution map (up0 = 1),
+        C1 = Cin - c_up of the skip (conv_halo.hip: conv3x3_halo_pp_kernel<64, 32, 32>, the inference kernel of the 9-tap form); scale = 1, shift = bias.
+      * dgrad_rows=(r0, n): the DATA-GRADIENT layer of the input channels r0 .. r0 + n - 1 alone (Cout -> n channels; v2x_pack_spec.src_rows / src_row0): the
+        32 -> 96 data gradient has no halo kernel (conv_halo.hip: it spills), 32 -> 64 and 32 -> 32 into one 96-channel map have.
+    -> PackedConv."""
+    import ctypes as C
+    from ._lib import PackSpec
+    lib = _lib.load()
+    w = weight.detach()
+    if w.dtype != torch.float32 or not w.is_cuda or not w.is_contiguous():
+        w = w.float().contiguous()
+    co_w, ci_w = w.shape[0], w.shape[1]
+    if dgrad_rows is None:
+        spec = PackSpec(Cout=co_w, Cin=ci_w, ksize=3, cin_pad=ci_w, w_layout=1, epilogue=V2X_EPI_BF16, chain=0)
+        cout, c0, c1, up0 = co_w, c_up, ci_w - c_up, 1 if c_up else 0
+    else:
+        r0, n = dgrad_rows
+        spec = PackSpec(Cout=n, Cin=co_w, ksize=3, cin_pad=co_w, w_layout=1, epilogue=V2X_EPI_BF16, chain=0, src_rows=ci_w, src_row0=r0)
+        cout, c0, c1, up0 = n, co_w, 0, 0
+    rows, kpad = C.c_int32(0), C.c_int32(0)
+    nbytes = lib.v2x_pack_conv_size(C.byref(spec), C.byref(rows), C.byref(kpad))
+    if nbytes == 0:
+        raise ValueError("pack_conv_device_halo(%s): %s" % (name, lib.v2x_last_error().decode()))
+    buf = torch.empty((nbytes // 2,), dtype=torch.bfloat16, device=w.device)
+    dgrad = dgrad_rows is not None
+    _lib.check(lib.v2x_pack_conv_device(C.byref(spec), C.c_void_p(w.data_ptr()), 1 if dgrad else 0, C.c_void_p(buf.data_ptr()),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)), "v2x_pack_conv_device(%s)" % name)
+    n_par = rows.value
+    scale = _const(n_par, 1.0, w.device, cout)
+    if bias is not None and not dgrad:
+        if n_par == cout and bias.dtype == torch.float32:
+            shift = bias.detach()
+        else:
+            shift = torch.zeros((n_par,), dtype=torch.float32, device=w.device)
+            shift[:cout] = bias.detach().float()
+    else:
+        shift = _const(n_par, 0.0, w.device)
+    pc = PackedConv(name=name, weight=buf, scale=scale, shift=shift, C0=c0, C1=c1, Cout=cout, ksize=3, stride=1, pad=1, up0=up0,
+                    epilogue=V2X_EPI_BF16, relu=False, w_rows=n_par, w_kpad=kpad.value, w_layout=1, Cout2=0)
+    pc.repack = _repack_info(spec, weight, w, dgrad, buf, shift, bias if not dgrad else None, cout)
+    return pc
+
+
 def pack_conv1x1_device(name, weight, bias, *, dgrad=False, cout_pad=0, f32_out=False):
     """One-launch device packing of a 1x1 layer for the training graph (v2x_pack_conv_device, gather layout): weight = the fp32 parameter ON THE
     DEVICE, [Cout, Cin, 1, 1] (or [Cout, Cin]).  dgrad: the layer dx = dy . W (the transposed weights; dy's channels zero-padded to cout_pad, no

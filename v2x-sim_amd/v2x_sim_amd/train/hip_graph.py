@@ -195,6 +195,18 @@ def _attached_channel_sum(dy):
     return tag[1]
 
 
+_ZEROS = {}
+
+
+def _zeros_f32(n, device):
+    """A shared read-only zero vector (never written: autograd's AccumulateGrad clones an incoming gradient it keeps)."""
+    key = (n, str(device))
+    z = _ZEROS.get(key)
+    if z is None:
+        z = _ZEROS[key] = torch.zeros((n,), dtype=torch.float32, device=device)
+    return z
+
+
 class _BnRelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
@@ -206,7 +218,16 @@ class _BnRelu(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta, mean, invstd = ctx.saved_tensors
-        dx, dgamma, dbeta, dsum = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu, dx_sum=True)
+        if tuning.get("TRAIN_BN_BIAS_ZERO") != 0:
+            # Round 6.  The bias of a convolution in front of a batch-statistics BatchNorm has a gradient that is IDENTICALLY ZERO: dx = a (g - mean(g) -
+            # xhat mean(g xhat)) sums to a (sum g - sum g - mean(g xhat) sum xhat) = 0 over the batch, and the bias cannot move the BN's output at all.  What
+            # autograd (and this kernel's dx_sum form) returns for it is the rounding residue of a cancelling sum of ~1e5-1e6 terms.  Returning the exact
+            # value saves the sum's accumulation in the dx pass and one finish launch per layer (22 launches, ~0.2 ms of a FaFNet step at any batch size);
+            # TRAIN_BN_BIAS_ZERO = 0 restores the computed residue (tests/test_gpu_train_kernels.py compares the two).
+            dx, dgamma, dbeta = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu)
+            dsum = _zeros_f32(x.shape[-1], x.device)
+        else:
+            dx, dgamma, dbeta, dsum = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu, dx_sum=True)
         dx._v2x_chsum = (dx._version, dsum)      # the bias gradient of the convolution in front of this BN (_attached_channel_sum)
         return dx, dgamma, dbeta, None, None, None, None, None
 
@@ -336,6 +357,66 @@ class _UpCat(torch.autograd.Function):
         return ops.upcat_backward(dcat.contiguous(), ctx.c0)
 
 
+def _layer_halo(kind, weight, bias, c_up, rows):
+    """Cached halo packings of the decoder's full-resolution `_1` layer (packing.pack_conv_device_halo): kind "up8.fwd" | "up8.dA" | "up8.dB"."""
+    key = (kind, id(weight), c_up, rows)
+    ver = _versions(weight, bias)
+    hit = _CACHE.get(key)
+    if hit is not None and hit[0] == ver and hit[2]() is weight:
+        return hit[1]
+    pc = packing.pack_conv_device_halo("train." + kind, weight, bias, c_up=c_up, dgrad_rows=rows)
+    _CACHE[key] = (ver, pc, weakref.ref(weight), None if bias is None else weakref.ref(bias))
+    return pc
+
+
+class _UpCatConv3x3(torch.autograd.Function):
+    """conv3x3(cat(up(lo), skip)) for the decoder's full-resolution layer (conv8_1: 64 half-resolution + 32 skip channels -> 32 at 256 x 256).  Until round 6
+    this layer -- and only this one -- ran on the gather kernel, forward (96 -> 32) AND data gradient (32 -> 96): 0.44 + 0.49 ms of an 11.9-ms FaFNet step at 40
+    maps (no halo kernel fits 96 input or output channels; the streamed kernels want >= 64 output rows).  Now:
+      forward        the inference kernel of the 9-tap form, reading lo and skip in place (conv3x3_halo_pp_kernel<64, 32, 32>);
+      data gradient  two launches into one 96-channel map: 32 -> 64 (conv3x3_halo_kernel<0, 32, 64>) and 32 -> 32 (conv3x3_halo_sb_kernel), packed from row
+                     slices of the transposed weights; then the usual upsample / concat backward (2 x 2 sums + slice);
+      weight gradient unchanged (v2x_conv3x3_wgrad on the materialised 96-channel map, which is built for it)."""
+
+    @staticmethod
+    def forward(ctx, lo, skip, weight, bias):
+        c_up = lo.shape[3]
+        cat = ops.upcat(lo, skip)                       # (the weight gradient contracts over it)
+        y = ops.conv2d(_layer_halo("up8.fwd", weight, bias, c_up, None), lo, skip)
+        ctx.save_for_backward(cat, weight)
+        ctx.c_up, ctx.has_bias = c_up, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        cat, weight = ctx.saved_tensors
+        dy_in, dy = dy, dy.contiguous()
+        c_up, cin = ctx.c_up, weight.shape[1]
+        d_lo = d_skip = dw = db = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dcat = torch.empty_like(cat)
+            ops.conv2d(_layer_halo("up8.dA", weight, None, c_up, (0, c_up)), dy, out=dcat, out_coff=0)
+            ops.conv2d(_layer_halo("up8.dB", weight, None, c_up, (c_up, cin - c_up)), dy, out=dcat, out_coff=c_up)
+            d_lo, d_skip = ops.upcat_backward(dcat, c_up)
+        if ctx.needs_input_grad[2]:
+            dw = ops.conv3x3_wgrad(cat, dy, cin_out=cin)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            db = _attached_channel_sum(dy_in)
+            if db is None:
+                db = ops.channel_sum(dy)
+        return d_lo, d_skip, dw, db
+
+
+def upcat_conv3x3(lo, skip, conv):
+    """conv(cat(up(lo), skip)) -- the fused form where the halo kernels cover the shape (64 + 32 -> 32, H % 8 == 0, W % 32 == 0), else conv3x3(upcat(...))."""
+    N, H, W, C = lo.shape
+    if (tuning.get("TRAIN_UPCAT_CONV") != 0 and tuning.get("UPCAT_HIP") != 0 and (C, skip.shape[3], conv.weight.shape[0]) == (64, 32, 32) and conv.stride[0] == 1
+            and lo.dtype == BF16 and skip.dtype == BF16 and skip.shape[:3] == (N, 2 * H, 2 * W) and (2 * H) % 8 == 0 and (2 * W) % 32 == 0
+            and conv.weight.shape[1] == C + skip.shape[3] and conv.weight.is_cuda and conv.weight.dtype == torch.float32):
+        return _UpCatConv3x3.apply(lo.contiguous(), skip.contiguous(), conv.weight, conv.bias)
+    return conv3x3(upcat(lo, skip), conv)
+
+
 def upcat(lo, skip):
     """cat(nearest x2 upsample of lo, skip) along the channels, NHWC."""
     N, H, W, C = lo.shape
@@ -371,7 +452,7 @@ def decoder(d, x, x_1, x_2, x_3, x_4):
     y = cbr(cbr(upcat(x_4, x_3), d.conv5_1, d.bn5_1), d.conv5_2, d.bn5_2)
     y = cbr(cbr(upcat(y, x_2), d.conv6_1, d.bn6_1), d.conv6_2, d.bn6_2)
     y = cbr(cbr(upcat(y, x_1), d.conv7_1, d.bn7_1), d.conv7_2, d.bn7_2)
-    return cbr(cbr(upcat(y, x), d.conv8_1, d.bn8_1), d.conv8_2, d.bn8_2)
+    return cbr(bn_relu(upcat_conv3x3(y, x, d.conv8_1), d.bn8_1), d.conv8_2, d.bn8_2)
 
 
 def heads(model, x):

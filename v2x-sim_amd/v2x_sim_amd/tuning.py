@@ -34,12 +34,16 @@ Host-side switches (this module):
     TAIL_FUSE 1  conv8_2 and the detection heads as ONE launch (conv_tail.hip: conv8_2's output never leaves the CU; bit-identical to the two launches);
                    0 = two launches.  Read at every forward
     TRAIN_HEAD_PACK 1  with TRAIN_HIP: the heads' fp32 logit gradients -> bf16, channel padding and bias gradient in one pass (v2x_cast_pad_chsum_f32); 0: torch ops
+    TRAIN_BN_BIAS_ZERO 1  with TRAIN_HIP: the bias gradient of a convolution in front of a batch-statistics BatchNorm is returned as its exact value, 0 (the BN removes
+                   the batch mean: the computed value is the rounding residue of a cancelling sum); 0: the residue, accumulated by the BN backward kernel
+    TRAIN_UPCAT_CONV 1  with TRAIN_HIP: conv8_1 (64 upsampled + 32 skip channels -> 32, full resolution) forward on the two-source halo kernel and its data gradient
+                   as two halo launches (32 -> 64, 32 -> 32) instead of the gather kernel both ways; 0: the gather kernel on the concatenated map
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
 The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1}
+_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "CONV1X1")
 
