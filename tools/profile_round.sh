@@ -33,10 +33,10 @@ TAG=${1:-vX}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --graph 0 --no-cpu-baseline --no-extras --no-calibration --no-shard-check > $OUT/kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o pf --output-format csv -- python3 bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline > $OUT/pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o pw --output-format csv -- python3 bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline > $OUT/pw.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq -o sq --output-format csv -- python3 bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline > $OUT/sq.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python3 bench.py --steps 20 --warmup 3 --graph 0 --no-cpu-baseline --no-gpu-baseline --no-extras --no-calibration --no-shard-check > $OUT/kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pf -o pf --output-format csv -- python3 bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-gpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline > $OUT/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pw -o pw --output-format csv -- python3 bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-gpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline > $OUT/pw.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE -d $OUT/sq -o sq --output-format csv -- python3 bench.py --steps 2 --warmup 1 --graph 0 --no-cpu-baseline --no-gpu-baseline --no-extras --no-calibration --no-shard-check --no-roofline > $OUT/sq.log 2>&1
 find $OUT -name "*.csv" | head -20
 python3 tools/pmc_traffic.py $(find $OUT/pf -name "*counter_collection.csv") $(find $OUT/pw -name "*counter_collection.csv") $OUT/pmc_traffic.json > $OUT/pmc_traffic.txt 2>&1
 python3 tools/pmc_sq_summary.py $(find $OUT/sq -name "*counter_collection.csv") $OUT/pmc_sq.csv > /dev/null 2>&1
