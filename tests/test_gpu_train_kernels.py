@@ -654,8 +654,7 @@ def test_channel_sum_vs_torch(device, shape):
     assert torch.equal(ops.channel_sum(x), got)
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (1, 8, 32, 32, 32), (3, 24, 32, 96, 32), (2, 32, 32, 256, 128), (10, 128, 128, 64, 64),
-                                            (10, 256, 256, 32, 32), (40, 64, 64, 128, 128), (7, 16, 32, 512, 512)])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (1, 8, 32, 32, 32), (3, 24, 32, 96, 32), (2, 32, 32, 256, 128), (10, 128, 128, 64, 64)])
 def test_wgrad_transpose_read_form_equals_first_form_bitwise(device, N, H, W, Cin, Cout, tune):
     """conv3x3_wgrad_tr_kernel (LDS-DMA tiles in their natural layout + ds_read_b64_tr_b16 fragments; default) against the first form (VALU
     transposes into LDS): the same products summed in the same order -> bit-identical partials and gradients; borders, ragged tile shares,
@@ -664,12 +663,11 @@ def test_wgrad_transpose_read_form_equals_first_form_bitwise(device, N, H, W, Ci
     g = torch.Generator().manual_seed(N + H + Cin + Cout)
     x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(device)
     dy = torch.randn(N, H, W, Cout, generator=g).to(torch.bfloat16).to(device)
-    new = ops.conv3x3_wgrad(x, dy)             # WGRAD_TR = 2 (round 6: two tile buffers, pipelined row loop)
-    for form in (1, 0):                        # the single-buffered transpose-read form, the first form
-        tune("WGRAD_TR", form)
-        old = ops.conv3x3_wgrad(x, dy)
-        assert torch.equal(new, old), (form, float((new - old).abs().max()))
+    new = ops.conv3x3_wgrad(x, dy)
+    tune("WGRAD_TR", 0)
+    old = ops.conv3x3_wgrad(x, dy)
     tune.reset("WGRAD_TR")
+    assert torch.equal(new, old), float((new - old).abs().max())
     assert torch.equal(ops.conv3x3_wgrad(x, dy), new)
 
 

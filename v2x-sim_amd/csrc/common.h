@@ -32,7 +32,7 @@ enum v2x_tune_id {
     V2X_TUNE_S2_G,            // 1: 8-wave three-tap stride-2 kernel (256-pixel tiles) for the 128-row layers wherever the SHAPE allows (never by batch size; a declared latency launch -- desc->small_batch -- keeps the 1-tap kernel below 4 tiles per CU); 0: the 1-tap kernel
     V2X_TUNE_GRU_XCD_WALK,    // 1: the ConvGRU's persistent grid walks 8 pixel x 4 channel tiles per XCD and round (fabric reads -16 %, same time, same bits); 0: 4 x 8
     V2X_TUNE_HALO_XCD,        // 1: the halo kernels' persistent grids give every XCD a contiguous eighth of the tiles (halo pixels cross the fabric once); 0: round-robin
-    V2X_TUNE_WGRAD_TR,        // 2 (default, round 6): the transpose-read weight-gradient kernel with two tile buffers and a pipelined row loop; 1: its single-buffered form; 0: the first form (VALU transposes) -- all three bit-identical
+    V2X_TUNE_WGRAD_TR,        // 1: weight-gradient kernel on LDS-DMA tiles + transpose reads; 0: the first form (VALU transposes)
     V2X_TUNE_CONV1X1,         // 1: gather-layout 1x1 layers (Cin, Cout <= 128) on the streaming kernel (conv1x1.hip; round 6); 0: the gather kernel -- bit-identical
     V2X_TUNE_COUNT
 };

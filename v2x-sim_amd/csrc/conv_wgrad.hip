@@ -20,8 +20,6 @@
 // slots (2*split, 2*split + 1), so the halves meet in the caller's fixed-order sum like any other pair of partials.
 #include "common.h"
 
-int v2x_num_cus();   // conv_stream.hip
-
 constexpr int WG_TH = 8, WG_TW = 32;                 // pixel tile
 constexpr int WG_CO = 64, WG_CI = 32;                // channel block (WG_CO: the 64-row form; LDS is sized for it)
 constexpr int WG_PX = WG_TH * WG_TW;                 // 256 pixels = k extent of one tile
@@ -158,10 +156,6 @@ typedef __attribute__((ext_vector_type(4))) short wg_s16x4_t;
 typedef const __attribute__((address_space(1))) void *wg_gptr_t;
 typedef __attribute__((address_space(3))) void *wg_lptr_t;
 __device__ __attribute__((aligned(64))) const uint32_t g_wgrad_zero_page[16] = {0};
-template <int N>
-__device__ __forceinline__ void wait_vmcnt_wg() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 constexpr int WT_X_PIX = (WG_TH + 2) * (WG_TW + 2);                 // 340 patch pixels
 constexpr int WT_X_BYTES = ((WT_X_PIX * 64 + 1023) / 1024) * 1024;   // 22 KiB (whole 1-KiB DMA pieces)
 
@@ -289,151 +283,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             }
 }
 
-// ---- third form (round 6): the transpose-read kernel with TWO tile buffers and a software-pipelined row loop ----------------------------------
-// What the second form leaves on the table (round 6, arithmetic from its own structure + profiles/r06_train_step_profile.txt: 2.3 ms of an 11.1-ms
-// FaFNet step at 40 maps = 25 % of the MFMA pipe): a workgroup ALTERNATES between waiting for its tile's 54 KiB of LDS-DMA (issue ~1 400 cycles + landing)
-// and a row loop in which every patch row's 14 transpose reads are waited for (lgkmcnt(0)) before its 18 MFMAs issue (~530 cycles per row, 288 of them
-// MFMAs) -- ~9 000 cycles per tile where its 144 MFMAs per wave take 2 304 -- and the 1.5 workgroups a CU gets from the 384-block grid cannot cover each
-// other.  Here, same tiles, same sums in the same order (bit-identical partials for the same n_split):
-//   * two buffers: the DMAs of tile i + 1 are issued BEFORE the row loop of tile i and land under its MFMAs; a wave waits for its OWN pieces of tile i
-//     with a COUNTED s_waitcnt vmcnt(pieces per wave and tile) -- every wave issues the same number (the patch is padded to 24 one-KiB pieces);
-//   * the row loop is pipelined in registers: the fragments of patch row r + 1 are requested before the MFMAs of row r (two B sets, a four-deep A ring),
-//     so a row's LDS latency hides under the previous row's MFMAs;
-//   * 108 KiB (64-row form) = one workgroup per CU, 76 KiB (32-row form) = two: v2x_conv3x3_wgrad_splits sizes the grid to exactly that residency.
-template <int CO>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv3x3_wgrad_tr2_kernel(const WgradArgs a) {
-    constexpr int RT = CO == 64 ? WG_TH : WG_TH / 2;
-    constexpr int DY_BYTES = WG_PX * CO * 2;
-    constexpr int DY_PIECES = DY_BYTES / 1024;
-    constexpr int X_PIECES = 24;                         // 22 real + 2 of padding: 6 per wave
-    constexpr int X_BYTES = X_PIECES * 1024;
-    constexpr int BUF = DY_BYTES + X_BYTES;
-    constexpr int NP = DY_PIECES / 4 + X_PIECES / 4;     // LDS-DMA instructions per wave and tile
-    constexpr int CPP = CO / 8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fj = lane & 15, fq = lane >> 4;
-    const int wco = CO == 64 ? wave : (wave & 1);
-    const int row0 = CO == 64 ? 0 : (wave >> 1) * RT;
-    const int n_ci_t = a.Cin / WG_CI;
-    const int blk = blockIdx.x;
-    const int split = blk % a.n_split;
-    const int cc = blk / a.n_split;
-    const int ci_t = cc % n_ci_t, co_t = cc / n_ci_t;
-    const int txy = a.tiles_x * a.tiles_y;
-
-    int dy_off[2], x_off[3][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int col = 8 * fq + 4 * h + (fj >> 2);
-        const int sw = CO == 64 ? (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : ((col >> 3) & 1);
-        dy_off[h] = col * (CO * 2) + ((wco ^ sw) * 32) + (fj & 3) * 8;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int pc = col + kx;
-            x_off[kx][h] = pc * 64 + (((pc >> 3) & 1) * 32) + (fj & 3) * 8;
-        }
-    }
-
-    auto issue_tile = [&](int tile, char *buf) {
-        const int n = tile / txy;
-        const int r0 = tile - n * txy;
-        const int ty = r0 / a.tiles_x;
-        const int y0 = ty * WG_TH, x0 = (r0 - ty * a.tiles_x) * WG_TW;
-#pragma unroll
-        for (int t = 0; t < DY_PIECES / 4; ++t) {
-            const int piece = wave + 4 * t;
-            const int L = piece * 64 + lane;
-            const int px = L / CPP, ch = L - px * CPP;
-            const int col = px & 31;
-            const int sw = CO == 64 ? (((col >> 1) & 1) | (((col >> 3) & 1) << 1)) : ((col >> 3) & 1);
-            const int lch = ch ^ (sw << 1);
-            const uint16_t *src = a.dy + ((size_t)(n * a.H + y0 + (px >> 5)) * a.W + x0 + col) * a.Cout + co_t * CO + lch * 8;
-            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + piece * 1024), 16, 0, 0);
-        }
-#pragma unroll
-        for (int t = 0; t < X_PIECES / 4; ++t) {
-            const int piece = wave + 4 * t;
-            const int L = piece * 64 + lane;
-            const int p = L >> 2, ch = L & 3;
-            const int pr = p / (WG_TW + 2), pc = p - pr * (WG_TW + 2);
-            const int y = y0 - 1 + pr, x = x0 - 1 + pc;
-            const bool ok = p < WT_X_PIX && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
-            const int lch = ch ^ (((pc >> 3) & 1) << 1);
-            const void *src = ok ? (const void *)(a.x + ((size_t)(n * a.H + y) * a.W + x) * a.Cin + ci_t * WG_CI + lch * 8) : (const void *)g_wgrad_zero_page;
-            __builtin_amdgcn_global_load_lds((wg_gptr_t)src, (wg_lptr_t)(buf + DY_BYTES + piece * 1024), 16, 0, 0);
-        }
-    };
-
-    f32x4_t acc[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[t][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-
-    int tile = split, b = 0;
-    if (tile < a.n_tiles) issue_tile(tile, smem);
-    for (; tile < a.n_tiles; tile += a.n_split, b ^= 1) {
-        const int next = tile + a.n_split;
-        // buffer b ^ 1 was read in the previous iteration's row loop: behind this barrier every wave has left it (its reads fed MFMAs already issued)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (next < a.n_tiles) {
-            issue_tile(next, smem + (b ^ 1) * BUF);
-            wait_vmcnt_wg<NP>();          // in order: this wave's pieces of `tile` have landed, those of `next` may still fly
-        } else {
-            wait_vmcnt_wg<0>();
-        }
-        __builtin_amdgcn_s_barrier();     // ... and everybody else's
-        asm volatile("" ::: "memory");
-        const char *s_dy = smem + b * BUF;
-        const char *s_x = s_dy + DY_BYTES;
-        bf16x8_t A[4];
-        bf16x8_t B[2][3][2];
-        // row pr's fragments: A (if pr < RT) and the six B of patch row row0 + pr
-        auto load_row = [&](int pr, bf16x8_t (&Bd)[3][2]) {
-            if (pr < RT) A[pr & 3] = wg_tr_frag(s_dy + (row0 + pr) * (WG_TW * CO * 2), dy_off[0], dy_off[1]);
-            const char *xrow = s_x + (row0 + pr) * ((WG_TW + 2) * 64);
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) Bd[kx][j] = wg_tr_frag(xrow, x_off[kx][0] ^ (j * 32), x_off[kx][1] ^ (j * 32));
-        };
-        load_row(0, B[0]);
-#pragma unroll
-        for (int pr = 0; pr < RT + 2; ++pr) {
-            if (pr + 1 < RT + 2) load_row(pr + 1, B[(pr + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int r = pr - ky;
-                if (r < 0 || r >= RT) continue;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[ky * 3 + kx][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[r & 3], B[pr & 1][kx][j], acc[ky * 3 + kx][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    const int slot = CO == 64 ? split : 2 * split + (wave >> 1);
-    float *dst = a.ws + (size_t)slot * a.Cout * 9 * a.Cin;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = co_t * CO + wco * 16 + fq * 4 + e;
-                const int ci = ci_t * WG_CI + j * 16 + fj;
-                dst[((size_t)co * 9 + t) * a.Cin + ci] = acc[t][j][e];
-            }
-}
-
 // dW[co][ci][ky][kx] (the parameter's own OIHW layout, ci < cin_out) = sum over the n_split partials ws[s][co][tap][ci], in slot order
 // (deterministic).  Replaces the caller's `ws.sum(0).permute(0, 3, 1, 2).contiguous()[:, :cin]` (a reduction and a permuting copy per layer).
 // A block = 32 output elements (ci fastest: coalesced reads of the partials) x 8 slices of the split range: a thread adds its slice's
@@ -487,14 +336,16 @@ extern "C" int v2x_conv3x3_wgrad_splits(int N, int H, int W, int Cin, int Cout) 
     const bool rows32 = Cout % WG_CO != 0;
     const long long tiles = (long long)N * (H / WG_TH) * (W / WG_TW);
     const long long pairs = (long long)(Cout / (rows32 ? 32 : WG_CO)) * (Cin / WG_CI);
-    // Round 6: the grid of the double-buffered form (conv3x3_wgrad_tr2_kernel) is its RESIDENCY -- one workgroup per CU at 64 rows (108 KiB of LDS), two at
-    // 32 rows (76 KiB): a persistent block per slot, no second, half-empty round.  (Rounds 3-5: 384 blocks = one and a half rounds of the CUs for the
-    // single-buffered form; every block writes a 74-KiB partial that the reduce reads back, so fewer, longer blocks win until the chip under-fills:
-    // captured FaFNet step 5.19 / 5.13 / 5.17 / 5.20 ms at 512 / 384 / 320 / 256.)  The value does NOT depend on the kernel form (WGRAD_TR): the
-    // forms stay bit-comparable.
-    const int cus = v2x_num_cus() > 0 ? v2x_num_cus() : 256;
-    const long long target = (long long)cus * (rows32 ? 2 : 1);
-    long long n = target / pairs;
+    // Round 6, measured and rejected (commit 943fb9d holds the code; profiles/r06_wgrad_tr2_rejected.txt): a third form of the kernel -- two tile buffers (the
+    // DMAs of tile i + 1 under the MFMAs of tile i, counted vmcnt) and a register-pipelined row loop (counted lgkmcnt(14): a row's transpose reads under the
+    // previous row's MFMAs), grid = the residency (1 workgroup per CU at 108 KiB, 2 at 76 KiB) -- bit-identical, and NO faster: FaFNet step 11.45 against 11.39 ms
+    // at 40 maps, 4.616 against 4.612 at 10.  The kernel is not waiting where that form helps: a 40-map step's weight gradients must read >= 4.5 GB of
+    // activations and activation gradients once (>= 0.9 ms at 5 TB/s) and read 7.1 GB because a dY tile is fetched once per 32-channel input tile of its layer
+    // (conv7_1: 6 x, conv8_1: 3 x) -- 2.3 ms is 1.6 x that stream, not 4 x its MFMAs.
+    // (384 workgroups = one and a half rounds of the CUs: every workgroup writes a 74-KiB partial that the reduce reads back -- 0.9 GB each way per
+    // 10-map FaFNet step at 512 -- so fewer, longer workgroups win until the chip under-fills: captured step 5.19 / 5.13 / 5.17 / 5.20 ms at
+    // 512 / 384 / 320 / 256, V2VNet 6.34 / 6.26 / 6.28 / 6.33)
+    long long n = (384 + pairs - 1) / pairs;
     if (n > 256) n = 256;
     if (n > tiles) n = tiles;
     if (n < 1) n = 1;
@@ -533,20 +384,6 @@ extern "C" int v2x_conv3x3_wgrad(const uint16_t *x, const uint16_t *dy, int N, i
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, WG_SMEM);
     }
     const int grid = (Cout / (rows32 ? 32 : WG_CO)) * (Cin / WG_CI) * a.n_split;
-    if (v2x_tune(V2X_TUNE_WGRAD_TR) >= 2) {   // round 6 (default): two tile buffers + pipelined row loop; same sums in the same order
-        constexpr int SM64 = 2 * (WG_PX * 64 * 2 + 24 * 1024), SM32 = 2 * (WG_PX * 32 * 2 + 24 * 1024);
-        static v2x_once_per_device tr2_once;
-        if (v2x_first_use_on_device(tr2_once)) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_tr2_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, SM64);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_wgrad_tr2_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, SM32);
-        }
-        if (rows32)
-            hipLaunchKernelGGL(conv3x3_wgrad_tr2_kernel<32>, dim3(grid), dim3(256), SM32, (hipStream_t)stream, a);
-        else
-            hipLaunchKernelGGL(conv3x3_wgrad_tr2_kernel<64>, dim3(grid), dim3(256), SM64, (hipStream_t)stream, a);
-        V2X_CHECK_LAUNCH("conv3x3_wgrad_tr2_kernel");
-        return V2X_OK;
-    }
     if (v2x_tune(V2X_TUNE_WGRAD_TR) != 0) {   // the transpose-read form (default); 0: the first form (A/B, bitwise-equality test)
         static v2x_once_per_device tr_once;
         if (v2x_first_use_on_device(tr_once)) {
