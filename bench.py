@@ -47,7 +47,7 @@ AGENTS = 5
 POINTS_PER_SWEEP = 65536
 # committed PMC traffic summaries, newest first (tools/profile_round.sh -> tools/pmc_traffic.py)
 LIVE_TRAFFIC = (None, "not attempted", 0.0)    # ({kernel: (read, write, launches)} | None, note, seconds): live_traffic_table
-TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
+TRAFFIC_FILES = ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")
 # algorithmic FLOPs of one 5-agent frame, points -> logits: encoder + decoder + heads, + one ConvGRU pass per GNN round
 # (h0 = 0: W_hh is never multiplied and not counted)
 GFLOP_PER_FRAME_BASE, GFLOP_PER_GNN_ROUND = 155.8, 36.2
@@ -1165,6 +1165,21 @@ def main():
     executed_gflop = executed_gflop_measured if executed_gflop_measured else reference_gflop - parity_saved
     if rank == 0 and isinstance(training, dict):
         training["frac_of_mfma_peak"] = training_fractions(training)
+        # the step's HBM side: bytes per step from the committed rocprofv3 --pmc passes (tools/train_step_profile.sh -> tools/train_traffic_table.py), priced at
+        # THIS run's step time -- the training step is memory-side (batch-statistics BatchNorm is 8 passes over every convolution's output), which is why its
+        # MFMA fraction is low; both fractions are reported
+        training["hbm"] = {}
+        for maps, key in ((10, "FaFNet_10_maps"), (40, "FaFNet_40_maps")):
+            tf = os.path.join(ROOT, "profiles", "r06_train_traffic_%d.json" % maps)
+            try:
+                with open(tf) as fh:
+                    tj = json.load(fh)
+                nbytes = tj["hbm_read_bytes_per_step"] + tj["hbm_write_bytes_per_step"]
+                ms = 3.0 * TRAIN_FWD_GFLOP_PER_MAP["FaFNet"] * maps / (training["frac_of_mfma_peak"][key] * PEAK_MFMA_TFLOPS)
+                training["hbm"][key] = {"bytes_per_step": nbytes, "source": "profiles/r06_train_traffic_%d.json (committed PMC passes)" % maps,
+                                        "tb_s": nbytes / ms / 1e9, "frac_of_8_tb_s": nbytes / ms / 1e9 / (PEAK_HBM_GBS / 1e3)}
+            except Exception as e:      # noqa: BLE001
+                training["hbm"][key] = {"error": repr(e)[:200]}
     if rank == 0:
         summary = build_summary(fps, ms_per_step, latency, configs, training, gpu_stock, cpu, roofline, executed_gflop, world)
         # the N > 1 self-checks as scalars too: a first SCALE run keeps them whatever the driver's parser drops

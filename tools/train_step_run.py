@@ -23,7 +23,8 @@ frames = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 data = synthetic_batch_on_device(cfg, frames, 5, seed=1, device=dev)
 opt = packing.watch_optimizer(torch.optim.Adam(model.parameters(), lr=torch.tensor(1e-4, device=dev), capturable=True, fused=True))   # the hook the training loops install: a fused step must invalidate the packed-weight caches
 tuning.set("TRAIN_HIP", 1)
-for it in range(24):    # 24 steps: the first one (lazy packings, optimizer state) weighs 4 % in the per-step averages
+STEPS = int(os.environ.get("V2X_TRAIN_RUN_STEPS", "24"))
+for it in range(STEPS):    # 24 steps: the first one (lazy packings, optimizer state) weighs 4 % in the per-step averages
     res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], frames)
     loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
     opt.zero_grad(set_to_none=True)
