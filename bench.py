@@ -41,6 +41,12 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 # MI355X peaks (/opt/skills/guides/MI355X_MICROARCH.md): HBM3E 8.0 TB/s spec, bf16 MFMA ~2.5 PF dense
+# rocprofv3 FETCH_SIZE -> bytes.  The guide's gfx950 correction (x 2: wide coalesced reads are tallied at half their bytes) was CALIBRATED in round 6 on this library's own access
+# patterns, as the guide prescribes for anything but wide reads (profiles/r06_fetch_calibration.txt: tools/fetch_calib_probe.hip, tools/r06/run9.sh): 1-KiB-per-instruction reads
+# x 2.00, 64-byte segment reads (the 32-channel patch chunks of the streamed kernels) x 1.0-1.1.  The ConvGRU kernel's raw count splits 54 % patch segments / 46 % weight pieces
+# (phase-removal builds) -> x 1.52.  Kernels without an entry keep the guide's x 2 (`fetch_factor_calibrated` in the record says which it was).
+FETCH_FACTOR_DEFAULT = 2.0
+FETCH_FACTOR = {"conv3x3_stream8g_kernel<96, 2, false>": (168.6 * 1.10 + 142.2 * 2.0) / 309.6}
 PEAK_HBM_GBS = 8000.0
 PEAK_MFMA_TFLOPS = 2500.0
 AGENTS = 5
@@ -106,7 +112,7 @@ def live_traffic_table(args):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     table = {}
     timeout_s = float(os.environ.get("V2X_BENCH_PMC_TIMEOUT_S", "120"))
-    for counter, factor in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):
+    for counter, factor in (("FETCH_SIZE", 1024.0), ("WRITE_SIZE", 1024.0)):       # KiB -> bytes; the FETCH_SIZE calibration factor is applied per kernel in apply_live_traffic
         out = tempfile.mkdtemp(prefix="v2x_pmc_", dir="/tmp")
         cmd = [rocprof, "--pmc", counter, "-d", out, "-o", "p", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                "--steps", "2", "--warmup", "1", "--graph", "0", "--frames-per-gpu", str(args.frames_per_gpu), "--gnn-iters", str(args.gnn_iters),
@@ -148,12 +154,18 @@ def apply_live_traffic(roofline, live, when):
     table, note, seconds = live
     dom = roofline.get("kernel")
     if table is not None and dom in table:
-        rd, wr, nl = table[dom]
+        raw, wr, nl = table[dom]
+        ff = FETCH_FACTOR.get(dom, FETCH_FACTOR_DEFAULT)
+        rd = ff * raw
         roofline["traffic_committed"] = roofline.get("traffic")
         roofline["traffic"] = rd + wr
+        roofline["traffic_uniform_x2"] = 2.0 * raw + wr           # rounds 2-5's convention (every kernel's FETCH_SIZE doubled), for continuity
+        roofline["fetch_factor"] = ff
+        roofline["fetch_factor_calibrated"] = dom in FETCH_FACTOR
         roofline["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes of this script %s "
-                                      "(separate, counters only; 2 eager steps each, %d launches of the kernel averaged; KiB -> bytes, FETCH_SIZE x 2 on gfx950): "
-                                      "read %.1f MB + write %.1f MB per launch" % (when, nl, rd / 1e6, wr / 1e6))
+                                      "(separate, counters only; 2 eager steps each, %d launches of the kernel averaged; KiB -> bytes; FETCH_SIZE x %.2f = this kernel's "
+                                      "calibrated mix of wide reads (x 2, the guide's gfx950 correction) and 64-byte segment reads (x 1.1), profiles/r06_fetch_calibration.txt): "
+                                      "read %.1f MB + write %.1f MB per launch" % (when, nl, ff, rd / 1e6, wr / 1e6))
         roofline.pop("traffic_live", None)
     else:
         roofline["traffic_live"] = "not re-measured: " + (note if table is None else "kernel not in the counter passes")
@@ -1086,7 +1098,8 @@ def main():
                     # (round-3 files name stream8g with its removed fourth template argument)
                     tk = tks.get(dom) or tks.get(dom.replace(", true>", ", true, false>").replace(", false>", ", false, false>"))
                 if tk:
-                    roofline["traffic"] = tk["hbm_bytes_per_launch"]
+                    ff = FETCH_FACTOR.get(dom, FETCH_FACTOR_DEFAULT)     # (the committed summaries hold FETCH_SIZE x 2: rescaled to the kernel's calibrated factor)
+                    roofline["traffic"] = tk["hbm_read_bytes_per_launch"] * ff / 2.0 + tk["hbm_write_bytes_per_launch"]
                     roofline["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc passes of this workload; not re-measured in this run)" % tname
                     break
         roofline["kernel"] = dom

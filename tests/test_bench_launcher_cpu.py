@@ -187,10 +187,15 @@ echo "\\"void conv3x3_stream8g_kernel<96, 2, false>(StreamArgs)\\",\\"$c\\",$v" 
 mkdir -p "$out/helper"; echo '"Kernel_Name","Counter_Name","Counter_Value"' > "$out/helper/q_counter_collection.csv"
 """)
     table, note, seconds = bench.live_traffic_table(args)     # (the LARGEST csv is the bench child's: the header-only one of a helper process is ignored)
-    assert note == "measured in this run" and table == {"conv3x3_stream8g_kernel<96, 2, false>": (2.0 * 1024.0 * 1000, 1024.0 * 300, 2)}
-    # the merge into a roofline record: measured value in, committed value kept beside it, the passes' duration recorded
+    assert note == "measured in this run" and table == {"conv3x3_stream8g_kernel<96, 2, false>": (1024.0 * 1000, 1024.0 * 300, 2)}     # RAW FETCH_SIZE bytes
+    # the merge into a roofline record: measured value in (FETCH_SIZE x the kernel's CALIBRATED factor, round 6), committed value kept beside it, the passes' duration recorded
     roof = bench.apply_live_traffic({"kernel": "conv3x3_stream8g_kernel<96, 2, false>", "traffic": 7.0, "traffic_live": "x"}, (table, note, 12.34), "AFTER the timed run")
-    assert roof["traffic"] == 2.0 * 1024.0 * 1000 + 1024.0 * 300 and roof["traffic_committed"] == 7.0 and roof["pmc_passes_s"] == 12.3
+    ff = bench.FETCH_FACTOR["conv3x3_stream8g_kernel<96, 2, false>"]
+    assert 1.45 < ff < 1.6 and roof["fetch_factor"] == ff and roof["fetch_factor_calibrated"] is True
+    assert roof["traffic"] == ff * 1024.0 * 1000 + 1024.0 * 300 and roof["traffic_uniform_x2"] == 2.0 * 1024.0 * 1000 + 1024.0 * 300
+    assert roof["traffic_committed"] == 7.0 and roof["pmc_passes_s"] == 12.3
+    other = bench.apply_live_traffic({"kernel": "k2", "traffic": 1.0}, ({"k2": (100.0, 10.0, 1)}, note, 1.0), "after")
+    assert other["traffic"] == 2.0 * 100.0 + 10.0 and other["fetch_factor_calibrated"] is False        # no entry: the guide's x 2
     assert "AFTER the timed run" in roof["traffic_source"] and "traffic_live" not in roof
     roof = bench.apply_live_traffic({"kernel": "other", "traffic": 7.0}, (table, note, 1.0), "after")
     assert roof["traffic"] == 7.0 and "kernel not in the counter passes" in roof["traffic_live"]
