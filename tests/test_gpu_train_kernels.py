@@ -1325,3 +1325,19 @@ def test_upcat_conv8_on_the_halo_kernels_vs_autograd_and_the_gather_path(device,
         assert float((res[1][k] - res[0][k]).abs().max()) <= ulp * scale, name
     assert torch.equal(res[1][3], res[0][3]) and torch.equal(res[1][4], res[0][4])
     assert float((res[1][3] - wr.grad).abs().max()) <= 2e-3 * float(wr.grad.abs().max())
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,cin_out", [(2, 16, 64, 64, 64, None), (1, 8, 32, 32, 32, 13), (3, 24, 32, 96, 32, None), (2, 32, 32, 256, 128, None), (10, 128, 128, 64, 64, None),
+                                                    (4, 16, 32, 512, 512, None), (2, 64, 64, 32, 32, 12)])
+def test_vectorised_wgrad_reduce_equals_the_scalar_form_bitwise(device, tune, N, H, W, Cin, Cout, cin_out):
+    """wgrad_reduce4_kernel (round 6: four consecutive ci per thread, 16-byte loads, eight partials in flight) against the scalar reduce: the same association (a slice's
+    partials in slot order, the eight slice sums in slice order) -> the same bits; cin_out % 4 != 0 (the 13-channel first layer) keeps the scalar form."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(N + H + Cin + Cout)
+    x = torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).to(device)
+    dy = torch.randn(N, H, W, Cout, generator=g).to(torch.bfloat16).to(device)
+    new = ops.conv3x3_wgrad(x, dy, cin_out=cin_out)
+    tune("WGRAD_REDUCE4", 0)
+    old = ops.conv3x3_wgrad(x, dy, cin_out=cin_out)
+    tune.reset("WGRAD_REDUCE4")
+    assert new.shape == old.shape == (Cout, cin_out or Cin, 3, 3) and torch.equal(new, old), float((new - old).abs().max())

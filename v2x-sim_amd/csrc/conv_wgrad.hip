@@ -320,8 +320,82 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
 }
 
+// The same sums for FOUR consecutive ci per thread (cin_out % 4 == 0: every layer but the 13-channel first one), 16-byte loads, eight partials in flight per thread
+// (round 6).  The scalar kernel above walks a slice's partials as one 4-byte load per add -- 48-64 dependent load-add pairs per thread: 15 us per launch for 19-28 MB of
+// partials (1.8 TB/s; 24 launches = 7 % of a 10-map FaFNet step, profiles/r06_train_step_profile.txt).  Same association as the scalar kernel -- a slice's partials in slot
+// order, the 8 slice sums in slice order -- so the two forms give the same bits (tests/test_gpu_train_kernels.py).
+__global__ __launch_bounds__(256) void wgrad_reduce4_kernel(const float *__restrict__ ws, int n_split, int Cout, int Cin, int cin_out, float *__restrict__ dw) {
+    __shared__ float4 part[8][32];
+    const int c4 = cin_out >> 2;
+    const long long total = (long long)Cout * 9 * c4;          // float4 elements
+    const size_t slab = (size_t)Cout * 9 * Cin;
+    const int e = threadIdx.x & 31, q = threadIdx.x >> 5;
+    const int per = (n_split + 7) / 8;
+    for (long long base = (long long)blockIdx.x * 32; base < total; base += (long long)gridDim.x * 32) {
+        const long long t = base + e;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        long long ct = 0;
+        int ci = 0;
+        if (t < total) {
+            ci = (int)(t % c4) * 4;
+            ct = t / c4;                            // co * 9 + tap
+            const int k0 = q * per;
+            const int k1 = (q + 1) * per < n_split ? (q + 1) * per : n_split;
+            const float *p = ws + (size_t)ct * Cin + ci;
+            int k = k0;
+            for (; k + 8 <= k1; k += 8) {           // eight loads in flight, added in slot order
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(p + (size_t)(k + u) * slab);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s.x += v[u].x;
+                    s.y += v[u].y;
+                    s.z += v[u].z;
+                    s.w += v[u].w;
+                }
+            }
+            for (; k < k1; ++k) {
+                const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)k * slab);
+                s.x += v.x;
+                s.y += v.y;
+                s.z += v.z;
+                s.w += v.w;
+            }
+        }
+        part[q][e] = s;
+        __syncthreads();
+        if (q == 0 && t < total) {
+            float4 v = part[0][e];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) {
+                v.x += part[j][e].x;
+                v.y += part[j][e].y;
+                v.z += part[j][e].z;
+                v.w += part[j][e].w;
+            }
+            const int tap = (int)(ct % 9);
+            const int co = (int)(ct / 9);
+            float *d = dw + ((size_t)co * cin_out + ci) * 9 + tap;      // OIHW: consecutive ci are 9 floats apart
+            d[0] = v.x;
+            d[9] = v.y;
+            d[18] = v.z;
+            d[27] = v.w;
+        }
+        __syncthreads();
+    }
+}
+
 extern "C" int v2x_conv3x3_wgrad_reduce(const float *workspace, int n_split, int Cout, int Cin, int cin_out, float *dw_oihw, v2x_stream_t stream) {
     V2X_REQUIRE(workspace && dw_oihw && n_split >= 1 && Cout > 0 && Cin > 0 && cin_out > 0 && cin_out <= Cin, "v2x_conv3x3_wgrad_reduce: bad arguments");
+    if (cin_out % 4 == 0 && Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && v2x_tune(V2X_TUNE_WGRAD_REDUCE4) != 0) {
+        const long long total4 = (long long)Cout * 9 * (cin_out / 4);
+        const long long blocks4 = (total4 + 31) / 32;
+        hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3((unsigned)(blocks4 < 8192 ? blocks4 : 8192)), dim3(256), 0, (hipStream_t)stream, workspace, n_split, Cout, Cin,
+                           cin_out, dw_oihw);
+        V2X_CHECK_LAUNCH("wgrad_reduce4_kernel");
+        return V2X_OK;
+    }
     const long long total = (long long)Cout * 9 * cin_out;
     const long long blocks = (total + 31) / 32;
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, workspace, n_split, Cout, Cin,
