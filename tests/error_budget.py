@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the end-to-end tolerance comes from: a DERIVED error budget for bf16 storage through the whole network, printed next to the measured
-errors.  CPU only (the oracle, oracle/coperception_ref.py -- test infrastructure; this tool is one of its callers like tests/).
+errors.  CPU only.  Lives under tests/ because it drives the oracle (oracle/coperception_ref.py is test infrastructure: only tests/, smoke() and bench.py's baseline legs may import it).
 
 Method (first-order propagation through the REAL network, not a formula): the bf16-emulating oracle rounds at known places -- `_q(...)`: a layer's input (a no-op
 when the producer already rounded it), its weights, its output.  With every rounding OFF the graph is the fp32 oracle; with ALL of them on it is the emulating
@@ -15,7 +15,7 @@ and the tests' bounds (3e-2 max, 3e-3 mean of max|ref|) can be read against it. 
 is what any correct bf16 pipeline -- the HIP path included -- shows up to a re-draw of the rounding noise (two correct pipelines with different fp32 summation orders
 decorrelate to exactly this level: tests/test_gpu_models.py's header).
 
-    python3 tools/error_budget.py [--model v2vnet|fafnet] [--seed 0] [--measured profiles/r06_e2e_errors_gpu.txt]
+    python3 tests/error_budget.py [--model v2vnet|fafnet] [--seed 0] [--measured profiles/r06_e2e_errors_gpu.txt]
 """
 import argparse
 import math

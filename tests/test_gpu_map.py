@@ -3,7 +3,7 @@
 PARITY UNPINNED w.r.t. the reference, and NO trained weights exist here (README.md:46 is an external
 download).  With random weights the foreground scores of ~400k anchors sit within a few 1e-2 of each
 other, so greedy NMS -- and therefore mAP -- is a chaotic function of rounding noise: the oracle's own
-fp32 and bf16-emulating runs differ by 5-10 mAP points (tools/diag_map.py).  What CAN be pinned, and is:
+fp32 and bf16-emulating runs differ by 5-10 mAP points (tests/diag_map.py).  What CAN be pinned, and is:
 
   1. pre-NMS: for every anchor whose oracle score is further than DELTA from the threshold, the HIP path
      makes the same keep/drop decision, and the decoded boxes of kept anchors agree to centimetres;
