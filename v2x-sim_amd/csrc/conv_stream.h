@@ -15,6 +15,19 @@ __device__ __forceinline__ float4 lds_ld4(lds_cf_t *p) {
 __device__ __forceinline__ void glds16s(const void *g, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
+// the same with a cache-policy field (aux: 2 = nt, 1 = sc0, 16 = sc1 on gfx950): round 6's experiment on the ConvGRU's two streams -- a non-temporal PATCH stream so that
+// the 5 MB of patches an XCD pulls per round stop evicting its 3.5 MB of weights from the 4-MiB L2 (the weights are re-fetched once per round: profiles/r06_fetch_calibration.txt).
+// Compile-time (-DV2X_STREAM8G_PATCH_AUX=n / -DV2X_STREAM8G_WEIGHT_AUX=n, tools/ab_build.sh); 0 = the default policy = glds16s.
+#ifndef V2X_STREAM8G_PATCH_AUX
+#define V2X_STREAM8G_PATCH_AUX 0
+#endif
+#ifndef V2X_STREAM8G_WEIGHT_AUX
+#define V2X_STREAM8G_WEIGHT_AUX 0
+#endif
+template <int AUX>
+__device__ __forceinline__ void glds16s_aux(const void *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, AUX);
+}
 
 struct StreamArgs {
     const uint16_t *in0, *in1;  // in0: first C0 channels (half resolution when up0), in1: next C1 channels

@@ -965,7 +965,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const uint16_t *src = first ? a.in0 : a.in1;
         const unsigned cs = first ? (unsigned)a.C0 : (unsigned)a.C1;
         const unsigned off = (unsigned)(d >> 5) * cs + (unsigned)((first ? kc : kc - nc0) * 32 + (d & 31));
-        glds16s(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + buf * PATCH8_BYTES + (wv + 4 * t) * 1024);
+        glds16s_aux<V2X_STREAM8G_PATCH_AUX>(d >= 0 ? (const void *)(src + off) : zero_page, s_patch + buf * PATCH8_BYTES + (wv + 4 * t) * 1024);
     };
     // weight pieces of step `st` (chunk st / 3, tap column st % 3): piece p = wq + NQ * u, p < 3 * W_PIECES, for worker wq of NQ
     // (the prologue spreads a step over all 8 waves, the steady state over the 4 waves of group 1);
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (p >= 3 * W_PIECES) break;                  // wave-uniform (96-row tiles: 18 pieces)
             ++cnt;
             const int ky = p / W_PIECES, pis = p - ky * W_PIECES;
-            glds16s(wbase + (size_t)(kc * 9 + ky * 3 + kx) * (BCO * 32) + pis * 512 + lane_w * 8,
+            glds16s_aux<V2X_STREAM8G_WEIGHT_AUX>(wbase + (size_t)(kc * 9 + ky * 3 + kx) * (BCO * 32) + pis * 512 + lane_w * 8,
                     s_ring + slot * STEP_BYTES + ky * SLICE_BYTES + pis * 1024);
         }
         return cnt;
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const int p = wave + 8 * u;
                 if (p >= 3 * W_PIECES) break;
                 const int ky = p / W_PIECES, pis = p - ky * W_PIECES;
-                glds16s(wbase + (size_t)((stp / 3) * 9 + ky * 3 + (stp % 3)) * (BCO * 32) + pis * 512 + lane_w * 8,
+                glds16s_aux<V2X_STREAM8G_WEIGHT_AUX>(wbase + (size_t)((stp / 3) * 9 + ky * 3 + (stp % 3)) * (BCO * 32) + pis * 512 + lane_w * 8,
                         s_ring + stp * STEP_BYTES + ky * SLICE_BYTES + pis * 1024);
             }
         }
