@@ -391,6 +391,21 @@ def build_summary(fps, ms_per_step, latency, configs, training, gpu_stock, cpu, 
     return sm
 
 
+def stream_ceiling_fractions(kernels, calibration):
+    """The HBM-side kernels against what a pure streaming kernel sustains ON THIS BOX at their read : write mix (calibration: v2x_calib_stream): the fused tail writes
+    3 bytes per byte it reads (fp32 logits), conv8_1 (parity-class) reads 2 : writes 1, conv1_1 reads 4 : writes 1 ... -> {kernel: algorithmic GB/s / ceiling}.  A value
+    near 1 means the kernel already moves its algorithmic bytes as fast as memory takes that mix -- VERDICT r5's "tail <= 1 100 us" asks for 4.9 TB/s at 1 : 3, above it."""
+    mixes = {"conv3x3_tail_kernel": "copy_1_3_tbs", "conv3x3_halo_ppc_kernel<64, 32, 32>": "copy_2_1_tbs", "conv3x3_s2_resident_kernel<64>": "copy_4_1_tbs",
+             "conv3x3_halo_sb_kernel<0, 32, 32, 0, 0, false>": "copy_1_1_tbs", "conv3x3_halo_pp_kernel<0, 64, 64, 0>": "copy_1_1_tbs"}
+    out = {}
+    if isinstance(kernels, dict) and isinstance(calibration, dict):
+        for k, key in mixes.items():
+            if k in kernels and calibration.get(key):
+                out[k] = {"mix": key[5:-4].replace("_", ":"), "algorithmic_tb_s": kernels[k]["gbs"] / 1e3, "stream_ceiling_tb_s": calibration[key],
+                          "frac": kernels[k]["gbs"] / 1e3 / calibration[key]}
+    return out
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -1233,7 +1248,7 @@ def main():
             "ranks_seen": ranks_seen, "exposed_exchange_ms_per_step": exposed_all,
             "exposed_exchange_note": "HIP-event time a half-batch's stream waits for its exchange; with the two half-batches on two streams the GPU runs "
                                      "the other half's kernels during that wait (one-stream order: --graph 4)",
-            "kernels": kernels, "roofline": roofline, "calibration": calibration, "cpu_baseline": cpu, "gpu_stock_baseline": gpu_stock, "latency": latency, "configs": configs,
+            "kernels": kernels, "hbm_side_kernels_vs_stream_ceiling": stream_ceiling_fractions(kernels, calibration), "roofline": roofline, "calibration": calibration, "cpu_baseline": cpu, "gpu_stock_baseline": gpu_stock, "latency": latency, "configs": configs,
             "training": training, "host_streaming": host_streaming,
         }
         # top-level scalars the driver's parser can keep (BASELINE.md section 3's batch sizes, the five configs, the N > 1 self-checks), then the
