@@ -1113,8 +1113,9 @@ def main():
                     # (round-3 files name stream8g with its removed fourth template argument)
                     tk = tks.get(dom) or tks.get(dom.replace(", true>", ", true, false>").replace(", false>", ", false, false>"))
                 if tk:
-                    ff = FETCH_FACTOR.get(dom, FETCH_FACTOR_DEFAULT)     # (the committed summaries hold FETCH_SIZE x 2: rescaled to the kernel's calibrated factor)
-                    roofline["traffic"] = tk["hbm_read_bytes_per_launch"] * ff / 2.0 + tk["hbm_write_bytes_per_launch"]
+                    ff = FETCH_FACTOR.get(dom, FETCH_FACTOR_DEFAULT)     # (summaries older than round 6 hold FETCH_SIZE x 2: rescaled to the kernel's calibrated factor)
+                    raw = tk.get("fetch_size_raw_bytes_per_launch", tk["hbm_read_bytes_per_launch"] / 2.0)
+                    roofline["traffic"] = raw * ff + tk["hbm_write_bytes_per_launch"]
                     roofline["traffic_source"] = "profiles/%s (committed rocprofv3 --pmc passes of this workload; not re-measured in this run)" % tname
                     break
         roofline["kernel"] = dom
