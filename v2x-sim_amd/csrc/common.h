@@ -26,7 +26,6 @@ enum v2x_tune_id {
     V2X_TUNE_STREAM_WIDE,     // 1: the wide 4-wave form for 64-row layers; 0: the 256-pixel kernel
     V2X_TUNE_WIDE3,           // 1: three taps per synchronisation in the wide form (>= 3 chunks); 0: the 1-tap wide form
     V2X_TUNE_HALO_PP,         // 1: 8-wave ping-pong halo kernel for conv8_1 / conv7_2; 0: the 4-wave kernel
-    V2X_TUNE_S2_RESIDENT,     // 1: resident-weights stride-2 kernel for conv1_1; 0: the streamed stride-2 kernel
     V2X_TUNE_VOXELIZE_LDS,    // 1: LDS-binned voxeliser when the grid fits; 0: the global-atomic form
     V2X_TUNE_WARP_LDS,        // 2 (default): LDS-staged warp kernel with the rotate set-ups shared through an LDS table; 1: the first LDS-staged form (per-item set-ups); 0: the direct form -- all three bit-identical
     V2X_TUNE_S2_G,            // 1: 8-wave three-tap stride-2 kernel (256-pixel tiles) for the 128-row layers wherever the SHAPE allows (never by batch size; a declared latency launch -- desc->small_batch -- keeps the 1-tap kernel below 4 tiles per CU); 0: the 1-tap kernel

@@ -963,7 +963,7 @@ int v2x_conv_stream_s2_dispatch(const v2x_conv_desc *d, hipStream_t s) {
     }
     if (t16) return rows == 128 ? launch_s2<128, 8, 16>(a, s) : launch_s2<64, 8, 16>(a, s);
     if (rows == 64 && a.n_co_tiles == 1 && d->C0 == 32) {   // one chunk, one channel tile: resident weights (conv1_1)
-        if (v2x_tune(V2X_TUNE_S2_RESIDENT) != 0) return launch_s2_resident(a, s);
+        return launch_s2_resident(a, s);   // (the switch S2_RESIDENT = 0 -> streamed form was retired in round 6: no test or tool exercised it since round 3)
     }
     return rows == 128 ? launch_s2<128>(a, s) : launch_s2<64>(a, s);
 }

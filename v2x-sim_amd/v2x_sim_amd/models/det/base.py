@@ -75,12 +75,9 @@ class LidarEncoder(_ParamsOnly):
                       packing.pack_conv_bn(prefix + "conv3d_1", c3.conv3d, c3.bn3d, device=device)]
                 s1, t1 = packing.fold_bn(c2.bias, b2, c2.out_channels)
                 s2, t2 = packing.fold_bn(c3.conv3d.bias, c3.bn3d, c3.conv3d.out_channels)
-                if packing.PP_64:   # resident-weights 8-wave ping-pong halo kernel, 1x1 chained in its store phase
-                    halo = packing.pack_conv_halo(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
-                                                  chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
-                else:               # wide streamed kernel, 1x1 chained in its epilogue
-                    halo = packing.pack_conv_stream(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
-                                                    chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
+                # resident-weights 8-wave ping-pong halo kernel, 1x1 chained in its store phase
+                halo = packing.pack_conv_halo(prefix + "conv1_2+conv3d_1", c2.weight, s1, t1, relu=True,
+                                              chain=(c3.conv3d.weight[:, :, 0], s2, t2, True), device=device)
                 stage.append(ops.Layer(fb, halo, name=prefix + "conv1_2+conv3d_1"))
             elif lvl == "2" and packing.CHAIN_STREAM and packing.STREAM_KERNEL:
                 # 128 -> 128 3x3, then the 1x1x1 "Conv3D" 128 -> 128: chained in the streamed kernel's epilogue (the

@@ -67,7 +67,7 @@ _CONV_TILES = {32: (32, 256, 1, 4), 48: (48, 256, 1, 4), 64: (64, 128, 2, 2), 12
 def conv_kernel_name(pc, H=0, W=0, bits=False, N=0):
     """Name of the template instantiation v2x_conv2d dispatches to (as rocprofv3 prints it)."""
     if pc.w_layout == 2 and pc.stride == 2:
-        if pc.Cout == 64 and pc.C0 == 32 and tuning.get("S2_RESIDENT") != 0:
+        if pc.Cout == 64 and pc.C0 == 32:
             return "conv3x3_s2_resident_kernel<64>"
         rows = 128 if pc.Cout % 128 == 0 else 64
         s2g = tuning.get("S2_G")
@@ -638,7 +638,7 @@ def run_layer(layer, in0, in1=None, zbits=0):
             return conv2d(layer.latency, in0, in1, split=layer.split, splitk=sk)
     if h is not None and h.stride == 2:
         # stride-2 streamed kernel: 4x32 output tiles, or 8x16 ones for narrow maps (conv4_1: 16x16 outputs)
-        if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and tuning.get("S2_T16") != 0):
+        if (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0):
             return conv2d(h, in0, in1, split=layer.split, splitk=small_batch_splitk(h, in0.shape[0], H, W))
     elif h is not None and halo_eligible(H, W, h.w_layout, max(h.C0, h.C1 or 0), h.Cout):
         use = True

@@ -598,7 +598,7 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
         key = (fb.C0 if fb.C1 else 0, fb.C1 if fb.C1 else cin_h, conv.out_channels)
         if key == (64, 32, 32) and fb.up0 == 1 and tuning.get("PARITY_CLASS") != 0:   # conv8_1: parity-class form
             h = pack_conv_halo_parity(name, conv.weight, scale, shift, C0=fb.C0, C1=fb.C1, relu=relu, device=device)
-        elif key in ((0, 32, 32), (64, 32, 32), (0, 64, 32)) or (key == (0, 64, 64) and (PP_64 or not STREAM_64)):   # (0, 64, 32): no model layer; the data gradient of conv1_1 (train_layout)
+        elif key in ((0, 32, 32), (64, 32, 32), (0, 64, 32)) or key == (0, 64, 64):   # (0, 64, 32): no model layer; the data gradient of conv1_1 (train_layout)
             h = pack_conv_halo(name, conv.weight, scale, shift, C0=fb.C0 if fb.C1 else cin_h, C1=fb.C1, relu=relu,
                                cin_pad=cin_h if not fb.C1 else None, device=device)
         elif (fb.C1 and fb.up0 == 1 and fb.C0 % 32 == 0 and fb.C1 % 32 == 0 and STREAM_KERNEL and
@@ -623,7 +623,8 @@ def layer_conv_bn(name, conv, bn, *, device, relu=True, halo=True, **kw):
 STREAM_KERNEL = True  # tools flip this to A/B the streamed-weights kernel against the gather kernel
 CHAIN_STREAM = True   # conv1_2 -> conv3d_1 and conv2_2 -> conv3d_2: 1x1 chained in the streamed kernel's epilogue (False: separate launches for conv3d_2)
 STREAM_64 = True      # 64 -> 64 layers (conv7_2): streamed (wide 4-wave) kernel instead of the resident-weights halo kernel (471 vs 495 us)
-PP_64 = tuning.get("PP_64") != 0   # 64 -> 64 layers (conv7_2): resident-weights 8-wave ping-pong halo kernel instead of the wide streamed one
+# (round 6: the switch PP_64 = 0 -- the 64 -> 64 full-resolution layers on the wide streamed kernel instead of the resident-weights ping-pong halo kernel -- was retired: measured
+#  slower in round 3, exercised by no test or tool since)
 STREAM_S2 = True      # stride-2 3x3 layers (conv1_1, conv2_1, conv3_1): patch-based stride-2 kernel instead of the gather kernel
 
 

@@ -127,7 +127,7 @@ def _repack_stale():
 def _zero_insert(dy):
     """dy (N, Ho, Wo, C) of a stride-2 layer -> (N, 2Ho, 2Wo, C) with dy at the even positions."""
     N, Ho, Wo, C = dy.shape
-    if dy.dtype == BF16 and C % 8 == 0 and dy.is_cuda and tuning.get("UPCAT_HIP") != 0:
+    if dy.dtype == BF16 and C % 8 == 0 and dy.is_cuda:
         return ops.zero_insert(dy.contiguous())            # one pass (v2x_zero_insert_bf16) instead of a fill and a strided copy
     z = torch.zeros((N, 2 * Ho, 2 * Wo, C), dtype=dy.dtype, device=dy.device)
     z[:, ::2, ::2] = dy
@@ -141,7 +141,7 @@ def _layer_runs(cin_p, cout, stride, H, W):
     if layout == 0:
         return True                                    # the gather kernel takes any extent
     if stride == 2:
-        return (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0 and tuning.get("S2_T16") != 0)
+        return (H % 8 == 0 and W % 64 == 0) or (H % 16 == 0 and W % 32 == 0)
     return ops.halo_eligible(H, W, layout, cin_p) and (layout != 2 or H * W >= 256)
 
 
@@ -410,7 +410,7 @@ class _UpCatConv3x3(torch.autograd.Function):
 def upcat_conv3x3(lo, skip, conv):
     """conv(cat(up(lo), skip)) -- the fused form where the halo kernels cover the shape (64 + 32 -> 32, H % 8 == 0, W % 32 == 0), else conv3x3(upcat(...))."""
     N, H, W, C = lo.shape
-    if (tuning.get("TRAIN_UPCAT_CONV") != 0 and tuning.get("UPCAT_HIP") != 0 and (C, skip.shape[3], conv.weight.shape[0]) == (64, 32, 32) and conv.stride[0] == 1
+    if (tuning.get("TRAIN_UPCAT_CONV") != 0 and (C, skip.shape[3], conv.weight.shape[0]) == (64, 32, 32) and conv.stride[0] == 1
             and lo.dtype == BF16 and skip.dtype == BF16 and skip.shape[:3] == (N, 2 * H, 2 * W) and (2 * H) % 8 == 0 and (2 * W) % 32 == 0
             and conv.weight.shape[1] == C + skip.shape[3] and conv.weight.is_cuda and conv.weight.dtype == torch.float32):
         return _UpCatConv3x3.apply(lo.contiguous(), skip.contiguous(), conv.weight, conv.bias)
@@ -420,7 +420,7 @@ def upcat_conv3x3(lo, skip, conv):
 def upcat(lo, skip):
     """cat(nearest x2 upsample of lo, skip) along the channels, NHWC."""
     N, H, W, C = lo.shape
-    if (tuning.get("UPCAT_HIP") != 0 and lo.dtype == BF16 and skip.dtype == BF16 and C % 8 == 0 and skip.shape[3] % 8 == 0
+    if (lo.dtype == BF16 and skip.dtype == BF16 and C % 8 == 0 and skip.shape[3] % 8 == 0
             and skip.shape[:3] == (N, 2 * H, 2 * W)):
         return _UpCat.apply(lo, skip)
     up = lo[:, :, None, :, None, :].expand(N, H, 2, W, 2, C).reshape(N, 2 * H, 2 * W, C)   # backward = a 2x2 sum (no atomics: deterministic)

@@ -2,13 +2,11 @@
 libv2x_amd.so for the kernel-selection ones) and changed afterwards only through set() -- nothing on the hot path calls os.environ.
 
 Kernel-selection switches live in the library (include/v2x_amd.h: v2x_tuning_set / v2x_tuning_get; defaults = the measured-fastest forms):
-    STREAM_WAVES STREAM_G STREAM_WT STORE_X4 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP S2_RESIDENT VOXELIZE_LDS WARP_LDS S2_G GRU_XCD_WALK HALO_XCD WGRAD_TR WGRAD_REDUCE4 CONV1X1
+    STREAM_WAVES STREAM_G STREAM_WT STORE_X4 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP VOXELIZE_LDS WARP_LDS S2_G GRU_XCD_WALK HALO_XCD WGRAD_TR WGRAD_REDUCE4 CONV1X1
     (STORE_X4 1: 16-byte output stores -- two channel tiles exchanged between the k-slot quarters with v_permlane16_swap_b32 -- in every bf16 epilogue
      that has the form; 0: 8-byte stores, same bytes and values)
 Host-side switches (this module):
-    S2_T16      1  stride-2 streamed kernel with 8x16 output tiles for narrow maps (conv4_1); 0: the gather kernel
     CONV_PAIR   1  conv_pre_1 -> conv_pre_2 as one launch from the bit grid; 0: two launches
-    PP_64       1  pack the 64 -> 64 full-resolution layers for the ping-pong halo kernel (read when a model is packed)
     SMALL_BATCH 2  latency dispatch: split-K for the streamed layers when a launch has fewer tiles than CUs (ops.small_batch_splitk) and the 1-tap
                    stride-2 kernel below four tiles per CU; results differ from the default kernels by fp32 summation order -- and, for conv5_1 / conv6_1,
                    by the weight form: a split launch multiplies the 9-tap bf16 weights, the throughput launch the pre-summed parity-class weights
@@ -20,7 +18,6 @@ Host-side switches (this module):
     TRAIN_GRAPH 0  with TRAIN_HIP: the whole step as one replayed hipGraph
     WARP_HIP    1  with TRAIN_HIP: the cross-agent warp of the fusion stage (forward + data gradient) on v2x_warp_affine_f32 / _bwd_f32;
                    0: F.grid_sample and its atomic-scatter backward
-    UPCAT_HIP   1  with TRAIN_HIP: the decoder's upsample + concat and its backward as one launch each (v2x_upcat_bf16 / _bwd_bf16); 0: torch ops
     WARP_XCD    1  inference warp + fuse: the output maps of one frame on one XCD (v2x_warp_fuse_ordered: each source map is fetched once per frame
                    instead of once per ego; bit-identical); 0: the plain grid
     SEG_FUSE    1  segmentation models: conv8_2 and the 1x1 class head as one halo launch (the 32-channel map never reaches HBM; bit-identical); 0: two layers
@@ -39,13 +36,14 @@ Host-side switches (this module):
     TRAIN_UPCAT_CONV 1  with TRAIN_HIP: conv8_1 (64 upsampled + 32 skip channels -> 32, full resolution) forward on the two-source halo kernel and its data gradient
                    as two halo launches (32 -> 64, 32 -> 32) instead of the gather kernel both ways; 0: the gather kernel on the concatenated map
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
+Retired in round 6 (their alternate forms had been measured slower for two rounds or more and no test or tool exercised them): S2_RESIDENT, S2_T16, PP_64, UPCAT_HIP.
 The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"S2_T16": 1, "CONV_PAIR": 1, "PP_64": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "UPCAT_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1}
+_HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
-                    "S2_RESIDENT", "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "WGRAD_REDUCE4", "CONV1X1")
+                    "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "WGRAD_REDUCE4", "CONV1X1")
 
 
 def _env_int(name, default):
