@@ -108,3 +108,21 @@ def test_pair_kernel_never_drains_its_stores_inside_the_tile_loop(tmp_path):
         waits = re.findall(r"s_waitcnt vmcnt\((\d+)\)", "\n".join(loop))
         assert waits and set(waits) <= allowed, (n, waits)
         assert sum(ln.startswith("v_mfma_f32_16x16x32_bf16") for ln in loop) == 132   # 5 x 6 x 2 (layer A) + 3 x 24 (layer B)
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_streaming_conv1x1_keeps_its_weights_in_registers(tmp_path):
+    """conv1x1.hip (round 6): every instantiation is spill-free, touches no LDS (the weights are MFMA fragments in registers, the pixels come straight from HBM), has no
+    barrier, and issues exactly KS x CT MFMAs per 16-pixel fragment in flight (PF of them per loop iteration)."""
+    asm = _asm("conv1x1.hip", tmp_path)
+    bodies, meta = _kernels(asm)
+    names = [n for n in bodies if n.startswith("_Z21conv1x1_stream_kernel")]
+    assert len(names) == 36, len(names)            # KS in {1, 2, 4} x CT in {1, 2, 3, 4, 6, 8} x {bf16, fp32}
+    for n in names:
+        body = bodies[n]
+        m = re.match(r"_Z21conv1x1_stream_kernelILi(\d+)ELi(\d+)ELb([01])ELi(\d+)E", n)
+        ks, ct, pf = int(m.group(1)), int(m.group(2)), int(m.group(4))
+        assert "scratch_" not in body and "ds_read" not in body and "ds_write" not in body and "s_barrier" not in body, n
+        assert len(re.findall(r"^\s+v_mfma_f32_16x16x32_bf16", body, flags=re.M)) == ks * ct * pf, n
+        seg = re.search(r"\.private_segment_fixed_size:\s+(\d+)", meta.get(n, ""))
+        assert seg and int(seg.group(1)) == 0, n
