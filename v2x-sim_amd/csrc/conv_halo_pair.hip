@@ -57,7 +57,10 @@ constexpr int IN_PLANE = IH * IW * 16;  // one 8-channel plane of the input wind
 constexpr int IN_BYTES = 2 * IN_PLANE; // 13 824: channels 0..7 | 8..15, planar so that 16 consecutive pixels are 256 contiguous bytes
 constexpr int MID_BYTES = NMID * 64;    // 21 760
 constexpr int LUT_BYTES = 256 * 16;     // byte of occupancy bits -> 8 bf16 {0,1}: the expansion is one ds_read_b128 instead of ~60 VALU ops
-constexpr int SMEM = 2 * W_BYTES + IN_BYTES + MID_BYTES + LUT_BYTES;
+#ifndef V2X_PAIR_LDS_PAD_BUILD
+#define V2X_PAIR_LDS_PAD_BUILD 0   // occupancy experiment (round 6, profiles/r06_pair_occupancy.txt): extra dynamic LDS per workgroup; 10240 -> 86 KiB = ONE workgroup per CU instead of two
+#endif
+constexpr int SMEM = 2 * W_BYTES + IN_BYTES + MID_BYTES + LUT_BYTES + V2X_PAIR_LDS_PAD_BUILD;
 #ifndef V2X_HALO_PSWZ_BUILD
 #define V2X_HALO_PSWZ_BUILD 1
 #endif
