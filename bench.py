@@ -222,7 +222,9 @@ def parse(argv=None):
     ap.add_argument("--no-calibration", action="store_true", help="skip the streaming / MFMA calibration probes (the `calibration` sub-record)")
     ap.add_argument("--graph", type=int, default=1,
                     help="1: four hipGraph segments with the exchange between them, the two half-batches on two streams (every N); "
-                         "4: the same on one stream; 0: eager launches; 2: the whole step as ONE hipGraph (N = 1 only, for comparison)")
+                         "4: the same on one stream; 0: eager launches; 2: the whole step as ONE hipGraph (N = 1 only, for comparison); "
+                         "5 (experiment, round 6): as 1 but the two half-batch streams FREE-RUN over the timed steps (no join at the end of a step; "
+                         "V2X_BENCH_STAGGER=1: half B starts one encoder behind half A) -- joined once, by the synchronize that ends the timed region")
     ap.add_argument("--transport", choices=("allgather", "needed"), default="allgather",
                     help="fusion-map exchange: RCCL all-gather (default) or grouped point-to-point of the needed rows only")
     ap.add_argument("--layout", choices=("spread", "agent-per-gpu"), default="spread",
@@ -820,7 +822,7 @@ class Workload:
             self.run = g.replay
             self._g = g
             self.exec_mode = "one hipGraph per step"
-        elif mode in (1, 4):
+        elif mode in (1, 4, 5):
             # four collective-free segments (encoder A, encoder B, fusion + decoder + heads A, B), each a hipGraph; the exchange (RCCL, eager) runs
             # between them on static buffers.  mode 1 (default): the two half-batches on TWO STREAMS -- kernels of one half fill the tails and the
             # HBM-bound phases (heads, conv8_2, conv1_1) of the other: +2.3...3.0 % at N = 1 against the one-stream order (mode 4), same box;
@@ -828,7 +830,10 @@ class Workload:
             # capture_error_mode="thread_local": RCCL's watchdog thread polls the events of earlier collectives while this
             # thread captures -- under the default global mode that query is "operation not permitted when stream is
             # capturing" and takes the process down (seen with V2X_FORCE_DIST=1 on one GPU)
-            two = mode == 1
+            two = mode in (1, 5)
+            free_run = mode == 5                       # no join at the end of a step: the streams drift / stay staggered; the device synchronize after the K steps joins them
+            stagger = free_run and os.environ.get("V2X_BENCH_STAGGER", "0") == "1"
+            self._stagger_armed = stagger
             shared_pool = torch.cuda.graph_pool_handle()
             streams = [torch.cuda.Stream(), torch.cuda.Stream()] if two else [torch.cuda.current_stream()] * 2
             with torch.no_grad():
@@ -852,22 +857,30 @@ class Workload:
             def run():
                 cur = torch.cuda.current_stream()
                 works = []
-                for h in halves:                    # encoder A, exchange A (async), encoder B, exchange B: the same host order on every rank
-                    if two:
+                ev = None
+                for hi, h in enumerate(halves):     # encoder A, exchange A (async), encoder B, exchange B: the same host order on every rank
+                    if two and not free_run:
                         h["stream"].wait_stream(cur)
                     with torch.cuda.stream(h["stream"]):
+                        if ev is not None:          # (stagger, first step after an arm only) half B waits for half A's encoder
+                            h["stream"].wait_event(ev)
                         h["g_enc"].replay()
+                        if self._stagger_armed and hi == 0:
+                            ev = torch.cuda.Event()
+                            ev.record(h["stream"])
                         works.append(runner.start_exchange(h["feats"][L], out=h["xbuf"])[1] if use_dist else None)
+                self._stagger_armed = False
                 for h, w in zip(halves, works):
                     with torch.cuda.stream(h["stream"]):
                         self.timed_wait(w)
                         h["g_dec"].replay()
-                if two:
+                if two and not free_run:
                     for h in halves:
                         cur.wait_stream(h["stream"])
             self.run = run
             self.exec_mode = ("4 hipGraph segments per step (encoder A, encoder B, fusion+decoder+heads A, B); exchange between them; "
-                              + ("the two half-batches on two streams, joined at the end of the step" if two else "one stream"))
+                              + (("the two half-batches on two FREE-RUNNING streams (no join between steps; experiment)" + (", half B one encoder behind half A" if stagger else ""))
+                                 if free_run else "the two half-batches on two streams, joined at the end of the step" if two else "one stream"))
         elif mode == 0:
             def run():
                 self.last_out = self.step()
@@ -879,7 +892,7 @@ class Workload:
 
     def outputs(self):
         """Logits of the last step, per half-batch (this rank's items)."""
-        if self.mode in (1, 4):
+        if self.mode in (1, 4, 5):
             return [h["out"] for h in self.halves]
         return list(self.last_out)
 
@@ -923,6 +936,8 @@ class Workload:
         self.barrier()
         _mark(MARK_FIRST)       # warm-up, capture and two replayed steps are behind EVERY rank (supervise() stops its stall timer here)
         torch.cuda.synchronize()
+        if self.mode == 5 and os.environ.get("V2X_BENCH_STAGGER", "0") == "1":
+            self._stagger_armed = True      # the synchronize above re-aligned the streams: the stagger is re-established INSIDE the timed region (its cost is in the number)
         t0 = time.perf_counter()
         for _ in range(args.steps):
             self.run()
@@ -930,7 +945,7 @@ class Workload:
         self.barrier()
         elapsed = time.perf_counter() - t0
         graph_equals_eager = None           # checked at N = 1 in the graph modes
-        if self.mode in (1, 4) and self.active and not self.use_dist:
+        if self.mode in (1, 4, 5) and self.active and not self.use_dist:
             # the graphs' outputs (the last replay; the two halves ran concurrently in mode 1) against an eager, one-stream recomputation of the same
             # step: every kernel is deterministic and the halves are independent, so the logits must agree bit for bit
             ref = self.step()
