@@ -269,9 +269,32 @@ def cpu_baseline(model_state, gnn_iters, budget_s=20.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 40:
             break
-    return {"value": n / el, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": "%d whole 5-agent V2VNet frames (65536 pts/agent, 256x256x13 BEV), oracle fp32 PyTorch-CPU, "
-                      "%d threads, after 1 warm-up frame" % (n, torch.get_num_threads())}
+    rec = {"value": n / el, "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": "%d whole 5-agent V2VNet frames (65536 pts/agent, 256x256x13 BEV), oracle fp32 PyTorch-CPU, "
+                     "%d threads, after 1 warm-up frame" % (n, torch.get_num_threads())}
+    # BASELINE.json config 0 AS WRITTEN -- "lowerbound (no-fusion) single-agent BEV detection on PyTorch CPU" -- is a CPU run of the reference; the product has no CPU
+    # path, so that config exists here only as the ORACLE's lowerbound network on these host cores (VERDICT r5 missing #5): the same five sweeps, no fusion stage
+    try:
+        lo = R.FaFNet().eval()
+        ren = lambda k: "stpn.encoder." + k[len("u_encoder."):] if k.startswith("u_encoder.") else ("stpn.decoder." + k[len("decoder."):] if k.startswith("decoder.") else k)   # noqa: E731
+        lo.load_state_dict({ren(k): v for k, v in model_state.items() if not k.startswith("convgru")})     # the V2VNet's own backbone and heads, minus its fusion stage
+
+        def lo_frame():
+            bev = np.stack([VR.voxelize_occupy(p) for p in pts])[:, None]
+            with torch.no_grad():
+                lo(torch.from_numpy(bev))
+        lo_frame()
+        m, t1 = 0, time.perf_counter()
+        while True:
+            lo_frame()
+            m += 1
+            el2 = time.perf_counter() - t1
+            if el2 > budget_s / 3.0 or m >= 20:
+                break
+        rec["config0_lowerbound_on_cpu"] = {"frames_per_s": m / el2, "frames": m, "what": "oracle FaFNet (lowerbound: no fusion), 5 agents per frame, fp32 PyTorch-CPU, %d threads" % torch.get_num_threads()}
+    except Exception as e:      # noqa: BLE001
+        rec["config0_lowerbound_on_cpu"] = {"error": repr(e)[:200]}
+    return rec
 
 
 def gpu_stock_baseline(model_state, gnn_iters, dev, frames=64, reps=10, warm=3):
