@@ -1035,6 +1035,12 @@ def main():
             pass
     if args.dry_run:
         sys.exit(dry_run(args, world, rank))
+    if os.environ.get("V2X_BENCH_INNER") == "1" and os.environ.get("V2X_BENCH_FAKE_RECORD"):
+        # test hook (tests/test_bench_launcher_cpu.py): the benchmark child of the N = 1 orchestrator replaced by a canned record, so that the parent's
+        # relay / counter passes / merge can be exercised on a box without a GPU
+        with open(os.environ["V2X_BENCH_FAKE_RECORD"]) as fh:
+            print(fh.read().strip(), flush=True)
+        sys.exit(0)
     global LIVE_TRAFFIC
     pmc_when = "before the timed run (V2X_BENCH_PMC_ORDER=before: round 5's order, kept for the paired comparison)"
     have_gpu = torch.cuda.device_count() > 0 or os.environ.get("V2X_BENCH_FORCE_ORCHESTRATE") == "1"     # (the second: the CPU test of the orchestrator)

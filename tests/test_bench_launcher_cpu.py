@@ -234,3 +234,43 @@ def test_summary_and_training_fractions():
     assert sm["latency_b8_frames_per_s"] == 5300.0 and sm["config4_v2vnet_seg_frames_per_s"] == 6900.0 and sm["speedup_vs_gpu_stock"] == 32.0
     assert sm["speedup_vs_cpu_baseline"] == 3200.0 and all(not isinstance(v, (dict, list)) for v in sm.values())
     assert abs(sm["whole_step_frac"] - 165.2e9 * 6400.0 / 2.5e15) < 1e-9
+
+
+def test_n1_orchestrator_merges_the_counter_passes_into_the_childs_record(tmp_path):
+    """The whole N = 1 path of round 6 on a CPU box: a canned child record (test hook V2X_BENCH_FAKE_RECORD) + a stand-in rocprofv3 that writes the csv the real one
+    writes -> ONE JSON line whose roofline.traffic is the counters' value with the kernel's CALIBRATED fetch factor, the uniform-x2 value and the committed value beside
+    it, `pmc_passes_s` recorded, and `summary` still the LAST key of the line (the driver keeps the tail of stdout)."""
+    import json
+    kern = "conv3x3_stream8g_kernel<96, 2, false>"
+    child = {"metric": "BEV frames/sec, V2VNet 5-agent detection (256x256 BEV)", "value": 6500.0, "unit": "frames/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+             "ms_per_step": 19.7, "roofline": {"bound": "mfma", "achieved": 1400.0, "peak": 2500.0, "frac": 0.56, "traffic": 7.0, "kernel": kern,
+                                               "traffic_live": "not re-measured: deferred to the parent process (after the timed run)"},
+             "cpu_baseline": {"value": 2.0}, "summary": {"headline_frames_per_s": 6500.0}}
+    rec_path = tmp_path / "child.json"
+    rec_path.write_text(json.dumps(child))
+    fake = tmp_path / "rocprofv3"
+    fake.write_text("""#!/bin/sh
+out=""; c=""
+while [ $# -gt 0 ]; do
+    case "$1" in --pmc) c=$2; shift;; -d) out=$2; shift;; --) break;; esac
+    shift
+done
+if [ "$c" = FETCH_SIZE ]; then v=600000; else v=160000; fi
+mkdir -p "$out/host"; f="$out/host/p_counter_collection.csv"
+echo '"Kernel_Name","Counter_Name","Counter_Value"' > "$f"
+echo "\\"void %s(StreamArgs)\\",\\"$c\\",$v" >> "$f"
+""" % kern)
+    fake.chmod(0o755)
+    env = {"V2X_BENCH_FORCE_ORCHESTRATE": "1", "V2X_BENCH_FAKE_RECORD": str(rec_path), "V2X_BENCH_LIVE_TRAFFIC": "1", "PATH": str(tmp_path) + os.pathsep + os.environ["PATH"]}
+    p = _run("--steps", "20", "--warmup", "5", env_extra=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    roof = rec["roofline"]
+    raw, wr = 1024.0 * 600000, 1024.0 * 160000
+    assert abs(roof["traffic"] - (roof["fetch_factor"] * raw + wr)) < 1.0 and 1.45 < roof["fetch_factor"] < 1.6 and roof["fetch_factor_calibrated"] is True
+    assert abs(roof["traffic_uniform_x2"] - (2.0 * raw + wr)) < 1.0 and roof["traffic_committed"] == 7.0 and "traffic_live" not in roof
+    assert "AFTER the timed run" in roof["traffic_source"] and roof["pmc_passes_s"] >= 0.0
+    assert list(rec)[-1] == "summary" and lines[0].rstrip().endswith('"summary": {"headline_frames_per_s": 6500.0}}')
+    assert rec["value"] == 6500.0 and rec["cpu_baseline"] == {"value": 2.0}
