@@ -38,6 +38,8 @@ extern "C" {
 
 typedef void *v2x_stream_t; /* hipStream_t */
 
+/* V2X_AMD_ABI_VERSION of the library; NEGATIVE (-V2X_AMD_ABI_VERSION) when the library contains an instrumented kernel object (a tools/probes/ timing build:
+ * phase-removal switches, time stamps -- its results are garbage): a caller that checks the version, as every caller should, then refuses it. */
 int v2x_abi_version(void);
 const char *v2x_last_error(void);
 

@@ -46,3 +46,30 @@ def test_uninstrumented_probe_equals_production(name, tmp_path):
     for k in prod:
         assert prod[k] == probe[k], "%s: the un-instrumented probe's instruction stream differs from the production kernel's (%d vs %d instructions)" % (
             k, len(probe[k]), len(prod[k]))
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_an_instrumented_build_is_refused_by_the_loader(tmp_path):
+    """a probe build carries the production ABI number and garbage results.  Round 6: an object built from a probe with a -DV2X_*_DBG_BUILD flag defines
+    v2x_probe_build_marker; v2x_abi_version() of a library that contains one is NEGATIVE; v2x_sim_amd._lib.load() refuses it unless V2X_ALLOW_PROBE_BUILD=1 (which
+    tools/probe_env.sh exports for the timing scripts)."""
+    import ctypes
+    import sys
+    gen = str(tmp_path / "conv_tail_probe.hip")
+    subprocess.check_call([os.path.join(ROOT, "tools", "probes", "gen_probe.sh"), "conv_tail", gen], stdout=subprocess.DEVNULL)
+    obj = str(tmp_path / "conv_tail.o")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", CSRC, "-DV2X_TAIL_DBG_BUILD=32", "-c", gen, "-o", obj], stderr=subprocess.DEVNULL)
+    build = os.path.join(CSRC, "build")
+    others = [os.path.join(build, f) for f in sorted(os.listdir(build)) if f.endswith(".o") and f != "conv_tail.o"] if os.path.isdir(build) else []
+    if len(others) < 15:
+        pytest.skip("the product objects are not built in-tree (csrc/build)")
+    so = str(tmp_path / "libprobe.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "--hip-link", "-shared", "-fPIC"] + others + [obj, "-o", so], stderr=subprocess.DEVNULL)
+    code = ("import sys; sys.path.insert(0, %r); import v2x_sim_amd._lib as L; L.LIB_PATH = %r\n"
+            "try:\n    L.load(); print('LOADED', L._lib.v2x_abi_version())\nexcept L.V2XLibraryError as e:\n    print('REFUSED', 'INSTRUMENTED' in str(e))\n") % (os.path.join(ROOT, "v2x-sim_amd"), so)
+    env = {k: v for k, v in os.environ.items() if k != "V2X_ALLOW_PROBE_BUILD"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout
+    assert "REFUSED True" in out, out
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, V2X_ALLOW_PROBE_BUILD="1")).stdout
+    assert "LOADED -" in out, out          # loaded on request; the library itself still says what it is
+    assert ctypes.CDLL(os.path.join(ROOT, "v2x-sim_amd", "v2x_sim_amd", "lib", "libv2x_amd.so")).v2x_abi_version() > 0      # the product

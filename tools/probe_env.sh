@@ -1,6 +1,7 @@
 # Sourced by the timing-experiment scripts (GPU box only).  An instrumented or re-flagged build REPLACES objects of the production libv2x_amd.so (same ABI
 # number, garbage results): whatever happens -- normal end, an error, Ctrl-C, a timeout's SIGTERM -- the EXIT trap removes those objects and rebuilds the
 # product (an interrupted run used to leave a wrong-results library in place).
+export V2X_ALLOW_PROBE_BUILD=1     # the loader refuses a library with an instrumented object (negative v2x_abi_version) unless asked
 BASE_FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function"
 PROBE_TOUCHED=""
 probe_restore() {

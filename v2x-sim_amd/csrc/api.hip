@@ -10,7 +10,10 @@ void v2x_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int v2x_abi_version(void) { return V2X_AMD_ABI_VERSION; }
+// A library that contains an INSTRUMENTED kernel object (tools/probes/*.patch built with a -DV2X_*_DBG_BUILD flag: phase-removal switches, time stamps -- its results are
+// garbage) defines v2x_probe_build_marker; the version then reads NEGATIVE, which every loader that checks it refuses (v2x_sim_amd/_lib.py: unless V2X_ALLOW_PROBE_BUILD=1).
+extern "C" __attribute__((weak)) int v2x_probe_build_marker;
+extern "C" int v2x_abi_version(void) { return &v2x_probe_build_marker != nullptr ? -V2X_AMD_ABI_VERSION : V2X_AMD_ABI_VERSION; }
 
 // ---- tuning switches (common.h: v2x_tune_id) -----------------------------------------------------------------------------------
 #include <atomic>

@@ -162,7 +162,13 @@ def load():
             raise V2XLibraryError("libv2x_amd.so does not export %s" % name) from e
         fn.restype = res
         fn.argtypes = args
-    if lib.v2x_abi_version() != ABI_VERSION:
+    ver = lib.v2x_abi_version()
+    if ver == -ABI_VERSION and os.environ.get("V2X_ALLOW_PROBE_BUILD") == "1":
+        ver = ABI_VERSION       # an instrumented timing build (tools/probes/): garbage results by design, loaded only on request (the probe scripts set this)
+    if ver == -ABI_VERSION:
+        raise V2XLibraryError("libv2x_amd.so contains an INSTRUMENTED kernel object (a tools/probes/ timing build: its results are garbage) -- rebuild the product "
+                              "(`make -C v2x-sim_amd/csrc` after removing build/<name>.o), or set V2X_ALLOW_PROBE_BUILD=1 for a timing experiment")
+    if ver != ABI_VERSION:
         raise V2XLibraryError("ABI mismatch: library %d, binding %d" % (lib.v2x_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
