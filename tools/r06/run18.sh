@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the BN_FOLD switch this script timed was removed again -- profiles/r06_bn_fold_rejected.txt)
 cd "$(dirname "$0")/../.."
 O=gpurun_out/r06_run18; mkdir -p $O
 timeout 1500 python -m pytest tests/test_gpu_train_kernels.py -m gpu -q -x -s -k "bn_ or training_step or hip_graph" > $O/t1.txt 2>&1
