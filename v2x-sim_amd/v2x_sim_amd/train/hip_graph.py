@@ -158,12 +158,23 @@ def hip_eligible(weight, stride, H, W, cin_pad=None):
     return _layer_runs(cin_p, cout, stride, H, W) and _layer_runs(cout, cin_p, 1, H, W)
 
 
+def _run_layer(layer, x):
+    """ops.run_layer as a DECLARED small-batch launch (TRAIN_SPLITK 1, round 6): at 10 maps the deep layers of a training step are 40-160 workgroups on 256
+    CUs, each walking all of its input chunks; inside ops.latency_dispatch() the streamed layers with fewer than 200 tiles split their chunk ranges
+    over 2-4 workgroups per tile (ops.small_batch_splitk: partial sums added in range order by one more launch -- fixed order, deterministic).  A
+    training step has no batch-invariance to keep (batch statistics), so the batch-dependent rule is free here; at 40 maps no layer qualifies."""
+    if tuning.get("TRAIN_SPLITK") != 0:
+        with ops.latency_dispatch():
+            return ops.run_layer(layer, x)
+    return ops.run_layer(layer, x)
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride):
         cin = weight.shape[1]
         cin_pad = x.shape[-1] if x.shape[-1] != cin else None          # conv_pre_1: 13 channels stored as 32
-        y = ops.run_layer(_layer("fwd", weight, bias, stride, cin_pad), x)
+        y = _run_layer(_layer("fwd", weight, bias, stride, cin_pad), x)
         ctx.save_for_backward(x, weight)
         ctx.stride, ctx.has_bias = stride, bias is not None
         return y
@@ -175,7 +186,7 @@ class _Conv3x3(torch.autograd.Function):
         dyz = _zero_insert(dy) if ctx.stride == 2 else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = ops.run_layer(_layer("dgrad", weight, None, 1, None), dyz)
+            dx = _run_layer(_layer("dgrad", weight, None, 1, None), dyz)
         if ctx.needs_input_grad[1]:
             dw = ops.conv3x3_wgrad(x, dyz, cin_out=weight.shape[1])
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -190,21 +201,42 @@ def _attached_channel_sum(dy):
     returns; autograd hands that same tensor object to the producing convolution's backward when the convolution's output has one
     consumer).  None when the gradient did not come from there, or was modified since: the caller then reduces it itself."""
     tag = getattr(dy, "_v2x_chsum", None)
-    if tag is None or tag[0] != dy._version or tag[1].shape[0] != dy.shape[-1]:
+    if tag is None or tag[0] != dy._version:
         return None
-    return tag[1]
+    if tag[1] is _EXACT_ZERO:
+        return _zero_slice(dy.shape[-1], dy.device)
+    return tag[1] if tag[1].shape[0] == dy.shape[-1] else None
 
 
-_ZEROS = {}
+_EXACT_ZERO = object()      # _BnRelu.backward's tag for "this gradient's channel sums are exactly zero"
+_ZERO_ARENA = {}            # device -> [fp32 zeros, cursor]
+_ZERO_ARENA_FLOATS = 1 << 15
 
 
-def _zeros_f32(n, device):
-    """A shared read-only zero vector (never written: autograd's AccumulateGrad clones an incoming gradient it keeps)."""
-    key = (n, str(device))
-    z = _ZEROS.get(key)
-    if z is None:
-        z = _ZEROS[key] = torch.zeros((n,), dtype=torch.float32, device=device)
+def _zero_slice(n, device):
+    """n fp32 zeros as a FRESH view into a per-device zero buffer.  autograd's AccumulateGrad keeps an incoming gradient without a copy only when nothing
+    else references the tensor object: a shared zero vector (rounds 6's first form) was cloned per layer -- 23 device-to-device copies of 128 B ... 2 KiB
+    in a FaFNet step, 3.6 us each (tools/train_op_census.py).  A view created here, at the point of use, is kept as it is: `conv.bias.grad` then aliases the
+    buffer.  The buffer is only ever READ by this package and by the optimizers; should user code write into a bias gradient in place (weight decay
+    added by hand), train_forward re-zeroes the buffer at the start of the next step (one fill), before any slice of it is handed out again."""
+    key = str(device)
+    st = _ZERO_ARENA.get(key)
+    if st is None:
+        st = _ZERO_ARENA[key] = [torch.zeros((_ZERO_ARENA_FLOATS,), dtype=torch.float32, device=device), 0]
+    span = (n + 63) // 64 * 64        # 256-byte steps: the fused optimizers' vector paths want 16-byte-aligned gradients
+    if span > _ZERO_ARENA_FLOATS:
+        return torch.zeros((n,), dtype=torch.float32, device=device)
+    if st[1] + span > _ZERO_ARENA_FLOATS:
+        st[1] = 0                     # wrapped: slices may then alias each other -- all of them are zero
+    z = st[0][st[1]:st[1] + n]
+    st[1] += span
     return z
+
+
+def _rezero_arena():
+    for st in _ZERO_ARENA.values():
+        st[0].zero_()
+        st[1] = 0
 
 
 class _BnRelu(torch.autograd.Function):
@@ -225,7 +257,7 @@ class _BnRelu(torch.autograd.Function):
             # value saves the sum's accumulation in the dx pass and one finish launch per layer (22 launches, ~0.2 ms of a FaFNet step at any batch size);
             # TRAIN_BN_BIAS_ZERO = 0 restores the computed residue (tests/test_gpu_train_kernels.py compares the two).
             dx, dgamma, dbeta = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu)
-            dsum = _zeros_f32(x.shape[-1], x.device)
+            dsum = _EXACT_ZERO
         else:
             dx, dgamma, dbeta, dsum = ops.bn_train_backward(x, dy.contiguous(), gamma.detach(), beta.detach(), mean, invstd, ctx.relu, dx_sum=True)
         dx._v2x_chsum = (dx._version, dsum)      # the bias gradient of the convolution in front of this BN (_attached_channel_sum)
@@ -511,6 +543,7 @@ def train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batch
     """See _train_forward; the BatchNorm layers' num_batches_tracked counters are bumped together, in one launch, when the forward is complete."""
     prev, _DEFER_COUNTERS[0] = _DEFER_COUNTERS[0], True
     _repack_stale()
+    _rezero_arena()
     try:
         return _train_forward(model, bevs, trans_matrices, num_agent_tensor, batch_size, inference)
     finally:
