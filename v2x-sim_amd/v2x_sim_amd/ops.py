@@ -36,12 +36,17 @@ _latency = _threading.local()   # per THREAD: a latency forward in o
 class latency_dispatch:
     """Context manager: launches of THIS thread inside the block are declared latency launches (see above)."""
 
+    def __init__(self, target=0):
+        self.target = target      # > 0: the number of workgroups small_batch_splitk aims at inside this block (default 320; the training graph's sweep)
+
     def __enter__(self):
         _latency.depth = getattr(_latency, "depth", 0) + 1
+        self.prev, _latency.target = getattr(_latency, "target", 0), self.target
         return self
 
     def __exit__(self, *exc):
         _latency.depth -= 1
+        _latency.target = self.prev
         return False
 
 
@@ -563,6 +568,11 @@ class Layer:
         self.name = name or self.fallback[0].name
 
 
+def _splitk_gate():
+    """Launches with at least this many tiles are never split: 200 (measured, one-frame inference), or 5/8 of a latency_dispatch(target=...) block's target."""
+    return max(200, (getattr(_latency, "target", 0) or 320) * 5 // 8)
+
+
 def small_batch_splitk(pc, N, H, W):
     """Latency mode (a declared latency launch: latency_launches() above): how many chunk ranges a streamed stride-1 layer is split into so
     that a launch has about one workgroup per CU.  One collaborative frame is 5 maps: a 32x32 layer with 256 output channels is then 40
@@ -585,9 +595,9 @@ def small_batch_splitk(pc, N, H, W):
             return 0
         tiles = N * ((H // 2) * (W // 2) // 128) * (pc.Cout // rows)
         chunks = pc.C0 // 32
-        if tiles >= 200 or chunks < 8:                 # (conv3_1, 4 chunks: two ranges + the reduce launch 21 us against 20 unsplit)
+        if tiles >= _splitk_gate() or chunks < 8:                 # (conv3_1, 4 chunks: two ranges + the reduce launch 21 us against 20 unsplit)
             return 0
-        want = min(chunks // 2, -(-320 // tiles))
+        want = min(chunks // 2, -(-(getattr(_latency, "target", 0) or 320) // tiles))
         while want > 1 and -(-chunks // want) * (want - 1) >= chunks:
             want -= 1
         return want if want > 1 else 0
@@ -599,9 +609,9 @@ def small_batch_splitk(pc, N, H, W):
     # Measured (one frame = 5 maps / eight = 40, tools/layer_profile.py): a split pays when the unsplit launch has fewer than ~200 tiles
     # AND every range keeps >= 2 chunks (conv6_2, 4 chunks: 4 ranges of one 35 us vs 32 unsplit); the 4-wave kernel WITHOUT a split is slower
     # than the 8-wave forms even at 160 workgroups (conv5_1 at 40 maps: 163 vs 137 us), so there is no "more, smaller tiles" mode.
-    if pc.Cout2 or tiles >= 200 or chunks < 4:
+    if pc.Cout2 or tiles >= _splitk_gate() or chunks < 4:
         return 0
-    want = min(chunks // 2, -(-320 // tiles))
+    want = min(chunks // 2, -(-(getattr(_latency, "target", 0) or 320) // tiles))
     while want > 1 and -(-chunks // want) * (want - 1) >= chunks:     # no empty range
         want -= 1
     return want if want > 1 else 0

@@ -159,12 +159,14 @@ def hip_eligible(weight, stride, H, W, cin_pad=None):
 
 
 def _run_layer(layer, x):
-    """ops.run_layer as a DECLARED small-batch launch (TRAIN_SPLITK 1, round 6): at 10 maps the deep layers of a training step are 40-160 workgroups on 256
-    CUs, each walking all of its input chunks; inside ops.latency_dispatch() the streamed layers with fewer than 200 tiles split their chunk ranges
-    over 2-4 workgroups per tile (ops.small_batch_splitk: partial sums added in range order by one more launch -- fixed order, deterministic).  A
-    training step has no batch-invariance to keep (batch statistics), so the batch-dependent rule is free here; at 40 maps no layer qualifies."""
-    if tuning.get("TRAIN_SPLITK") != 0:
-        with ops.latency_dispatch():
+    """ops.run_layer as a DECLARED small-batch launch (TRAIN_SPLITK, round 6): at 10 maps the deep layers of a training step are 40-160 workgroups on 256
+    CUs, each walking all of its input chunks; inside ops.latency_dispatch() the streamed layers below the gate split their chunk ranges over 2-6
+    workgroups per tile (ops.small_batch_splitk: partial sums added in range order by one more launch -- fixed order, deterministic).  A training step has
+    no batch-invariance to keep (batch statistics), so the batch-dependent rule is free here.  Target 480 workgroups / gate 300 tiles from a paired sweep
+    (FaFNet 4.40 -> 4.22 ms at 10 maps, 6.50 -> 6.38 at 20; at 40 maps no layer qualifies)."""
+    sk = tuning.get("TRAIN_SPLITK")
+    if sk != 0:
+        with ops.latency_dispatch(target=sk if sk > 1 else 0):
             return ops.run_layer(layer, x)
     return ops.run_layer(layer, x)
 
