@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define V2X_AMD_ABI_VERSION 17
+#define V2X_AMD_ABI_VERSION 18
 
 #define V2X_OK 0
 #define V2X_EINVAL (-22) /* bad argument / unsupported shape */
@@ -429,6 +429,31 @@ int v2x_det_loss_backward(const float *cls, const float *labels, const float *lo
  * grid_sampler_2d_backward.  Agreement with torch: fp32 rounding of the coordinate arithmetic (tests/test_gpu_train_kernels.py). */
 int v2x_warp_affine_f32(const float *in, const float *theta, int P, int C, int H, int W, float *out, v2x_stream_t stream);
 int v2x_warp_affine_bwd_f32(const float *dout, const float *theta, int P, int C, int H, int W, float *din, v2x_stream_t stream);
+
+/* f-3 (round 6): V2VNet's message-passing round of the TRAINING graph on bf16 NHWC maps -- no layout or precision change around the fusion stage.
+ * Replaces, of coperception/models/det/V2VNet.py::forward (not in /root/reference; README.md:101 names the model; restated in
+ * v2x_sim_amd/train/graph.py::v2v_fuse): the per-pair index_select, the two feature_transformation passes (F.affine_grid + F.grid_sample: rotation
+ * about the map centre, then translation by (4 T03 / 128, -4 T13 / 128)), the mean over an ego's K neighbours and torch.cat([ego, mean], 1) -- and
+ * their autograd backward.  Every item m = 0 .. M-1 has exactly K pairs, consecutive (pair = m K + k).
+ *   v2x_v2v_message_bf16: cur, base bf16 [N][H][W][C] (the ego maps; the maps the neighbours send -- the same pointer unless a later round sends the
+ *     un-updated maps), trans fp32 [*][4][4], src / tsel int32 [M K] (a pair's row of base / matrix of trans), rows int32 [M] (item m's row of cur)
+ *     -> conv_in bf16 [M][H][W][2C] = [cur[rows[m]] | mean_k warp2(base[src[m K + k]])].  The two resampling passes are evaluated without the
+ *     intermediate map, with the arithmetic and the order of additions of v2x_warp_affine_f32 applied twice (fp32; one bf16 rounding at the store).
+ *   v2x_v2v_message_bwd_bf16: dconv_in bf16 [M][H][W][2C], inv int32 [N][K] (the pairs that read row r of base, in pair order), item_of_row int32 [N]
+ *     (the item whose ego map row r is, or -1) -> dbase bf16 [N][H][W][C], the exact transpose (a gather over both passes' candidate pixels in a
+ *     fixed order: bit-reproducible); dcur = NULL: the ego half is added into dbase (base == cur), else it is written to dcur [N][H][W][C].
+ * The ConvGRU's gates on bf16 NHWC (the arithmetic of v2x_gru_gates_f32): gi bf16 [P][3C] (P = maps x pixels), bias_hh fp32 [3C] -> h bf16 [P][C];
+ * backward: dh bf16 [P][C] -> dgi bf16 [P][3C] and sums6c fp32 [6C] = (channel sums of dgi AS STORED: r, z, n = d bias_ih of the input convolution |
+ * the r and z sums again, the sums of d(pre-activation of n) * r = d bias_hh), per-workgroup partials in workspace
+ * (v2x_gru_gates_nhwc_workspace_size bytes; 0 = unsupported shape) added in a fixed order.  C / 8 must divide 256. */
+int v2x_v2v_message_bf16(const uint16_t *cur, const uint16_t *base, const float *trans, const int *src, const int *tsel, const int *rows, int M, int K, int N,
+                         int C, int H, int W, uint16_t *conv_in, v2x_stream_t stream);
+int v2x_v2v_message_bwd_bf16(const uint16_t *dconv_in, const float *trans, const int *inv, const int *tsel, const int *item_of_row, int M, int K, int N, int C,
+                             int H, int W, uint16_t *dbase, uint16_t *dcur, v2x_stream_t stream);
+int v2x_gru_gates_nhwc_bf16(const uint16_t *gi, const float *bias_hh, long long P, int C, uint16_t *h, v2x_stream_t stream);
+long long v2x_gru_gates_nhwc_workspace_size(long long P, int C);
+int v2x_gru_gates_nhwc_bwd_bf16(const uint16_t *gi, const float *bias_hh, const uint16_t *dh, long long P, int C, uint16_t *dgi, float *sums6c,
+                                float *workspace, v2x_stream_t stream);
 
 /* f-3: the decoder's up + concat of the TRAINING graph and its backward (the inference kernels fold it into their loaders: v2x_conv_desc.up0).
  * Replaces torch.cat((F.interpolate(x, scale_factor=(2, 2)), skip), dim=1) of Backbone.py::LidarDecoder and its autograd backward.

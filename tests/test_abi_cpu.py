@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
     for n in names:
         assert hasattr(lib, n), n
-    assert lib.v2x_abi_version() == _lib.ABI_VERSION == 17
+    assert lib.v2x_abi_version() == _lib.ABI_VERSION == 18
 
 
 def test_conv_desc_mirror_matches_header():

@@ -777,8 +777,9 @@ def test_v2vnet_hip_graph_warp_on_kernels_matches_grid_sample_path(device, tune)
         graph._affine_sample_override = None
     print("fp32 graph, warp on the kernels vs grid_sample: loss %.6f vs %.6f, gradient difference %.2e of the norm" % (l1, l0, rel(g1, g0)))
     assert set(g1) == set(g0) and abs(l1 - l0) <= 1e-5 * max(1.0, abs(l0)) and rel(g1, g0) < 1e-2
-    # (b) HIP graph
+    # (b) HIP graph (the fp32 fusion stage: round 6's NHWC stage has its own tests below)
     tune("TRAIN_HIP", 1)
+    tune("TRAIN_V2V_NHWC", 0)
     tune("WARP_HIP", 1)
     l1, g1 = run()
     l1b, g1b = run()
@@ -1341,3 +1342,162 @@ def test_vectorised_wgrad_reduce_equals_the_scalar_form_bitwise(device, tune, N,
     old = ops.conv3x3_wgrad(x, dy, cin_out=cin_out)
     tune.reset("WGRAD_REDUCE4")
     assert new.shape == old.shape == (Cout, cin_out or Cin, 3, 3) and torch.equal(new, old), float((new - old).abs().max())
+
+
+# ------------------------------------------------------------------ V2VNet's fusion stage on bf16 NHWC (csrc/v2v_train.hip, round 6)
+def _v2v_case(A, B, C, H, W, seed, device, shrink=False):
+    """Agent-major maps, poses (small rotations + translations of a few cells, one pair pushed mostly off the map) and the plan tables of hip_graph._v2v_plan."""
+    from v2x_sim_amd.models.det.base import IntermediateModelBase
+    from v2x_sim_amd.train import hip_graph
+    g = torch.Generator().manual_seed(seed)
+    N = A * B
+    feat = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    ang = (torch.rand(B, A, A, generator=g) - 0.5) * 1.2
+    T = torch.zeros(B, A, A, 4, 4)
+    T[..., 0, 0], T[..., 0, 1], T[..., 1, 0], T[..., 1, 1] = torch.cos(ang), -torch.sin(ang), torch.sin(ang), torch.cos(ang)
+    T[..., 0, 3] = (torch.rand(B, A, A, generator=g) - 0.5) * 12.0
+    T[..., 1, 3] = (torch.rand(B, A, A, generator=g) - 0.5) * 12.0
+    T[0, 0, 1, 0, 3] = 40.0          # one neighbour almost entirely outside the ego's map
+    T[..., 2, 2] = T[..., 3, 3] = 1.0
+    if shrink:                       # a strongly shrinking pose: many output pixels per input pixel -- the backward kernel's direct loops
+        T[0, 1, 0, :2, :2] *= 0.3
+    nat = torch.full((B, A), A)
+    counts, items, rows = IntermediateModelBase.frame_plan(nat, B, A)
+
+    class _M:        # (the plan cache lives in the model's __dict__)
+        pass
+    plan = hip_graph._v2v_plan(_M(), counts, items, rows, B, A, T, N, device)
+    assert plan is not None and plan["identity"]
+    return feat, T, plan, counts, items
+
+
+def _v2v_reference(base32, cur32, T, counts, items, B):
+    """graph.py::v2v_fuse's message + concat with torch ops (F.grid_sample twice per pair, mean, cat) on fp32 NCHW maps."""
+    from v2x_sim_amd.train import graph
+    pairs = [(m, j * B + f, f, a, j) for m, (a, f) in enumerate(items) for j in range(counts[f]) if j != a]
+    src = torch.tensor([p[1] for p in pairs])
+    Tp = torch.stack([T[f, a, j] for (_, _, f, a, j) in pairs])
+    warped = graph.warp_batch(base32.index_select(0, src), Tp)
+    K = counts[0] - 1
+    mean = warped.view((len(items), K) + tuple(base32.shape[1:])).mean(1)
+    return torch.cat([cur32, mean], 1)
+
+
+@pytest.mark.parametrize("A,B,C,H,W,two,shrink", [(3, 2, 32, 16, 32, False, False), (5, 1, 64, 32, 32, False, False), (4, 2, 32, 8, 32, True, False),
+                                                  (2, 3, 256, 32, 32, False, False), (3, 1, 512, 16, 16, False, False), (3, 1, 32, 16, 32, False, True),
+                                                  (5, 1, 96, 12, 20, True, False)])
+def test_v2v_message_forward_and_backward_vs_torch(device, A, B, C, H, W, two, shrink):
+    """v2x_v2v_message_bf16 / _bwd_bf16 against F.grid_sample o F.grid_sample, mean, cat and their autograd backward in fp32 on the same bf16 maps: the
+    forward to one bf16 rounding of the value (+ the coordinate arithmetic's fp32 noise), the backward likewise and as the exact transpose of the forward
+    (<d, F(x)> == <F^T d, x> to fp32 summation noise); bit-identical from run to run."""
+    from v2x_sim_amd import ops
+    feat, T, plan, counts, items = _v2v_case(A, B, C, H, W, 100 * A + C, device, shrink)
+    g = torch.Generator().manual_seed(7)
+    other = torch.randn(feat.shape, generator=g).to(torch.bfloat16)
+    cur, base = (other, feat) if two else (feat, feat)
+    x = base.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    c = cur.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    ref = _v2v_reference(x, c if two else x, T, counts, items, B)
+    Td = T.to(device)
+    got = ops.v2v_message(cur.to(device), base.to(device) if two else None, Td, plan)
+    got2 = ops.v2v_message(cur.to(device), base.to(device) if two else None, Td, plan)
+    assert torch.equal(got, got2)
+    refn = ref.detach().permute(0, 2, 3, 1)
+    err = (got.cpu().float() - refn).abs()
+    tol = 2.0 ** -8 * refn.abs() + 2e-5 * float(refn.abs().max())
+    assert bool((err <= tol).all()), float((err - tol).max())
+    assert torch.equal(got.cpu()[..., :C], cur)                                   # the ego half is a copy
+    d = torch.randn(ref.shape, generator=g).to(torch.bfloat16)                    # NCHW values
+    ref.backward(d.float())
+    dn = d.permute(0, 2, 3, 1).contiguous().to(device)
+    dbase, dcur = ops.v2v_message_backward(dn, Td, plan, feat.shape[0], two)
+    dbase2, _ = ops.v2v_message_backward(dn, Td, plan, feat.shape[0], two)
+    assert torch.equal(dbase, dbase2)
+    gx = x.grad.permute(0, 2, 3, 1)
+    e = (dbase.cpu().float() - gx).abs()
+    t = 2.0 ** -8 * gx.abs() + 5e-5 * float(gx.abs().max())
+    assert bool((e <= t).all()), float((e - t).max())
+    if two:
+        assert torch.equal(dcur.cpu(), d.permute(0, 2, 3, 1)[..., :C].contiguous())
+    # transpose identity on the message half (fp64 inner products of the kernels' own outputs; bf16 rounding of both sides bounds the mismatch)
+    msg = got.cpu().double()[..., C:]
+    lhs = float((d.permute(0, 2, 3, 1).double()[..., C:] * msg).sum())
+    dmsg_only = dn.clone()
+    dmsg_only[..., :C] = 0
+    db_only, _ = ops.v2v_message_backward(dmsg_only, Td, plan, feat.shape[0], two)
+    rhs = float((db_only.cpu().double() * base.double()).sum())
+    scale = float((d.double().abs().permute(0, 2, 3, 1)[..., C:] * msg.abs()).sum())
+    # (both sides carry one bf16 rounding per element, random in sign: ~2^-9 scale / sqrt(n) ~ 1e-5 scale; unrelated operators would differ by ~4e-3 scale)
+    assert abs(lhs - rhs) <= 1e-4 * scale, (lhs, rhs, scale)
+
+
+@pytest.mark.parametrize("P,C", [(2 * 32 * 32, 256), (3 * 16 * 32, 64), (1001, 32)])
+def test_gru_gates_nhwc_vs_torch(device, P, C):
+    """v2x_gru_gates_nhwc_bf16 / _bwd_bf16 against the PyTorch ops of graph.py::_gru_step in fp32 on the same bf16 pre-activations: h and dgi to one bf16
+    rounding, the six channel-sum vectors against sums of the stored dgi (d bias_ih) and of the fp32 dpre_n * r (d bias_hh); fixed order."""
+    from v2x_sim_amd import ops
+    g = torch.Generator().manual_seed(P + C)
+    gi = (torch.randn(P, 3 * C, generator=g) * 1.5).to(torch.bfloat16)
+    bhh = torch.randn(3 * C, generator=g) * 0.5
+    dh = torch.randn(P, C, generator=g).to(torch.bfloat16)
+    x = gi.float().requires_grad_(True)
+    b = bhh.clone().requires_grad_(True)
+    i_r, i_z, i_n = x.chunk(3, 1)
+    h_r, h_z, h_n = b.view(1, -1).chunk(3, 1)
+    r = torch.sigmoid(i_r + h_r)
+    z = torch.sigmoid(i_z + h_z)
+    n = torch.tanh(i_n + r * h_n)
+    h = n - z * n
+    h.backward(dh.float())
+    got = ops.gru_gates_nhwc(gi.to(device), bhh.to(device))
+    hb = h.detach().to(torch.bfloat16).float()
+    assert bool(((got.cpu().float() - hb).abs() <= 2.0 ** -7 * hb.abs() + 1e-6).all())
+    dgi, sums = ops.gru_gates_nhwc_backward(gi.to(device), bhh.to(device), dh.to(device))
+    dgi2, sums2 = ops.gru_gates_nhwc_backward(gi.to(device), bhh.to(device), dh.to(device))
+    assert torch.equal(dgi, dgi2) and torch.equal(sums, sums2)
+    gb = x.grad.to(torch.bfloat16).float()
+    assert bool(((dgi.cpu().float() - gb).abs() <= 2.0 ** -7 * gb.abs() + 1e-6 * float(gb.abs().max())).all())
+    stored = dgi.cpu().double().sum(0)
+    s = sums.cpu().double()
+    tol = 1e-6 * float(dgi.cpu().double().abs().sum(0).max()) + 1e-7
+    assert float((s[:3 * C] - stored).abs().max()) <= tol
+    assert torch.equal(sums[3 * C:5 * C], sums[:2 * C])
+    ref_bhh = b.grad.double()
+    assert float((s[5 * C:] - ref_bhh[2 * C:]).abs().max()) <= 1e-4 * float(ref_bhh.abs().max()) + 1e-5
+    assert float((s[3 * C:5 * C] - ref_bhh[:2 * C]).abs().max()) <= 2e-3 * float(ref_bhh.abs().max()) + 1e-4      # (sums of bf16-rounded terms vs fp32 terms)
+
+
+@pytest.mark.parametrize("rounds,source", [(1, "initial"), (2, "initial"), (2, "updated")])
+def test_v2vnet_training_step_nhwc_fusion_stage_vs_fp32_stage(device, tune, rounds, source):
+    """A V2VNet training step with the message-passing rounds on bf16 NHWC (TRAIN_V2V_NHWC 1) against the same step with the fp32 NCHW stage around the warp /
+    gates kernels (0): same loss to 2e-3, gradients within the bf16 graph's own amplification (the bound of the WARP_HIP test), every parameter has a
+    gradient either way, bit-reproducible run to run -- and no PyTorch-op launch is left in the stage (asserted on the op names torch.profiler records)."""
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import V2VNet
+    from v2x_sim_amd.train import detection_loss, train_forward
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    cfg = Config("train", binary=True, only_det=True)
+    model = init_for_training(V2VNet(cfg, num_agent=3, gnn_iter_times=rounds, neighbor_source=source), seed=2).to(device).train()
+    data = synthetic_batch_on_device(cfg, 2, 3, seed=5, device=device)
+    tune("TRAIN_HIP", 1)
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        res = train_forward(model, data["bev_seq"], data["trans_matrices"], data["num_agent"], 2)
+        loss = detection_loss(res, data["labels"], data["reg_targets"], data["reg_loss_mask"])[0]
+        loss.backward()
+        return float(loss.detach()), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    def rel(ga, gb):
+        den = sum(float(gb[n].double().pow(2).sum()) for n in gb) ** 0.5
+        return sum(float((ga[n].double() - gb[n].double()).pow(2).sum()) for n in gb) ** 0.5 / den
+    tune("TRAIN_V2V_NHWC", 1)
+    l1, g1 = run()
+    l1b, g1b = run()
+    tune("TRAIN_V2V_NHWC", 0)
+    l0, g0 = run()
+    assert l1 == l1b and all(torch.equal(g1[n], g1b[n]) for n in g1)
+    gru = [n for n in g0 if "convgru" in n]
+    print("V2VNet step, %d round(s), neighbours '%s': loss %.6f (NHWC stage) vs %.6f (fp32 stage); gradient difference %.2e of the norm (ConvGRU parameters alone: %.2e)"
+          % (rounds, source, l1, l0, rel(g1, g0), rel({n: g1[n] for n in gru}, {n: g0[n] for n in gru})))
+    assert set(g1) == set(g0) and abs(l1 - l0) <= 2e-3 * max(1.0, abs(l0)) and rel(g1, g0) < 0.25

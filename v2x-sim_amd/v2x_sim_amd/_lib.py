@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libv2x_amd.so")
 
 V2X_EPI_BF16, V2X_EPI_F32, V2X_EPI_GRU, V2X_EPI_DET = 0, 1, 2, 3
 V2X_FUSE_WSUM, V2X_FUSE_MEAN, V2X_FUSE_MAX = 0, 1, 2
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 
 class ConvDesc(C.Structure):
@@ -86,6 +86,11 @@ SIGNATURES = {
     "v2x_channel_sum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_cast_pad_chsum_workspace_size": (C.c_longlong, [C.c_longlong, C.c_int]),
     "v2x_cast_pad_chsum_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_v2v_message_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
+    "v2x_v2v_message_bwd_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_gru_gates_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),
+    "v2x_gru_gates_nhwc_workspace_size": (C.c_longlong, [C.c_longlong, C.c_int]),
+    "v2x_gru_gates_nhwc_bwd_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_warp_affine_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_warp_affine_bwd_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "v2x_upcat_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

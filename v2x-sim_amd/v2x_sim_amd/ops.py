@@ -669,7 +669,8 @@ def run_layer(layer, in0, in1=None, zbits=0):
 # ------------------------------------------------------------------ rows f-1 and f-3 live in their own modules; `ops.<name>` keeps working
 from .ops_post import conv2d_det, det_nms_candidates, det_postprocess, match_detections, rotated_iou  # noqa: E402,F401
 from .ops_train import (bn_train_backward, bn_train_forward, cast_pad_chsum, channel_sum, conv3x3_wgrad, det_loss_backward, det_loss_forward,  # noqa: E402,F401
-                        gru_gates, gru_gates_backward, upcat, upcat_backward, warp_affine, zero_insert)
+                        gru_gates, gru_gates_backward, gru_gates_nhwc, gru_gates_nhwc_backward, gru_gates_nhwc_ok, upcat, upcat_backward, v2v_message,
+                        v2v_message_backward, warp_affine, zero_insert)
 
 
 # `ops.PROFILE = []` / `ops.PROFILE` (bench.py, tools/): one list for every wrapper module, kept in _launch

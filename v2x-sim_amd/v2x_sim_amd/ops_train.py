@@ -53,6 +53,68 @@ def gru_gates_backward(gi, bias_hh, dh):
     return dgi, dn_r
 
 
+def v2v_message(cur, base, trans, plan):
+    """v2x_v2v_message_bf16: cur, base (N, H, W, C) bf16 NHWC (base None: the same maps), trans fp32 (..., 4, 4) contiguous, plan = the int32 device tables of
+    train/hip_graph.py::_v2v_plan -> conv_in (M, H, W, 2C) bf16 = [cur[rows[m]] | mean over item m's K neighbours of the twice-warped base maps]."""
+    lib = _lib.load()
+    N, H, W, Cc = cur.shape
+    M, K = plan["M"], plan["K"]
+    out = torch.empty((M, H, W, 2 * Cc), dtype=torch.bfloat16, device=cur.device)
+    b = cur if base is None else base
+    _lib.check(lib.v2x_v2v_message_bf16(_dev(cur, torch.bfloat16, "cur"), _dev(b, torch.bfloat16, "base"), _dev(trans, torch.float32, "trans"),
+                                        _dev(plan["src"], torch.int32, "src"), _dev(plan["tsel"], torch.int32, "tsel"), _dev(plan["rows"], torch.int32, "rows"),
+                                        M, K, N, Cc, H, W, _dev(out, torch.bfloat16, "conv_in"), _stream()), "v2x_v2v_message_bf16")
+    return out
+
+
+def v2v_message_backward(dconv_in, trans, plan, N, separate_cur):
+    """v2x_v2v_message_bwd_bf16: dconv_in (M, H, W, 2C) bf16 -> dbase (N, H, W, C) bf16 (the exact transpose of v2v_message w.r.t. base), with the ego half
+    added in (separate_cur False: base and cur were the same maps) or returned beside it as dcur."""
+    lib = _lib.load()
+    M, H, W, C2 = dconv_in.shape
+    Cc = C2 // 2
+    dbase = torch.empty((N, H, W, Cc), dtype=torch.bfloat16, device=dconv_in.device)
+    dcur = torch.empty_like(dbase) if separate_cur else None
+    _lib.check(lib.v2x_v2v_message_bwd_bf16(_dev(dconv_in, torch.bfloat16, "dconv_in"), _dev(trans, torch.float32, "trans"), _dev(plan["inv"], torch.int32, "inv"),
+                                            _dev(plan["tsel"], torch.int32, "tsel"), _dev(plan["item_of_row"], torch.int32, "item_of_row"), M, plan["K"], N, Cc, H, W,
+                                            _dev(dbase, torch.bfloat16, "dbase"), None if dcur is None else _dev(dcur, torch.bfloat16, "dcur"), _stream()),
+               "v2x_v2v_message_bwd_bf16")
+    return dbase, dcur
+
+
+def gru_gates_nhwc_ok(P, Cc):
+    return _lib.load().v2x_gru_gates_nhwc_workspace_size(P, Cc) > 0
+
+
+def gru_gates_nhwc(gi, bias_hh):
+    """v2x_gru_gates_nhwc_bf16: gi (..., 3C) bf16 NHWC, bias_hh (3C,) fp32 -> h (..., C) bf16 (h0 = 0: h = n - z n)."""
+    lib = _lib.load()
+    C3 = gi.shape[-1]
+    P = gi.numel() // C3
+    h = torch.empty(tuple(gi.shape[:-1]) + (C3 // 3,), dtype=torch.bfloat16, device=gi.device)
+    _lib.check(lib.v2x_gru_gates_nhwc_bf16(_dev(gi, torch.bfloat16, "gi"), _dev(bias_hh, torch.float32, "bias_hh"), P, C3 // 3, _dev(h, torch.bfloat16, "h"), _stream()),
+               "v2x_gru_gates_nhwc_bf16")
+    return h
+
+
+def gru_gates_nhwc_backward(gi, bias_hh, dh):
+    """v2x_gru_gates_nhwc_bwd_bf16: -> (dgi like gi, sums (6C,) fp32 = channel sums of dgi as stored (3C: d bias_ih) | d bias_hh (3C)); fixed order."""
+    lib = _lib.load()
+    C3 = gi.shape[-1]
+    Cc = C3 // 3
+    P = gi.numel() // C3
+    nbytes = lib.v2x_gru_gates_nhwc_workspace_size(P, Cc)
+    if nbytes == 0:
+        raise ValueError("gru_gates_nhwc_backward: C / 8 must divide 256, got C=%d" % Cc)
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=gi.device)
+    dgi = torch.empty_like(gi)
+    sums = torch.empty((6 * Cc,), dtype=torch.float32, device=gi.device)
+    _lib.check(lib.v2x_gru_gates_nhwc_bwd_bf16(_dev(gi, torch.bfloat16, "gi"), _dev(bias_hh, torch.float32, "bias_hh"), _dev(dh, torch.bfloat16, "dh"), P, Cc,
+                                               _dev(dgi, torch.bfloat16, "dgi"), _dev(sums, torch.float32, "sums6c"), _dev(ws, torch.float32, "workspace"), _stream()),
+               "v2x_gru_gates_nhwc_bwd_bf16")
+    return dgi, sums
+
+
 def det_loss_forward(cls, labels, loc, targets, mask, alpha, beta):
     """v2x_det_loss_forward: fp32 contiguous device tensors cls / labels (n, 2), loc / targets (n, 6), mask (n,) bool or uint8 ->
     out4 (4,) fp32 = (loss, cls_loss, loc_loss, n_pos clamped to >= 1)."""

@@ -525,6 +525,106 @@ class _AffineSample(torch.autograd.Function):
         return ops.warp_affine(dy.contiguous(), theta, backward=True), None
 
 
+# ---------------------------------------------------------------------------------------------- V2VNet's fusion stage on bf16 NHWC (round 6)
+class _V2VMessage(torch.autograd.Function):
+    """cur (N, H, W, C) [, base] -> conv_in (M, H, W, 2C) = [ego map | mean over the neighbours of the twice-warped base maps] (csrc/v2v_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, cur, base, trans, plan):
+        ctx.plan, ctx.N, ctx.two = plan, cur.shape[0], base is not None
+        ctx.save_for_backward(trans)
+        return ops.v2v_message(cur.contiguous(), None if base is None else base.contiguous(), trans, plan)
+
+    @staticmethod
+    def backward(ctx, d):
+        trans, = ctx.saved_tensors
+        dbase, dcur = ops.v2v_message_backward(d.contiguous(), trans, ctx.plan, ctx.N, ctx.two)
+        return (dcur, dbase, None, None) if ctx.two else (dbase, None, None, None)
+
+
+class _GruGatesNhwc(torch.autograd.Function):
+    """graph.py::_gru_step's gate arithmetic on the bf16 NHWC pre-activations of the input convolution; the backward also produces both bias gradients
+    (the convolution's, attached to dgi for _Conv3x3.backward, and bias_hh's) from per-workgroup partial sums -- no reduction pass over dgi."""
+
+    @staticmethod
+    def forward(ctx, gi, bias_hh):
+        bhh = bias_hh.detach().float().contiguous()
+        ctx.save_for_backward(gi, bhh)
+        return ops.gru_gates_nhwc(gi, bhh)
+
+    @staticmethod
+    def backward(ctx, dh):
+        gi, bhh = ctx.saved_tensors
+        dgi, sums = ops.gru_gates_nhwc_backward(gi, bhh, dh.contiguous())
+        c3 = gi.shape[-1]
+        dgi._v2x_chsum = (dgi._version, sums[:c3])
+        return dgi, (sums[c3:] if ctx.needs_input_grad[1] else None)
+
+
+def _v2v_plan(model, counts, items, rows, B, A, trans, N, device):
+    """The int32 device tables of one (agent table, B): graph.py::v2v_fuse's pair enumeration (pairs of an ego item consecutive, neighbours in agent order)."""
+    A1, A2 = trans.shape[1], trans.shape[2]
+    key = (tuple(counts), B, A, A1, A2, str(device))
+    cache = model.__dict__.setdefault("_v2v_nhwc_plan_cache", {})
+    plan = cache.get(key)
+    if plan is None:
+        pairs = [(m, j * B + f, f, a, j) for m, (a, f) in enumerate(items) for j in range(counts[f]) if j != a]
+        K = counts[0] - 1
+        uses = {}
+        for pi, p in enumerate(pairs):
+            uses.setdefault(p[1], []).append(pi)
+        ok = len(pairs) == len(items) * K and len(uses) == N and all(len(v) == K for v in uses.values())
+        cache.clear()
+        if not ok:
+            plan = cache[key] = False
+        else:
+            i32 = lambda v: torch.tensor(v, dtype=torch.int32, device=device)  # noqa: E731
+            item_of_row = [-1] * N
+            for m, r in enumerate(rows):
+                item_of_row[r] = m
+            plan = cache[key] = {"M": len(items), "K": K, "src": i32([p[1] for p in pairs]), "tsel": i32([(f * A1 + a) * A2 + j for (_, _, f, a, j) in pairs]),
+                                 "rows": i32(rows), "inv": i32([uses[r] for r in range(N)]), "item_of_row": i32(item_of_row),
+                                 "identity": list(rows) == list(range(N)), "rows_long": torch.tensor(rows, device=device)}
+    return plan or None
+
+
+def v2v_fuse_nhwc(model, feat, trans, num_agent_tensor, B):
+    """V2VNet's message-passing rounds on the bf16 NHWC fusion-layer maps feat (A*B, H, W, C): per round a message launch, the ConvGRU's input convolution and
+    a gates launch (TRAIN_V2V_NHWC 1).  -> the updated maps, or None when this form does not cover the batch (a frame with fewer agents than another, a
+    channel count or extent the kernels do not tile): the caller then runs graph.v2v_fuse on the fp32 graph."""
+    if tuning.get("TRAIN_V2V_NHWC") == 0 or feat.dtype != BF16 or trans is None:
+        return None
+    g = model.convgru
+    N, H, W, C = feat.shape
+    A = model.agent_num
+    counts, items, rows = model.frame_plan(num_agent_tensor, B, A)
+    if min(counts) < 2:
+        raise RuntimeError("V2VNet needs >= 2 agents in every frame (stack expects a non-empty TensorList)")
+    w = g.weight_ih_l0
+    if min(counts) != max(counts) or tuple(w.shape) != (3 * C, 2 * C, 3, 3) or C % 32 or not hip_eligible(w, 1, H, W) or not ops.gru_gates_nhwc_ok(N * H * W, C) \
+            or g.bias_ih_l0 is None or g.bias_hh_l0 is None:
+        return None
+    plan = _v2v_plan(model, counts, items, rows, B, A, trans, N, feat.device)
+    if plan is None:
+        return None
+    T = trans.detach().to(torch.float32).contiguous()
+    cur = feat
+    for _ in range(model.gnn_rounds()):
+        base = cur if model.neighbor_source == "updated" else feat
+        conv_in = _V2VMessage.apply(cur, None if base is cur else base, T, plan)
+        h = _GruGatesNhwc.apply(_Conv3x3.apply(conv_in, w, g.bias_ih_l0, 1), g.bias_hh_l0)
+        cur = h if plan["identity"] else cur.index_copy(0, plan["rows_long"], h)
+    return cur
+
+
+def _v2v_stage(model, feat, T, num_agent_tensor, batch_size):
+    from . import graph
+    out = v2v_fuse_nhwc(model, feat, T, num_agent_tensor, batch_size)
+    if out is None:      # warp + gate arithmetic on the fp32 graph, the GRU's convolution on the kernels (rounds 3-5's form)
+        out, = _fused_on_fp32_graph(graph.v2v_fuse, model, feat, T, num_agent_tensor, batch_size, _gru_conv_hip)
+    return out
+
+
 def _fused_on_fp32_graph(fuse, model, feat, *args):
     """The cross-agent fusion runs on the fp32 NCHW graph (train/graph.py): convert the fusion-layer maps, fuse, convert back.  The warp
     inside it (graph.warp_batch) runs on the hand-written kernels, forward and backward (WARP_HIP=0: F.grid_sample and its atomic backward)."""
@@ -569,15 +669,15 @@ def _train_forward(model, bevs, trans_matrices=None, num_agent_tensor=None, batc
             y = decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x))
         else:
             feats = encoder(model.u_encoder, x)
-            feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size, _gru_conv_hip)
+            feats[model.layer] = _v2v_stage(model, feats[model.layer], T, num_agent_tensor, batch_size)
             y = decoder(model.decoder, *feats)
         return conv1x1(y, model.outc.conv.weight, model.outc.conv.bias, f32_out=True)
     if hasattr(model, "stpn"):                      # FaFNet: lowerbound / upperbound
         return heads(model, decoder(model.stpn.decoder, *encoder(model.stpn.encoder, x)))
     feats = encoder(model.u_encoder, x)
     res_extra = {}
-    if hasattr(model, "convgru"):                   # V2VNet: warp + gate arithmetic on the fp32 graph, the GRU's convolution on the kernels
-        feats[model.layer], = _fused_on_fp32_graph(graph.v2v_fuse, model, feats[model.layer], T, num_agent_tensor, batch_size, _gru_conv_hip)
+    if hasattr(model, "convgru"):                   # V2VNet: the message-passing rounds on the kernels (v2v_fuse_nhwc); a ragged batch on the fp32 graph
+        feats[model.layer] = _v2v_stage(model, feats[model.layer], T, num_agent_tensor, batch_size)
     elif hasattr(model, "query_key_net"):           # when2com / who2com: its key / query tower reads the input on the fp32 graph
         x32 = bevs[:, 0].permute(0, 3, 1, 2).to(torch.float32)
         fused, prob, coef = _fused_on_fp32_graph(lambda m, f: graph.when2com_fuse(m, x32, f, T, num_agent_tensor, batch_size, model.training, inference),
