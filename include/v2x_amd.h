@@ -455,6 +455,24 @@ long long v2x_gru_gates_nhwc_workspace_size(long long P, int C);
 int v2x_gru_gates_nhwc_bwd_bf16(const uint16_t *gi, const float *bias_hh, const uint16_t *dh, long long P, int C, uint16_t *dgi, float *sums6c,
                                 float *workspace, v2x_stream_t stream);
 
+/* f-3 (round 6): the optimizer step.  Adam with torch.optim.Adam's arithmetic (the optimizer upstream's train scripts build, README.md:101:
+ *     g = grad (+ weight_decay p);  m += (1 - beta1)(g - m);  v = beta2 v + (1 - beta2) g g;  p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps))
+ * over up to V2X_ADAM_MAX_TENSORS parameter tensors in ONE launch.  `tensors` is a HOST table of DEVICE fp32 pointers (it travels in the kernel
+ * arguments: nothing is uploaded, the launch is capturable); step[i] = the tensor's DEVICE step counter t, already incremented (capturable optimizers),
+ * or NULL: t = step_host.  lr_dev = a DEVICE learning rate or NULL: lr.  The hyper-parameters are doubles, as Python holds them: 1 - beta and 1 - beta^t
+ * are formed in fp64 ((float)0.999 is 1.3e-5 away from 0.999 in 1 - beta2^t), the per-element arithmetic is fp32.  Tensors with numel 0 are skipped. */
+#define V2X_ADAM_MAX_TENSORS 72
+typedef struct v2x_adam_tensors {
+    float *param[V2X_ADAM_MAX_TENSORS];
+    const float *grad[V2X_ADAM_MAX_TENSORS];
+    float *exp_avg[V2X_ADAM_MAX_TENSORS];
+    float *exp_avg_sq[V2X_ADAM_MAX_TENSORS];
+    const float *step[V2X_ADAM_MAX_TENSORS];
+    long long numel[V2X_ADAM_MAX_TENSORS];
+} v2x_adam_tensors;
+int v2x_adam_step_f32(const v2x_adam_tensors *tensors, int n_tensors, const float *lr_dev, double lr, double beta1, double beta2, double eps, double weight_decay,
+                      double step_host, v2x_stream_t stream);
+
 /* f-3: the decoder's up + concat of the TRAINING graph and its backward (the inference kernels fold it into their loaders: v2x_conv_desc.up0).
  * Replaces torch.cat((F.interpolate(x, scale_factor=(2, 2)), skip), dim=1) of Backbone.py::LidarDecoder and its autograd backward.
  * lo bf16 [N][H][W][C0] (H, W = the LOW-resolution extent), skip bf16 [N][2H][2W][C1] -> out bf16 [N][2H][2W][C0 + C1] (lo's channels first).

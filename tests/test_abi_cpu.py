@@ -81,7 +81,7 @@ def test_tile_rows_and_validation_without_gpu():
 # ---- every prototype of the header against the ctypes signature table, argument by argument -------------------------
 _INT = {"int": 4, "int32_t": 4, "uint32_t": 4, "unsigned": 4, "unsigned int": 4, "int64_t": 8, "long long": 8, "unsigned long long": 8, "size_t": 8,
         "uint64_t": 8}
-_STRUCTS = {"v2x_conv_desc": "ConvDesc", "v2x_pack_spec": "PackSpec", "v2x_pack_job": "PackJob"}
+_STRUCTS = {"v2x_conv_desc": "ConvDesc", "v2x_pack_spec": "PackSpec", "v2x_pack_job": "PackJob", "v2x_adam_tensors": "AdamTensors"}
 
 
 def _c_kind(ctype_text):
@@ -186,3 +186,29 @@ def test_pack_structs_mirror_the_header():
         for (n, k), (_, ct) in zip(fields, mirror):
             assert k == _ctypes_kind(ct)[:2], (cname, n, k, ct)
         assert C.sizeof(getattr(_lib, pyname)) % 4 == 0
+
+
+def test_adam_tensor_table_mirrors_the_header():
+    """v2x_adam_tensors (six arrays of V2X_ADAM_MAX_TENSORS entries, passed by host pointer): names, order, element sizes and length against _lib.AdamTensors;
+    the table must fit the kernel-argument segment (4 KiB) with the launch's scalars."""
+    import ctypes as C
+    from v2x_sim_amd import _lib
+    src = open(HEADER).read()
+    n = int(re.search(r"#define V2X_ADAM_MAX_TENSORS (\d+)", src).group(1))
+    assert n == _lib.ADAM_MAX_TENSORS
+    body = re.search(r"typedef struct v2x_adam_tensors \{(.*?)\} v2x_adam_tensors;", src, flags=re.S).group(1)
+    fields = []
+    for decl in body.split(";"):
+        decl = " ".join(decl.split())
+        if not decl:
+            continue
+        m = re.match(r"^(.*?)(\w+)\[V2X_ADAM_MAX_TENSORS\]$", decl)
+        assert m, decl
+        fields.append((m.group(2), 8))          # pointers and long long: 8 bytes each
+    mirror = _lib.AdamTensors._fields_
+    assert [f[0] for f in fields] == [f[0] for f in mirror]
+    for (_, size), (_, ct) in zip(fields, mirror):
+        assert ct._length_ == n and C.sizeof(ct._type_) == size
+    assert C.sizeof(_lib.AdamTensors) == 6 * 8 * n
+    # device-side table: 5 pointers + int numel + int start (+1) per tensor, + 56 bytes of scalars
+    assert n * (5 * 8 + 4) + (n + 1) * 4 + 56 <= 4096

@@ -446,11 +446,14 @@ def test_graphed_step_keeps_optimizer_state_and_survives_epochs(device, tune):
         opt.step()
         return float(loss.detach())
 
+    from v2x_sim_amd.train.optim import use_hip_adam
+    # (both optimizers on the library's step from the start: GraphedTrainStep switches a plain torch.optim.Adam anyway, and torch's own step differs from it
+    #  by fp32 rounding, which the bf16 weight packing turns into 1e-4-level loss differences within two steps)
     ref = copy.deepcopy(base).train()
-    opt_r = torch.optim.Adam(ref.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True)
+    opt_r = use_hip_adam(torch.optim.Adam(ref.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True))
     losses_r = [eager_step(ref, opt_r, d) for d in batches]
     mixed = copy.deepcopy(base).train()
-    opt_m = torch.optim.Adam(mixed.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True)
+    opt_m = use_hip_adam(torch.optim.Adam(mixed.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True))
     losses_m = [eager_step(mixed, opt_m, d) for d in batches[:3]]
     p0 = next(iter(opt_m.state))
     before = {k: v.clone() for k, v in opt_m.state[p0].items() if torch.is_tensor(v)}
@@ -1501,3 +1504,92 @@ def test_v2vnet_training_step_nhwc_fusion_stage_vs_fp32_stage(device, tune, roun
     print("V2VNet step, %d round(s), neighbours '%s': loss %.6f (NHWC stage) vs %.6f (fp32 stage); gradient difference %.2e of the norm (ConvGRU parameters alone: %.2e)"
           % (rounds, source, l1, l0, rel(g1, g0), rel({n: g1[n] for n in gru}, {n: g0[n] for n in gru})))
     assert set(g1) == set(g0) and abs(l1 - l0) <= 2e-3 * max(1.0, abs(l0)) and rel(g1, g0) < 0.25
+
+
+# ------------------------------------------------------------------ the optimizer step (csrc/adam.hip, train/optim.py; round 6)
+@pytest.mark.parametrize("mode,wd", [("capturable", 0.0), ("fused", 0.0), ("plain", 0.0), ("capturable", 0.01), ("plain", 0.01)])
+def test_hip_adam_matches_torch_adam(device, tune, mode, wd):
+    """train/optim.py::HipAdam (v2x_adam_step_f32) against torch.optim.Adam on the same parameters and gradients, 6 steps: parameters and both moments agree
+    to fp32 rounding of the update; 150 tensors of odd sizes (three launches, scalar tails, a zero-element tensor, one tensor that joins late in the
+    non-capturable modes' fallback); the state dicts are interchangeable both ways."""
+    from v2x_sim_amd.train.optim import HipAdam, use_hip_adam
+    g = torch.Generator().manual_seed(11)
+    sizes = [1, 7, 4096, 5000, 100003, 16384, 0] + [int(s) for s in torch.randint(1, 3000, (143,), generator=g)]
+    base = [torch.randn(n, generator=g) for n in sizes]
+    pa = [torch.nn.Parameter(b.clone().to(device)) for b in base]
+    pb = [torch.nn.Parameter(b.clone().to(device)) for b in base]
+    kw = dict(betas=(0.9, 0.999), eps=1e-8, weight_decay=wd)
+    if mode == "capturable":
+        kw.update(lr=torch.tensor(3e-3, device=device), capturable=True)
+    elif mode == "fused":
+        kw.update(lr=3e-3, fused=True)
+    else:
+        kw.update(lr=3e-3)
+    ref = torch.optim.Adam(pa, **{k: (v.clone() if torch.is_tensor(v) else v) for k, v in kw.items()}, **({} if mode == "fused" else {"foreach": True}))
+    opt = use_hip_adam(torch.optim.Adam(pb, **kw))
+    assert isinstance(opt, HipAdam)
+    tune("TRAIN_ADAM_HIP", 1)
+    for it in range(6):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).to(device) * (0.1 + it)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        ref.step()
+        opt.step()
+    for i, (a, b) in enumerate(zip(pa, pb)):
+        assert torch.allclose(a, b, rtol=2e-6, atol=2e-7), (i, sizes[i], float((a - b).abs().max()))
+        if a.numel():
+            sa, sb = ref.state[a], opt.state[b]
+            # (fp32 rounding of the two forms of the moving averages, relative to the tensor's scale: an element of m near zero is a cancelling sum)
+            assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-5, atol=1e-6 * float(sa["exp_avg"].abs().max()))
+            assert torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-5, atol=1e-6 * float(sa["exp_avg_sq"].abs().max()))
+            assert float(sa["step"]) == float(sb["step"]) == 6.0
+    # interchangeable state
+    import copy
+    ref.load_state_dict(copy.deepcopy(opt.state_dict()))          # (load_state_dict keeps same-device tensors by reference: copies, or the two would share moments)
+    opt.load_state_dict(copy.deepcopy(ref.state_dict()))
+    for a, b in zip(pa, pb):
+        gr = torch.randn(a.shape, generator=g).to(device)
+        a.grad, b.grad = gr.clone(), gr.clone()
+    ref.step()
+    opt.step()
+    assert all(torch.allclose(a, b, rtol=2e-6, atol=2e-7) for a, b in zip(pa, pb))
+    # the switch off: torch's own step inside the same object
+    tune("TRAIN_ADAM_HIP", 0)
+    opt.step()
+    ref.step()
+    assert all(torch.allclose(a, b, rtol=2e-6, atol=2e-7) for a, b in zip(pa, pb))
+
+
+def test_hip_adam_step_is_captured_with_the_training_step(device, tune):
+    """GraphedTrainStep with a plain torch.optim.Adam(capturable=True): the optimizer is switched to the library's kernel, the captured step contains no
+    multi_tensor_apply launch of torch's fused Adam, and three replays equal three eager steps of a twin model on torch's own Adam to 1e-5 of the weights' scale."""
+    from v2x_sim_amd.configs import Config
+    from v2x_sim_amd.models.det import FaFNet
+    from v2x_sim_amd.train.graph_step import GraphedTrainStep
+    from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device
+    from v2x_sim_amd.train.optim import HipAdam
+    import copy
+    tune("TRAIN_HIP", 1)
+    cfg = Config("train", binary=True, only_det=True)
+    m1 = init_for_training(FaFNet(cfg, kd_flag=0, num_agent=2), seed=3).to(device).train()
+    m0 = copy.deepcopy(m1)
+    data = synthetic_batch_on_device(cfg, 1, 2, seed=4, device=device)
+    o1 = torch.optim.Adam(m1.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True)
+    step1 = GraphedTrainStep(m1, o1, data, 1)
+    assert isinstance(o1, HipAdam)
+    tune("TRAIN_ADAM_HIP", 0)
+    o0 = torch.optim.Adam(m0.parameters(), lr=torch.tensor(1e-3, device=device), capturable=True)
+    step0 = GraphedTrainStep(m0, o0, data, 1)
+    assert type(o0) is torch.optim.Adam
+    for _ in range(3):
+        l1 = step1(data)[0]
+        l0 = step0(data)[0]
+    torch.cuda.synchronize()
+    assert abs(float(l1) - float(l0)) <= 5e-3 * max(1.0, abs(float(l0)))
+    # Adam normalises the gradient: where it is near zero, bf16-level differences between the two runs decide its sign, and each step moves the parameter by up
+    # to lr either way -- the bound is 2 x 3 steps x lr absolute, plus 1 % of the tensor's scale
+    worst = 0.0
+    for (n, a), (_, b) in zip(m1.named_parameters(), m0.named_parameters()):
+        worst = max(worst, float((a - b).abs().max()) / (6 * 1e-3 + 1e-2 * float(b.abs().max())))
+    print("three captured steps, HIP Adam vs torch Adam: loss %.6f vs %.6f, worst parameter difference %.2f of its bound" % (float(l1), float(l0), worst))
+    assert worst <= 1.0

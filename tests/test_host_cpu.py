@@ -234,3 +234,13 @@ def test_latency_dispatch_is_per_thread():
                         "worker_out": False}, seen
     finally:
         tuning.set("SMALL_BATCH", old)
+
+
+def test_use_hip_adam_leaves_cpu_and_foreign_optimizers_alone():
+    """train/optim.py::use_hip_adam switches only a plain torch.optim.Adam whose parameters are CUDA fp32 tensors (the kernel has no CPU form)."""
+    from v2x_sim_amd.train.optim import use_hip_adam
+    p = torch.nn.Parameter(torch.randn(5))
+    for opt in (torch.optim.Adam([p], lr=1e-3), torch.optim.SGD([p], lr=1e-3), torch.optim.AdamW([p], lr=1e-3)):
+        cls = type(opt)
+        assert use_hip_adam(opt) is opt and type(opt) is cls
+    assert use_hip_adam(None) is None

@@ -51,6 +51,15 @@ class PackSpec(C.Structure):
                 ("src_rows", C.c_int32), ("src_row0", C.c_int32)]
 
 
+ADAM_MAX_TENSORS = 72     # V2X_ADAM_MAX_TENSORS
+
+
+class AdamTensors(C.Structure):
+    """Mirror of `struct v2x_adam_tensors` (include/v2x_amd.h): a host table of device pointers."""
+    _fields_ = [("param", C.c_void_p * ADAM_MAX_TENSORS), ("grad", C.c_void_p * ADAM_MAX_TENSORS), ("exp_avg", C.c_void_p * ADAM_MAX_TENSORS),
+                ("exp_avg_sq", C.c_void_p * ADAM_MAX_TENSORS), ("step", C.c_void_p * ADAM_MAX_TENSORS), ("numel", C.c_int64 * ADAM_MAX_TENSORS)]
+
+
 # name -> (restype, argtypes); every symbol include/v2x_amd.h declares
 SIGNATURES = {
     "v2x_abi_version": (C.c_int, []),
@@ -86,6 +95,7 @@ SIGNATURES = {
     "v2x_channel_sum_bf16": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_cast_pad_chsum_workspace_size": (C.c_longlong, [C.c_longlong, C.c_int]),
     "v2x_cast_pad_chsum_f32": (C.c_int, [C.c_void_p, C.c_longlong, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "v2x_adam_step_f32": (C.c_int, [C.POINTER(AdamTensors), C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_void_p]),
     "v2x_v2v_message_bf16": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p]),
     "v2x_v2v_message_bwd_bf16": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 6 + [C.c_void_p, C.c_void_p, C.c_void_p]),
     "v2x_gru_gates_nhwc_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p]),

@@ -44,6 +44,8 @@ def watch_optimizer(opt):
     """Idempotent: after every opt.step() the packed-weight caches see the optimizer's parameters as changed."""
     if opt is None or opt.__dict__.get("_v2x_watched") or not hasattr(opt, "register_step_post_hook"):
         return opt
+    from .train.optim import use_hip_adam
+    use_hip_adam(opt)                    # a plain torch.optim.Adam on CUDA fp32 parameters steps on the library's kernel from here on (same state, same hooks)
 
     def _hook(o, *_a, **_k):
         for g in o.param_groups:

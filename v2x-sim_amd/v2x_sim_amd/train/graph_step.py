@@ -25,6 +25,8 @@ class GraphedTrainStep:
         for g in optimizer.param_groups:
             if "capturable" in g and not g["capturable"]:
                 raise ValueError("GraphedTrainStep needs an optimizer created with capturable=True (its step counter lives on the host otherwise)")
+        from .optim import use_hip_adam
+        use_hip_adam(optimizer)          # (a plain torch.optim.Adam steps on the library's kernel: train/optim.py)
         self.model, self.optimizer, self.batch_size = model, optimizer, batch_size
         self.normalizer = normalizer     # configs.Config.loss_normalizer (oracle/ASSUMPTIONS.md row 49)
         self.static = {k: data[k].clone() for k in _KEYS if data.get(k) is not None}

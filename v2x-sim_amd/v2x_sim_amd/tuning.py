@@ -40,13 +40,15 @@ Host-side switches (this module):
                    step; swept 160 ... 800, profiles/r06_train_switch_ab_4.txt); 1: the one-frame inference rule (320 / 200); 0: one workgroup per tile at any batch
     TRAIN_V2V_NHWC 1  with TRAIN_HIP: V2VNet's message-passing rounds on the bf16 NHWC maps (csrc/v2v_train.hip: message, input convolution, gates -- four launches
                    forward, four backward per round) when every frame of the batch has the same number of agents; 0: the fp32 NCHW graph around the warp / gates kernels
+    TRAIN_ADAM_HIP 1  a plain torch.optim.Adam handed to FaFModule / SegModule / make_optimizer / GraphedTrainStep steps on v2x_adam_step_f32 (train/optim.py: same state,
+                   same update; one launch per 72 tensors); 0: torch's own step
     TRAIN_HIP_CONV 0  only the eligible 3x3 layers of the fp32 graph on the kernels (the first step of row f-3, kept for its tests)
 Retired in round 6 (their alternate forms had been measured slower for two rounds or more and no test or tool exercised them): S2_RESIDENT, S2_T16, PP_64, UPCAT_HIP.
 The tests use the `tune` fixture (tests/conftest.py), which restores every value it touched."""
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1, "TRAIN_SPLITK": 480, "TRAIN_V2V_NHWC": 1}
+_HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1, "TRAIN_SPLITK": 480, "TRAIN_V2V_NHWC": 1, "TRAIN_ADAM_HIP": 1}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "WGRAD_REDUCE4", "CONV1X1")
 
