@@ -1,0 +1,9 @@
+#!/bin/bash
+cd "$(dirname "$0")/../.."
+O=gpurun_out/r06_run26; mkdir -p $O
+bash tools/train_step_profile.sh > $O/train_step_profile_stdout.txt 2>&1
+cp gpurun_out/train_prof/*_kernels.txt gpurun_out/train_prof/*_traffic.txt gpurun_out/train_prof/*_traffic.json $O/ 2>/dev/null
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err
+echo "bench rc=$?"; tail -c 1500 $O/bench.json
+timeout 2400 python -m pytest tests -m gpu -q -x > $O/suite.txt 2>&1
+echo "rc=$?" >> $O/suite.txt; tail -4 $O/suite.txt
