@@ -570,7 +570,7 @@ class Layer:
 
 def _splitk_gate():
     """Launches with at least this many tiles are never split: 200 (measured, one-frame inference), or 5/8 of a latency_dispatch(target=...) block's target."""
-    return max(200, (getattr(_latency, "target", 0) or 320) * 5 // 8)
+    return max(200, (getattr(_latency, "target", 0) or tuning.get("SPLITK_TARGET")) * 5 // 8)
 
 
 def small_batch_splitk(pc, N, H, W):
@@ -597,7 +597,7 @@ def small_batch_splitk(pc, N, H, W):
         chunks = pc.C0 // 32
         if tiles >= _splitk_gate() or chunks < 8:                 # (conv3_1, 4 chunks: two ranges + the reduce launch 21 us against 20 unsplit)
             return 0
-        want = min(chunks // 2, -(-(getattr(_latency, "target", 0) or 320) // tiles))
+        want = min(chunks // 2, -(-(getattr(_latency, "target", 0) or tuning.get("SPLITK_TARGET")) // tiles))
         while want > 1 and -(-chunks // want) * (want - 1) >= chunks:
             want -= 1
         return want if want > 1 else 0
@@ -611,7 +611,7 @@ def small_batch_splitk(pc, N, H, W):
     # than the 8-wave forms even at 160 workgroups (conv5_1 at 40 maps: 163 vs 137 us), so there is no "more, smaller tiles" mode.
     if pc.Cout2 or tiles >= _splitk_gate() or chunks < 4:
         return 0
-    want = min(chunks // 2, -(-(getattr(_latency, "target", 0) or 320) // tiles))
+    want = min(chunks // 2, -(-(getattr(_latency, "target", 0) or tuning.get("SPLITK_TARGET")) // tiles))
     while want > 1 and -(-chunks // want) * (want - 1) >= chunks:     # no empty range
         want -= 1
     return want if want > 1 else 0

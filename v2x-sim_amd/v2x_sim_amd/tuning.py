@@ -13,6 +13,8 @@ Host-side switches (this module):
                    (ops.py header; bounded in tests/test_gpu_bits_input.py).  0: never; 1: every
                    launch of the process (explicit pin, also for the sharded runners); 2: only inside `with ops.latency_dispatch():`, which the
                    plain single-GPU model classes enter in forward() -- the sharded runners never do (R-rank == 1-rank bitwise)
+    SPLITK_TARGET 320  the number of workgroups a declared latency launch's split-K aims at (ops.small_batch_splitk; launches with >= max(200, 5/8 of it) tiles
+                   are never split); the training graph passes its own (TRAIN_SPLITK)
     TRAIN_HIP   1  training graph on the hand-written kernels (train/hip_graph.py: bf16 NHWC activations, fp32 master weights); 0: the fp32
                    PyTorch-ROCm (MIOpen) graph of train/graph.py -- upstream's precision, 5x slower
     TRAIN_GRAPH 0  with TRAIN_HIP: the whole step as one replayed hipGraph
@@ -48,7 +50,7 @@ The tests use the `tune` fixture (tests/conftest.py), which restores every value
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1, "TRAIN_SPLITK": 480, "TRAIN_V2V_NHWC": 1, "TRAIN_ADAM_HIP": 1}
+_HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1, "TRAIN_SPLITK": 480, "TRAIN_V2V_NHWC": 1, "TRAIN_ADAM_HIP": 1, "SPLITK_TARGET": 320}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "WGRAD_REDUCE4", "CONV1X1")
 
