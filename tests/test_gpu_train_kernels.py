@@ -1388,7 +1388,7 @@ def _v2v_reference(base32, cur32, T, counts, items, B):
 
 @pytest.mark.parametrize("A,B,C,H,W,two,shrink", [(3, 2, 32, 16, 32, False, False), (5, 1, 64, 32, 32, False, False), (4, 2, 32, 8, 32, True, False),
                                                   (2, 3, 256, 32, 32, False, False), (3, 1, 512, 16, 16, False, False), (3, 1, 32, 16, 32, False, True),
-                                                  (5, 1, 96, 12, 20, True, False)])
+                                                  (5, 1, 96, 12, 20, True, False), (6, 1, 32, 16, 32, False, False), (10, 1, 32, 8, 32, False, False)])
 def test_v2v_message_forward_and_backward_vs_torch(device, A, B, C, H, W, two, shrink):
     """v2x_v2v_message_bf16 / _bwd_bf16 against F.grid_sample o F.grid_sample, mean, cat and their autograd backward in fp32 on the same bf16 maps: the
     forward to one bf16 rounding of the value (+ the coordinate arithmetic's fp32 noise), the backward likewise and as the exact transpose of the forward

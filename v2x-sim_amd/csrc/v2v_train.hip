@@ -187,11 +187,14 @@ __global__ __launch_bounds__(256) void v2v_message_kernel(const V2vMsgArgs a) {
 // The order of additions is the direct form's: candidates row-major, the inner sum before the outer product.
 constexpr int VB_PIX = 8, VB_KMAX = 8;
 
+template <int KMAX>
 struct VbTables {
-    float w1[VB_PIX][VB_KMAX][9];      // weight of outer candidate c1 (0: none)
-    int n2[VB_PIX][VB_KMAX][9];        // its inner candidates with a non-zero weight, in row-major order, padded with (pixel 0, weight 0) to a multiple of 4
-    float w2[VB_PIX][VB_KMAX][9][12];
-    int q2[VB_PIX][VB_KMAX][9][12];
+    float w1[VB_PIX][KMAX][9];      // weight of outer candidate c1 (0: none)
+    int n2[VB_PIX][KMAX][9];        // its inner candidates with a non-zero weight, in row-major order, padded with (pixel 0, weight 0) to a multiple of 4
+    float w2[VB_PIX][KMAX][9][12];
+    int q2[VB_PIX][KMAX][9][12];
+    float th[KMAX][12];             // rot | tr of pair k of this row, loaded once per workgroup
+    int item[KMAX];                 // the item whose message pair k feeds
     int irregular;
 };
 
@@ -219,16 +222,29 @@ __device__ __forceinline__ void vb_direct(const V2vMsgArgs &a, const float rot[6
         }
 }
 
+// KMAX = 4 (up to five agents: 28 KiB of tables, five workgroups per CU) or 8 (57 KiB, two)
+template <int KMAX>
 __global__ __launch_bounds__(256) void v2v_message_bwd_kernel(const V2vMsgArgs a) {
-    __shared__ VbTables tb;
+    __shared__ VbTables<KMAX> tb;
     const int G = a.C >> 3, HW = a.H * a.W;
     const int chunks = (HW + VB_PIX - 1) / VB_PIX;
     const int r = blockIdx.x / chunks, p0 = (blockIdx.x - r * chunks) * VB_PIX;
     const int t = threadIdx.x;
-    if (t == 0) tb.irregular = a.K > VB_KMAX ? 1 : 0;
+    if (t == 0) tb.irregular = a.K > KMAX ? 1 : 0;
+    if (t < a.K && t < KMAX) {          // phase 0: the row's K poses
+        const int pi = a.inv[r * a.K + t];
+        float rot[6], tr[6];
+        vt_thetas(a.trans + (size_t)a.tsel[pi] * 16, rot, tr);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            tb.th[t][c] = rot[c];
+            tb.th[t][6 + c] = tr[c];
+        }
+        tb.item[t] = pi / a.K;
+    }
     __syncthreads();
     // phase 1: one thread per (pixel, pair, outer candidate)
-    if (a.K <= VB_KMAX) {
+    if (a.K <= KMAX) {
         for (int it = t; it < VB_PIX * a.K * 9; it += 256) {
             const int c1 = it % 9, k = (it / 9) % a.K, pl = it / (9 * a.K);
             const int pix = p0 + pl;
@@ -241,9 +257,12 @@ __global__ __launch_bounds__(256) void v2v_message_bwd_kernel(const V2vMsgArgs a
             }
             if (pix < HW) {
                 const int y = pix / a.W, x = pix - y * a.W;
-                const int pi = a.inv[r * a.K + k];
                 float rot[6], tr[6];
-                vt_thetas(a.trans + (size_t)a.tsel[pi] * 16, rot, tr);
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    rot[c] = tb.th[k][c];
+                    tr[c] = tb.th[k][6 + c];
+                }
                 const VtBox b1 = vt_candidates(rot, x, y, a.H, a.W);
                 if (b1.jhi - b1.jlo > 2 || b1.ihi - b1.ilo > 2) tb.irregular = 1;
                 const int i1 = b1.ilo + c1 / 3, j1 = b1.jlo + c1 % 3;
@@ -284,17 +303,17 @@ __global__ __launch_bounds__(256) void v2v_message_bwd_kernel(const V2vMsgArgs a
         for (int c = 0; c < 8; ++c) acc[c] = ego[c] = 0.f;
         if (me >= 0) vt_unpack8(d[((size_t)me * HW + pix) * (2 * G) + g], ego);
         for (int k = 0; k < a.K; ++k) {
-            const int pi = a.inv[r * a.K + k];
-            const int m = pi / a.K;
-            const uint4 *dm = d + (size_t)m * HW * (2 * G) + G + g;       // the message half of item m's gradient
             float ak[8];
 #pragma unroll
             for (int c = 0; c < 8; ++c) ak[c] = 0.f;
             if (direct) {
+                const int pi = a.inv[r * a.K + k];
+                const uint4 *dm = d + (size_t)(pi / a.K) * HW * (2 * G) + G + g;
                 float rot[6], tr[6];
                 vt_thetas(a.trans + (size_t)a.tsel[pi] * 16, rot, tr);
                 vb_direct(a, rot, tr, dm, G, x, y, kf, ak);
             } else {
+                const uint4 *dm = d + (size_t)tb.item[k] * HW * (2 * G) + G + g;       // the message half of that item's gradient
                 for (int c1 = 0; c1 < 9; ++c1) {
                     const float w1 = tb.w1[pl][k][c1];
                     if (w1 == 0.f) continue;
@@ -509,7 +528,8 @@ extern "C" int v2x_v2v_message_bwd_bf16(const uint16_t *dconv_in, const float *t
     a.M = M; a.K = K; a.N = N; a.C = C; a.H = H; a.W = W;
     const long long blocks = (long long)N * (((long long)H * W + VB_PIX - 1) / VB_PIX);
     V2X_REQUIRE(blocks < (1ll << 31), "v2x_v2v_message_bwd_bf16: too many pixels for one launch");
-    hipLaunchKernelGGL(v2v_message_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (K <= 4) hipLaunchKernelGGL(v2v_message_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(v2v_message_bwd_kernel<VB_KMAX>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     V2X_CHECK_LAUNCH("v2v_message_bwd_kernel");
     return V2X_OK;
 }
