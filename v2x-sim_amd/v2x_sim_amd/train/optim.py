@@ -48,7 +48,11 @@ class HipAdam(torch.optim.Adam):
         lib = _lib.load()
         for group in self.param_groups:
             params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
-            self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)       # torch's own lazy state initialisation
+            try:
+                self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)   # torch's own lazy state initialisation (a private method:
+            except TypeError:                                                                  #  another torch version may spell it differently)
+                super().step(None)
+                return loss
             if not params:
                 continue
             if any(st.dtype != torch.float32 for st in steps):
