@@ -46,7 +46,8 @@ class HipAdam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.load()
-        for group in self.param_groups:
+        work = []
+        for group in self.param_groups:          # gather first: nothing is updated before every group is known to take the kernel
             params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
             try:
                 self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)   # torch's own lazy state initialisation (a private method:
@@ -58,18 +59,14 @@ class HipAdam(torch.optim.Adam):
             if any(st.dtype != torch.float32 for st in steps):
                 super().step(None)
                 return loss
+            if not steps[0].is_cuda and len({float(st) for st in steps}) > 1:      # host counters at different steps (parameters that sat out earlier
+                super().step(None)                                                  #  steps): torch's per-tensor bias corrections
+                return loss
+            work.append((group, params, grads, exp_avgs, exp_avg_sqs, steps))
+        for group, params, grads, exp_avgs, exp_avg_sqs, steps in work:
             dev_steps = steps[0].is_cuda
-            step_host = 0.0
-            if dev_steps:
-                torch._foreach_add_(steps, 1)
-            else:
-                torch._foreach_add_(steps, 1)                      # host counters (capturable=False): every tensor of a launch must be at the same step
-                vals = [float(s) for s in steps]
-                if max(vals) != min(vals):                         # (parameters that sat out earlier steps: torch's per-tensor bias corrections)
-                    torch._foreach_sub_(steps, 1)
-                    super().step(None)
-                    return loss
-                step_host = vals[0]
+            torch._foreach_add_(steps, 1)
+            step_host = 0.0 if dev_steps else float(steps[0])
             lr = group["lr"]
             lr_dev, lr_f = (C.c_void_p(lr.data_ptr()), 0.0) if torch.is_tensor(lr) else (None, float(lr))
             b1, b2 = group["betas"]
