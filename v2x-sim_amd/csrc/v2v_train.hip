@@ -198,7 +198,7 @@ struct VbTables {
     int irregular;
 };
 
-__device__ __forceinline__ void vb_direct(const V2vMsgArgs &a, const float rot[6], const float tr[6], const uint4 *dm, int G, int x, int y, float kf, float ak[8]) {
+__device__ __forceinline__ void vb_direct(const V2vMsgArgs &a, const float rot[6], const float tr[6], const uint4 *dm, int G, int x, int y, float ak[8]) {
     const VtBox b1 = vt_candidates(rot, x, y, a.H, a.W);            // pixels of the rotated map that read (x, y)
     for (int i1 = b1.ilo; i1 <= b1.ihi; ++i1)
         for (int j1 = b1.jlo; j1 <= b1.jhi; ++j1) {
@@ -215,7 +215,7 @@ __device__ __forceinline__ void vb_direct(const V2vMsgArgs &a, const float rot[6
                     float gq[8];
                     vt_unpack8(dm[(size_t)(i2 * a.W + j2) * (2 * G)], gq);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) d1[c] += w2 * (gq[c] / kf);     // (mean's backward: the gradient / K)
+                    for (int c = 0; c < 8; ++c) d1[c] += w2 * gq[c];
                 }
 #pragma unroll
             for (int c = 0; c < 8; ++c) ak[c] += w1 * d1[c];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void v2v_message_bwd_kernel(const V2vMsgArgs a
                 const uint4 *dm = d + (size_t)(pi / a.K) * HW * (2 * G) + G + g;
                 float rot[6], tr[6];
                 vt_thetas(a.trans + (size_t)a.tsel[pi] * 16, rot, tr);
-                vb_direct(a, rot, tr, dm, G, x, y, kf, ak);
+                vb_direct(a, rot, tr, dm, G, x, y, ak);
             } else {
                 const uint4 *dm = d + (size_t)tb.item[k] * HW * (2 * G) + G + g;       // the message half of that item's gradient
                 for (int c1 = 0; c1 < 9; ++c1) {
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(256) void v2v_message_bwd_kernel(const V2vMsgArgs a
                             float gq[8];
                             vt_unpack8(raw[e], gq);
 #pragma unroll
-                            for (int c = 0; c < 8; ++c) d1[c] += w2[e] * (gq[c] / kf);
+                            for (int c = 0; c < 8; ++c) d1[c] += w2[e] * gq[c];
                         }
                     }
 #pragma unroll
@@ -344,6 +344,9 @@ __global__ __launch_bounds__(256) void v2v_message_bwd_kernel(const V2vMsgArgs a
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] += ak[c];
         }
+        // mean's backward (the gradient / K) applied ONCE, to the sum: an IEEE division per tap and channel was most of this kernel's instructions (106 -> 46 us per 10-map step)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = acc[c] / kf;
         if (a.add_ego) {
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[c] += ego[c];
