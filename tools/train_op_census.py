@@ -20,7 +20,17 @@ from v2x_sim_amd.train import detection_loss, train_forward  # noqa: E402
 from v2x_sim_amd.train.loop import init_for_training, synthetic_batch_on_device  # noqa: E402
 
 OURS = ("conv3x3_", "conv1x1_", "bn_", "wgrad_", "upcat_", "cast_pad_", "channel_sum", "det_loss", "pack_conv", "zero_insert", "dense_f32", "warp_affine", "gru_", "voxel",
-        "(anonymous namespace)::upcat", "(anonymous namespace)::warp", "conv_igemm", "conv_gather", "adam_")
+        "conv_igemm", "conv_gather", "adam_", "splitk_reduce", "v2v_", "vt_sum", "warp_fuse", "attn_", "seg_")
+
+
+def _ours(name):
+    n = name
+    for pre in ("void ", "(anonymous namespace)::"):
+        if n.startswith(pre):
+            n = n[len(pre):]
+    if n.startswith("(anonymous namespace)::"):
+        n = n[len("(anonymous namespace)::"):]
+    return any(n.startswith(p) for p in OURS)
 
 
 def main(family="faf", frames=2):
@@ -51,7 +61,7 @@ def main(family="faf", frames=2):
     for ev in events:
         for k in ev.kernels:
             name = k.name
-            if any(name.startswith(p) or ("void " + p) in name[:64] or name.startswith("void " + p) for p in OURS):
+            if _ours(name):
                 ours_n += 1
                 ours_t += k.duration
                 continue
