@@ -64,6 +64,8 @@ def main(family="faf", frames=2):
             if _ours(name):
                 ours_n += 1
                 ours_t += k.duration
+                if os.environ.get("V2X_CENSUS_SHOW") and os.environ["V2X_CENSUS_SHOW"] in name:
+                    print("# %-60s %8.1f us" % (name[:60], k.duration))
                 continue
             where = "?"
             for fr in (ev.stack or []):
