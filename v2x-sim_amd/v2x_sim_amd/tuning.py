@@ -17,7 +17,10 @@ Host-side switches (this module):
                    are never split); the training graph passes its own (TRAIN_SPLITK)
     TRAIN_HIP   1  training graph on the hand-written kernels (train/hip_graph.py: bf16 NHWC activations, fp32 master weights); 0: the fp32
                    PyTorch-ROCm (MIOpen) graph of train/graph.py -- upstream's precision, 5x slower
-    TRAIN_GRAPH 0  with TRAIN_HIP: the whole step as one replayed hipGraph
+    TRAIN_GRAPH 1  with TRAIN_HIP: FaFModule.step replays the whole step (forward, loss, backward, optimizer) as ONE hipGraph where that is possible -- FaFNet
+                   always, V2VNet while the agent table equals the captured one, an optimizer that is capturable (train.loop.make_optimizer builds one; a plain
+                   `optim.Adam(params, lr=float)` is not: eager) -- one captured step per batch shape, kept on the optimizer; anything else runs eagerly.  0: always eager
+                   (round 6 made 1 the default: 4.1-4.3 ms instead of 5.0-6.4 ms per 10-map FaFNet step, the eager step is host-bound)
     WARP_HIP    1  with TRAIN_HIP: the cross-agent warp of the fusion stage (forward + data gradient) on v2x_warp_affine_f32 / _bwd_f32;
                    0: F.grid_sample and its atomic-scatter backward
     WARP_XCD    1  inference warp + fuse: the output maps of one frame on one XCD (v2x_warp_fuse_ordered: each source map is fetched once per frame
@@ -50,7 +53,7 @@ The tests use the `tune` fixture (tests/conftest.py), which restores every value
 import ctypes as C
 import os
 
-_HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 0, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1, "TRAIN_SPLITK": 480, "TRAIN_V2V_NHWC": 1, "TRAIN_ADAM_HIP": 1, "SPLITK_TARGET": 320}
+_HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 1, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1, "TRAIN_SPLITK": 480, "TRAIN_V2V_NHWC": 1, "TRAIN_ADAM_HIP": 1, "SPLITK_TARGET": 320}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
                     "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "WGRAD_REDUCE4", "CONV1X1")
 
