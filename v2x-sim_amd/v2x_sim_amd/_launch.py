@@ -5,7 +5,14 @@ import ctypes as C
 import torch
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)     # the handle without a torch.cuda.Stream object around it (what torch's own
+                                                                         # compiled-kernel launchers call): 0.4 us instead of 6.5 us per launch
+
+
 def _stream():
+    """The current HIP stream of the current device, as the C ABI takes it."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
