@@ -46,7 +46,7 @@ const char *v2x_last_error(void);
 /* Kernel-selection switches.  The library picks, per layer shape, the kernel form that measured fastest; a few shapes have a second
  * form that computes the same result (the bitwise-equality tests and the paired A/B tool compare them).  `name` is one of
  *   STREAM_WAVES (8 | 4)  STREAM_G  STREAM_WT (0 | 1 | 2)  STORE_X4  STREAM_PERSIST  STREAM_WIDE  WIDE3  HALO_PP  S2_G
- *   VOXELIZE_LDS (0 | 1 | 2)  WARP_LDS  GRU_XCD_WALK  HALO_XCD  WGRAD_TR  WGRAD_REDUCE4  CONV1X1     (0 | 1 unless noted; case-insensitive, an optional "V2X_" prefix is ignored)
+ *   VOXELIZE_LDS (0 | 1 | 2)  WARP_LDS  GRU_XCD_WALK  HALO_XCD  WGRAD_TR  BN_PARTIAL_T  WGRAD_REDUCE4  CONV1X1     (0 | 1 unless noted; case-insensitive, an optional "V2X_" prefix is ignored)
  * Each switch is initialised ONCE, at first use, from the environment variable V2X_<NAME> when that is set; afterwards only
  * v2x_tuning_set changes it (process-wide, relaxed atomics: set it before the launches it should affect).  No upstream
  * counterpart (the reference has one implementation per operator).  Unknown name -> V2X_EINVAL. */

@@ -113,13 +113,16 @@ def test_training_step_on_hip_conv_kernels(device, tune):
 
 
 # ------------------------------------------------------------------ batch-statistics BN + ReLU kernels (bn_train.hip)
+@pytest.mark.parametrize("layout", [1, 0])
 @pytest.mark.parametrize("M,C,relu", [(2 * 256 * 256, 32, True), (3 * 64 * 64, 128, True), (5 * 16 * 16, 512, True), (1000, 64, False),
-                                      (7, 8, True)])
-def test_bn_train_kernels_vs_autograd(device, M, C, relu):
+                                      (7, 8, True), (40 * 16 * 16, 512, True)])
+def test_bn_train_kernels_vs_autograd(device, tune, M, C, relu, layout):
     """v2x_bn_train_forward / backward against F.batch_norm(training=True) (+ relu) in fp32 on the same bf16 inputs: statistics and
     parameter gradients to 1e-5 / 2e-4 of their scale, y and dx within one bf16 rounding, running statistics as nn.BatchNorm updates
-    them, and bit-identical results on a second run (no atomics)."""
+    them, and bit-identical results on a second run (no atomics).  Both layouts of the per-workgroup partial sums (BN_PARTIAL_T: round 6's
+    [kind][channel][workgroup], which the finish kernels read as contiguous floats, and the earlier [workgroup][kind][channel])."""
     from v2x_sim_amd import ops
+    tune("BN_PARTIAL_T", layout)
     g = torch.Generator().manual_seed(M + C)
     x = (torch.randn(M, C, generator=g) * (0.5 + torch.rand(C, generator=g)) + torch.randn(C, generator=g)).to(torch.bfloat16)
     dy = torch.randn(M, C, generator=g).to(torch.bfloat16)

@@ -23,7 +23,7 @@ namespace {
 struct TuneEntry { const char *name; int def; };
 const TuneEntry kTune[V2X_TUNE_COUNT] = {
     {"STREAM_WAVES", 8}, {"STREAM_G", 1}, {"STREAM_WT", 1}, {"STORE_X4", 1}, {"STREAM_PERSIST", 1}, {"STREAM_WIDE", 1},
-    {"WIDE3", 1}, {"HALO_PP", 1}, {"VOXELIZE_LDS", 1}, {"WARP_LDS", 2}, {"S2_G", 1}, {"GRU_XCD_WALK", 1}, {"HALO_XCD", 1}, {"WGRAD_TR", 1}, {"WGRAD_REDUCE4", 1}, {"CONV1X1", 1},
+    {"WIDE3", 1}, {"HALO_PP", 1}, {"VOXELIZE_LDS", 1}, {"WARP_LDS", 2}, {"S2_G", 1}, {"GRU_XCD_WALK", 1}, {"HALO_XCD", 1}, {"WGRAD_TR", 1}, {"BN_PARTIAL_T", 1}, {"WGRAD_REDUCE4", 1}, {"CONV1X1", 1},
 };
 std::atomic<int> g_tune[V2X_TUNE_COUNT];
 std::once_flag g_tune_once;

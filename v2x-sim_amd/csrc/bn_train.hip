@@ -35,6 +35,7 @@ struct BnArgs {
     long long vec_per_block;   // 16-B vectors per workgroup (a multiple of BN_THREADS)
     float eps, momentum;
     int relu;
+    int partial_t;         // layout of `partial`: 1 = [kind][channel][workgroup] (round 6), 0 = [workgroup][kind][channel]
 };
 
 __device__ __forceinline__ void unpack8(const uint4 v, float f[8]) {
@@ -105,44 +106,56 @@ __global__ __launch_bounds__(BN_THREADS) void bn_partial_kernel(const BnArgs a) 
         const int gg = o >> 4, i = o & 15;
         float s = 0.f;
         for (int r = gg; r < BN_THREADS; r += a.G) s += red[r][i];
-        a.partial[((size_t)blockIdx.x * 2 + (i >> 3)) * a.C + gg * 8 + (i & 7)] = s;
+        // [kind][channel][workgroup]: the finish kernel (one workgroup per channel) then reads its channel's partials as contiguous floats -- in the
+        // [workgroup][kind][channel] layout of rounds 3-5 every one of its loads touched its own 64-byte line, which 16 workgroups re-read (134 MB of L2
+        // traffic per finish launch at 512 channels x 2048 partials)
+        if (a.partial_t) a.partial[((size_t)(i >> 3) * a.C + gg * 8 + (i & 7)) * a.n_blocks + blockIdx.x] = s;
+        else a.partial[((size_t)blockIdx.x * 2 + (i >> 3)) * a.C + gg * 8 + (i & 7)] = s;
     }
 }
 
-// One workgroup per channel: thread t adds partials t, t + 256, ... in fp64, then a fixed-shape tree over the 256 threads (the same
-// association every run).  A single thread walking all <= 2048 partials was 0.3 ms of dependent loads per launch.
+// One workgroup per channel: thread t adds partials t, t + 256, ... in fp64 (coalesced: the channel's partials are contiguous), then a fixed-shape
+// reduction -- xor shuffles inside a wave, the four wave sums added in wave order by every thread: the same association every run, one barrier
+// (rounds 3-5: an eight-level LDS tree, eight barriers).  A single thread walking all <= 2048 partials was 0.3 ms of dependent loads per launch.
 __device__ __forceinline__ void bn_sum_partials(const BnArgs &a, int c, double &s_out, double &q_out) {
-    __shared__ double rs[BN_THREADS], rq[BN_THREADS];
+    __shared__ double rs[BN_THREADS / 64], rq[BN_THREADS / 64];
     const int t = threadIdx.x;
     double s = 0.0, q = 0.0;
     // all of the thread's (at most 8) loads first, then the additions in the same order as a plain loop: one memory latency instead of eight
-    // (these finish kernels are pure latency: 6.5 us per launch, 44 launches per training step, before this)
     constexpr int NP = BN_MAX_BLOCKS / BN_THREADS;
     float vs[NP], vq[NP];
+    const float *ps = a.partial + (size_t)c * a.n_blocks, *pq = a.partial + ((size_t)a.C + c) * a.n_blocks;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int b = t + k * BN_THREADS;
         const bool ok = b < a.n_blocks;
-        vs[k] = ok ? a.partial[((size_t)b * 2) * a.C + c] : 0.f;
-        vq[k] = ok ? a.partial[((size_t)b * 2 + 1) * a.C + c] : 0.f;
+        vs[k] = ok ? (a.partial_t ? ps[b] : a.partial[((size_t)b * 2) * a.C + c]) : 0.f;
+        vq[k] = ok ? (a.partial_t ? pq[b] : a.partial[((size_t)b * 2 + 1) * a.C + c]) : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         s += (double)vs[k];
         q += (double)vq[k];
     }
-    rs[t] = s;
-    rq[t] = q;
-    __syncthreads();
-    for (int w = BN_THREADS / 2; w > 0; w >>= 1) {
-        if (t < w) {
-            rs[t] += rs[t + w];
-            rq[t] += rq[t + w];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
     }
-    s_out = rs[0];
-    q_out = rq[0];
+    if ((t & 63) == 0) {
+        rs[t >> 6] = s;
+        rq[t >> 6] = q;
+    }
+    __syncthreads();
+    s = rs[0];
+    q = rq[0];
+#pragma unroll
+    for (int w = 1; w < BN_THREADS / 64; ++w) {
+        s += rs[w];
+        q += rq[w];
+    }
+    s_out = s;
+    q_out = q;
 }
 
 __global__ __launch_bounds__(BN_THREADS) void bn_finish_stats_kernel(const BnArgs a) {
@@ -300,6 +313,7 @@ static int bn_plan(long long M, int C, BnArgs &a) {
     if (per < BN_THREADS) per = BN_THREADS;
     a.vec_per_block = per;
     a.n_blocks = (int)((total + per - 1) / per);
+    a.partial_t = v2x_tune(V2X_TUNE_BN_PARTIAL_T) != 0;
     return a.n_blocks;
 }
 

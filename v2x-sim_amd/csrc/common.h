@@ -32,6 +32,7 @@ enum v2x_tune_id {
     V2X_TUNE_GRU_XCD_WALK,    // 1: the ConvGRU's persistent grid walks 8 pixel x 4 channel tiles per XCD and round (fabric reads -16 %, same time, same bits); 0: 4 x 8
     V2X_TUNE_HALO_XCD,        // 1: the halo kernels' persistent grids give every XCD a contiguous eighth of the tiles (halo pixels cross the fabric once); 0: round-robin
     V2X_TUNE_WGRAD_TR,        // 1: weight-gradient kernel on LDS-DMA tiles + transpose reads; 0: the first form (VALU transposes)
+    V2X_TUNE_BN_PARTIAL_T,    // 1: the training BatchNorm's per-workgroup partial sums stored [kind][channel][workgroup] (the finish kernels read contiguous floats); 0: [workgroup][kind][channel]
     V2X_TUNE_WGRAD_REDUCE4,   // 1: the weight-gradient reduce with 16-byte loads, eight partials in flight (round 6); 0: the scalar form -- bit-identical
     V2X_TUNE_CONV1X1,         // 1: gather-layout 1x1 layers (Cin, Cout <= 128) on the streaming kernel (conv1x1.hip; round 6); 0: the gather kernel -- bit-identical
     V2X_TUNE_COUNT

@@ -2,7 +2,7 @@
 libv2x_amd.so for the kernel-selection ones) and changed afterwards only through set() -- nothing on the hot path calls os.environ.
 
 Kernel-selection switches live in the library (include/v2x_amd.h: v2x_tuning_set / v2x_tuning_get; defaults = the measured-fastest forms):
-    STREAM_WAVES STREAM_G STREAM_WT STORE_X4 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP VOXELIZE_LDS WARP_LDS S2_G GRU_XCD_WALK HALO_XCD WGRAD_TR WGRAD_REDUCE4 CONV1X1
+    STREAM_WAVES STREAM_G STREAM_WT STORE_X4 STREAM_PERSIST STREAM_WIDE WIDE3 HALO_PP VOXELIZE_LDS WARP_LDS S2_G GRU_XCD_WALK HALO_XCD WGRAD_TR BN_PARTIAL_T WGRAD_REDUCE4 CONV1X1
     (STORE_X4 1: 16-byte output stores -- two channel tiles exchanged between the k-slot quarters with v_permlane16_swap_b32 -- in every bf16 epilogue
      that has the form; 0: 8-byte stores, same bytes and values)
 Host-side switches (this module):
@@ -55,7 +55,7 @@ import os
 
 _HOST_DEFAULTS = {"CONV_PAIR": 1, "TRAIN_HIP": 1, "TRAIN_GRAPH": 1, "TRAIN_HIP_CONV": 0, "SMALL_BATCH": 2, "WARP_HIP": 1, "WARP_XCD": 1, "SEG_FUSE": 1, "TRAIN_PACK_BATCH": 1, "TRAIN_LOSS_HIP": 1, "TRAIN_GATES_HIP": 1, "PARITY_CLASS": 3, "TAIL_FUSE": 1, "TRAIN_HEAD_PACK": 1, "TRAIN_BN_BIAS_ZERO": 1, "TRAIN_UPCAT_CONV": 1, "TRAIN_SPLITK": 480, "TRAIN_V2V_NHWC": 1, "TRAIN_ADAM_HIP": 1, "SPLITK_TARGET": 320}
 LIBRARY_SWITCHES = ("STREAM_WAVES", "STREAM_G", "STREAM_WT", "STORE_X4", "STREAM_PERSIST", "STREAM_WIDE", "WIDE3", "HALO_PP",
-                    "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "WGRAD_REDUCE4", "CONV1X1")
+                    "VOXELIZE_LDS", "WARP_LDS", "S2_G", "GRU_XCD_WALK", "HALO_XCD", "WGRAD_TR", "BN_PARTIAL_T", "WGRAD_REDUCE4", "CONV1X1")
 
 
 def _env_int(name, default):
